@@ -1,0 +1,144 @@
+"""ctypes binding of the CPU oracle (oracle/wrenc_oracle.h). TEST INFRASTRUCTURE ONLY.
+
+May be imported by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg,
+never by the product package (wrenc_amd/).
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libwrenc_oracle.so")
+
+
+class _Params(C.Structure):
+    _fields_ = [("width", C.c_int), ("height", C.c_int), ("qp", C.c_int), ("max_split_depth", C.c_int)]
+
+
+class _PicOut(C.Structure):
+    _fields_ = [
+        ("rec_y", C.c_void_p), ("rec_cb", C.c_void_p), ("rec_cr", C.c_void_p),
+        ("lev_y", C.c_void_p), ("lev_cb", C.c_void_p), ("lev_cr", C.c_void_p),
+        ("cu_log2_size", C.c_void_p), ("luma_mode", C.c_void_p), ("chroma_mode", C.c_void_p),
+        ("ctu_cost", C.c_void_p),
+    ]
+
+
+def build(force=False):
+    src = os.path.join(_HERE, "wrenc_oracle.cpp")
+    if force or not os.path.exists(_SO) or (
+            os.path.exists(src) and os.path.getmtime(src) > os.path.getmtime(_SO)):
+        subprocess.check_call(["make", "-C", _HERE, "-s"])
+    return _SO
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        _lib = C.CDLL(_SO)
+        _lib.wro_encode_picture.restype = C.c_int
+        _lib.wro_last_final_pass_mismatches.restype = C.c_long
+        _lib.wro_level_cost.restype = C.c_int64
+        _lib.wro_header_bits.restype = C.c_int64
+        _lib.wro_chroma_header_bits.restype = C.c_int64
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def encode_picture(y, cb, cr, qp, max_split_depth):
+    """Run search + final pass of one picture. Returns a dict of numpy arrays."""
+    h, w = y.shape
+    y = np.ascontiguousarray(y, dtype=np.uint8)
+    cb = np.ascontiguousarray(cb, dtype=np.uint8)
+    cr = np.ascontiguousarray(cr, dtype=np.uint8)
+    out = {
+        "rec_y": np.zeros((h, w), np.uint8),
+        "rec_cb": np.zeros((h // 2, w // 2), np.uint8),
+        "rec_cr": np.zeros((h // 2, w // 2), np.uint8),
+        "lev_y": np.zeros((h, w), np.int16),
+        "lev_cb": np.zeros((h // 2, w // 2), np.int16),
+        "lev_cr": np.zeros((h // 2, w // 2), np.int16),
+        "cu_log2_size": np.zeros((h // 4, w // 4), np.uint8),
+        "luma_mode": np.zeros((h // 4, w // 4), np.uint8),
+        "chroma_mode": np.zeros((h // 8, w // 8), np.uint8),
+        "ctu_cost": np.zeros(((h // 32) * (w // 32),), np.float32),
+    }
+    po = _PicOut(*[_p(out[k]) for k in ("rec_y", "rec_cb", "rec_cr", "lev_y", "lev_cb", "lev_cr",
+                                         "cu_log2_size", "luma_mode", "chroma_mode", "ctu_cost")])
+    prm = _Params(w, h, qp, max_split_depth)
+    rc = lib().wro_encode_picture(C.byref(prm), _p(y), _p(cb), _p(cr), C.byref(po))
+    if rc != 0:
+        raise ValueError("wro_encode_picture failed: %d" % rc)
+    out["final_pass_mismatches"] = int(lib().wro_last_final_pass_mismatches())
+    return out
+
+
+def fwd_dct(res):
+    n = res.shape[0]
+    res = np.ascontiguousarray(res, np.int16)
+    out = np.zeros_like(res)
+    lib().wro_fwd_dct(_p(res), int(n).bit_length() - 1, _p(out))
+    return out
+
+
+def inv_dct(deq):
+    n = deq.shape[0]
+    deq = np.ascontiguousarray(deq, np.int16)
+    out = np.zeros_like(deq)
+    lib().wro_inv_dct(_p(deq), int(n).bit_length() - 1, _p(out))
+    return out
+
+
+def quantize(coef, qp, viterbi=False):
+    n = coef.shape[0]
+    coef = np.ascontiguousarray(coef, np.int16)
+    out = np.zeros_like(coef)
+    fn = lib().wro_quantize_viterbi if viterbi else lib().wro_quantize
+    fn(_p(coef), int(n).bit_length() - 1, int(qp), _p(out))
+    return out
+
+
+def dequantize(levels, qp):
+    n = levels.shape[0]
+    levels = np.ascontiguousarray(levels, np.int16)
+    out = np.zeros_like(levels)
+    lib().wro_dequantize(_p(levels), int(n).bit_length() - 1, int(qp), _p(out))
+    return out
+
+
+def level_cost(levels):
+    n = levels.shape[0]
+    levels = np.ascontiguousarray(levels, np.int16)
+    return int(lib().wro_level_cost(_p(levels), int(n).bit_length() - 1))
+
+
+def tables(qp):
+    lv = np.zeros(1024, np.int64)
+    dq = np.zeros(1024, np.int64)
+    lq = C.c_int64()
+    lr = C.c_float()
+    lib().wro_tables(int(qp), _p(lv), _p(dq), C.byref(lq), C.byref(lr))
+    return lv, dq, int(lq.value), float(lr.value)
+
+
+def header_bits(tree, non_planar, mpm_flag, mpm_idx, mpm_rem, cclm_flag, cclm_idx):
+    return int(lib().wro_header_bits(tree, non_planar, mpm_flag, mpm_idx, mpm_rem, cclm_flag, cclm_idx))
+
+
+def chroma_header_bits(cclm_flag, cclm_idx):
+    return int(lib().wro_chroma_header_bits(cclm_flag, cclm_idx))
+
+
+def dct64():
+    m = np.zeros((64, 64), np.int16)
+    lib().wro_dct64(_p(m))
+    return m

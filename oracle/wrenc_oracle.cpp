@@ -1,0 +1,1930 @@
+// wrenc_oracle.cpp -- TEST INFRASTRUCTURE ONLY (see wrenc_oracle.h).
+//
+// Literal C++17 restatement of wrenc's per-CTU RD search + final pass for the
+// live configuration: CTU 32, QT only (32/16/8/4), 8-bit 4:2:0,
+// dep-quant on, DCT-2 only, CCLM on, fixed QP.  PARITY UNPINNED (no reference
+// golden vectors exist; the Rust reference cannot be built in this image).
+//
+// Conventions: every function cites the reference lines it follows.  Integer
+// types mirror the reference (i16 intermediates are re-narrowed with (int16_t)
+// where the reference computes in i16; Rust release builds wrap, Cargo.toml:21).
+// Build with -ffp-contract=off: the f32 cost arithmetic must not be fused.
+
+#include "wrenc_oracle.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <memory>
+#include <vector>
+
+namespace {
+
+// ---------------------------------------------------------------------------
+// Tables
+// ---------------------------------------------------------------------------
+
+// DCT-2: integer cosine values c[j] ~ 64*sqrt(2)*cos(j*pi/128) as fixed by
+// H.266 8.7.4.5 (same numbers as transformer.rs:934-1191, where row k of the
+// 64-point matrix is c[(2n+1)k] with the usual cosine symmetries).
+static const int kCos[65] = {
+    64, 91, 90, 90, 90, 90, 90, 90, 89, 88, 88, 87, 87, 86, 85, 84, 83, 83, 82, 81, 80,
+    79, 78, 77, 75, 73, 73, 71, 70, 69, 67, 65, 64, 62, 61, 59, 57, 56, 54, 52, 50, 48,
+    46, 44, 43, 41, 38, 37, 36, 33, 31, 28, 25, 24, 22, 20, 18, 15, 13, 11, 9,  7,  4,
+    2,  0};
+
+static int16_t g_dct64[64][64];
+static bool g_tables_ready = false;
+
+// intraPredAngle for predModeIntra -14..80 (H.266 Table 24; common.rs:145)
+static const int kIntraAngle[95] = {
+    512, 341, 256, 171, 128, 102, 86,  73,  64,  57,  51,  45,  39,  35,  0,   0,
+    32,  29,  26,  23,  20,  18,  16,  14,  12,  10,  8,   6,   4,   3,   2,   1,
+    0,   -1,  -2,  -3,  -4,  -6,  -8,  -10, -12, -14, -16, -18, -20, -23, -26, -29,
+    -32, -29, -26, -23, -20, -18, -16, -14, -12, -10, -8,  -6,  -4,  -3,  -2,  -1,
+    0,   1,   2,   3,   4,   6,   8,   10,  12,  14,  16,  18,  20,  23,  26,  29,
+    32,  35,  39,  45,  51,  57,  64,  73,  86,  102, 128, 171, 256, 341, 512};
+
+// fC interpolation filter (H.266 Table 25; common.rs:153)
+static const int kFC[32][4] = {
+    {0, 64, 0, 0},    {-1, 63, 2, 0},   {-2, 62, 4, 0},   {-2, 60, 7, -1},
+    {-2, 58, 10, -2}, {-3, 57, 12, -2}, {-4, 56, 14, -2}, {-4, 55, 15, -2},
+    {-4, 54, 16, -2}, {-5, 53, 18, -2}, {-6, 52, 20, -2}, {-6, 49, 24, -3},
+    {-6, 46, 28, -4}, {-5, 44, 29, -4}, {-4, 42, 30, -4}, {-4, 39, 33, -4},
+    {-4, 36, 36, -4}, {-4, 33, 39, -4}, {-4, 30, 42, -4}, {-4, 29, 44, -5},
+    {-4, 28, 46, -6}, {-3, 24, 49, -6}, {-2, 20, 52, -6}, {-2, 18, 53, -5},
+    {-2, 16, 54, -4}, {-2, 15, 55, -4}, {-2, 14, 56, -4}, {-2, 12, 57, -3},
+    {-2, 10, 58, -2}, {-1, 7, 60, -2},  {0, 4, 62, -2},   {0, 2, 63, -1}};
+
+static int g_fg[32][4];         // fG (common.rs:188): {16-(p>>1), 32-(p>>1), 16+(p>>1), p>>1}
+static int16_t g_pdpc_w[3][64]; // PDPSF_WEIGHTS intra_predictor.rs:36-52: 32 >> ((i<<1)>>nScale)
+
+struct XY {
+    int x, y;
+};
+static std::vector<XY> g_diag[5][5]; // [log2h][log2w], ctu.rs:14-81
+
+static inline int ilog2(int v) {
+    int r = 0;
+    while (v > 1) {
+        v >>= 1;
+        ++r;
+    }
+    return r;
+}
+
+static void init_tables() {
+    if (g_tables_ready) return;
+    for (int k = 0; k < 64; ++k)
+        for (int n = 0; n < 64; ++n) {
+            int t = ((2 * n + 1) * k) % 256; // angle in units of pi/128
+            if (t > 128) t = 256 - t;
+            int v = (t > 64) ? -kCos[128 - t] : kCos[t];
+            g_dct64[k][n] = (int16_t)v;
+        }
+    for (int p = 0; p < 32; ++p) {
+        g_fg[p][0] = 16 - (p >> 1);
+        g_fg[p][1] = 32 - (p >> 1);
+        g_fg[p][2] = 16 + (p >> 1);
+        g_fg[p][3] = p >> 1;
+    }
+    for (int s = 0; s < 3; ++s)
+        for (int i = 0; i < 64; ++i) {
+            int sh = (i << 1) >> s;
+            g_pdpc_w[s][i] = (int16_t)(sh > 5 ? 0 : (32 >> sh));
+        }
+    // ctu.rs:54-77 up-right diagonal scan
+    for (int lh = 0; lh <= 4; ++lh)
+        for (int lw = 0; lw <= 4; ++lw) {
+            int bw = 1 << lw, bh = 1 << lh;
+            std::vector<XY>& o = g_diag[lh][lw];
+            o.assign((size_t)bw * bh, XY{0, 0});
+            int i = 0, x = 0, y = 0;
+            bool stop = false;
+            while (!stop) {
+                while (y >= 0) {
+                    if (x < bw && y < bh) {
+                        o[i].x = x;
+                        o[i].y = y;
+                        ++i;
+                    }
+                    --y;
+                    ++x;
+                }
+                y = x;
+                x = 0;
+                if (i >= bw * bh) stop = true;
+            }
+        }
+    g_tables_ready = true;
+}
+
+static const int kQStateTrans[4][2] = {{0, 2}, {2, 0}, {1, 3}, {3, 1}}; // encoder_context.rs:339
+static const int kLevelScale0[6] = {40, 45, 51, 57, 64, 72};           // quantizer.rs:8
+
+// ---------------------------------------------------------------------------
+// RD-model constants (defaults; block_splitter.rs / quantizer.rs)
+// ---------------------------------------------------------------------------
+struct RdConst {
+    int64_t lv[1024]; // lv_dq_trellis_table, block_splitter.rs:51-52
+    int64_t dq[1024]; // dq_table, quantizer.rs:20-21
+    int64_t lambda_q; // quantizer.rs:683
+    int qp;
+    // f32 model terms (trellis + dep-quant variants)
+    float non_planar_offset = 2.2153597f;   // :195
+    float mpm_idx_offset = 1.3660221f;      // :211
+    float mpm_remainder_mult = 0.5007182f;  // :227
+    float mpm_remainder_offset = 2.2973304f; // :243
+    float planar_offset = 0.9626864f;       // :260 (key "planer_offset_dq_trellis")
+    float header_bits = 1.1772872f;         // :276
+    float chroma_header_bits = 1.309252f;   // :634
+    float qp_div = 4.4043665f;              // :292
+    float lambda_mul = 1.1282581f;          // :308
+    float cclm_pow = 0.4587651f;            // :318
+    float mpm_idx_pow = 0.40271285f;        // :322
+    float mpm_remainder_pow = 0.34385094f;  // :326
+    float cclm_mode_idx_offset = 2.1f;      // :336
+    float non_cclm_offset = 0.89f;          // :352
+    float cclm_offset = 0.53f;              // :368
+};
+
+static void init_rd(RdConst& r, int qp) {
+    r.qp = qp;
+    const double lv_pow = 0.48592678233563835, lv_off = 0.15150746310196822;
+    for (int i = 0; i < 1024; ++i) {
+        r.lv[i] = (int64_t)(std::pow((double)i + lv_off, lv_pow) * 16384.0);
+        r.dq[i] = (int64_t)std::pow((double)(i * 16384), 0.5004010166085378);
+    }
+    // quantizer.rs:683  (2.0f64.powf(qp/qp_div) * lambda_mul) as i64 + lambda_offset
+    r.lambda_q = (int64_t)(std::pow(2.0, (double)qp / 5.218413785332902) * 1.2709404305806742) + 11;
+}
+
+// block_splitter.rs:472 / :775-778
+static inline float rd_lambda(const RdConst& r) {
+    return std::pow(2.0f, (float)r.qp / r.qp_div) * r.lambda_mul;
+}
+
+// block_splitter.rs:377-406
+static int64_t header_bits_luma(const RdConst& r, int tree, bool non_planar, bool mpm_flag,
+                                int mpm_idx, int mpm_rem, bool cclm_flag, int cclm_idx) {
+    float cclm_bits;
+    if (cclm_flag)
+        cclm_bits = r.cclm_offset + std::pow((float)cclm_idx + r.cclm_mode_idx_offset, r.cclm_pow);
+    else if (tree == 1)
+        cclm_bits = 0.0f;
+    else
+        cclm_bits = r.non_cclm_offset;
+    float mode_bits;
+    if (non_planar) {
+        float t;
+        if (mpm_flag)
+            t = std::pow((float)mpm_idx + r.mpm_idx_offset, r.mpm_idx_pow);
+        else
+            t = r.mpm_remainder_mult *
+                std::pow((float)mpm_rem + r.mpm_remainder_offset, r.mpm_remainder_pow);
+        mode_bits = r.non_planar_offset + t;
+    } else {
+        mode_bits = r.planar_offset;
+    }
+    mode_bits = mode_bits + cclm_bits;
+    float hb;
+    if (tree == 0)
+        hb = r.header_bits + mode_bits;
+    else if (tree == 1)
+        hb = r.header_bits / 3.0f + mode_bits;
+    else
+        hb = cclm_bits;
+    return (int64_t)(hb * 16384.0f);
+}
+
+// block_splitter.rs:695-712
+static int64_t header_bits_chroma(const RdConst& r, bool cclm_flag, int cclm_idx) {
+    float mode_bits;
+    if (cclm_flag)
+        mode_bits = r.cclm_offset + std::pow((float)cclm_idx + r.cclm_mode_idx_offset, r.cclm_pow);
+    else
+        mode_bits = r.non_cclm_offset;
+    return (int64_t)((r.chroma_header_bits + mode_bits) * 16384.0f);
+}
+
+// ---------------------------------------------------------------------------
+// Transform (transformer.rs)
+// ---------------------------------------------------------------------------
+
+// transformer.rs:2040-2378, DCT-2 both directions (mts_idx == 0, :1894-1902)
+static void fwd_dct(const int16_t* res, int log2n, int16_t* coef) {
+    const int n = 1 << log2n;
+    const int step = 64 >> log2n; // S[6-log2n][i][x] = B[i<<shift][x], :1212-1221
+    std::vector<int32_t> h((size_t)n * n), t((size_t)n * n);
+    // stage 1 (:2180-2188): h[y][i] = sum_x T[i][x]*r[y][x]
+    for (int y = 0; y < n; ++y)
+        for (int i = 0; i < n; ++i) {
+            int32_t s = 0;
+            for (int x = 0; x < n; ++x)
+                s += (int32_t)g_dct64[i * step][x] * (int32_t)res[y * n + x];
+            h[y * n + i] = s;
+        }
+    // :2201-2209
+    {
+        const int shift = log2n - 1;
+        const int32_t d = 1 << (shift - 1);
+        for (int k = 0; k < n * n; ++k) h[k] = (h[k] + d) >> shift;
+    }
+    // stage 2 (:2287-2295): t[i][x] = sum_y T[i][y]*h[y][x]
+    for (int x = 0; x < n; ++x)
+        for (int i = 0; i < n; ++i) {
+            int32_t s = 0;
+            for (int y = 0; y < n; ++y) s += (int32_t)g_dct64[i * step][y] * h[y * n + x];
+            t[i * n + x] = s;
+        }
+    // :2309-2316
+    {
+        const int shift = log2n + 6;
+        const int32_t d = 1 << (shift - 1);
+        for (int k = 0; k < n * n; ++k) coef[k] = (int16_t)((t[k] + d) >> shift); // :2371 `as i16`
+    }
+}
+
+// transformer.rs:2380-2737
+static void inv_dct(const int16_t* deq, int log2n, int16_t* res) {
+    const int n = 1 << log2n;
+    const int step = 64 >> log2n; // I[shift][x][i] = B[i<<shift][x], :1222-1231
+    std::vector<int32_t> v((size_t)n * n), it((size_t)n * n);
+    // stage 1 vertical (:2545-2554): v[y][x] = sum_i T[i][y]*d[i][x]
+    for (int x = 0; x < n; ++x)
+        for (int y = 0; y < n; ++y) {
+            int32_t s = 0;
+            for (int i = 0; i < n; ++i)
+                s += (int32_t)g_dct64[i * step][y] * (int32_t)deq[i * n + x];
+            v[y * n + x] = s;
+        }
+    // :2569-2580
+    for (int k = 0; k < n * n; ++k) {
+        int32_t c = (v[k] + 64) >> 7;
+        v[k] = std::min(std::max(c, -32768), 32767);
+    }
+    // stage 2 horizontal (:2663-2671): it[y][x] = sum_i T[i][x]*v[y][i]
+    for (int y = 0; y < n; ++y)
+        for (int x = 0; x < n; ++x) {
+            int32_t s = 0;
+            for (int i = 0; i < n; ++i) s += (int32_t)g_dct64[i * step][x] * v[y * n + i];
+            it[y * n + x] = s;
+        }
+    // :2687-2700  bd_shift = 20 - bit_depth = 12
+    for (int k = 0; k < n * n; ++k) res[k] = (int16_t)((it[k] + 2048) >> 12);
+}
+
+// ---------------------------------------------------------------------------
+// Quantiser (quantizer.rs)
+// ---------------------------------------------------------------------------
+
+// quantizer.rs:617-622 + derive_ls :326-333, flat m == 16 (:571-583)
+static inline int32_t level_scale(int qp) {
+    return (int32_t)((16 * kLevelScale0[(qp + 1) % 6]) << ((qp + 1) / 6));
+}
+// quantizer.rs:558-569: bit_depth + rect(0) + (log2w+log2h)/2 - 5 + dep_quant(1)
+static inline int quant_bd_shift(int log2n) { return 8 + log2n - 5 + 1; }
+
+// ctu.rs:827-845 for square TBs >= 4: 4x4 sub-blocks
+struct ScanGeom {
+    int log2n, n, log2_sb = 2, num_sb_coeff = 16, num_sb;
+    const std::vector<XY>* coeff_order;
+    const std::vector<XY>* sb_order;
+    explicit ScanGeom(int l2) : log2n(l2), n(1 << l2) {
+        num_sb = 1 << (2 * l2 - 4);
+        coeff_order = &g_diag[2][2];
+        sb_order = &g_diag[l2 - 2][l2 - 2];
+    }
+    inline void pos(int sb, int sp, int& xc, int& yc) const {
+        const XY s = (*sb_order)[sb];
+        const XY c = (*coeff_order)[sp];
+        xc = (s.x << 2) + c.x;
+        yc = (s.y << 2) + c.y;
+    }
+};
+
+struct TrellisEntry {
+    size_t a;
+    int16_t q;
+    int64_t cost;
+};
+
+struct Trellis {
+    const RdConst& rd;
+    const int16_t* t;
+    ScanGeom g;
+    int32_t lsc;
+    int bd_shift;
+    int32_t bd_offset;
+    int64_t lambda;
+    std::vector<TrellisEntry> table; // [sb][pos][state]
+    Trellis(const RdConst& r, const int16_t* coef, int log2n, int qp)
+        : rd(r), t(coef), g(log2n) {
+        lsc = level_scale(qp);
+        bd_shift = quant_bd_shift(log2n);
+        bd_offset = (1 << bd_shift) >> 1;
+        lambda = r.lambda_q;
+        table.assign((size_t)g.num_sb * 16 * 4, TrellisEntry{0, 0, INT64_MIN});
+    }
+    inline int64_t dq_cost(int64_t dist, int64_t bits) const { // quantizer.rs:29-31
+        return 128 * dist + lambda * rd.dq[bits];
+    }
+    // quantizer.rs:338-517 (memo key omits is_trailing_zeros: first visit wins)
+    TrellisEntry search(int q_state, int last_scan_pos, int last_sub_block, size_t depth,
+                        bool is_trailing_zeros) {
+        TrellisEntry& slot = table[((size_t)last_sub_block * 16 + last_scan_pos) * 4 + q_state];
+        if (slot.cost != INT64_MIN) return slot;
+        int xc, yc;
+        g.pos(last_sub_block, last_scan_pos, xc, yc);
+        const int32_t tc = (int32_t)t[yc * g.n + xc];
+        size_t a;
+        int16_t q;
+        int64_t cost;
+        if (depth == 0 || (last_scan_pos == 0 && last_sub_block == 0)) {
+            if (tc == 0) {
+                cost = dq_cost(0, 1 - (int64_t)is_trailing_zeros);
+                a = 0;
+                q = 0;
+            } else {
+                const size_t delta = (q_state > 1) ? 1 : 0;
+                int32_t s = (int32_t)((uint32_t)tc << bd_shift) - bd_offset;
+                if (tc < 0) s = -s;
+                const size_t a0 = (size_t)(s / lsc / 2);
+                int16_t q0 = (int16_t)(2 * a0 - delta); // usize wrap, then `as i16` (:379)
+                if (tc < 0) q0 = (int16_t)(-q0);
+                const int32_t dq0 = ((int32_t)q0 * lsc + bd_offset) >> bd_shift;
+                const int32_t d0 = std::abs(tc - dq0);
+                const int64_t cost0 =
+                    dq_cost(d0, (int64_t)(a0 + 1) * (int64_t)(a0 != 0 || !is_trailing_zeros));
+                const size_t a1 = a0 + 1;
+                int16_t q1 = (int16_t)(2 * a1 - delta);
+                if (tc < 0) q1 = (int16_t)(-q1);
+                const int32_t dq1 = ((int32_t)q1 * lsc + bd_offset) >> bd_shift;
+                const int32_t d1 = std::abs(tc - dq1);
+                const int64_t cost1 = dq_cost(d1, (int64_t)(a1 + 1));
+                if (cost0 <= cost1) {
+                    a = a0;
+                    q = q0;
+                    cost = cost0;
+                } else {
+                    a = a1;
+                    q = q1;
+                    cost = cost1;
+                }
+            }
+        } else {
+            const int* trans = kQStateTrans[q_state];
+            int next_scan_pos, next_sub_block;
+            if (last_scan_pos == 0) {
+                next_scan_pos = g.num_sb_coeff - 1;
+                next_sub_block = last_sub_block - 1;
+            } else {
+                next_scan_pos = last_scan_pos - 1;
+                next_sub_block = last_sub_block;
+            }
+            if (tc == 0) {
+                const int nq = trans[0];
+                const TrellisEntry n =
+                    search(nq, next_scan_pos, next_sub_block, depth - 1, is_trailing_zeros);
+                cost = n.cost + dq_cost(0, 1 - (int64_t)is_trailing_zeros);
+                a = 0;
+                q = 0;
+            } else {
+                int32_t s = (int32_t)((uint32_t)tc << bd_shift) - bd_offset;
+                if (tc < 0) s = -s;
+                const int32_t delta = (q_state > 1) ? 1 : 0;
+                const size_t a0 = (size_t)((s / lsc + delta) / 2);
+                const int nq0 = trans[a0 & 1];
+                int32_t q0 = a0 > 0 ? 2 * (int32_t)a0 - delta : 0;
+                if (tc < 0) q0 = -q0;
+                const int32_t dq0 = (q0 * lsc + bd_offset) >> bd_shift;
+                const int32_t d0 = std::abs(tc - dq0);
+                int64_t cost0 = (a0 == 0 && is_trailing_zeros) ? dq_cost(d0, 0)
+                                                                 : dq_cost(d0, (int64_t)(a0 + 1));
+                const TrellisEntry n0 = search(nq0, next_scan_pos, next_sub_block, depth - 1,
+                                               is_trailing_zeros && a0 == 0);
+                cost0 += n0.cost;
+                const size_t a1 = a0 + 1;
+                const int nq1 = trans[a1 & 1];
+                int64_t q1 = 2 * (int64_t)a1 - (int64_t)(q_state > 1);
+                if (tc < 0) q1 = -q1;
+                const int32_t dq1 = ((int32_t)q1 * lsc + bd_offset) >> bd_shift;
+                const int32_t d1 = std::abs(tc - dq1);
+                int64_t cost1 = dq_cost(d1, (int64_t)(a1 + 1));
+                const TrellisEntry n1 =
+                    search(nq1, next_scan_pos, next_sub_block, depth - 1, false);
+                cost1 += n1.cost;
+                if (cost0 <= cost1) {
+                    a = a0;
+                    q = (int16_t)q0;
+                    cost = cost0;
+                } else {
+                    a = a1;
+                    q = (int16_t)q1;
+                    cost = cost1;
+                }
+            }
+        }
+        if (last_scan_pos == 0 && is_trailing_zeros && a == 0) cost -= lambda * rd.dq[1]; // :512-514
+        // (re-fetch: recursion may not reallocate, table is pre-sized)
+        TrellisEntry& out = table[((size_t)last_sub_block * 16 + last_scan_pos) * 4 + q_state];
+        out = TrellisEntry{a, q, cost};
+        return out;
+    }
+};
+
+// quantizer.rs:633-721 (dep-quant, trellis=true)
+static void quantize(const RdConst& rd, const int16_t* coef, int log2n, int qp, int16_t* levels) {
+    Trellis tr(rd, coef, log2n, qp);
+    const ScanGeom& g = tr.g;
+    int q_state = 0;
+    int last_scan_pos = g.num_sb_coeff;
+    int last_sub_block = g.num_sb - 1;
+    bool is_not_first_sub_block = last_sub_block > 0;
+    bool is_trailing_zeros = true;
+    const size_t depth = (size_t)g.n * g.n;
+    do {
+        if (last_scan_pos == 0) {
+            last_scan_pos = g.num_sb_coeff;
+            last_sub_block -= 1;
+            is_not_first_sub_block = last_sub_block > 0;
+        }
+        last_scan_pos -= 1;
+        int xc, yc;
+        g.pos(last_sub_block, last_scan_pos, xc, yc);
+        const TrellisEntry e =
+            tr.search(q_state, last_scan_pos, last_sub_block, depth, is_trailing_zeros);
+        is_trailing_zeros = is_trailing_zeros && (e.a == 0);
+        levels[yc * g.n + xc] = e.q;
+        q_state = kQStateTrans[q_state][e.a & 1];
+    } while (last_scan_pos > 0 || is_not_first_sub_block);
+}
+
+// Backward 4-state Viterbi equivalent of the memoised DFS above.
+// First visit of node (i, s) in the DFS has trailing == (s == 0 && i <= istar)
+// where positions i count in reverse scan order (0 = last scan position) and
+// istar is the first i whose state-0 a0 is > 0 (all positions if none).
+static void quantize_viterbi(const RdConst& rd, const int16_t* coef, int log2n, int qp,
+                             int16_t* levels) {
+    ScanGeom g(log2n);
+    const int N = g.n * g.n;
+    const int32_t lsc = level_scale(qp);
+    const int bd_shift = quant_bd_shift(log2n);
+    const int32_t bd_offset = (1 << bd_shift) >> 1;
+    const int64_t lambda = rd.lambda_q;
+    std::vector<int32_t> tc(N);
+    std::vector<uint8_t> first_in_sb(N);
+    std::vector<int> px(N), py(N);
+    {
+        int i = 0;
+        for (int sb = g.num_sb - 1; sb >= 0; --sb)
+            for (int sp = 15; sp >= 0; --sp, ++i) {
+                int xc, yc;
+                g.pos(sb, sp, xc, yc);
+                px[i] = xc;
+                py[i] = yc;
+                tc[i] = coef[yc * g.n + xc];
+                first_in_sb[i] = (sp == 0);
+            }
+    }
+    auto sval = [&](int32_t t) {
+        int32_t s = (int32_t)((uint32_t)t << bd_shift) - bd_offset;
+        return t < 0 ? -s : s;
+    };
+    int istar = N; // exclusive bound: state-0 nodes with i <= istar are "trailing"
+    for (int i = 0; i < N; ++i) {
+        if (tc[i] == 0) continue;
+        const int32_t a0 = (sval(tc[i]) / lsc) / 2; // delta == 0 in state 0; DC formula is the same
+        if (a0 > 0) {
+            istar = i;
+            break;
+        }
+    }
+    auto trailing = [&](int i, int s) { return s == 0 && i <= istar; };
+    auto dqc = [&](int64_t dist, int64_t bits) { return 128 * dist + lambda * rd.dq[bits]; };
+    std::vector<int64_t> C((size_t)(N + 1) * 4, 0);
+    std::vector<uint32_t> A((size_t)N * 4);
+    std::vector<int16_t> Q((size_t)N * 4);
+    for (int i = N - 1; i >= 0; --i)
+        for (int s = 0; s < 4; ++s) {
+            const bool tz = trailing(i, s);
+            const int32_t t = tc[i];
+            size_t a;
+            int16_t q;
+            int64_t cost;
+            if (i == N - 1) {
+                if (t == 0) {
+                    cost = dqc(0, 1 - (int64_t)tz);
+                    a = 0;
+                    q = 0;
+                } else {
+                    const size_t delta = s > 1;
+                    const size_t a0 = (size_t)(sval(t) / lsc / 2);
+                    int16_t q0 = (int16_t)(2 * a0 - delta);
+                    if (t < 0) q0 = (int16_t)-q0;
+                    const int32_t d0 = std::abs(t - (((int32_t)q0 * lsc + bd_offset) >> bd_shift));
+                    const int64_t c0 = dqc(d0, (int64_t)(a0 + 1) * (int64_t)(a0 != 0 || !tz));
+                    const size_t a1 = a0 + 1;
+                    int16_t q1 = (int16_t)(2 * a1 - delta);
+                    if (t < 0) q1 = (int16_t)-q1;
+                    const int32_t d1 = std::abs(t - (((int32_t)q1 * lsc + bd_offset) >> bd_shift));
+                    const int64_t c1 = dqc(d1, (int64_t)(a1 + 1));
+                    if (c0 <= c1) {
+                        a = a0;
+                        q = q0;
+                        cost = c0;
+                    } else {
+                        a = a1;
+                        q = q1;
+                        cost = c1;
+                    }
+                }
+            } else {
+                const int* trans = kQStateTrans[s];
+                if (t == 0) {
+                    cost = C[(size_t)(i + 1) * 4 + trans[0]] + dqc(0, 1 - (int64_t)tz);
+                    a = 0;
+                    q = 0;
+                } else {
+                    const int32_t delta = s > 1;
+                    const size_t a0 = (size_t)((sval(t) / lsc + delta) / 2);
+                    int32_t q0 = a0 > 0 ? 2 * (int32_t)a0 - delta : 0;
+                    if (t < 0) q0 = -q0;
+                    const int32_t d0 = std::abs(t - ((q0 * lsc + bd_offset) >> bd_shift));
+                    int64_t c0 = (a0 == 0 && tz) ? dqc(d0, 0) : dqc(d0, (int64_t)(a0 + 1));
+                    c0 += C[(size_t)(i + 1) * 4 + trans[a0 & 1]];
+                    const size_t a1 = a0 + 1;
+                    int32_t q1 = 2 * (int32_t)a1 - delta;
+                    if (t < 0) q1 = -q1;
+                    const int32_t d1 = std::abs(t - ((q1 * lsc + bd_offset) >> bd_shift));
+                    int64_t c1 = dqc(d1, (int64_t)(a1 + 1));
+                    c1 += C[(size_t)(i + 1) * 4 + trans[a1 & 1]];
+                    if (c0 <= c1) {
+                        a = a0;
+                        q = (int16_t)q0;
+                        cost = c0;
+                    } else {
+                        a = a1;
+                        q = (int16_t)q1;
+                        cost = c1;
+                    }
+                }
+            }
+            if (first_in_sb[i] && tz && a == 0) cost -= lambda * rd.dq[1];
+            C[(size_t)i * 4 + s] = cost;
+            A[(size_t)i * 4 + s] = (uint32_t)a;
+            Q[(size_t)i * 4 + s] = q;
+        }
+    int s = 0;
+    for (int i = 0; i < N; ++i) {
+        levels[py[i] * g.n + px[i]] = Q[(size_t)i * 4 + s];
+        s = kQStateTrans[s][A[(size_t)i * 4 + s] & 1];
+    }
+}
+
+// quantizer.rs:1068-1077
+static void dequantize(const int16_t* levels, int log2n, int qp, int16_t* deq) {
+    const int n = 1 << log2n;
+    const int32_t lsc = level_scale(qp);
+    const int bd_shift = quant_bd_shift(log2n);
+    const int32_t bd_offset = (1 << bd_shift) >> 1;
+    for (int k = 0; k < n * n; ++k) {
+        int32_t v = ((int32_t)levels[k] * lsc + bd_offset) >> bd_shift;
+        deq[k] = (int16_t)std::min(std::max(v, -32768), 32767);
+    }
+}
+
+// block_splitter.rs:415-460 (one component)
+static int64_t level_cost(const RdConst& rd, const int16_t* levels, int log2n) {
+    ScanGeom g(log2n);
+    int64_t sum = 0;
+    int q_state = 0;
+    int last_scan_pos = g.num_sb_coeff;
+    int last_sub_block = g.num_sb - 1;
+    bool is_not_first_sub_block = last_sub_block > 0;
+    bool is_trailing_zeros = true;
+    do {
+        if (last_scan_pos == 0) {
+            last_scan_pos = g.num_sb_coeff;
+            last_sub_block -= 1;
+            is_not_first_sub_block = last_sub_block > 0;
+        }
+        last_scan_pos -= 1;
+        int xc, yc;
+        g.pos(last_sub_block, last_scan_pos, xc, yc);
+        const size_t qc = (size_t)std::abs((int)levels[yc * g.n + xc]);
+        if (qc == 0) {
+            sum += is_trailing_zeros ? 0 : rd.lv[0];
+            q_state = kQStateTrans[q_state][0];
+        } else {
+            const size_t a = (qc + (q_state > 1 ? 1 : 0)) / 2;
+            sum += rd.lv[a];
+            q_state = kQStateTrans[q_state][a & 1];
+        }
+        is_trailing_zeros = is_trailing_zeros && (qc == 0);
+    } while (last_scan_pos > 0 || is_not_first_sub_block);
+    return sum;
+}
+
+// ---------------------------------------------------------------------------
+// Data model (ctu.rs, tile.rs)
+// ---------------------------------------------------------------------------
+enum TreeType { SINGLE_TREE = 0, DUAL_TREE_LUMA = 1, DUAL_TREE_CHROMA = 2 };
+enum { MODE_TYPE_ALL = 4, MODE_TYPE_INTRA = 6 };
+enum { PLANAR = 0, DC = 1, LT_CCLM = 81, L_CCLM = 82, T_CCLM = 83 };
+
+struct Node;
+
+// CodingUnit + its single TransformTree/TransformUnit (ctu.rs:324-497,1190-1358)
+struct CU {
+    int x, y, w, h; // luma units
+    TreeType tree;
+    Node* parent;
+    int ipm[3] = {PLANAR, PLANAR, PLANAR};    // CodingUnit.intra_pred_mode (:1328)
+    int tu_ipm[3] = {PLANAR, PLANAR, PLANAR}; // TransformUnit.cu_intra_pred_mode (:361,:421)
+    // TU coefficient buffers (ctu.rs:340-344), one per component, row-major n*n
+    std::vector<int16_t> resid[3], coef[3], lev[3], deq[3], itr[3];
+    bool active(int c) const { // ctu.rs:499-505
+        if (tree == DUAL_TREE_LUMA) return c == 0;
+        if (tree == DUAL_TREE_CHROMA) return c != 0;
+        return true;
+    }
+    int csize(int c) const { return c == 0 ? w : w / 2; }
+    int cx(int c) const { return c == 0 ? x : x / 2; }
+    int cy(int c) const { return c == 0 ? y : y / 2; }
+    bool cclm_flag() const { return ipm[1] >= LT_CCLM && ipm[1] <= T_CCLM; } // ctu.rs:1411-1416
+    int cclm_idx() const { return cclm_flag() ? ipm[1] - LT_CCLM : 0; }      // :1418-1424
+    // ctu.rs:1637-1741 with intra_chroma_pred_mode == 4 (:1298), no MIP/IBC/ACT/BDPCM
+    int derived_chroma_mode() const {
+        if (cclm_flag()) return LT_CCLM + cclm_idx();
+        return ipm[0];
+    }
+    // ctu.rs:1372-1381
+    void set_intra_pred_mode(const int m[3]) {
+        ipm[0] = m[0];
+        ipm[1] = m[1];
+        ipm[2] = m[2];
+        const int c = derived_chroma_mode();
+        ipm[1] = c;
+        ipm[2] = c;
+        tu_ipm[0] = m[0];
+        tu_ipm[1] = m[1];
+        tu_ipm[2] = m[2];
+    }
+};
+
+// CodingTree (ctu.rs:1793-1901)
+struct Node {
+    int x, y, w, h;
+    int depth;
+    TreeType tree;
+    int mode_type;
+    bool split_qt = false;
+    std::vector<Node*> cts;
+    std::vector<CU*> cus;
+    Node* parent = nullptr;
+};
+
+struct Picture {
+    int W, H, qp, max_depth;
+    RdConst rd;
+    std::vector<uint8_t> org[3], pred[3], rec[3];
+    int stride[3];
+    std::vector<std::unique_ptr<Node>> node_pool;
+    std::vector<std::unique_ptr<CU>> cu_pool;
+    std::vector<Node*> ctu_root; // ctu.ct[0] per CTU (raster)
+    int ctu_cols, ctu_rows;
+    long final_mismatch = 0;
+
+    Node* new_node(int x, int y, int size, int depth, TreeType tree, int mode_type, Node* parent) {
+        node_pool.emplace_back(new Node());
+        Node* n = node_pool.back().get();
+        n->x = x;
+        n->y = y;
+        n->w = n->h = size;
+        n->depth = depth;
+        n->tree = tree;
+        n->mode_type = mode_type;
+        n->parent = parent;
+        // ctu.rs:1882-1899: every new CT owns one CU with one TU
+        cu_pool.emplace_back(new CU());
+        CU* cu = cu_pool.back().get();
+        cu->x = x;
+        cu->y = y;
+        cu->w = cu->h = size;
+        cu->tree = tree;
+        cu->parent = n;
+        for (int c = 0; c < 3; ++c) {
+            const int s = (c == 0) ? size : size / 2;
+            const size_t e = (size_t)s * s;
+            cu->resid[c].assign(e, 0);
+            cu->coef[c].assign(e, 0);
+            cu->lev[c].assign(e, 0);
+            cu->deq[c].assign(e, 0);
+            cu->itr[c].assign(e, 0);
+        }
+        n->cus.push_back(cu);
+        return n;
+    }
+
+    // tile.rs:63-83 -> ctu.rs:265-281 -> ctu.rs:2372-2396
+    CU* get_cu(int x, int y) const {
+        if (x < 0 || y < 0 || x >= W || y >= H) return nullptr;
+        const Node* n = ctu_root[(y >> 5) * ctu_cols + (x >> 5)];
+        for (;;) {
+            if (!n->cts.empty()) {
+                const Node* next = nullptr;
+                for (const Node* c : n->cts)
+                    if (x >= c->x && x < c->x + c->w && y >= c->y && y < c->y + c->h) {
+                        next = c;
+                        break;
+                    }
+                if (!next) abort();
+                n = next;
+            } else {
+                for (CU* cu : n->cus)
+                    if (x >= cu->x && x < cu->x + cu->w && y >= cu->y && y < cu->y + cu->h)
+                        return cu;
+                abort();
+            }
+        }
+    }
+};
+
+// ctu.rs:2120-2188 (x_tile = y_tile = 0, one tile = picture)
+static bool ct_above_right(const Picture& p, const Node* n) {
+    if (n->x + n->w >= p.W) return false;
+    const Node* ct = n->parent;
+    if (ct) {
+        if (n->w == ct->w && n->h == ct->h) return ct_above_right(p, ct);
+        if (ct->cts.size() > 1) {
+            // SPLIT_QT
+            if (n->x == ct->x && n->y == ct->y) return 0 < n->y;
+            if (n->y == ct->y) return ct_above_right(p, ct);
+            if (n->x == ct->x) return true;
+            return false;
+        }
+        return ct_above_right(p, ct);
+    }
+    return 0 < n->y && n->x + n->w < p.W;
+}
+
+// ctu.rs:2083-2118
+static bool ct_below_left(const Picture& p, const Node* n) {
+    if (n->y + n->h >= p.H) return false;
+    const Node* ct = n->parent;
+    if (ct) {
+        if (ct->cts.size() > 1) {
+            if (ct->x < n->x) return false;
+            if (n->y + n->h < ct->y + ct->h) return 0 < n->x;
+            return ct_below_left(p, ct);
+        }
+        return ct_below_left(p, ct);
+    }
+    return false;
+}
+
+// TU -> TT -> CU -> CT chains (ctu.rs:525-591,1077-1151,1426-1490): each level
+// first applies the same picture-edge test, then defers (single TU/TT/CU).
+static bool tu_above_right(const Picture& p, const CU* cu) {
+    if (cu->x + cu->w >= p.W) return false;
+    return ct_above_right(p, cu->parent);
+}
+static bool tu_below_left(const Picture& p, const CU* cu) {
+    if (cu->y + cu->h >= p.H) return false;
+    return ct_below_left(p, cu->parent);
+}
+
+// encoder_context.rs:918-956 (check_pred_mode_y = false, no WPP)
+static bool nb_available(const Picture& p, int x_curr, int y_curr, int x_nb, int y_nb, int width,
+                         int height, bool above_right, bool below_left) {
+    return x_nb >= 0 && y_nb >= 0 && x_nb < p.W && y_nb < p.H &&
+           ((x_nb >> 5) <= (x_curr >> 5) || (y_nb >> 5) < (y_curr >> 5)) &&
+           (y_nb >> 5) < (y_curr >> 5) + 1 && (x_nb < x_curr + width || above_right) &&
+           (y_nb < y_curr + height || below_left);
+}
+
+// ctu.rs:1498-1635
+static void mpm_flag_idx_rem(const Picture& p, const CU* cu, bool& mpm_flag, int& mpm_idx,
+                             int& mpm_rem) {
+    if (cu->ipm[0] == PLANAR) {
+        mpm_flag = true;
+        mpm_idx = 0;
+        mpm_rem = 0;
+        return;
+    }
+    const CU* left_cu = p.get_cu(cu->x - 1, cu->y + cu->h - 1);
+    const CU* above_cu = p.get_cu(cu->x + cu->w - 1, cu->y - 1);
+    const int left = left_cu ? left_cu->ipm[0] : PLANAR;
+    int above;
+    if (above_cu) {
+        if (cu->y - 1 < ((cu->y >> 5) << 5))
+            above = PLANAR;
+        else
+            above = above_cu->ipm[0];
+    } else {
+        above = PLANAR;
+    }
+    int cand[5];
+    if (left == above && left > DC) {
+        const int m = left;
+        cand[0] = m;
+        cand[1] = 2 + (m + 61) % 64;
+        cand[2] = 2 + (m - 1) % 64;
+        cand[3] = 2 + (m + 60) % 64;
+        cand[4] = 2 + m % 64;
+    } else if (left != above && (left > DC || above > DC)) {
+        const int mn = std::min(left, above), mx = std::max(left, above);
+        if (mn > DC) {
+            const int d = mx - mn;
+            cand[0] = left;
+            cand[1] = above;
+            if (d == 1) {
+                cand[2] = 2 + (mn + 61) % 64;
+                cand[3] = 2 + (mx - 1) % 64;
+                cand[4] = 2 + (mn + 60) % 64;
+            } else if (d >= 62) {
+                cand[2] = 2 + (mn - 1) % 64;
+                cand[3] = 2 + (mx + 61) % 64;
+                cand[4] = 2 + mn % 64;
+            } else if (d == 2) {
+                cand[2] = 2 + (mn - 1) % 64;
+                cand[3] = 2 + (mn + 61) % 64;
+                cand[4] = 2 + (mx - 1) % 64;
+            } else {
+                cand[2] = 2 + (mn + 61) % 64;
+                cand[3] = 2 + (mn - 1) % 64;
+                cand[4] = 2 + (mx + 61) % 64;
+            }
+        } else {
+            cand[0] = mx;
+            cand[1] = 2 + (mx + 61) % 64;
+            cand[2] = 2 + (mx - 1) % 64;
+            cand[3] = 2 + (mx + 60) % 64;
+            cand[4] = 2 + mx % 64;
+        }
+    } else {
+        cand[0] = DC;
+        cand[1] = 50;
+        cand[2] = 18;
+        cand[3] = 46;
+        cand[4] = 54;
+    }
+    const int mode = cu->ipm[0];
+    for (int i = 0; i < 5; ++i)
+        if (cand[i] == mode) {
+            mpm_flag = true;
+            mpm_idx = i;
+            mpm_rem = 0;
+            return;
+        }
+    std::sort(cand, cand + 5);
+    mpm_flag = false;
+    mpm_idx = 0;
+    if (mode > cand[4])
+        mpm_rem = mode - 6;
+    else if (mode > cand[3])
+        mpm_rem = mode - 5;
+    else if (mode > cand[2])
+        mpm_rem = mode - 4;
+    else if (mode > cand[1])
+        mpm_rem = mode - 3;
+    else if (mode > cand[0])
+        mpm_rem = mode - 2;
+    else
+        mpm_rem = mode - 1;
+}
+
+// ---------------------------------------------------------------------------
+// Intra prediction (intra_predictor.rs)
+// ---------------------------------------------------------------------------
+struct Predictor {
+    Picture& p;
+    int16_t left_ref[130], above_ref[129];   // :13-14
+    int16_t left_f[130] = {0}, above_f[129] = {0}; // filtered (:15-16), persistent
+    int16_t ref_l[64][64], ref_t[64][64];    // :11-12
+    explicit Predictor(Picture& pic) : p(pic) {}
+
+    inline uint8_t& P(int c, int x, int y) { return p.pred[c][(size_t)y * p.stride[c] + x]; }
+    inline uint8_t R(int c, int x, int y) const { return p.rec[c][(size_t)y * p.stride[c] + x]; }
+    inline uint8_t O(int c, int x, int y) const { return p.org[c][(size_t)y * p.stride[c] + x]; }
+
+    // intra_predictor.rs:146-353 (ref_idx = 0, no ISP)
+    void set_refs(const CU* tu, int c) {
+        const int xt = tu->cx(c), yt = tu->cy(c);
+        const int nw = tu->csize(c), nh = nw;
+        const int ref_w = nw * 2, ref_h = nh * 2;
+        const int mode = tu->tu_ipm[c];
+        const bool ref_filter_flag = (mode == 0 || mode == 2 || mode == 34 || mode == 66); // :185-188
+        const int nl = ref_h + 1, na = ref_w;
+        for (int i = 0; i < nl; ++i) left_ref[i] = -1;
+        for (int i = 0; i < na; ++i) above_ref[i] = -1;
+        const bool ar = tu_above_right(p, tu), bl = tu_below_left(p, tu);
+        bool available = true;
+        const int cs = (c != 0) ? 1 : 0;
+        {
+            const int x_nb_cmp = xt - 1;
+            const int x_nb_y = x_nb_cmp * (1 << cs);
+            for (int y = -1; y <= ref_h - 1; ++y) {
+                const int y_nb_cmp = yt + y;
+                const int y_nb_y = y_nb_cmp * (1 << cs);
+                if (y == -1 || y % 4 == 0)
+                    available = nb_available(p, tu->x, tu->y, x_nb_y, y_nb_y, tu->w, tu->h, ar, bl);
+                if (available) left_ref[y + 1] = (int16_t)R(c, x_nb_cmp, y_nb_cmp);
+            }
+        }
+        {
+            const int y_nb_cmp = yt - 1;
+            const int y_nb_y = y_nb_cmp * (1 << cs);
+            const int row = y_nb_cmp >= 0 ? y_nb_cmp : 0;
+            for (int x = 0; x <= ref_w - 1; ++x) {
+                const int x_nb_cmp = xt + x;
+                const int x_nb_y = x_nb_cmp * (1 << cs);
+                if (x == 0 || x % 4 == 0)
+                    available = nb_available(p, tu->x, tu->y, x_nb_y, y_nb_y, tu->w, tu->h, ar, bl);
+                if (available) above_ref[x] = (int16_t)R(c, x_nb_cmp, row);
+            }
+        }
+        // substitution :263-302
+        bool left_all = true, above_all = true;
+        for (int i = 0; i < nl; ++i) left_all = left_all && left_ref[i] < 0;
+        for (int i = 0; i < na; ++i) above_all = above_all && above_ref[i] < 0;
+        if (left_all && above_all) {
+            for (int i = 0; i < nl; ++i) left_ref[i] = 128;
+            for (int i = 0; i < na; ++i) above_ref[i] = 128;
+        } else {
+            if (left_ref[nl - 1] < 0) {
+                bool found = false;
+                for (int i = nl - 2; i >= 0; --i)
+                    if (left_ref[i] >= 0) {
+                        left_ref[nl - 1] = left_ref[i];
+                        found = true;
+                        break;
+                    }
+                if (!found)
+                    for (int i = 0; i < na; ++i)
+                        if (above_ref[i] >= 0) {
+                            left_ref[nl - 1] = above_ref[i];
+                            break;
+                        }
+            }
+            for (int y = ref_h - 2; y >= -1; --y)
+                if (left_ref[y + 1] < 0) left_ref[y + 1] = left_ref[y + 2];
+        }
+        if (above_ref[0] < 0) above_ref[0] = left_ref[0];
+        for (int x = 1; x <= ref_w - 1; ++x)
+            if (above_ref[x] < 0) above_ref[x] = above_ref[x - 1];
+        // filtering :304-352
+        const bool filter_flag = nw * nh > 32 && c == 0 && ref_filter_flag;
+        if (filter_flag) {
+            left_f[0] = (int16_t)((left_ref[1] + 2 * left_ref[0] + above_ref[0] + 2) >> 2);
+            for (int y = 0; y < ref_h - 1; ++y)
+                left_f[1 + y] = (int16_t)((left_ref[2 + y] + 2 * left_ref[1 + y] + left_ref[y] + 2) >> 2);
+            left_f[ref_h] = left_ref[ref_h];
+            above_f[0] = (int16_t)((left_ref[0] + 2 * above_ref[0] + above_ref[1] + 2) >> 2);
+            for (int x = 0; x < ref_w - 2; ++x)
+                above_f[1 + x] =
+                    (int16_t)((above_ref[x] + 2 * above_ref[x + 1] + above_ref[x + 2] + 2) >> 2);
+            above_f[ref_w - 1] = above_ref[ref_w - 1];
+        } else {
+            for (int i = 0; i < nl; ++i) left_f[i] = left_ref[i];
+            for (int i = 0; i < na; ++i) above_f[i] = above_ref[i];
+        }
+    }
+
+    // intra_predictor.rs:355-757 (scalar arm :745-755)
+    void pdpc(const int16_t* above, const int16_t* left, int16_t alrs, const CU* tu, int c,
+              int pred_mode, int inv_angle) {
+        const int tw = tu->csize(c), th = tw;
+        const int tx = tu->cx(c), ty = tu->cy(c);
+        int n_scale;
+        if (pred_mode > 50)
+            n_scale = std::min(ilog2(th) - ilog2(3 * inv_angle - 2) + 8, 2);
+        else if (pred_mode > 1 && pred_mode < 18)
+            n_scale = std::min(ilog2(tw) - ilog2(3 * inv_angle - 2) + 8, 2);
+        else
+            n_scale = (ilog2(tw) + ilog2(th) - 2) >> 2;
+        static const int16_t zero_w[64] = {0};
+        const int16_t *w_l, *w_t;
+        if (pred_mode < 2) {
+            for (int y = 0; y < th; ++y)
+                for (int x = 0; x < tw; ++x) {
+                    ref_l[y][x] = left[y];
+                    ref_t[y][x] = above[x];
+                }
+            w_l = g_pdpc_w[n_scale];
+            w_t = g_pdpc_w[n_scale];
+        } else if (pred_mode == 18 || pred_mode == 50) {
+            for (int y = 0; y < th; ++y)
+                for (int x = 0; x < tw; ++x) {
+                    const int16_t pp = (int16_t)P(c, tx + x, ty + y);
+                    ref_l[y][x] = (int16_t)(left[y] - alrs + pp);
+                    ref_t[y][x] = (int16_t)(above[x] - alrs + pp);
+                }
+            w_l = pred_mode == 50 ? g_pdpc_w[n_scale] : zero_w;
+            w_t = pred_mode == 18 ? g_pdpc_w[n_scale] : zero_w;
+        } else if (pred_mode < 18 && n_scale >= 0) {
+            for (int y = 0; y < th; ++y) {
+                const int16_t dx_int = (int16_t)(((y + 1) * inv_angle + 256) >> 9);
+                for (int x = 0; x < tw; ++x) {
+                    ref_l[y][x] = 0;
+                    ref_t[y][x] = (y < (3 << n_scale)) ? above[(int16_t)(x + dx_int)] : (int16_t)0;
+                }
+            }
+            w_l = zero_w;
+            w_t = g_pdpc_w[n_scale];
+        } else if (pred_mode > 50 && n_scale >= 0) {
+            for (int y = 0; y < th; ++y)
+                for (int x = 0; x < tw; ++x) {
+                    const int16_t dy_int = (int16_t)(((x + 1) * inv_angle + 256) >> 9);
+                    ref_t[y][x] = 0;
+                    ref_l[y][x] = (x < (3 << n_scale)) ? left[(int16_t)(y + dy_int)] : (int16_t)0;
+                }
+            w_l = g_pdpc_w[n_scale];
+            w_t = zero_w;
+        } else {
+            for (int y = 0; y < th; ++y)
+                for (int x = 0; x < tw; ++x) {
+                    ref_l[y][x] = 0;
+                    ref_t[y][x] = 0;
+                }
+            w_l = zero_w;
+            w_t = zero_w;
+        }
+        for (int y = 0; y < th; ++y) {
+            const int16_t w_ty = w_t[y];
+            const int16_t neg_w_ty = (int16_t)(64 - w_ty);
+            for (int x = 0; x < tw; ++x) {
+                uint8_t& tp = P(c, tx + x, ty + y);
+                // i16 arithmetic with release-mode wrap (:747-752)
+                int16_t v = (int16_t)(ref_l[y][x] * w_l[x]);
+                v = (int16_t)(v + (int16_t)(ref_t[y][x] * w_ty));
+                v = (int16_t)(v + (int16_t)((int16_t)(neg_w_ty - w_l[x]) * (int16_t)tp));
+                v = (int16_t)(v + 32);
+                v = (int16_t)(v >> 6);
+                tp = (uint8_t)std::min<int>(std::max<int>(v, 0), 255);
+            }
+        }
+    }
+
+    // intra_predictor.rs:759-1146 (square arm, scalar :929-940,:1090-1099)
+    void predict_planar(const CU* tu, int c) {
+        set_refs(tu, c);
+        const int tw = tu->csize(c), th = tw;
+        const int tx = tu->cx(c), ty = tu->cy(c);
+        const int16_t alrs = left_f[0];
+        const int16_t* lrs = left_f + 1;
+        const int16_t* ars = above_f;
+        const int16_t ars_r = ars[tw];
+        const int16_t lrs_b = lrs[th];
+        const int shift = ilog2(tw) + 1;
+        for (int y = 0; y < th; ++y) {
+            const int16_t rv = (int16_t)(th - 1 - y);
+            const int16_t ry = (int16_t)((int16_t)(y + 1) * lrs_b);
+            for (int x = 0; x < tw; ++x) {
+                const int16_t rx = (int16_t)((int16_t)(x + 1) * ars_r);
+                const int16_t pv = (int16_t)((int16_t)(rv * ars[x]) + ry);
+                const int16_t ph = (int16_t)((int16_t)((int16_t)(tw - 1 - x) * lrs[y]) + rx);
+                const int16_t val = (int16_t)((int16_t)((int16_t)(pv + ph) + (int16_t)tw) >> shift);
+                P(c, tx + x, ty + y) = (uint8_t)val;
+            }
+        }
+        pdpc(ars, lrs, alrs, tu, c, PLANAR, 0); // tw>=4 && th>=4 always (:1133)
+    }
+
+    // intra_predictor.rs:1148-1285
+    void predict_dc(const CU* tu, int c) {
+        set_refs(tu, c);
+        const int tw = tu->csize(c), th = tw;
+        const int tx = tu->cx(c), ty = tu->cy(c);
+        const int16_t alrs = left_f[0];
+        const int16_t* lrs = left_f + 1;
+        const int16_t* ars = above_f;
+        int16_t v = (int16_t)tw;
+        int16_t sa = 0, sl = 0;
+        for (int i = 0; i < tw; ++i) sa = (int16_t)(sa + ars[i]);
+        for (int i = 0; i < th; ++i) sl = (int16_t)(sl + lrs[i]);
+        v = (int16_t)(v + (int16_t)(sa + sl));
+        const uint8_t dc_val = (uint8_t)(int16_t)(v >> (ilog2(tw) + 1));
+        for (int y = 0; y < th; ++y)
+            for (int x = 0; x < tw; ++x) P(c, tx + x, ty + y) = dc_val;
+        pdpc(ars, lrs, alrs, tu, c, DC, 0);
+    }
+
+    // intra_predictor.rs:1287-1602 (square blocks: no wide-angle remap)
+    void predict_angular(const CU* tu, int c) {
+        const int mode = tu->tu_ipm[c];
+        set_refs(tu, c);
+        const int tw = tu->csize(c), th = tw;
+        const int tx = tu->cx(c), ty = tu->cy(c);
+        const int n_tb_w = tw, n_tb_h = th, ref_w = 2 * tw, ref_h = 2 * th;
+        const int16_t* lrs = left_f; // index 0 = corner
+        const int16_t alrs = lrs[0];
+        const int16_t* ars = above_f;
+        const int n_tb_s = (ilog2(tw) + ilog2(th)) >> 1;
+        const bool ref_filter_flag = (mode == 0 || mode == 2 || mode == 34 || mode == 66);
+        bool filter_flag;
+        if (ref_filter_flag) {
+            filter_flag = false;
+        } else {
+            const int md = std::min(std::abs(mode - 50), std::abs(mode - 18));
+            int thr;
+            switch (n_tb_s) {
+            case 2: thr = 24; break;
+            case 3: thr = 14; break;
+            case 4: thr = 2; break;
+            case 5: thr = 0; break;
+            case 6: thr = 0; break;
+            default: abort();
+            }
+            filter_flag = md > thr;
+        }
+        const int angle = kIntraAngle[14 + mode];
+        int inv_angle;
+        if (angle > 0)
+            inv_angle = (512 * 32 + angle / 2) / angle;
+        else if (angle < 0)
+            inv_angle = -((512 * 32 + (-angle) / 2) / -angle);
+        else
+            inv_angle = 0;
+        std::vector<int16_t> refx;
+        if (mode >= 34) {
+            refx.assign((size_t)tw + 2, 0);
+            refx[0] = alrs;
+            for (int x = 0; x <= tw; ++x) refx[x + 1] = ars[x];
+            if (angle < 0) {
+                for (int x = -n_tb_h; x <= -1; ++x)
+                    refx.push_back(lrs[std::min((x * inv_angle + 256) >> 9, n_tb_h)]);
+            } else {
+                for (int x = n_tb_w + 2; x < ref_w; ++x) refx.push_back(ars[x - 1]);
+                for (int k = 1; k <= 3; ++k) refx.push_back(ars[ref_w - 1]);
+            }
+            const int len = (int)refx.size();
+            for (int y = 0; y < th; ++y) {
+                const int i_idx = ((y + 1) * angle) >> 5;
+                const int i_fact = ((y + 1) * angle) & 31;
+                if (c == 0) {
+                    const int* f = filter_flag ? g_fg[i_fact] : kFC[i_fact];
+                    for (int x = 0; x < tw; ++x) {
+                        long s = 0;
+                        for (int i = 0; i <= 3; ++i) {
+                            int idx = x + i_idx + i;
+                            if (idx < 0) idx = len + idx;
+                            s += (long)f[i] * (long)refx[idx];
+                        }
+                        P(c, tx + x, ty + y) = (uint8_t)std::min<long>(std::max<long>((s + 32) >> 6, 0), 255);
+                    }
+                } else if (i_fact != 0) {
+                    for (int x = 0; x < tw; ++x) {
+                        int idx0 = x + i_idx + 1;
+                        if (idx0 < 0) idx0 = len + idx0;
+                        int idx1 = x + i_idx + 2;
+                        if (idx1 < 0) idx1 = len + idx1;
+                        P(c, tx + x, ty + y) =
+                            (uint8_t)(((32 - i_fact) * (long)refx[idx0] + i_fact * (long)refx[idx1] + 16) >> 5);
+                    }
+                } else {
+                    for (int x = 0; x < tw; ++x) {
+                        int idx = x + i_idx + 1;
+                        if (idx < 0) idx = len + idx;
+                        P(c, tx + x, ty + y) = (uint8_t)refx[idx];
+                    }
+                }
+            }
+        } else {
+            refx.assign((size_t)n_tb_h + 2, 0);
+            for (int x = 0; x <= n_tb_h + 1; ++x) refx[x] = lrs[x];
+            if (angle < 0) {
+                for (int x = -n_tb_w; x <= -1; ++x) {
+                    const int idx = std::min((x * inv_angle + 256) >> 9, n_tb_w);
+                    refx.push_back(idx == 0 ? alrs : ars[idx - 1]);
+                }
+            } else {
+                for (int x = n_tb_h + 2; x <= ref_h; ++x) refx.push_back(lrs[x]);
+                for (int k = 1; k <= 2; ++k) refx.push_back(lrs[ref_h]);
+            }
+            const int len = (int)refx.size();
+            for (int x = 0; x < tw; ++x) {
+                const int i_idx = ((x + 1) * angle) >> 5;
+                const int i_fact = ((x + 1) * angle) & 31;
+                if (c == 0) {
+                    const int* f = filter_flag ? g_fg[i_fact] : kFC[i_fact];
+                    for (int y = 0; y < th; ++y) {
+                        long s = 0;
+                        for (int i = 0; i <= 3; ++i) {
+                            int idx = y + i_idx + i;
+                            if (idx < 0) idx = len + idx;
+                            s += (long)f[i] * (long)refx[idx];
+                        }
+                        P(c, tx + x, ty + y) = (uint8_t)std::min<long>(std::max<long>((s + 32) >> 6, 0), 255);
+                    }
+                } else if (i_fact != 0) {
+                    for (int y = 0; y < th; ++y) {
+                        int idx0 = y + i_idx + 1;
+                        if (idx0 < 0) idx0 = len + idx0;
+                        int idx1 = y + i_idx + 2;
+                        if (idx1 < 0) idx1 = len + idx1;
+                        P(c, tx + x, ty + y) =
+                            (uint8_t)(((32 - i_fact) * (long)refx[idx0] + i_fact * (long)refx[idx1] + 16) >> 5);
+                    }
+                } else {
+                    for (int y = 0; y < th; ++y) {
+                        int idx = y + i_idx + 1;
+                        if (idx < 0) idx = len + idx;
+                        P(c, tx + x, ty + y) = (uint8_t)refx[idx];
+                    }
+                }
+            }
+        }
+        if (mode <= 18 || (mode >= 50 && mode < LT_CCLM)) // :1571-1578
+            pdpc(ars, lrs + 1, alrs, tu, c, mode, inv_angle);
+    }
+
+    // intra_predictor.rs:1604-2055 (4:2:0, not vertically collocated)
+    void predict_cclm(const CU* tu, int c) {
+        const int tw = tu->csize(c), th = tw;
+        const int tx = tu->cx(c), ty = tu->cy(c);
+        const int mode = tu->tu_ipm[c];
+        const bool avail_l = nb_available(p, tu->x, tu->y, tu->x - 1, tu->y, tu->w, tu->h, false, false);
+        const bool avail_t = nb_available(p, tu->x, tu->y, tu->x, tu->y - 1, tu->w, tu->h, false, false);
+        int num_top_right = 0;
+        if (mode == T_CCLM) {
+            const bool ar = tu_above_right(p, tu), bl = tu_below_left(p, tu);
+            bool avail_tr = true;
+            for (int x = tw; x < 2 * tw; ++x) {
+                if (!avail_tr) break;
+                avail_tr = nb_available(p, tu->x, tu->y, tu->x + x * 2, tu->y - 1, tu->w, tu->h, ar, bl);
+                if (avail_tr) ++num_top_right;
+            }
+        }
+        int num_below_left = 0;
+        if (mode == L_CCLM) {
+            const bool ar = tu_above_right(p, tu), bl = tu_below_left(p, tu);
+            bool avail_bl = true;
+            for (int y = th; y < 2 * th; ++y) {
+                if (!avail_bl) break;
+                avail_bl = nb_available(p, tu->x, tu->y, tu->x - 1, tu->y + y * 2, tu->w, tu->h, ar, bl);
+                if (avail_bl) ++num_below_left;
+            }
+        }
+        int num_samp_t, num_samp_l;
+        if (mode == LT_CCLM) {
+            num_samp_t = avail_t ? tw : 0;
+            num_samp_l = avail_l ? th : 0;
+        } else {
+            num_samp_t = (avail_t && mode == T_CCLM) ? tw + std::min(num_top_right, th) : 0;
+            num_samp_l = (avail_l && mode == L_CCLM) ? th + std::min(num_below_left, tw) : 0;
+        }
+        const bool b_ctu_boundary = (tu->y & 31) == 0;
+        const int num_is_4 = !(avail_t && avail_l && mode == LT_CCLM) ? 1 : 0;
+        const int start_pos_t = num_samp_t >> (2 + num_is_4);
+        const int pick_step_t = std::max(num_samp_t >> (1 + num_is_4), 1);
+        int cnt_t = 0, pick_pos_t[4] = {0, 0, 0, 0};
+        if (avail_t && (mode == LT_CCLM || mode == T_CCLM)) {
+            cnt_t = std::min((1 + num_is_4) << 1, num_samp_t);
+            for (int i = 0; i < cnt_t; ++i) pick_pos_t[i] = start_pos_t + i * pick_step_t;
+        }
+        const int start_pos_l = num_samp_l >> (2 + num_is_4);
+        const int pick_step_l = std::max(num_samp_l >> (1 + num_is_4), 1);
+        int cnt_l = 0, pick_pos_l[4] = {0, 0, 0, 0};
+        if (avail_l && (mode == LT_CCLM || mode == L_CCLM)) {
+            cnt_l = std::min((1 + num_is_4) << 1, num_samp_l);
+            for (int i = 0; i < cnt_l; ++i) pick_pos_l[i] = start_pos_l + i * pick_step_l;
+        }
+        if (num_samp_l == 0 && num_samp_t == 0) {
+            for (int y = 0; y < th; ++y)
+                for (int x = 0; x < tw; ++x) P(c, tx + x, ty + y) = 128;
+            return;
+        }
+        const int dim = tu->h + tu->w + 3;
+        std::vector<long> win((size_t)dim * dim, 0);
+        const int ox = 3, oy = 3;
+        auto Wn = [&](int y, int x) -> long& { return win[(size_t)(y + oy) * dim + (x + ox)]; };
+        for (int y = 0; y < tu->h; ++y)
+            for (int x = 0; x < tu->w; ++x) Wn(y, x) = R(0, tu->x + x, tu->y + y);
+        if (avail_l)
+            for (int y = (avail_t ? -1 : 0); y < 2 * std::max(num_samp_l, th); ++y)
+                for (int x = -3; x <= -1; ++x) Wn(y, x) = R(0, tu->x + x, tu->y + y);
+        if (!avail_t)
+            for (int y = -2; y <= -1; ++y)
+                for (int x = -2; x < tu->w; ++x) Wn(y, x) = Wn(0, x);
+        if (avail_t)
+            for (int y = -3; y <= -1; ++y)
+                for (int x = (avail_l ? -1 : 0); x < 2 * std::max(num_samp_t, tw); ++x)
+                    Wn(y, x) = R(0, tu->x + x, tu->y + y);
+        if (!avail_l)
+            for (int y = -2; y < 2 * th; ++y) Wn(y, -1) = Wn(y, 0);
+        std::vector<long> pds((size_t)tw * th);
+        for (int y = 0; y < th; ++y)
+            for (int x = 0; x < tw; ++x) {
+                const int sx = 2 * x, sy = 2 * y;
+                pds[(size_t)y * tw + x] = (Wn(sy, sx - 1) + Wn(sy + 1, sx - 1) + Wn(sy, sx) * 2 +
+                                          Wn(sy + 1, sx) * 2 + Wn(sy, sx + 1) + Wn(sy + 1, sx + 1) + 4) >> 3;
+            }
+        long sel_y[4] = {0, 0, 0, 0}, sel_c[4] = {0, 0, 0, 0};
+        if (num_samp_t > 0) {
+            for (int i = 0; i < cnt_t; ++i) sel_c[i] = R(c, tx + pick_pos_t[i], ty - 1);
+            for (int i = 0; i < cnt_t; ++i) {
+                const int sx = 2 * pick_pos_t[i];
+                if (!b_ctu_boundary)
+                    sel_y[i] = (Wn(-1, sx - 1) + Wn(-2, sx - 1) + Wn(-1, sx) * 2 + Wn(-2, sx) * 2 +
+                                Wn(-1, sx + 1) + Wn(-2, sx + 1) + 4) >> 3;
+                else
+                    sel_y[i] = (Wn(-1, sx - 1) + Wn(-1, sx) * 2 + Wn(-1, sx + 1) + 2) >> 2;
+            }
+        }
+        if (num_samp_l > 0) {
+            for (int i = cnt_t; i < cnt_t + cnt_l; ++i) sel_c[i] = R(c, tx - 1, ty + pick_pos_l[i - cnt_t]);
+            for (int i = cnt_t; i < cnt_t + cnt_l; ++i) {
+                const int sx = -2;
+                const int sy = 2 * pick_pos_l[i - cnt_t];
+                sel_y[i] = (Wn(sy, sx - 1) + Wn(sy + 1, sx - 1) + Wn(sy, sx) * 2 + Wn(sy + 1, sx) * 2 +
+                            Wn(sy, sx + 1) + Wn(sy + 1, sx + 1) + 4) >> 3;
+            }
+        }
+        if (cnt_t + cnt_l == 2) abort(); // :1967-1972 unreachable for 4:2:0 >= 4x4
+        int min_grp[2] = {0, 2}, max_grp[2] = {1, 3};
+        if (sel_y[min_grp[0]] > sel_y[min_grp[1]]) std::swap(min_grp[0], min_grp[1]);
+        if (sel_y[max_grp[0]] > sel_y[max_grp[1]]) std::swap(max_grp[0], max_grp[1]);
+        if (sel_y[min_grp[0]] > sel_y[max_grp[1]]) {
+            std::swap(min_grp[0], max_grp[0]);
+            std::swap(min_grp[1], max_grp[1]);
+        }
+        if (sel_y[min_grp[1]] > sel_y[max_grp[0]]) std::swap(min_grp[1], max_grp[0]);
+        const long max_y = (sel_y[max_grp[0]] + sel_y[max_grp[1]] + 1) >> 1;
+        const long max_c = (sel_c[max_grp[0]] + sel_c[max_grp[1]] + 1) >> 1;
+        const long min_y = (sel_y[min_grp[0]] + sel_y[min_grp[1]] + 1) >> 1;
+        const long min_c = (sel_c[min_grp[0]] + sel_c[min_grp[1]] + 1) >> 1;
+        const long diff = max_y - min_y;
+        long a, b;
+        int k;
+        if (diff != 0) {
+            const long diff_c = max_c - min_c;
+            int x = ilog2((int)diff);
+            const long norm_diff = ((diff << 4) >> x) & 15;
+            x += (norm_diff != 0) ? 1 : 0;
+            const int y = std::labs(diff_c) > 0 ? ilog2((int)std::labs(diff_c)) + 1 : 0;
+            static const long div_sig[16] = {0, 7, 6, 5, 5, 4, 4, 3, 3, 2, 2, 1, 1, 1, 1, 0};
+            a = (diff_c == 0) ? 0 : (diff_c * (div_sig[norm_diff] | 8) + (1L << (y - 1))) >> y;
+            if (3 + x - y < 1) {
+                k = 1;
+                a = a < 0 ? -15 : (a > 0 ? 15 : 0);
+            } else {
+                k = 3 + x - y;
+            }
+            b = min_c - ((a * min_y) >> k);
+        } else {
+            a = 0;
+            k = 0;
+            b = min_c;
+        }
+        for (int y = 0; y < th; ++y)
+            for (int x = 0; x < tw; ++x) {
+                const long v = ((pds[(size_t)y * tw + x] * a) >> k) + b;
+                P(c, tx + x, ty + y) = (uint8_t)std::min<long>(std::max<long>(v, 0), 255);
+            }
+    }
+
+    // intra_predictor.rs:56-144
+    void predict(CU* tu, int c) {
+        const int mode = tu->tu_ipm[c];
+        if (mode == PLANAR)
+            predict_planar(tu, c);
+        else if (mode == DC)
+            predict_dc(tu, c);
+        else if (mode <= 66)
+            predict_angular(tu, c);
+        else
+            predict_cclm(tu, c);
+        const int tw = tu->csize(c), tx = tu->cx(c), ty = tu->cy(c);
+        for (int y = 0; y < tw; ++y)
+            for (int x = 0; x < tw; ++x)
+                tu->resid[c][(size_t)y * tw + x] =
+                    (int16_t)((int16_t)O(c, tx + x, ty + y) - (int16_t)P(c, tx + x, ty + y));
+    }
+};
+
+// ---------------------------------------------------------------------------
+// RD search (block_splitter.rs)
+// ---------------------------------------------------------------------------
+struct Splitter {
+    Picture& p;
+    Predictor ip;
+    explicit Splitter(Picture& pic) : p(pic), ip(pic) {}
+
+    // predict -> T -> Q -> DQ -> IT for one component (block_splitter.rs:148-160)
+    void code_component(CU* tu, int c) {
+        const int log2n = ilog2(tu->csize(c));
+        ip.predict(tu, c);
+        fwd_dct(tu->resid[c].data(), log2n, tu->coef[c].data());
+        quantize(p.rd, tu->coef[c].data(), log2n, p.qp, tu->lev[c].data());
+        dequantize(tu->lev[c].data(), log2n, p.qp, tu->deq[c].data());
+        inv_dct(tu->deq[c].data(), log2n, tu->itr[c].data());
+    }
+
+    // rec = clamp(pred + res) and SSD (block_splitter.rs:170-183)
+    size_t reconstruct(CU* tu, int c, bool with_ssd) {
+        const int tw = tu->csize(c), tx = tu->cx(c), ty = tu->cy(c);
+        size_t ssd = 0;
+        for (int y = 0; y < tw; ++y)
+            for (int x = 0; x < tw; ++x) {
+                const size_t o = (size_t)(ty + y) * p.stride[c] + tx + x;
+                const int16_t v = (int16_t)((int16_t)p.pred[c][o] + tu->itr[c][(size_t)y * tw + x]);
+                const uint8_t rec = (uint8_t)std::min<int>(std::max<int>(v, 0), 255);
+                p.rec[c][o] = rec;
+                if (with_ssd) {
+                    const int d = (int)rec - (int)p.org[c][o];
+                    ssd += (size_t)(d * d);
+                }
+            }
+        return ssd;
+    }
+
+    size_t sad(CU* tu, int c) {
+        const int tw = tu->csize(c), tx = tu->cx(c), ty = tu->cy(c);
+        size_t s = 0;
+        for (int y = 0; y < tw; ++y)
+            for (int x = 0; x < tw; ++x) {
+                const size_t o = (size_t)(ty + y) * p.stride[c] + tx + x;
+                s += (size_t)std::abs((int)p.pred[c][o] - (int)p.org[c][o]);
+            }
+        return s;
+    }
+
+    // block_splitter.rs:64-108
+    float get_intra_pred_aux_cost(const int mode[3], Node* ct) {
+        CU* cu = ct->cus[0];
+        cu->set_intra_pred_mode(mode);
+        size_t s = 0;
+        for (int c = 0; c < 3; ++c)
+            if (cu->active(c)) {
+                ip.predict(cu, c);
+                s += sad(cu, c);
+            }
+        return (float)s;
+    }
+
+    // block_splitter.rs:110-474
+    float get_intra_pred_cost(const int mode[3], Node* ct) {
+        CU* cu = ct->cus[0];
+        const int tree_type = ct->tree;
+        cu->set_intra_pred_mode(mode);
+        const bool non_planar = cu->ipm[0] != PLANAR;
+        bool mpm_flag;
+        int mpm_idx, mpm_rem;
+        mpm_flag_idx_rem(p, cu, mpm_flag, mpm_idx, mpm_rem);
+        const bool cclm_flag = cu->cclm_flag();
+        const int cclm_idx = cu->cclm_idx();
+        size_t ssd = 0;
+        for (int c = 0; c < 3; ++c)
+            if (cu->active(c)) {
+                code_component(cu, c);
+                ssd += reconstruct(cu, c, true);
+            }
+        const int64_t hb = header_bits_luma(p.rd, tree_type, non_planar, mpm_flag, mpm_idx, mpm_rem,
+                                            cclm_flag, cclm_idx);
+        int64_t sum = 0;
+        for (int c = 0; c < 3; ++c) {
+            if (!cu->active(c)) continue;
+            sum += level_cost(p.rd, cu->lev[c].data(), ilog2(cu->csize(c)));
+        }
+        const int64_t level = sum + hb;
+        const float lambda = rd_lambda(p.rd);
+        return (float)ssd + lambda * ((float)level / 16384.0f);
+    }
+
+    // block_splitter.rs:476-522
+    float get_chroma_intra_pred_aux_cost(int m, Node* ct) {
+        CU* cu = ct->cus[0];
+        int mode[3] = {cu->ipm[0], m, m};
+        cu->set_intra_pred_mode(mode);
+        size_t s = 0;
+        for (int c = 1; c < 3; ++c)
+            if (cu->active(c)) {
+                ip.predict(cu, c);
+                s += sad(cu, c);
+            }
+        return (float)s;
+    }
+
+    // block_splitter.rs:524-780
+    float get_chroma_intra_pred_cost(int m, Node* ct) {
+        CU* cu = ct->cus[0];
+        int mode[3] = {cu->ipm[0], m, m};
+        cu->set_intra_pred_mode(mode);
+        const bool cclm_flag = cu->cclm_flag();
+        const int cclm_idx = cu->cclm_idx();
+        size_t ssd = 0;
+        for (int c = 1; c < 3; ++c)
+            if (cu->active(c)) {
+                code_component(cu, c);
+                ssd += reconstruct(cu, c, true);
+            }
+        if (ct->tree == DUAL_TREE_LUMA) abort(); // :709
+        const int64_t hb = header_bits_chroma(p.rd, cclm_flag, cclm_idx);
+        int64_t sum = 0;
+        for (int c = 1; c < 3; ++c) sum += level_cost(p.rd, cu->lev[c].data(), ilog2(cu->csize(1)));
+        const int64_t level = sum + hb;
+        const float lambda = rd_lambda(p.rd);
+        return (float)ssd + lambda * ((float)level / 16384.0f);
+    }
+
+    void cache_reconsts(const Node* ct, int c0, int c1, std::vector<uint8_t> out[3]) {
+        for (int c = c0; c < c1; ++c) {
+            const int cx = c == 0 ? ct->x : ct->x / 2, cy = c == 0 ? ct->y : ct->y / 2;
+            const int cw = c == 0 ? ct->w : ct->w / 2;
+            out[c].resize((size_t)cw * cw);
+            for (int y = 0; y < cw; ++y)
+                for (int x = 0; x < cw; ++x)
+                    out[c][(size_t)y * cw + x] = p.rec[c][(size_t)(cy + y) * p.stride[c] + cx + x];
+        }
+    }
+    void restore_reconsts(const Node* ct, int c0, int c1, const std::vector<uint8_t> in[3]) {
+        for (int c = c0; c < c1; ++c) {
+            const int cx = c == 0 ? ct->x : ct->x / 2, cy = c == 0 ? ct->y : ct->y / 2;
+            const int cw = c == 0 ? ct->w : ct->w / 2;
+            for (int y = 0; y < cw; ++y)
+                for (int x = 0; x < cw; ++x)
+                    p.rec[c][(size_t)(cy + y) * p.stride[c] + cx + x] = in[c][(size_t)y * cw + x];
+        }
+    }
+
+    static float fmin_fold(const float* v, int n) { // iter().fold(f32::MAX, |m, v| v.min(m))
+        float m = 3.40282347e+38f;
+        for (int i = 0; i < n; ++i) m = std::fmin(v[i], m);
+        return m;
+    }
+    static int first_eq(const float* v, int n, float m) {
+        for (int i = 0; i < n; ++i)
+            if (v[i] == m) return i;
+        abort();
+    }
+
+    // ctu.rs:1960-2064 (SPLIT_QT only)
+    void split(Node* self) {
+        self->split_qt = true;
+        self->cus.clear();
+        // get_mode_type_condition (ctu.rs:1923-1958): 1 iff 8x8 QT split of a MODE_TYPE_ALL node
+        int mode_type_condition = 0;
+        if (self->mode_type == MODE_TYPE_ALL && self->w * self->h == 64) mode_type_condition = 1;
+        const int mode_type = mode_type_condition == 1 ? MODE_TYPE_INTRA : self->mode_type;
+        TreeType tree_type = mode_type == MODE_TYPE_INTRA ? DUAL_TREE_LUMA : self->tree;
+        if (self->w == 8 && self->h == 8 && tree_type == SINGLE_TREE) abort(); // ctu.rs:1995-1997
+        self->cts.clear();
+        for (int i = 0; i < 4; ++i)
+            self->cts.push_back(p.new_node(self->x + (i % 2) * (self->w / 2),
+                                           self->y + (i / 2) * (self->h / 2), self->w / 2,
+                                           self->depth + 1, tree_type, mode_type, self));
+        if (self->mode_type == MODE_TYPE_ALL && mode_type == MODE_TYPE_INTRA)
+            self->cts.push_back(p.new_node(self->x, self->y, self->w, self->depth, DUAL_TREE_CHROMA,
+                                           mode_type, self));
+    }
+
+    // block_splitter.rs:782-1154
+    float split_ct(Node* ct, int max_depth) {
+        if (max_depth == 0) {
+            const TreeType tree_type = ct->tree;
+            if (tree_type == DUAL_TREE_CHROMA) {
+                Node* par = ct->parent;
+                CU* luma_cu = nullptr;
+                // parent.get_cu(x + w/2, y + h/2) through the parent's own children (:795-800)
+                {
+                    const int qx = par->x + par->w / 2, qy = par->y + par->h / 2;
+                    const Node* n = par;
+                    for (;;) {
+                        if (!n->cts.empty()) {
+                            const Node* next = nullptr;
+                            for (const Node* ch : n->cts)
+                                if (qx >= ch->x && qx < ch->x + ch->w && qy >= ch->y && qy < ch->y + ch->h) {
+                                    next = ch;
+                                    break;
+                                }
+                            if (!next) abort();
+                            n = next;
+                        } else {
+                            luma_cu = n->cus[0];
+                            break;
+                        }
+                    }
+                }
+                const int chroma_pred_mode = luma_cu->derived_chroma_mode(); // :801-805
+                // cclm_enabled_flag == true (:806)
+                const float cclm_lt = get_chroma_intra_pred_aux_cost(LT_CCLM, ct);
+                const float cclm_t = get_chroma_intra_pred_aux_cost(T_CCLM, ct);
+                const float cclm_l = get_chroma_intra_pred_aux_cost(L_CCLM, ct);
+                int cclm_mode;
+                if (cclm_lt <= cclm_t && cclm_lt <= cclm_l)
+                    cclm_mode = LT_CCLM;
+                else if (cclm_t <= cclm_l)
+                    cclm_mode = T_CCLM;
+                else
+                    cclm_mode = L_CCLM;
+                const float cclm_cost = get_chroma_intra_pred_cost(cclm_mode, ct);
+                std::vector<uint8_t> cache[3];
+                cache_reconsts(ct, 1, 3, cache);
+                const float current_cost = get_chroma_intra_pred_cost(chroma_pred_mode, ct);
+                const float cands[2] = {current_cost, cclm_cost};
+                const float mn = fmin_fold(cands, 2);
+                const int idx = first_eq(cands, 2, mn);
+                if (idx == 1) {
+                    const int m3[3] = {cclm_mode, cclm_mode, cclm_mode};
+                    ct->cus[0]->set_intra_pred_mode(m3);
+                    restore_reconsts(ct, 1, 3, cache);
+                }
+                return mn;
+            }
+            static const int cand_modes0[15] = {0, 1, 2, 7, 13, 18, 23, 29, 34, 39, 45, 50, 55, 60, 66};
+            float cand_costs[15];
+            for (int i = 0; i < 15; ++i) {
+                const int m3[3] = {cand_modes0[i], cand_modes0[i], cand_modes0[i]};
+                cand_costs[i] = cand_modes0[i] <= 1 ? get_intra_pred_cost(m3, ct)
+                                                   : get_intra_pred_aux_cost(m3, ct);
+            }
+            const float min_dir_cost = fmin_fold(cand_costs + 2, 13);
+            const int min_dir_idx = first_eq(cand_costs + 2, 13, min_dir_cost) + 2;
+            auto step_search = [&](int current_mode, int step, float current_cost, bool aux,
+                                   float& out_cost) -> int {
+                if (!aux) {
+                    const int m3[3] = {current_mode, current_mode, current_mode};
+                    current_cost = get_intra_pred_cost(m3, ct);
+                }
+                while (step > 0) {
+                    float cost0, cost1;
+                    if (current_mode < 2 + step) {
+                        cost0 = 3.40282347e+38f;
+                    } else {
+                        const int m = current_mode - step;
+                        const int m3[3] = {m, m, m};
+                        cost0 = aux ? get_intra_pred_aux_cost(m3, ct) : get_intra_pred_cost(m3, ct);
+                    }
+                    if (current_mode + step > 66) {
+                        cost1 = 3.40282347e+38f;
+                    } else {
+                        const int m = current_mode + step;
+                        const int m3[3] = {m, m, m};
+                        cost1 = aux ? get_intra_pred_aux_cost(m3, ct) : get_intra_pred_cost(m3, ct);
+                    }
+                    const float min_cost = std::fmin(std::fmin(current_cost, cost0), cost1);
+                    if (current_cost == min_cost) {
+                    } else if (cost0 == min_cost) {
+                        current_mode = current_mode - step;
+                        current_cost = cost0;
+                    } else {
+                        current_mode = current_mode + step;
+                        current_cost = cost1;
+                    }
+                    step /= 2;
+                }
+                out_cost = current_cost;
+                return current_mode;
+            };
+            float tmp_cost, dir_cost;
+            int dir_mode = step_search(cand_modes0[min_dir_idx], 2, min_dir_cost, true, tmp_cost);
+            dir_mode = step_search(dir_mode, 1, min_dir_cost, false, dir_cost);
+            const int cand_modes[3] = {0, 1, dir_mode};
+            const float cc[3] = {cand_costs[0], cand_costs[1], dir_cost};
+            float min_cost = fmin_fold(cc, 3);
+            const int min_idx = first_eq(cc, 3, min_cost);
+            CU* cu = ct->cus[0];
+            const int mode = cand_modes[min_idx];
+            {
+                const int m3[3] = {mode, mode, mode};
+                cu->set_intra_pred_mode(m3);
+            }
+            if (cu->active(0)) { // luma re-run :989-1037
+                code_component(cu, 0);
+                reconstruct(cu, 0, false);
+            }
+            if (tree_type != DUAL_TREE_LUMA) { // cclm_enabled_flag (:1039)
+                const float current_cost = get_chroma_intra_pred_cost(mode, ct);
+                const float cclm_lt = get_chroma_intra_pred_aux_cost(LT_CCLM, ct);
+                const float cclm_t = get_chroma_intra_pred_aux_cost(T_CCLM, ct);
+                const float cclm_l = get_chroma_intra_pred_aux_cost(L_CCLM, ct);
+                int cclm_mode;
+                if (cclm_lt <= cclm_t && cclm_lt <= cclm_l)
+                    cclm_mode = LT_CCLM;
+                else if (cclm_t <= cclm_l)
+                    cclm_mode = T_CCLM;
+                else
+                    cclm_mode = L_CCLM;
+                const float cclm_cost = get_chroma_intra_pred_cost(cclm_mode, ct);
+                const float cands[2] = {current_cost, cclm_cost};
+                const float mn = fmin_fold(cands, 2);
+                const int idx = first_eq(cands, 2, mn);
+                if (idx == 0) {
+                    const int m3[3] = {mode, mode, mode};
+                    cu->set_intra_pred_mode(m3);
+                    min_cost = get_intra_pred_cost(m3, ct);
+                } else {
+                    const int m3[3] = {mode, cclm_mode, cclm_mode};
+                    min_cost = get_intra_pred_cost(m3, ct);
+                }
+            } else if (mode <= 1) {
+                const int m3[3] = {mode, mode, mode};
+                min_cost = get_intra_pred_cost(m3, ct);
+            }
+            return min_cost;
+        }
+        const float no_split_cost = split_ct(ct, 0);
+        // split_ct = Arc::new(Mutex::new(ct.clone())) : shallow clone (ctu.rs:1793 derive(Clone))
+        p.node_pool.emplace_back(new Node(*ct));
+        Node* sct = p.node_pool.back().get();
+        std::vector<uint8_t> no_split[3];
+        int c0 = 0, c1 = 3;
+        if (ct->tree == DUAL_TREE_LUMA) c1 = 1;
+        if (ct->tree == DUAL_TREE_CHROMA) c0 = 1;
+        cache_reconsts(ct, c0, c1, no_split);
+        split(sct);
+        const size_t n = sct->cts.size();
+        float split_cost = 0.0f;
+        for (size_t i = 0; i < n; ++i) split_cost += split_ct(sct->cts[i], max_depth - 1);
+        if (split_cost > no_split_cost) {
+            restore_reconsts(ct, c0, c1, no_split);
+            return no_split_cost;
+        }
+        // *ct = split_ct.clone()
+        Node* keep_parent = ct->parent; // identical in the clone
+        *ct = *sct;
+        ct->parent = keep_parent;
+        return split_cost;
+    }
+
+    // ctu_encoder.rs:1421-1461, in coding order (ctu_encoder.rs:448-465)
+    void final_pass(Node* n) {
+        if (!n->cts.empty()) {
+            for (Node* c : n->cts) final_pass(c);
+            return;
+        }
+        for (CU* cu : n->cus)
+            for (int c = 0; c < 3; ++c)
+                if (cu->active(c)) {
+                    const int tw = cu->csize(c), tx = cu->cx(c), ty = cu->cy(c);
+                    std::vector<uint8_t> before((size_t)tw * tw);
+                    for (int y = 0; y < tw; ++y)
+                        for (int x = 0; x < tw; ++x)
+                            before[(size_t)y * tw + x] = p.rec[c][(size_t)(ty + y) * p.stride[c] + tx + x];
+                    code_component(cu, c);
+                    reconstruct(cu, c, false);
+                    for (int y = 0; y < tw; ++y)
+                        for (int x = 0; x < tw; ++x)
+                            if (before[(size_t)y * tw + x] != p.rec[c][(size_t)(ty + y) * p.stride[c] + tx + x])
+                                ++p.final_mismatch;
+                }
+    }
+};
+
+static long g_last_final_mismatch = 0;
+
+static void export_tree(const Picture& p, const Node* n, wro_picture_out* out) {
+    if (!n->cts.empty()) {
+        for (const Node* c : n->cts) export_tree(p, c, out);
+        return;
+    }
+    for (const CU* cu : n->cus) {
+        if (cu->tree != DUAL_TREE_CHROMA) {
+            const int w4 = p.W / 4;
+            for (int y = cu->y / 4; y < (cu->y + cu->h) / 4; ++y)
+                for (int x = cu->x / 4; x < (cu->x + cu->w) / 4; ++x) {
+                    out->cu_log2_size[y * w4 + x] = (uint8_t)ilog2(cu->w);
+                    out->luma_mode[y * w4 + x] = (uint8_t)cu->ipm[0];
+                }
+        }
+        if (cu->tree != DUAL_TREE_LUMA) {
+            const int w8 = p.W / 8;
+            for (int y = cu->y / 8; y < (cu->y + cu->h) / 8; ++y)
+                for (int x = cu->x / 8; x < (cu->x + cu->w) / 8; ++x)
+                    out->chroma_mode[y * w8 + x] = (uint8_t)cu->tu_ipm[1];
+        }
+        for (int c = 0; c < 3; ++c)
+            if (cu->active(c)) {
+                int16_t* dst = c == 0 ? out->lev_y : (c == 1 ? out->lev_cb : out->lev_cr);
+                const int tw = cu->csize(c), tx = cu->cx(c), ty = cu->cy(c);
+                for (int y = 0; y < tw; ++y)
+                    for (int x = 0; x < tw; ++x)
+                        dst[(size_t)(ty + y) * p.stride[c] + tx + x] = cu->lev[c][(size_t)y * tw + x];
+            }
+    }
+}
+
+} // namespace
+
+extern "C" {
+
+int wro_encode_picture(const wro_params* prm, const uint8_t* y, const uint8_t* cb, const uint8_t* cr,
+                       wro_picture_out* out) {
+    init_tables();
+    if (!prm || prm->width <= 0 || prm->height <= 0 || (prm->width & 31) || (prm->height & 31))
+        return -1;
+    if (prm->max_split_depth < 0 || prm->max_split_depth > 3) return -2;
+    if (prm->qp < 0 || prm->qp > 63) return -3;
+    Picture p;
+    p.W = prm->width;
+    p.H = prm->height;
+    p.qp = prm->qp;
+    p.max_depth = prm->max_split_depth;
+    init_rd(p.rd, p.qp);
+    p.stride[0] = p.W;
+    p.stride[1] = p.stride[2] = p.W / 2;
+    const uint8_t* src[3] = {y, cb, cr};
+    for (int c = 0; c < 3; ++c) {
+        const size_t n = (size_t)p.stride[c] * (c == 0 ? p.H : p.H / 2);
+        p.org[c].assign(src[c], src[c] + n);
+        p.pred[c].assign(n, 0); // tile.rs:49-58 zero-initialised planes
+        p.rec[c].assign(n, 0);
+    }
+    p.ctu_cols = p.W / 32;
+    p.ctu_rows = p.H / 32;
+    // picture.rs:70-103 init_ctus: one SINGLE_TREE / MODE_TYPE_ALL root CT per CTU
+    for (int r = 0; r < p.ctu_rows; ++r)
+        for (int c = 0; c < p.ctu_cols; ++c)
+            p.ctu_root.push_back(p.new_node(c * 32, r * 32, 32, 0, SINGLE_TREE, MODE_TYPE_ALL, nullptr));
+    // slice_encoder.rs:352-379: CTUs in raster order; per CTU search then emit (final pass)
+    for (int i = 0; i < p.ctu_cols * p.ctu_rows; ++i) {
+        Splitter sp(p); // ctu_encoder.rs:53 BlockSplitter::new per CTU
+        const float cost = sp.split_ct(p.ctu_root[i], p.max_depth);
+        if (out && out->ctu_cost) out->ctu_cost[i] = cost;
+        sp.final_pass(p.ctu_root[i]);
+    }
+    g_last_final_mismatch = p.final_mismatch;
+    if (out) {
+        for (int c = 0; c < 3; ++c) {
+            uint8_t* dst = c == 0 ? out->rec_y : (c == 1 ? out->rec_cb : out->rec_cr);
+            if (dst) memcpy(dst, p.rec[c].data(), p.rec[c].size());
+        }
+        if (out->lev_y && out->lev_cb && out->lev_cr && out->cu_log2_size && out->luma_mode &&
+            out->chroma_mode)
+            for (Node* root : p.ctu_root) export_tree(p, root, out);
+    }
+    return 0;
+}
+
+long wro_last_final_pass_mismatches(void) { return g_last_final_mismatch; }
+
+void wro_fwd_dct(const int16_t* res, int log2n, int16_t* coef) {
+    init_tables();
+    fwd_dct(res, log2n, coef);
+}
+void wro_inv_dct(const int16_t* deq, int log2n, int16_t* res) {
+    init_tables();
+    inv_dct(deq, log2n, res);
+}
+void wro_quantize(const int16_t* coef, int log2n, int qp, int16_t* levels) {
+    init_tables();
+    static thread_local RdConst rd;
+    static thread_local int rd_qp = -1;
+    if (rd_qp != qp) {
+        init_rd(rd, qp);
+        rd_qp = qp;
+    }
+    quantize(rd, coef, log2n, qp, levels);
+}
+void wro_quantize_viterbi(const int16_t* coef, int log2n, int qp, int16_t* levels) {
+    init_tables();
+    static thread_local RdConst rd;
+    static thread_local int rd_qp = -1;
+    if (rd_qp != qp) {
+        init_rd(rd, qp);
+        rd_qp = qp;
+    }
+    quantize_viterbi(rd, coef, log2n, qp, levels);
+}
+void wro_dequantize(const int16_t* levels, int log2n, int qp, int16_t* deq) {
+    dequantize(levels, log2n, qp, deq);
+}
+int64_t wro_level_cost(const int16_t* levels, int log2n) {
+    init_tables();
+    static thread_local RdConst rd;
+    static thread_local bool ready = false;
+    if (!ready) {
+        init_rd(rd, 32);
+        ready = true;
+    }
+    return level_cost(rd, levels, log2n);
+}
+void wro_tables(int qp, int64_t* lv, int64_t* dq, int64_t* lambda_q, float* lambda_rd) {
+    RdConst rd;
+    init_rd(rd, qp);
+    if (lv) memcpy(lv, rd.lv, sizeof(rd.lv));
+    if (dq) memcpy(dq, rd.dq, sizeof(rd.dq));
+    if (lambda_q) *lambda_q = rd.lambda_q;
+    if (lambda_rd) *lambda_rd = rd_lambda(rd);
+}
+int64_t wro_header_bits(int tree, int non_planar, int mpm_flag, int mpm_idx, int mpm_rem,
+                        int cclm_flag, int cclm_idx) {
+    RdConst rd;
+    rd.qp = 32;
+    return header_bits_luma(rd, tree, non_planar != 0, mpm_flag != 0, mpm_idx, mpm_rem, cclm_flag != 0,
+                            cclm_idx);
+}
+int64_t wro_chroma_header_bits(int cclm_flag, int cclm_idx) {
+    RdConst rd;
+    rd.qp = 32;
+    return header_bits_chroma(rd, cclm_flag != 0, cclm_idx);
+}
+void wro_dct64(int16_t* m) {
+    init_tables();
+    memcpy(m, g_dct64, sizeof(g_dct64));
+}
+
+} // extern "C"

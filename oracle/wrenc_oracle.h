@@ -1,0 +1,91 @@
+// wrenc_oracle.h -- TEST INFRASTRUCTURE ONLY.
+//
+// CPU restatement ("oracle") of the per-CTU RD-search hot path of hjmkt/wrenc
+// (reference paths below are relative to the reference tree's src/):
+//   block_splitter.rs  (split_ct, get_intra_pred_cost, ...)
+//   intra_predictor.rs (PLANAR / DC / ANGULAR / CCLM / PDPC, reference samples)
+//   transformer.rs     (integer DCT-2 4/8/16/32 forward + inverse)
+//   quantizer.rs       (dependent quantisation trellis, dequantisation)
+//   ctu.rs             (CT split, MPM derivation, availability walkers)
+//   ctu_encoder.rs:1421-1461 (final pass)
+//
+// PARITY UNPINNED: the reference is Rust; no Rust toolchain exists in the build
+// image and the reference ships no golden vectors for this path, so this
+// restatement cannot be checked against reference output.  It follows the
+// reference source line by line (scalar arms, release-profile wrap semantics).
+//
+// Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may link
+// or call this code.  The product path (wrenc_amd/) never does.
+#pragma once
+#include <cstdint>
+#include <cstddef>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+// Resolved RD-model constants (defaults of block_splitter.rs:187-375,594-693 and
+// quantizer.rs:16-25,650-683; every live call site passes trellis=true and
+// dep_quant_used_flag=true, so only the *_dq_trellis variants are live).
+typedef struct wro_params {
+    int width;            // luma, multiple of 32 (picture.rs:178-181 panics otherwise)
+    int height;
+    int qp;               // fixed QP (main.rs:193-198); 26 when --qp absent
+    int max_split_depth;  // 0..3 (main.rs:108-109)
+} wro_params;
+
+// Output of one picture.  All buffers caller-allocated.
+typedef struct wro_picture_out {
+    uint8_t* rec_y;        // width*height
+    uint8_t* rec_cb;       // (width/2)*(height/2)
+    uint8_t* rec_cr;
+    int16_t* lev_y;        // TransCoeffLevel planes (final pass, ctu_encoder.rs:1437)
+    int16_t* lev_cb;
+    int16_t* lev_cr;
+    uint8_t* cu_log2_size; // (width/4)*(height/4): log2 of the luma CU covering each 4x4
+    uint8_t* luma_mode;    // (width/4)*(height/4): CU intra_pred_mode[0]
+    uint8_t* chroma_mode;  // (width/8)*(height/8): TU cu_intra_pred_mode[1] of the chroma block
+    float* ctu_cost;       // one per CTU (return value of split_ct at ctu_encoder.rs:54)
+} wro_picture_out;
+
+// Encode (search + final pass) one picture. Returns 0 on success.
+int wro_encode_picture(const wro_params* p, const uint8_t* y, const uint8_t* cb,
+                       const uint8_t* cr, wro_picture_out* out);
+
+// Final-pass consistency: number of samples where the final pass recon differs
+// from the recon the search left in the planes (expected 0).
+long wro_last_final_pass_mismatches(void);
+
+// ---- building blocks exposed for kernel-level parity tests ----
+// transformer.rs:2040-2378 (DCT-2 only). in/out: n*n row-major, n = 1<<log2n.
+void wro_fwd_dct(const int16_t* res, int log2n, int16_t* coef);
+// transformer.rs:2380-2737
+void wro_inv_dct(const int16_t* deq, int log2n, int16_t* res);
+// quantizer.rs:519-759 with the literal memoised DFS search_dq (:338-517)
+void wro_quantize(const int16_t* coef, int log2n, int qp, int16_t* levels);
+// same result via backward 4-state Viterbi; used to prove the
+// equivalence the GPU kernel relies on
+void wro_quantize_viterbi(const int16_t* coef, int log2n, int qp, int16_t* levels);
+// quantizer.rs:761-1079
+void wro_dequantize(const int16_t* levels, int log2n, int qp, int16_t* deq);
+// block_splitter.rs:415-460 level-cost walk of one TB (no header bits)
+int64_t wro_level_cost(const int16_t* levels, int log2n);
+
+// Constant tables (block_splitter.rs:29-53, quantizer.rs:16-25,650-683,
+// block_splitter.rs:472). Used by tests to compare with the product's resolver.
+void wro_tables(int qp, int64_t* lv_table1024, int64_t* dq_table1024,
+                int64_t* lambda_q, float* lambda_rd);
+// header bits ( (x*16384.0) as i64 ) for the luma/single-tree cost function
+// (block_splitter.rs:377-406). tree: 0 single, 1 dual luma, 2 dual chroma.
+// non_planar: 0/1; mpm_flag; mpm_idx; mpm_rem; cclm_flag; cclm_idx
+int64_t wro_header_bits(int tree, int non_planar, int mpm_flag, int mpm_idx,
+                        int mpm_rem, int cclm_flag, int cclm_idx);
+// chroma cost function header bits (block_splitter.rs:695-712)
+int64_t wro_chroma_header_bits(int cclm_flag, int cclm_idx);
+
+// 64x64 DCT-2 matrix rows (transformer.rs:934-1191 after symmetric extension)
+void wro_dct64(int16_t* m64x64);
+
+#ifdef __cplusplus
+}
+#endif
