@@ -1,0 +1,146 @@
+/* wrenc_gpu.h -- C ABI of the MI355X (gfx950) all-intra RD-search path.
+ *
+ * Drop-in boundary for the ONE hot path of hjmkt/wrenc: the per-CTU RD search
+ * (BlockSplitter::split_ct and everything it calls) plus the per-TU final pass.
+ * The reference has no FFI; the seam is two call sites (paths relative to the
+ * reference's src/):
+ *   - search:     BlockSplitter::new + split_ct            ctu_encoder.rs:53-54
+ *   - final pass: predict/transform/quantize/dequantize/
+ *                 inverse_transform/recon per TU component  ctu_encoder.rs:1421-1461
+ * Both are entered once per CTU from CtuEncoder::encode (ctu_encoder.rs:33) inside
+ * SliceEncoder::encode's raster CTU loop (slice_encoder.rs:352-379).  Nothing in
+ * them reads CABAC state, so this ABI is picture-granular: the device runs the
+ * search of whole pictures (CTU wavefront inside a picture, many pictures in
+ * flight) and hands back what the host entropy coder needs.
+ *
+ * Plain C: pointers and sizes only.  All functions return 0 on success or a
+ * negative wrenc_gpu_status; wrenc_gpu_last_error() gives the text.  Nothing
+ * aborts across this boundary (the reference panics or exit(0)s, main.rs:127-133).
+ * One context per GPU, one host thread per context.
+ */
+#ifndef WRENC_GPU_H
+#define WRENC_GPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct wrenc_gpu_ctx wrenc_gpu_ctx;
+
+enum wrenc_gpu_status {
+    WRENC_GPU_OK = 0,
+    WRENC_GPU_EINVAL = -1,   /* bad argument (size not a multiple of 32: picture.rs:178-181) */
+    WRENC_GPU_ENODEV = -2,   /* no usable HIP device / wrong architecture */
+    WRENC_GPU_ENOMEM = -3,
+    WRENC_GPU_EHIP = -4,     /* HIP runtime error, see last_error */
+    WRENC_GPU_ESTATE = -5,   /* slot not submitted / still in flight */
+    WRENC_GPU_ELEVEL = -6    /* a quantised level reached 1024 (reference would panic,
+                                block_splitter.rs:453) */
+};
+
+/* Resolved configuration.  The RD-model constants are resolved on the host
+ * (libm pow/powf, exactly as block_splitter.rs:29-53,187-375 and
+ * quantizer.rs:16-25,650-683 do) and passed as tables so that device code does
+ * no transcendental math.  wrenc_gpu_default_config() fills every table from the
+ * reference's defaults for a given QP. */
+typedef struct wrenc_gpu_config {
+    int32_t width;            /* luma, multiple of 32 (CLI --output-size, main.rs:176-191) */
+    int32_t height;
+    int32_t qp;               /* CLI --qp (main.rs:193-198), 26 when absent (ctu.rs:382) */
+    int32_t max_split_depth;  /* CLI --max-split-depth 0..3 (main.rs:108-109) */
+    int32_t device;           /* HIP device ordinal */
+    int32_t n_slots;          /* pictures resident on the device at once (>= 1) */
+    int64_t lv_table[1024];   /* lv_dq_trellis_table, block_splitter.rs:51-52 */
+    int64_t dq_table[1024];   /* quantizer.rs:20-21 */
+    int64_t lambda_q;         /* quantizer.rs:683 */
+    float lambda_rd;          /* block_splitter.rs:472 */
+    float lambda_rd_chroma;   /* block_splitter.rs:775-778 (extra-param "a") */
+    /* header bits ((x*16384.0) as i64), block_splitter.rs:377-406.
+     * [tree: 0 SINGLE_TREE, 1 DUAL_TREE_LUMA]
+     * [cclm class: 0 not CCLM, 1..3 = cclm_mode_idx 0..2]
+     * [mode class: 0 planar, 1..5 = mpm_idx 0..4, 6..66 = mpm_remainder 0..60] */
+    int64_t header_bits_luma[2][4][67];
+    /* block_splitter.rs:695-712. [0 not CCLM, 1..3 = cclm_mode_idx 0..2] */
+    int64_t header_bits_chroma[4];
+} wrenc_gpu_config;
+
+/* Per-picture result (caller-allocated; any pointer may be NULL to skip it).
+ * Replaces what the reference keeps in its Rust object graph:
+ *   CT tree ctu.rs:1794-1821, CodingUnit.intra_pred_mode ctu.rs:1241,
+ *   TransformUnit.cu_intra_pred_mode ctu.rs:361,
+ *   TransformUnit.quantized_transformed_coeffs ctu.rs:340 (TransCoeffLevel,
+ *   written by the final pass), Tile.reconst_pixels tile.rs:17. */
+typedef struct wrenc_gpu_picture {
+    uint8_t* rec_y;         /* width*height */
+    uint8_t* rec_cb;        /* (width/2)*(height/2) */
+    uint8_t* rec_cr;
+    int16_t* lev_y;         /* TransCoeffLevel planes, each TB at its own position */
+    int16_t* lev_cb;
+    int16_t* lev_cr;
+    uint8_t* cu_log2_size;  /* (width/4)*(height/4): log2 size of the luma CU covering the 4x4 */
+    uint8_t* luma_mode;     /* (width/4)*(height/4): intra_pred_mode[0] of that CU */
+    uint8_t* chroma_mode;   /* (width/8)*(height/8): chroma prediction mode of the chroma block
+                               (TU array: 0..66, or 81 LT_CCLM / 82 L_CCLM / 83 T_CCLM) */
+    float* ctu_cost;        /* one f32 per CTU: value split_ct returns at ctu_encoder.rs:54 */
+} wrenc_gpu_picture;
+
+/* Fill cfg (all tables) from the reference's default constants for this QP. */
+int wrenc_gpu_default_config(wrenc_gpu_config* cfg, int width, int height, int qp,
+                             int max_split_depth);
+
+int wrenc_gpu_create(const wrenc_gpu_config* cfg, wrenc_gpu_ctx** out);
+void wrenc_gpu_destroy(wrenc_gpu_ctx* ctx);
+const char* wrenc_gpu_last_error(const wrenc_gpu_ctx* ctx); /* ctx may be NULL: create errors */
+
+/* Copy one picture's planes (host memory, given strides in bytes) into slot `slot`
+ * (asynchronous on the context's stream; the host buffers must stay valid until
+ * wrenc_gpu_sync or wrenc_gpu_download of that slot). Replaces main.rs:318-350 +
+ * picture.rs:169-196. */
+int wrenc_gpu_upload(wrenc_gpu_ctx* ctx, int slot, const uint8_t* y, const uint8_t* cb,
+                     const uint8_t* cr, size_t stride_y, size_t stride_c);
+
+/* Run search + final pass for slots [first_slot, first_slot + n_pictures) whose
+ * planes are resident.  Asynchronous.  This is the call a C++ SliceEncoder::encode
+ * makes in place of the per-CTU split_ct loop. */
+int wrenc_gpu_encode(wrenc_gpu_ctx* ctx, int first_slot, int n_pictures);
+
+/* Wait for everything queued on the context. */
+int wrenc_gpu_sync(wrenc_gpu_ctx* ctx);
+
+/* Copy a finished slot's results to host memory (blocking). */
+int wrenc_gpu_download(wrenc_gpu_ctx* ctx, int slot, wrenc_gpu_picture* out);
+
+/* Convenience: upload + encode + download of a single picture through slot 0. */
+int wrenc_gpu_encode_picture(wrenc_gpu_ctx* ctx, const uint8_t* y, const uint8_t* cb,
+                             const uint8_t* cr, wrenc_gpu_picture* out);
+
+/* Device time (ms, HIP events on the context's own stream) and launch count of
+ * the search kernel during the last wrenc_gpu_encode call; valid after sync. */
+int wrenc_gpu_last_encode_stats(wrenc_gpu_ctx* ctx, float* total_ms, float* kernel_ms_sum,
+                                int* n_launches);
+
+/* Samples where the final pass reconstruction differed from what the search left
+ * (expected 0; SURVEY.md 3.4 "treat as a property to test"), accumulated since
+ * context creation. */
+int wrenc_gpu_final_pass_mismatches(wrenc_gpu_ctx* ctx, long long* count);
+
+/* ---- kernel-level entry points (parity tests of the building blocks) ----
+ * Each runs `count` independent square blocks of side 1<<log2n (2..5), row-major
+ * int16, host pointers.  Same arithmetic as the picture path. */
+int wrenc_gpu_test_fwd_dct(wrenc_gpu_ctx* ctx, const int16_t* res, int log2n, int count,
+                           int16_t* coef);                              /* transformer.rs:2040 */
+int wrenc_gpu_test_inv_dct(wrenc_gpu_ctx* ctx, const int16_t* deq, int log2n, int count,
+                           int16_t* res);                               /* transformer.rs:2380 */
+int wrenc_gpu_test_quantize(wrenc_gpu_ctx* ctx, const int16_t* coef, int log2n, int count,
+                            int16_t* levels, int64_t* level_cost);      /* quantizer.rs:519 +
+                                                                           block_splitter.rs:415-460 */
+int wrenc_gpu_test_dequantize(wrenc_gpu_ctx* ctx, const int16_t* levels, int log2n, int count,
+                              int16_t* deq);                            /* quantizer.rs:761 */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* WRENC_GPU_H */

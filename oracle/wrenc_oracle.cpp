@@ -1405,6 +1405,9 @@ struct Predictor {
     }
 };
 
+static unsigned long long g_dbg_ssd = 0;
+static long long g_dbg_level = 0;
+
 // ---------------------------------------------------------------------------
 // RD search (block_splitter.rs)
 // ---------------------------------------------------------------------------
@@ -1491,6 +1494,8 @@ struct Splitter {
         }
         const int64_t level = sum + hb;
         const float lambda = rd_lambda(p.rd);
+        g_dbg_ssd = ssd;
+        g_dbg_level = level;
         return (float)ssd + lambda * ((float)level / 16384.0f);
     }
 
@@ -1860,6 +1865,10 @@ int wro_encode_picture(const wro_params* prm, const uint8_t* y, const uint8_t* c
 }
 
 long wro_last_final_pass_mismatches(void) { return g_last_final_mismatch; }
+void wro_debug_last_cost(unsigned long long* ssd, long long* level) {
+    *ssd = g_dbg_ssd;
+    *level = g_dbg_level;
+}
 
 void wro_fwd_dct(const int16_t* res, int log2n, int16_t* coef) {
     init_tables();

@@ -55,6 +55,8 @@ int wro_encode_picture(const wro_params* p, const uint8_t* y, const uint8_t* cb,
 // Final-pass consistency: number of samples where the final pass recon differs
 // from the recon the search left in the planes (expected 0).
 long wro_last_final_pass_mismatches(void);
+// debug: ssd and level (incl. header bits) of the most recent get_intra_pred_cost call
+void wro_debug_last_cost(unsigned long long* ssd, long long* level);
 
 // ---- building blocks exposed for kernel-level parity tests ----
 // transformer.rs:2040-2378 (DCT-2 only). in/out: n*n row-major, n = 1<<log2n.

@@ -1,0 +1,77 @@
+"""Kernel-level parity (bit-exact) of the HIP building blocks against the CPU oracle."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def enc(built):
+    from wrenc_amd import gpu
+    e = gpu.Encoder(64, 64, qp=32, max_split_depth=0)
+    yield e
+    e.close()
+
+
+def _rand_blocks(rng, count, n, scale):
+    return (rng.standard_normal((count, n, n)) * scale).clip(-32768, 32767).astype(np.int16)
+
+
+@pytest.mark.parametrize("n", [4, 8, 16, 32])
+def test_fwd_dct(enc, n):
+    from oracle import pyoracle as po
+    rng = np.random.default_rng(10 + n)
+    blocks = rng.integers(-255, 256, (24, n, n)).astype(np.int16)
+    blocks[0] = 255
+    blocks[1] = -255
+    blocks[2] = ((np.indices((n, n)).sum(0) & 1) * 510 - 255).astype(np.int16)
+    got = enc.fwd_dct(blocks)
+    for i in range(blocks.shape[0]):
+        assert np.array_equal(got[i], po.fwd_dct(blocks[i])), (n, i)
+
+
+@pytest.mark.parametrize("n", [4, 8, 16, 32])
+def test_inv_dct(enc, n):
+    from oracle import pyoracle as po
+    rng = np.random.default_rng(20 + n)
+    blocks = _rand_blocks(rng, 24, n, 400)
+    blocks[0] = 32767
+    blocks[1] = -32768
+    got = enc.inv_dct(blocks)
+    for i in range(blocks.shape[0]):
+        assert np.array_equal(got[i], po.inv_dct(blocks[i])), (n, i)
+
+
+@pytest.mark.parametrize("n", [4, 8, 16, 32])
+def test_dequantize(enc, n):
+    from oracle import pyoracle as po
+    rng = np.random.default_rng(30 + n)
+    blocks = _rand_blocks(rng, 8, n, 60)
+    got = enc.dequantize(blocks)
+    for i in range(blocks.shape[0]):
+        assert np.array_equal(got[i], po.dequantize(blocks[i], 32)), (n, i)
+
+
+@pytest.mark.parametrize("n", [4, 8, 16, 32])
+def test_quantize_trellis(enc, n):
+    """Viterbi-on-lanes == the reference's memoised DFS, incl. the level cost walk."""
+    from oracle import pyoracle as po
+    rng = np.random.default_rng(40 + n)
+    decay = np.exp(-np.add.outer(np.arange(n), np.arange(n)) / (n / 3.0))
+    blocks = []
+    for it in range(40):
+        scale = [3, 30, 200, 1500][it % 4]
+        b = (rng.standard_normal((n, n)) * scale * decay).clip(-32768, 32767).astype(np.int16)
+        if it % 7 == 0:
+            b[:] = 0
+        if it % 11 == 0:
+            b = rng.integers(-3, 4, (n, n)).astype(np.int16)
+        if it % 13 == 0:
+            b[0, 0] = [1, -1, 40, -40][it % 4]
+        blocks.append(b)
+    blocks = np.stack(blocks)
+    got, cost = enc.quantize(blocks)
+    for i in range(blocks.shape[0]):
+        ref = po.quantize(blocks[i], 32)
+        assert np.array_equal(got[i], ref), (n, i)
+        assert int(cost[i]) == po.level_cost(ref), (n, i)

@@ -1,0 +1,1422 @@
+// wrenc_dev.h -- CDNA4 (gfx950) device code of the all-intra RD-search path.
+//
+// Execution model: ONE 64-lane wavefront owns one 32x32 CTU.  Every block is a
+// single wave (blockDim.x == 64), so control flow is wave-uniform and
+// __syncthreads() is only a compiler/LDS ordering point.  The CTU's original
+// samples, its reconstruction (with the neighbour border needed for intra
+// reference samples), all transform buffers and the decision maps live in LDS;
+// HBM is touched once to load the CTU + border and once to store recon, levels
+// and decisions.
+//
+// What is computed follows the reference function by function (paths relative to
+// the reference's src/); how it is computed is wave-parallel:
+//   predict        intra_predictor.rs:56-2055
+//   fwd/inv DCT-2  transformer.rs:2040-2737
+//   dep-quant      quantizer.rs:338-759 as a backward 4-state Viterbi, one lane
+//                  per state, exchanging path costs with DPP quad permutes
+//   leaf search    block_splitter.rs:782-1154
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace wrenc {
+
+enum { PLANAR = 0, DC = 1, LT_CCLM = 81, L_CCLM = 82, T_CCLM = 83 };
+enum { TREE_SINGLE = 0, TREE_DUAL_LUMA = 1, TREE_DUAL_CHROMA = 2 };
+
+// Constants resolved on the host (see wrenc_gpu_config in include/wrenc_gpu.h).
+struct DevConst {
+    int32_t W, H, qp, max_depth, ctu_cols, ctu_rows;
+    int32_t lsc;              // quantizer.rs:617-622 (16*LEVEL_SCALE[0][(qp+1)%6]) << ((qp+1)/6)
+    uint64_t div_magic;       // floor(2^47 / lsc) + 1: exact n / lsc for n < 2^26
+    int64_t lambda_q;
+    float lambda_rd;
+    float lambda_rd_chroma;
+    int64_t ldq[1024];        // lambda_q * dq_table[bits]  (quantizer.rs:29-31)
+    int64_t lv[1024];
+    int64_t hb_luma[2][4][67];
+    int64_t hb_chroma[4];
+    int16_t dct[4][32][32];   // T_N[u][k] = dct64[u * 64/N][k], N = 4 << idx (transformer.rs:1212-1221)
+    int16_t dct_t[4][32][32]; // transposed: dct_t[idx][y][i] = T_N[i][y]
+    uint8_t diag4[16][2];     // 4x4 up-right diagonal scan (x, y)   (ctu.rs:14-81)
+    uint8_t diag_sb[4][64][2]; // sub-block scan for 1, 4, 16, 64 sub-blocks
+    int16_t intra_angle[95];  // common.rs:145
+    int8_t fc[32][4];         // common.rs:153
+};
+
+// One picture's device buffers.
+struct PicBufs {
+    const uint8_t* org[3];
+    uint8_t* rec[3];
+    int16_t* lev[3];
+    uint8_t* cu_log2;
+    uint8_t* luma_mode;
+    uint8_t* chroma_mode;
+    float* ctu_cost;
+};
+
+// LDS working set of one wave / one CTU.
+struct __attribute__((aligned(16))) Lds {
+    int16_t bufA[1024];
+    int16_t bufB[1024];
+    int16_t bufC[1024];
+    int32_t bufH[33 * 32];
+    int32_t ldq[256];
+    int32_t lv[256];
+    int16_t refL[136];
+    int16_t refA[136];
+    int16_t refLf[136];
+    int16_t refAf[136];
+    uint8_t pred[1024];
+    uint8_t orgY[32 * 32];
+    uint8_t orgC[2][16 * 16];
+    uint8_t recYtop[72];       // y = -1, x = -4..67 (index x+4)
+    uint8_t recY[32 * 36];     // x = -4..31 (index x+4), stride 36
+    uint8_t recCtop[2][40];    // y = -1, x = -4..35
+    uint8_t recC[2][16 * 20];  // x = -4..15, stride 20
+    uint8_t saveY[1024 + 256 + 64];
+    uint8_t saveC[2][256 + 64 + 16];
+    uint8_t saveCclm[2][256];
+    uint8_t decn[1024];        // trellis decisions: 4 bits per position
+    uint8_t cu_log2[64];       // per 4x4 luma unit
+    uint8_t luma_mode[64];
+    uint8_t chroma_mode[16];   // per 8x8 luma unit
+    uint8_t left_mode[8];      // luma mode of the CU left of the CTU, per 4 rows
+};
+
+// Per-wave uniform context.
+struct Ctx {
+    const DevConst* k;
+    Lds* s;
+    int ctu_x, ctu_y; // luma, picture coordinates
+    int lane;
+    int cu32_mode;    // in-CTU neighbour lookups during search resolve to the root CU
+    unsigned long long* mismatch;
+};
+
+#define WSYNC() __syncthreads()
+
+// ---------------------------------------------------------------------------
+// wave helpers
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ int wave_sum_i32(int v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+    return v;
+}
+__device__ __forceinline__ int wave_min_i32(int v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v = min(v, __shfl_xor(v, m, 64));
+    return v;
+}
+__device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+    return v;
+}
+__device__ __forceinline__ int ilog2i(int v) { return 31 - __clz(v); }
+
+// ---------------------------------------------------------------------------
+// recon tile access (CTU-local component coordinates)
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ int rec_get(const Lds* s, int c, int x, int y) {
+    if (c == 0) return y < 0 ? s->recYtop[x + 4] : s->recY[y * 36 + x + 4];
+    return y < 0 ? s->recCtop[c - 1][x + 4] : s->recC[c - 1][y * 20 + x + 4];
+}
+__device__ __forceinline__ void rec_put(Lds* s, int c, int x, int y, int v) {
+    if (c == 0)
+        s->recY[y * 36 + x + 4] = (uint8_t)v;
+    else
+        s->recC[c - 1][y * 20 + x + 4] = (uint8_t)v;
+}
+__device__ __forceinline__ int org_get(const Lds* s, int c, int x, int y) {
+    return c == 0 ? s->orgY[y * 32 + x] : s->orgC[c - 1][y * 16 + x];
+}
+
+// ---------------------------------------------------------------------------
+// availability (ctu.rs:2083-2188, encoder_context.rs:918-956)
+// bx, by: CTU-local luma position, lg: log2 luma size
+// ---------------------------------------------------------------------------
+__device__ inline bool above_right_avail(const Ctx& c, int bx, int by, int lg) {
+    for (;;) {
+        const int n = 1 << lg;
+        if (c.ctu_x + bx + n >= c.k->W) return false;
+        if (lg == 5) return c.ctu_y > 0 && c.ctu_x + 32 < c.k->W;
+        const int px = bx & ~(2 * n - 1), py = by & ~(2 * n - 1);
+        if (bx == px && by == py) return c.ctu_y + by > 0;
+        if (by == py) { // top-right child: parent's
+            bx = px;
+            by = py;
+            lg += 1;
+            continue;
+        }
+        if (bx == px) return true;
+        return false;
+    }
+}
+__device__ inline bool below_left_avail(const Ctx& c, int bx, int by, int lg) {
+    for (;;) {
+        const int n = 1 << lg;
+        if (c.ctu_y + by + n >= c.k->H) return false;
+        if (lg == 5) return false;
+        const int px = bx & ~(2 * n - 1), py = by & ~(2 * n - 1);
+        if (px < bx) return false;
+        if (by + n < py + 2 * n) return c.ctu_x + bx > 0;
+        bx = px;
+        by = py;
+        lg += 1;
+    }
+}
+__device__ __forceinline__ bool nb_avail(const Ctx& c, int gx, int gy, int tn, int xn, int yn,
+                                         bool ar, bool bl) {
+    return xn >= 0 && yn >= 0 && xn < c.k->W && yn < c.k->H &&
+           ((xn >> 5) <= (gx >> 5) || (yn >> 5) < (gy >> 5)) && (yn >> 5) < (gy >> 5) + 1 &&
+           (xn < gx + tn || ar) && (yn < gy + tn || bl);
+}
+
+// ---------------------------------------------------------------------------
+// Intra prediction.  tx, ty: CTU-local luma position of the TU, tlg: log2 luma
+// size, comp: component, mode: TU-array prediction mode.
+// Writes s->pred (compact n*n) and the residual org - pred into s->bufA.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ int pdpc_w(int n_scale, int i) {
+    const int sh = (i << 1) >> n_scale;
+    return sh > 5 ? 0 : (32 >> sh);
+}
+
+__device__ void build_refs(const Ctx& c, int comp, int tx, int ty, int tlg, int mode) {
+    Lds* s = c.s;
+    const int cs = comp ? 1 : 0;
+    const int n = 1 << (tlg - cs);
+    const int tn = 1 << tlg;
+    const int cx = tx >> cs, cy = ty >> cs;
+    const int gx = c.ctu_x + tx, gy = c.ctu_y + ty;
+    const bool ar = above_right_avail(c, tx, ty, tlg);
+    const bool bl = below_left_avail(c, tx, ty, tlg);
+    const int st = 1 << cs;
+    // segment availabilities in substitution-scan order: BL, L, corner, A, AR
+    bool av[5];
+    av[0] = nb_avail(c, gx, gy, tn, gx - st, gy + tn, ar, bl);
+    av[1] = nb_avail(c, gx, gy, tn, gx - st, gy, ar, bl);
+    av[2] = nb_avail(c, gx, gy, tn, gx - st, gy - st, ar, bl);
+    av[3] = nb_avail(c, gx, gy, tn, gx, gy - st, ar, bl);
+    av[4] = nb_avail(c, gx, gy, tn, gx + tn, gy - st, ar, bl);
+    const bool any = av[0] || av[1] || av[2] || av[3] || av[4];
+    const int total = 4 * n + 1;
+    for (int t = c.lane; t < total; t += 64) {
+        // unified item: t <= 2n -> left index li = t (li 0 = corner, li k -> y = k-1); else above
+        int seg;
+        const bool is_left = t <= 2 * n;
+        const int li = t, ai = t - (2 * n + 1);
+        if (is_left)
+            seg = li == 0 ? 2 : (li <= n ? 1 : 0);
+        else
+            seg = ai < n ? 3 : 4;
+        int v;
+        if (!any) {
+            v = 128;
+        } else {
+            // source sample: own position if available, else nearest available in scan order
+            int sli = li, sai = ai;
+            bool src_left = is_left;
+            if (!av[seg]) {
+                int j = seg - 1;
+                while (j >= 0 && !av[j]) --j;
+                if (j >= 0) { // last sample (in scan order) of the nearest earlier available segment
+                    if (j == 0) { src_left = true; sli = n + 1; }
+                    else if (j == 1) { src_left = true; sli = 1; }
+                    else if (j == 2) { src_left = true; sli = 0; }
+                    else { src_left = false; sai = n - 1; }
+                } else { // first sample of the first available later segment
+                    j = seg + 1;
+                    while (!av[j]) ++j;
+                    if (j == 1) { src_left = true; sli = n; }
+                    else if (j == 2) { src_left = true; sli = 0; }
+                    else if (j == 3) { src_left = false; sai = 0; }
+                    else { src_left = false; sai = n; }
+                }
+            }
+            v = src_left ? rec_get(s, comp, cx - 1, cy + sli - 1) : rec_get(s, comp, cx + sai, cy - 1);
+        }
+        if (is_left)
+            s->refL[li] = (int16_t)v;
+        else
+            s->refA[ai] = (int16_t)v;
+    }
+    WSYNC();
+    // [1 2 1] filter, intra_predictor.rs:304-352
+    const bool filt = comp == 0 && n * n > 32 && (mode == 0 || mode == 2 || mode == 34 || mode == 66);
+    for (int t = c.lane; t < total; t += 64) {
+        if (t <= 2 * n) {
+            const int li = t;
+            int v;
+            if (!filt || li == 2 * n)
+                v = s->refL[li];
+            else if (li == 0)
+                v = (s->refL[1] + 2 * s->refL[0] + s->refA[0] + 2) >> 2;
+            else
+                v = (s->refL[li + 1] + 2 * s->refL[li] + s->refL[li - 1] + 2) >> 2;
+            s->refLf[li] = (int16_t)v;
+        } else {
+            const int ai = t - (2 * n + 1);
+            int v;
+            if (!filt || ai == 2 * n - 1)
+                v = s->refA[ai];
+            else if (ai == 0)
+                v = (s->refL[0] + 2 * s->refA[0] + s->refA[1] + 2) >> 2;
+            else
+                v = (s->refA[ai - 1] + 2 * s->refA[ai] + s->refA[ai + 1] + 2) >> 2;
+            s->refAf[ai] = (int16_t)v;
+        }
+    }
+    WSYNC();
+}
+
+// CCLM model parameters (intra_predictor.rs:1604-2031); uniform across the wave
+struct CclmParams {
+    int a, k, b;
+    bool flat128;
+    bool avail_l;
+};
+
+__device__ __forceinline__ int cclm_w(const Ctx& c, int tx, int ty, int y, int x, bool avail_l) {
+    // padded luma window p_y_xm3_ym3 (:1766-1818): column -1 repeats column 0 when the left
+    // neighbour is unavailable; every other read hits reconstructed luma
+    if (x < 0 && !avail_l) x = 0;
+    return rec_get(c.s, 0, tx + x, ty + y);
+}
+__device__ __forceinline__ int cclm_ds6(const Ctx& c, int tx, int ty, int sy, int sx, bool avail_l) {
+    return (cclm_w(c, tx, ty, sy, sx - 1, avail_l) + cclm_w(c, tx, ty, sy + 1, sx - 1, avail_l) +
+            cclm_w(c, tx, ty, sy, sx, avail_l) * 2 + cclm_w(c, tx, ty, sy + 1, sx, avail_l) * 2 +
+            cclm_w(c, tx, ty, sy, sx + 1, avail_l) + cclm_w(c, tx, ty, sy + 1, sx + 1, avail_l) + 4) >> 3;
+}
+
+__device__ CclmParams cclm_params(const Ctx& c, int comp, int tx, int ty, int tlg, int mode) {
+    CclmParams r;
+    const int tn = 1 << tlg;
+    const int tw = tn >> 1, th = tw;
+    const int cx = tx >> 1, cy = ty >> 1;
+    const int gx = c.ctu_x + tx, gy = c.ctu_y + ty;
+    const bool avail_l = nb_avail(c, gx, gy, tn, gx - 1, gy, false, false);
+    const bool avail_t = nb_avail(c, gx, gy, tn, gx, gy - 1, false, false);
+    r.avail_l = avail_l;
+    int num_top_right = 0, num_below_left = 0;
+    if (mode == T_CCLM) {
+        const bool ar = above_right_avail(c, tx, ty, tlg), bl = below_left_avail(c, tx, ty, tlg);
+        bool a = true;
+        for (int x = tw; x < 2 * tw && a; ++x) {
+            a = nb_avail(c, gx, gy, tn, gx + x * 2, gy - 1, ar, bl);
+            if (a) ++num_top_right;
+        }
+    }
+    if (mode == L_CCLM) {
+        const bool ar = above_right_avail(c, tx, ty, tlg), bl = below_left_avail(c, tx, ty, tlg);
+        bool a = true;
+        for (int y = th; y < 2 * th && a; ++y) {
+            a = nb_avail(c, gx, gy, tn, gx - 1, gy + y * 2, ar, bl);
+            if (a) ++num_below_left;
+        }
+    }
+    int num_samp_t, num_samp_l;
+    if (mode == LT_CCLM) {
+        num_samp_t = avail_t ? tw : 0;
+        num_samp_l = avail_l ? th : 0;
+    } else {
+        num_samp_t = (avail_t && mode == T_CCLM) ? tw + min(num_top_right, th) : 0;
+        num_samp_l = (avail_l && mode == L_CCLM) ? th + min(num_below_left, tw) : 0;
+    }
+    r.flat128 = (num_samp_l == 0 && num_samp_t == 0);
+    r.a = 0;
+    r.k = 0;
+    r.b = 128;
+    if (r.flat128) return r;
+    const bool b_ctu_boundary = ((c.ctu_y + ty) & 31) == 0;
+    const int num_is_4 = !(avail_t && avail_l && mode == LT_CCLM) ? 1 : 0;
+    int cnt_t = 0, cnt_l = 0;
+    int sel_y[4] = {0, 0, 0, 0}, sel_c[4] = {0, 0, 0, 0};
+    if (avail_t && (mode == LT_CCLM || mode == T_CCLM)) {
+        const int start = num_samp_t >> (2 + num_is_4);
+        const int step = max(num_samp_t >> (1 + num_is_4), 1);
+        cnt_t = min((1 + num_is_4) << 1, num_samp_t);
+        for (int i = 0; i < cnt_t; ++i) {
+            const int pos = start + i * step;
+            sel_c[i] = rec_get(c.s, comp, cx + pos, cy - 1);
+            const int sx = 2 * pos;
+            if (!b_ctu_boundary)
+                sel_y[i] = (cclm_w(c, tx, ty, -1, sx - 1, avail_l) + cclm_w(c, tx, ty, -2, sx - 1, avail_l) +
+                            cclm_w(c, tx, ty, -1, sx, avail_l) * 2 + cclm_w(c, tx, ty, -2, sx, avail_l) * 2 +
+                            cclm_w(c, tx, ty, -1, sx + 1, avail_l) + cclm_w(c, tx, ty, -2, sx + 1, avail_l) + 4) >> 3;
+            else
+                sel_y[i] = (cclm_w(c, tx, ty, -1, sx - 1, avail_l) + cclm_w(c, tx, ty, -1, sx, avail_l) * 2 +
+                            cclm_w(c, tx, ty, -1, sx + 1, avail_l) + 2) >> 2;
+        }
+    }
+    if (avail_l && (mode == LT_CCLM || mode == L_CCLM)) {
+        const int start = num_samp_l >> (2 + num_is_4);
+        const int step = max(num_samp_l >> (1 + num_is_4), 1);
+        cnt_l = min((1 + num_is_4) << 1, num_samp_l);
+        for (int i = 0; i < cnt_l; ++i) {
+            const int pos = start + i * step;
+            sel_c[cnt_t + i] = rec_get(c.s, comp, cx - 1, cy + pos);
+            sel_y[cnt_t + i] = cclm_ds6(c, tx, ty, 2 * pos, -2, avail_l);
+        }
+    }
+    int mn0 = 0, mn1 = 2, mx0 = 1, mx1 = 3;
+    int t;
+    if (sel_y[mn0] > sel_y[mn1]) { t = mn0; mn0 = mn1; mn1 = t; }
+    if (sel_y[mx0] > sel_y[mx1]) { t = mx0; mx0 = mx1; mx1 = t; }
+    if (sel_y[mn0] > sel_y[mx1]) { t = mn0; mn0 = mx0; mx0 = t; t = mn1; mn1 = mx1; mx1 = t; }
+    if (sel_y[mn1] > sel_y[mx0]) { t = mn1; mn1 = mx0; mx0 = t; }
+    const int max_y = (sel_y[mx0] + sel_y[mx1] + 1) >> 1;
+    const int max_c = (sel_c[mx0] + sel_c[mx1] + 1) >> 1;
+    const int min_y = (sel_y[mn0] + sel_y[mn1] + 1) >> 1;
+    const int min_c = (sel_c[mn0] + sel_c[mn1] + 1) >> 1;
+    const int diff = max_y - min_y;
+    if (diff != 0) {
+        const int diff_c = max_c - min_c;
+        int x = ilog2i(diff);
+        const int norm_diff = ((diff << 4) >> x) & 15;
+        x += (norm_diff != 0) ? 1 : 0;
+        const int adc = diff_c < 0 ? -diff_c : diff_c;
+        const int y = adc > 0 ? ilog2i(adc) + 1 : 0;
+        const int div_sig = (int)((0x0111122334455670ULL >> (4 * norm_diff)) & 15); // {0,7,6,5,5,4,4,3,3,2,2,1,1,1,1,0}
+        int a = diff_c == 0 ? 0 : (diff_c * (div_sig | 8) + (1 << (y - 1))) >> y;
+        int k;
+        if (3 + x - y < 1) {
+            k = 1;
+            a = a < 0 ? -15 : (a > 0 ? 15 : 0);
+        } else {
+            k = 3 + x - y;
+        }
+        r.a = a;
+        r.k = k;
+        r.b = min_c - ((a * min_y) >> k);
+    } else {
+        r.a = 0;
+        r.k = 0;
+        r.b = min_c;
+    }
+    return r;
+}
+
+__device__ void predict(const Ctx& c, int comp, int tx, int ty, int tlg, int mode) {
+    Lds* s = c.s;
+    const int cs = comp ? 1 : 0;
+    const int lg = tlg - cs;
+    const int n = 1 << lg;
+    const int cx = tx >> cs, cy = ty >> cs;
+    const int nn = n * n;
+    if (mode >= LT_CCLM) {
+        const CclmParams cp = cclm_params(c, comp, tx, ty, tlg, mode);
+        for (int i = c.lane; i < nn; i += 64) {
+            const int x = i & (n - 1), y = i >> lg;
+            int v;
+            if (cp.flat128) {
+                v = 128;
+            } else {
+                const int ds = cclm_ds6(c, tx, ty, 2 * y, 2 * x, cp.avail_l);
+                v = ((ds * cp.a) >> cp.k) + cp.b;
+                v = min(max(v, 0), 255);
+            }
+            s->pred[i] = (uint8_t)v;
+            s->bufA[i] = (int16_t)(org_get(s, comp, cx + x, cy + y) - v);
+        }
+        WSYNC();
+        return;
+    }
+    build_refs(c, comp, tx, ty, tlg, mode);
+    const int16_t* L = s->refLf; // index 0 = corner
+    const int16_t* A = s->refAf;
+    const int alrs = L[0];
+    if (mode == PLANAR || mode == DC) {
+        int dcv = 0;
+        if (mode == DC) {
+            int part = 0;
+            for (int t = c.lane; t < 2 * n; t += 64) part += t < n ? A[t] : L[t - n + 1];
+            dcv = (wave_sum_i32(part) + n) >> (lg + 1);
+            dcv &= 0xFF; // `as u8`
+        }
+        const int n_scale = (2 * lg - 2) >> 2;
+        for (int i = c.lane; i < nn; i += 64) {
+            const int x = i & (n - 1), y = i >> lg;
+            int v;
+            if (mode == PLANAR) {
+                const int pv = (n - 1 - y) * A[x] + (y + 1) * L[n + 1];
+                const int ph = (n - 1 - x) * L[y + 1] + (x + 1) * A[n];
+                v = ((pv + ph + n) >> (lg + 1)) & 0xFF;
+            } else {
+                v = dcv;
+            }
+            const int wl = pdpc_w(n_scale, x), wt = pdpc_w(n_scale, y);
+            v = (int16_t)(L[y + 1] * wl + A[x] * wt + (64 - wt - wl) * v + 32) >> 6;
+            v = min(max(v, 0), 255);
+            s->pred[i] = (uint8_t)v;
+            s->bufA[i] = (int16_t)(org_get(s, comp, cx + x, cy + y) - v);
+        }
+        WSYNC();
+        return;
+    }
+    // angular 2..66 (intra_predictor.rs:1287-1602), square blocks
+    const int angle = c.k->intra_angle[14 + mode];
+    int inv_angle = 0;
+    if (angle > 0)
+        inv_angle = (512 * 32 + angle / 2) / angle;
+    else if (angle < 0)
+        inv_angle = -((512 * 32 + (-angle) / 2) / -angle);
+    bool filter_flag = false;
+    if (!(mode == 2 || mode == 34 || mode == 66)) {
+        const int md = min(abs(mode - 50), abs(mode - 18));
+        const int thr = lg == 2 ? 24 : (lg == 3 ? 14 : (lg == 4 ? 2 : 0));
+        filter_flag = md > thr;
+    }
+    const bool do_pdpc = mode <= 18 || mode >= 50;
+    int n_scale = 0;
+    if (mode > 50 || (mode > 1 && mode < 18))
+        n_scale = min(lg - ilog2i(3 * inv_angle - 2) + 8, 2);
+    else
+        n_scale = (2 * lg - 2) >> 2;
+    for (int i = c.lane; i < nn; i += 64) {
+        const int x = i & (n - 1), y = i >> lg;
+        int v;
+        if (mode >= 34) {
+            const int i_idx = ((y + 1) * angle) >> 5;
+            const int i_fact = ((y + 1) * angle) & 31;
+            // refx[idx]: 0 corner, 1.. above; negative idx -> projected left samples
+            auto ref = [&](int idx) -> int {
+                if (idx < 0) return L[min((idx * inv_angle + 256) >> 9, n)];
+                if (idx == 0) return alrs;
+                return A[min(idx - 1, 2 * n - 1)];
+            };
+            if (comp == 0) {
+                int acc = 0;
+                for (int t = 0; t < 4; ++t) {
+                    const int f = filter_flag ? (t == 0 ? 16 - (i_fact >> 1)
+                                                        : t == 1 ? 32 - (i_fact >> 1)
+                                                                 : t == 2 ? 16 + (i_fact >> 1) : (i_fact >> 1))
+                                              : (int)c.k->fc[i_fact][t];
+                    acc += f * ref(x + i_idx + t);
+                }
+                v = min(max((acc + 32) >> 6, 0), 255);
+            } else if (i_fact != 0) {
+                v = (((32 - i_fact) * ref(x + i_idx + 1) + i_fact * ref(x + i_idx + 2) + 16) >> 5) & 0xFF;
+            } else {
+                v = ref(x + i_idx + 1) & 0xFF;
+            }
+        } else {
+            const int i_idx = ((x + 1) * angle) >> 5;
+            const int i_fact = ((x + 1) * angle) & 31;
+            auto ref = [&](int idx) -> int {
+                if (idx < 0) {
+                    const int t = min((idx * inv_angle + 256) >> 9, n);
+                    return t == 0 ? alrs : A[t - 1];
+                }
+                return L[min(idx, 2 * n)];
+            };
+            if (comp == 0) {
+                int acc = 0;
+                for (int t = 0; t < 4; ++t) {
+                    const int f = filter_flag ? (t == 0 ? 16 - (i_fact >> 1)
+                                                        : t == 1 ? 32 - (i_fact >> 1)
+                                                                 : t == 2 ? 16 + (i_fact >> 1) : (i_fact >> 1))
+                                              : (int)c.k->fc[i_fact][t];
+                    acc += f * ref(y + i_idx + t);
+                }
+                v = min(max((acc + 32) >> 6, 0), 255);
+            } else if (i_fact != 0) {
+                v = (((32 - i_fact) * ref(y + i_idx + 1) + i_fact * ref(y + i_idx + 2) + 16) >> 5) & 0xFF;
+            } else {
+                v = ref(y + i_idx + 1) & 0xFF;
+            }
+        }
+        if (do_pdpc) {
+            // intra_predictor.rs:355-757; left[] = L+1, above[] = A
+            int rl = 0, rt = 0, wl = 0, wt = 0;
+            if (mode == 18 || mode == 50) {
+                rl = (int16_t)(L[y + 1] - alrs + v);
+                rt = (int16_t)(A[x] - alrs + v);
+                wl = mode == 50 ? pdpc_w(n_scale, x) : 0;
+                wt = mode == 18 ? pdpc_w(n_scale, y) : 0;
+            } else if (mode < 18 && n_scale >= 0) {
+                const int dx_int = ((y + 1) * inv_angle + 256) >> 9;
+                rt = y < (3 << n_scale) ? A[x + dx_int] : 0;
+                wt = pdpc_w(n_scale, y);
+            } else if (mode > 50 && n_scale >= 0) {
+                const int dy_int = ((x + 1) * inv_angle + 256) >> 9;
+                rl = x < (3 << n_scale) ? L[1 + y + dy_int] : 0;
+                wl = pdpc_w(n_scale, x);
+            }
+            v = (int16_t)(rl * wl + rt * wt + (64 - wt - wl) * v + 32) >> 6;
+            v = min(max(v, 0), 255);
+        }
+        s->pred[i] = (uint8_t)v;
+        s->bufA[i] = (int16_t)(org_get(s, comp, cx + x, cy + y) - v);
+    }
+    WSYNC();
+}
+
+// ---------------------------------------------------------------------------
+// DCT-2 (transformer.rs).  Lane u = lane % N owns basis row T_N[u][.] in
+// registers; G = 64/N lane groups walk the rows/columns; the other operand is
+// read from LDS as a wave-broadcast.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ int dot2(uint32_t a, uint32_t b, int acc) {
+#if __has_builtin(__builtin_amdgcn_sdot2)
+    typedef short s2 __attribute__((ext_vector_type(2)));
+    s2 va, vb;
+    va.x = (short)(a & 0xFFFF);
+    va.y = (short)(a >> 16);
+    vb.x = (short)(b & 0xFFFF);
+    vb.y = (short)(b >> 16);
+    return __builtin_amdgcn_sdot2(va, vb, acc, false);
+#else
+    return acc + (int)(short)(a & 0xFFFF) * (int)(short)(b & 0xFFFF) + ((int)a >> 16) * ((int)b >> 16);
+#endif
+}
+
+// forward: residual bufA (n*n i16) -> coefficients bufB (n*n i16); transformer.rs:2040-2378
+template <int LG>
+__device__ void fwd_dct(const Ctx& c) {
+    constexpr int N = 1 << LG;
+    constexpr int G = 64 / N;
+    constexpr int HS = N + 1; // bufH row stride
+    Lds* s = c.s;
+    const int u = c.lane & (N - 1);
+    const int g = c.lane >> LG;
+    uint32_t t[N / 2];
+    {
+        const uint32_t* src = (const uint32_t*)&c.k->dct[LG - 2][u][0];
+#pragma unroll
+        for (int k = 0; k < N / 2; ++k) t[k] = src[k];
+    }
+    // stage 1: H[u][y] = (sum_x T[u][x] r[y][x] + d) >> (LG-1)   (:2139-2209)
+    for (int y = g; y < N; y += G) {
+        const uint32_t* row = (const uint32_t*)&s->bufA[y * N];
+        int acc = 0;
+#pragma unroll
+        for (int k = 0; k < N / 2; ++k) acc = dot2(row[k], t[k], acc);
+        s->bufH[u * HS + y] = (acc + (1 << (LG - 2))) >> (LG - 1);
+    }
+    WSYNC();
+    // stage 2: C[v][x] = (sum_y T[v][y] H[x][y] + d) >> (LG+6)  (:2246-2316); lane v = u
+    for (int x = g; x < N; x += G) {
+        const int32_t* col = &s->bufH[x * HS];
+        int acc = 0;
+#pragma unroll
+        for (int k = 0; k < N / 2; ++k) {
+            acc += (int)(short)(t[k] & 0xFFFF) * col[2 * k];
+            acc += ((int)t[k] >> 16) * col[2 * k + 1];
+        }
+        s->bufB[u * N + x] = (int16_t)((acc + (1 << (LG + 5))) >> (LG + 6));
+    }
+    WSYNC();
+}
+
+// inverse: transposed dequantised coefficients bufA (dT[x][i]) -> residual bufA (r[y][x]);
+// uses bufB for the intermediate.  transformer.rs:2380-2737
+template <int LG>
+__device__ void inv_dct(const Ctx& c) {
+    constexpr int N = 1 << LG;
+    constexpr int G = 64 / N;
+    Lds* s = c.s;
+    const int u = c.lane & (N - 1);
+    const int g = c.lane >> LG;
+    uint32_t t[N / 2]; // Tt[u][i] = T_N[i][u]
+    {
+        const uint32_t* src = (const uint32_t*)&c.k->dct_t[LG - 2][u][0];
+#pragma unroll
+        for (int k = 0; k < N / 2; ++k) t[k] = src[k];
+    }
+    // stage 1 (vertical): V[y][x] = clamp16((sum_i T[i][y] d[i][x] + 64) >> 7); lane y = u
+    for (int x = g; x < N; x += G) {
+        const uint32_t* col = (const uint32_t*)&s->bufA[x * N]; // dT[x][.]
+        int acc = 0;
+#pragma unroll
+        for (int k = 0; k < N / 2; ++k) acc = dot2(col[k], t[k], acc);
+        int v = (acc + 64) >> 7;
+        v = min(max(v, -32768), 32767);
+        s->bufB[u * N + x] = (int16_t)v;
+    }
+    WSYNC();
+    // stage 2 (horizontal): r[y][x] = (sum_i T[i][x] V[y][i] + 2048) >> 12; lane x = u
+    for (int y = g; y < N; y += G) {
+        const uint32_t* row = (const uint32_t*)&s->bufB[y * N];
+        int acc = 0;
+#pragma unroll
+        for (int k = 0; k < N / 2; ++k) acc = dot2(row[k], t[k], acc);
+        s->bufA[y * N + u] = (int16_t)((acc + 2048) >> 12);
+    }
+    WSYNC();
+}
+
+__device__ void fwd_dct_lg(const Ctx& c, int lg) {
+    switch (lg) {
+    case 2: fwd_dct<2>(c); break;
+    case 3: fwd_dct<3>(c); break;
+    case 4: fwd_dct<4>(c); break;
+    default: fwd_dct<5>(c); break;
+    }
+}
+__device__ void inv_dct_lg(const Ctx& c, int lg) {
+    switch (lg) {
+    case 2: inv_dct<2>(c); break;
+    case 3: inv_dct<3>(c); break;
+    case 4: inv_dct<4>(c); break;
+    default: inv_dct<5>(c); break;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Dependent quantisation (quantizer.rs:338-759) + level cost (block_splitter.rs:415-460)
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ long long ldq_at(const Ctx& c, int bits) {
+    return bits < 256 ? (long long)c.s->ldq[bits] : c.k->ldq[bits];
+}
+__device__ __forceinline__ long long lv_at(const Ctx& c, int a) {
+    return a < 256 ? (long long)c.s->lv[a] : c.k->lv[a];
+}
+__device__ __forceinline__ void scan_pos(const DevConst* k, int lg, int p, int& x, int& y) {
+    // p = reverse-scan index (0 = last coefficient of the scan, P-1 = DC)
+    const int nsb = 1 << (2 * lg - 4);
+    const int sb = nsb - 1 - (p >> 4);
+    const int sp = 15 - (p & 15);
+    const uint8_t* sbp = k->diag_sb[lg - 2][sb];
+    x = (sbp[0] << 2) + k->diag4[sp][0];
+    y = (sbp[1] << 2) + k->diag4[sp][1];
+}
+
+template <int CTRL>
+__device__ __forceinline__ long long dpp_quad64(long long v) {
+    int lo = (int)(v & 0xFFFFFFFFLL), hi = (int)(v >> 32);
+    lo = __builtin_amdgcn_mov_dpp(lo, CTRL, 0xF, 0xF, true);
+    hi = __builtin_amdgcn_mov_dpp(hi, CTRL, 0xF, 0xF, true);
+    return ((long long)hi << 32) | (unsigned int)lo;
+}
+
+// coefficients bufB (n*n row-major) -> levels bufC (n*n row-major).  Returns the
+// level cost of the TB (block_splitter.rs:436-458).  Uses bufH and decn as scratch.
+// `*overflow` is set when a level needs a table entry >= 1024 (reference panics).
+__device__ long long quantize(const Ctx& c, int lg, int* overflow) {
+    Lds* s = c.s;
+    const DevConst* k = c.k;
+    const int n = 1 << lg;
+    const int P = n * n;
+    const int sh = 8 + lg - 5 + 1; // quantizer.rs:558-569
+    const int off = (1 << sh) >> 1;
+    const int lsc = k->lsc;
+    int16_t* tcs = (int16_t*)s->bufH;        // coefficient in reverse-scan order
+    int16_t* qds = (int16_t*)s->bufH + 1024; // |(tc << sh) - off| / lsc
+    int first = P;
+    for (int p = c.lane; p < P; p += 64) {
+        int x, y;
+        scan_pos(k, lg, p, x, y);
+        const int tc = s->bufB[y * n + x];
+        int S = (int)((unsigned)tc << sh) - off;
+        if (tc < 0) S = -S;
+        const int qd = tc == 0 ? 0 : (int)(((unsigned long long)(unsigned)S * k->div_magic) >> 47);
+        tcs[p] = (int16_t)tc;
+        qds[p] = (int16_t)qd;
+        if (tc != 0 && (qd >> 1) > 0) first = min(first, p);
+    }
+    const int istar = wave_min_i32(first);
+    WSYNC();
+    const long long ldq1 = ldq_at(c, 1);
+    // backward Viterbi: lane s (0..3) carries C(p, s); lanes >= 4 mirror lane&3 (harmless)
+    const int st = c.lane & 3;
+    const int delta = st > 1 ? 1 : 0;
+    long long C;
+    int ovf = 0;
+    {
+        const int p = P - 1;
+        const int tc = tcs[p];
+        const int qd = qds[p];
+        const bool tz = st == 0 && p <= istar;
+        bool pick1 = false;
+        if (tc == 0) {
+            C = tz ? 0 : ldq1;
+            if (tz) C -= ldq1; // last_scan_pos == 0 && trailing && a == 0 (quantizer.rs:512-514)
+        } else {
+            const int a0 = qd >> 1; // quantizer.rs:378 (no delta at the DC node)
+            int q0 = (int)(int16_t)(2 * a0 - delta);
+            if (tc < 0) q0 = (int)(int16_t)(-q0);
+            const int d0 = abs(tc - ((q0 * lsc + off) >> sh));
+            const int bits0 = (a0 + 1) * ((a0 != 0 || !tz) ? 1 : 0);
+            const int a1 = a0 + 1;
+            int q1 = (int)(int16_t)(2 * a1 - delta);
+            if (tc < 0) q1 = (int)(int16_t)(-q1);
+            const int d1 = abs(tc - ((q1 * lsc + off) >> sh));
+            if (a1 + 1 >= 1024) ovf = 1;
+            const long long c0 = 128LL * d0 + ldq_at(c, min(bits0, 1023));
+            const long long c1 = 128LL * d1 + ldq_at(c, min(a1 + 1, 1023));
+            if (c0 <= c1) {
+                C = c0;
+                if (a0 == 0 && tz) C -= ldq1;
+            } else {
+                C = c1;
+                pick1 = true;
+            }
+        }
+        const unsigned nib = (unsigned)(__ballot(pick1) & 0xFULL);
+        if (c.lane == 0) s->decn[p] = (uint8_t)nib;
+    }
+    for (int p = P - 2; p >= 0; --p) {
+        const int tc = tcs[p];
+        const int qd = qds[p];
+        const bool tz = st == 0 && p <= istar;
+        const bool first_in_sb = (p & 15) == 15;
+        const long long CA = dpp_quad64<0xD8>(C); // C[trans[s][0]]: quad_perm [0,2,1,3]
+        const long long CB = dpp_quad64<0x72>(C); // C[trans[s][1]]: quad_perm [2,0,3,1]
+        bool pick1 = false;
+        if (tc == 0) {
+            C = CA + (tz ? 0 : ldq1);
+            if (first_in_sb && tz) C -= ldq1;
+        } else {
+            const int a0 = (qd + delta) >> 1;
+            int q0 = a0 > 0 ? 2 * a0 - delta : 0;
+            if (tc < 0) q0 = -q0;
+            const int d0 = abs(tc - ((q0 * lsc + off) >> sh));
+            const int bits0 = (a0 == 0 && tz) ? 0 : a0 + 1;
+            const int a1 = a0 + 1;
+            int q1 = 2 * a1 - delta;
+            if (tc < 0) q1 = -q1;
+            const int d1 = abs(tc - ((q1 * lsc + off) >> sh));
+            if (a1 + 1 >= 1024) ovf = 1;
+            const long long c0 = 128LL * d0 + ldq_at(c, min(bits0, 1023));
+            const long long c1 = 128LL * d1 + ldq_at(c, min(a1 + 1, 1023));
+            const long long K0 = c0 + ((a0 & 1) ? CB : CA);
+            const long long K1 = c1 + ((a0 & 1) ? CA : CB);
+            if (K0 <= K1) {
+                C = K0;
+                if (a0 == 0 && tz && first_in_sb) C -= ldq1;
+            } else {
+                C = K1;
+                pick1 = true;
+            }
+        }
+        const unsigned nib = (unsigned)(__ballot(pick1) & 0xFULL);
+        if (c.lane == 0) s->decn[p] = (uint8_t)nib;
+    }
+    WSYNC();
+    // forward trace from state 0 (quantizer.rs:686-721) fused with the level-cost walk
+    int state = 0;
+    long long sum = 0;
+    bool trailing = true;
+    for (int p = 0; p < P; ++p) {
+        const int tc = tcs[p];
+        const int qd = qds[p];
+        const int nib = s->decn[p];
+        int q = 0, a = 0;
+        const int dl = state > 1 ? 1 : 0;
+        if (tc != 0) {
+            const int a0 = (p == P - 1) ? (qd >> 1) : ((qd + dl) >> 1);
+            a = a0 + ((nib >> state) & 1);
+            if (p == P - 1)
+                q = (int)(int16_t)(2 * a - dl); // usize wrap + `as i16` (quantizer.rs:379,391)
+            else
+                q = a > 0 ? 2 * a - dl : 0;
+            if (tc < 0) q = -q;
+        }
+        int x, y;
+        scan_pos(k, lg, p, x, y);
+        if (c.lane == 0) s->bufC[y * n + x] = (int16_t)q;
+        const int qc = abs(q);
+        if (qc == 0) {
+            if (!trailing) sum += lv_at(c, 0);
+        } else {
+            const int aw = (qc + dl) >> 1;
+            if (aw >= 1024) ovf = 1;
+            sum += lv_at(c, min(aw, 1023));
+        }
+        trailing = trailing && qc == 0;
+        state = (0x7D28 >> (2 * (2 * state + (a & 1)))) & 3; // {{0,2},{2,0},{1,3},{3,1}}, 2 bits each
+    }
+    if (__ballot(ovf != 0) != 0ULL) *overflow = 1;
+    WSYNC();
+    return sum;
+}
+
+// levels bufC (row-major) -> transposed dequantised coefficients bufA (dT[x][i] = d[i][x]);
+// quantizer.rs:761-1079
+__device__ void dequantize_t(const Ctx& c, int lg) {
+    Lds* s = c.s;
+    const int n = 1 << lg;
+    const int sh = 8 + lg - 5 + 1;
+    const int off = (1 << sh) >> 1;
+    const int lsc = c.k->lsc;
+    for (int i = c.lane; i < n * n; i += 64) {
+        const int x = i & (n - 1), y = i >> lg;
+        int v = ((int)s->bufC[i] * lsc + off) >> sh;
+        v = min(max(v, -32768), 32767);
+        s->bufA[x * n + y] = (int16_t)v;
+    }
+    WSYNC();
+}
+
+// ---------------------------------------------------------------------------
+// RD search building blocks (block_splitter.rs)
+// ---------------------------------------------------------------------------
+struct CompCost {
+    unsigned long long ssd;
+    long long level;
+};
+
+// predict -> T -> Q -> DQ -> IT -> recon (+SSD) of one component
+// (block_splitter.rs:146-185); levels stay in bufC.
+__device__ CompCost code_component(const Ctx& c, int comp, int tx, int ty, int tlg, int mode,
+                                   int* overflow) {
+    Lds* s = c.s;
+    const int cs = comp ? 1 : 0;
+    const int lg = tlg - cs;
+    const int n = 1 << lg;
+    const int cx = tx >> cs, cy = ty >> cs;
+    predict(c, comp, tx, ty, tlg, mode);
+    fwd_dct_lg(c, lg);
+    CompCost r;
+    r.level = quantize(c, lg, overflow);
+    dequantize_t(c, lg);
+    inv_dct_lg(c, lg);
+    unsigned int part = 0;
+    for (int i = c.lane; i < n * n; i += 64) {
+        const int x = i & (n - 1), y = i >> lg;
+        int v = (int16_t)((int)s->pred[i] + (int)s->bufA[i]);
+        v = min(max(v, 0), 255);
+        rec_put(s, comp, cx + x, cy + y, v);
+        const int d = v - org_get(s, comp, cx + x, cy + y);
+        part += (unsigned)(d * d);
+    }
+    r.ssd = wave_sum_u64((unsigned long long)part);
+    WSYNC();
+    return r;
+}
+
+// predict + SAD (block_splitter.rs:64-108)
+__device__ unsigned int sad_component(const Ctx& c, int comp, int tx, int ty, int tlg, int mode) {
+    Lds* s = c.s;
+    const int cs = comp ? 1 : 0;
+    const int n = 1 << (tlg - cs);
+    predict(c, comp, tx, ty, tlg, mode);
+    int part = 0;
+    for (int i = c.lane; i < n * n; i += 64) part += abs((int)s->bufA[i]);
+    const int total = wave_sum_i32(part);
+    WSYNC();
+    return (unsigned)total;
+}
+
+// luma mode of the CU covering picture position (CTU-local x, y), as the search sees it
+// (SURVEY.md Q7): inside the CTU -> root CU's mode; left CTU -> its final map; else none.
+__device__ __forceinline__ int nb_luma_mode(const Ctx& c, int x, int y, bool* exists) {
+    if (x >= 0 && y >= 0) {
+        *exists = true;
+        return c.cu32_mode;
+    }
+    if (y >= 0 && x < 0 && c.ctu_x > 0) {
+        *exists = true;
+        return c.s->left_mode[y >> 2];
+    }
+    *exists = false;
+    return PLANAR;
+}
+
+// mode class index for the header-bit table: 0 planar, 1..5 mpm_idx, 6..66 remainder
+// (ctu.rs:1498-1635)
+__device__ int mpm_class(const Ctx& c, int bx, int by, int lg, int mode) {
+    if (mode == PLANAR) return 0;
+    const int n = 1 << lg;
+    bool le, ae;
+    int left = nb_luma_mode(c, bx - 1, by + n - 1, &le);
+    if (!le) left = PLANAR;
+    int above;
+    if (by - 1 < 0) {
+        // above the CTU: either no CU (picture edge) or forced PLANAR across the CTU row (:1518-1523)
+        above = PLANAR;
+    } else {
+        above = nb_luma_mode(c, bx + n - 1, by - 1, &ae);
+        if (!ae) above = PLANAR;
+    }
+    int cand[5];
+    if (left == above && left > DC) {
+        const int m = left;
+        cand[0] = m;
+        cand[1] = 2 + (m + 61) % 64;
+        cand[2] = 2 + (m - 1) % 64;
+        cand[3] = 2 + (m + 60) % 64;
+        cand[4] = 2 + m % 64;
+    } else if (left != above && (left > DC || above > DC)) {
+        const int mn = min(left, above), mx = max(left, above);
+        if (mn > DC) {
+            const int d = mx - mn;
+            cand[0] = left;
+            cand[1] = above;
+            if (d == 1) {
+                cand[2] = 2 + (mn + 61) % 64;
+                cand[3] = 2 + (mx - 1) % 64;
+                cand[4] = 2 + (mn + 60) % 64;
+            } else if (d >= 62) {
+                cand[2] = 2 + (mn - 1) % 64;
+                cand[3] = 2 + (mx + 61) % 64;
+                cand[4] = 2 + mn % 64;
+            } else if (d == 2) {
+                cand[2] = 2 + (mn - 1) % 64;
+                cand[3] = 2 + (mn + 61) % 64;
+                cand[4] = 2 + (mx - 1) % 64;
+            } else {
+                cand[2] = 2 + (mn + 61) % 64;
+                cand[3] = 2 + (mn - 1) % 64;
+                cand[4] = 2 + (mx + 61) % 64;
+            }
+        } else {
+            cand[0] = mx;
+            cand[1] = 2 + (mx + 61) % 64;
+            cand[2] = 2 + (mx - 1) % 64;
+            cand[3] = 2 + (mx + 60) % 64;
+            cand[4] = 2 + mx % 64;
+        }
+    } else {
+        cand[0] = DC;
+        cand[1] = 50;
+        cand[2] = 18;
+        cand[3] = 46;
+        cand[4] = 54;
+    }
+    for (int i = 0; i < 5; ++i)
+        if (cand[i] == mode) return 1 + i;
+    int smaller = 0; // remainder = mode - 1 - #(candidates below mode) after sorting (:1613-1628)
+    for (int i = 0; i < 5; ++i) smaller += cand[i] < mode ? 1 : 0;
+    return 6 + (mode - 1 - smaller);
+}
+
+__device__ __forceinline__ float rd_cost(unsigned long long ssd, long long level, float lambda) {
+    // block_splitter.rs:472-473: ssd as f32 + lambda * (level as f32 / 16384.0).  Rust never
+    // contracts a*b+c into an FMA; HIP's default -ffp-contract=fast would, so contraction is
+    // switched off here (and with -ffp-contract=off on the command line).
+#pragma clang fp contract(off)
+    const float lv = (float)level * (1.0f / 16384.0f);
+    const float prod = lambda * lv;
+    return (float)ssd + prod;
+}
+
+struct LeafResult {
+    float cost;
+    int luma_mode;
+    int chroma_mode; // TU-array chroma prediction mode
+};
+
+// get_intra_pred_cost (block_splitter.rs:110-474) for modes [ml, mc, mc]
+__device__ float full_cost(const Ctx& c, int tree, int bx, int by, int lg, int ml, int mc,
+                           int* overflow) {
+    const int cls = mpm_class(c, bx, by, lg, ml);
+    const bool cclm = mc >= LT_CCLM;
+    unsigned long long ssd = 0;
+    long long level = 0;
+    {
+        const CompCost r = code_component(c, 0, bx, by, lg, ml, overflow);
+        ssd += r.ssd;
+        level += r.level;
+    }
+    if (tree == TREE_SINGLE) {
+        for (int comp = 1; comp < 3; ++comp) {
+            const CompCost r = code_component(c, comp, bx, by, lg, mc, overflow);
+            ssd += r.ssd;
+            level += r.level;
+        }
+    }
+    const int cc = (tree == TREE_SINGLE && cclm) ? 1 + (mc - LT_CCLM) : 0;
+    level += c.k->hb_luma[tree == TREE_SINGLE ? 0 : 1][cc][cls];
+    return rd_cost(ssd, level, c.k->lambda_rd);
+}
+
+// get_intra_pred_aux_cost (block_splitter.rs:64-108) for modes [m; 3]
+__device__ float aux_cost(const Ctx& c, int tree, int bx, int by, int lg, int m) {
+    unsigned long long sad = sad_component(c, 0, bx, by, lg, m);
+    if (tree == TREE_SINGLE) {
+        sad += sad_component(c, 1, bx, by, lg, m);
+        sad += sad_component(c, 2, bx, by, lg, m);
+    }
+    return (float)sad;
+}
+
+// get_chroma_intra_pred_cost (block_splitter.rs:524-780)
+__device__ float chroma_full_cost(const Ctx& c, int bx, int by, int lg, int mc, int* overflow) {
+    unsigned long long ssd = 0;
+    long long level = 0;
+    for (int comp = 1; comp < 3; ++comp) {
+        const CompCost r = code_component(c, comp, bx, by, lg, mc, overflow);
+        ssd += r.ssd;
+        level += r.level;
+    }
+    level += c.k->hb_chroma[mc >= LT_CCLM ? 1 + (mc - LT_CCLM) : 0];
+    return rd_cost(ssd, level, c.k->lambda_rd_chroma);
+}
+
+// get_chroma_intra_pred_aux_cost (block_splitter.rs:476-522)
+__device__ float chroma_aux_cost(const Ctx& c, int bx, int by, int lg, int mc) {
+    unsigned long long sad = sad_component(c, 1, bx, by, lg, mc);
+    sad += sad_component(c, 2, bx, by, lg, mc);
+    return (float)sad;
+}
+
+__device__ void save_chroma(const Ctx& c, int bx, int by, int lg, uint8_t (*dst)[256]) {
+    const int n = 1 << (lg - 1);
+    for (int comp = 1; comp < 3; ++comp)
+        for (int i = c.lane; i < n * n; i += 64)
+            dst[comp - 1][i] = (uint8_t)rec_get(c.s, comp, (bx >> 1) + (i & (n - 1)), (by >> 1) + (i >> (lg - 1)));
+    WSYNC();
+}
+__device__ void restore_chroma(const Ctx& c, int bx, int by, int lg, const uint8_t (*src)[256]) {
+    const int n = 1 << (lg - 1);
+    for (int comp = 1; comp < 3; ++comp)
+        for (int i = c.lane; i < n * n; i += 64)
+            rec_put(c.s, comp, (bx >> 1) + (i & (n - 1)), (by >> 1) + (i >> (lg - 1)), src[comp - 1][i]);
+    WSYNC();
+}
+
+__device__ __forceinline__ int pick_cclm(float lt, float t, float l) {
+    // block_splitter.rs:847-854
+    if (lt <= t && lt <= l) return LT_CCLM;
+    if (t <= l) return T_CCLM;
+    return L_CCLM;
+}
+
+// leaf search of a DUAL_TREE_CHROMA block (block_splitter.rs:794-885); lg = luma log2 (3)
+__device__ LeafResult leaf_chroma(const Ctx& c, int bx, int by, int lg, int dm_mode, int* overflow) {
+    const float lt = chroma_aux_cost(c, bx, by, lg, LT_CCLM);
+    const float t = chroma_aux_cost(c, bx, by, lg, T_CCLM);
+    const float l = chroma_aux_cost(c, bx, by, lg, L_CCLM);
+    const int cclm_mode = pick_cclm(lt, t, l);
+    const float cclm_cost = chroma_full_cost(c, bx, by, lg, cclm_mode, overflow);
+    save_chroma(c, bx, by, lg, c.s->saveCclm);
+    const float cur = chroma_full_cost(c, bx, by, lg, dm_mode, overflow);
+    LeafResult r;
+    r.luma_mode = 0;
+    const float mn = fminf(cclm_cost, fminf(cur, 3.40282347e+38f));
+    if (cur == mn) {
+        r.cost = mn;
+        r.chroma_mode = dm_mode;
+    } else {
+        r.cost = mn;
+        r.chroma_mode = cclm_mode;
+        restore_chroma(c, bx, by, lg, c.s->saveCclm);
+    }
+    return r;
+}
+
+// leaf search of a SINGLE_TREE / DUAL_TREE_LUMA block (block_splitter.rs:886-1078)
+__device__ LeafResult leaf_luma(const Ctx& c, int tree, int bx, int by, int lg, int* overflow) {
+    const int cand_modes[15] = {0, 1, 2, 7, 13, 18, 23, 29, 34, 39, 45, 50, 55, 60, 66};
+    float cost_planar = 0.f, cost_dc = 0.f;
+    float min_dir_cost = 3.40282347e+38f;
+    int min_dir_mode = 2;
+    for (int i = 0; i < 15; ++i) {
+        const int m = cand_modes[i];
+        if (m <= 1) {
+            const float v = full_cost(c, tree, bx, by, lg, m, m, overflow);
+            if (m == 0) cost_planar = v; else cost_dc = v;
+        } else {
+            const float v = aux_cost(c, tree, bx, by, lg, m);
+            if (v < min_dir_cost) { // first minimum (:899-904)
+                min_dir_cost = v;
+                min_dir_mode = m;
+            }
+        }
+    }
+    // step_search(mode, 2, cost, aux=true) (:905-973)
+    int cur_mode = min_dir_mode;
+    float cur_cost = min_dir_cost;
+    for (int step = 2; step > 0; step >>= 1) {
+        const float c0 = cur_mode < 2 + step ? 3.40282347e+38f : aux_cost(c, tree, bx, by, lg, cur_mode - step);
+        const float c1 = cur_mode + step > 66 ? 3.40282347e+38f : aux_cost(c, tree, bx, by, lg, cur_mode + step);
+        const float mn = fminf(fminf(cur_cost, c0), c1);
+        if (cur_cost == mn) {
+        } else if (c0 == mn) {
+            cur_mode -= step;
+            cur_cost = c0;
+        } else {
+            cur_mode += step;
+            cur_cost = c1;
+        }
+    }
+    // step_search(mode, 1, _, aux=false) (:974)
+    {
+        cur_cost = full_cost(c, tree, bx, by, lg, cur_mode, cur_mode, overflow);
+        const float c0 = cur_mode < 3 ? 3.40282347e+38f
+                                      : full_cost(c, tree, bx, by, lg, cur_mode - 1, cur_mode - 1, overflow);
+        const float c1 = cur_mode + 1 > 66 ? 3.40282347e+38f
+                                           : full_cost(c, tree, bx, by, lg, cur_mode + 1, cur_mode + 1, overflow);
+        const float mn = fminf(fminf(cur_cost, c0), c1);
+        if (cur_cost == mn) {
+        } else if (c0 == mn) {
+            cur_mode -= 1;
+            cur_cost = c0;
+        } else {
+            cur_mode += 1;
+            cur_cost = c1;
+        }
+    }
+    // min of {planar, DC, dir}, first index wins (:975-978)
+    float min_cost = fminf(cur_cost, fminf(cost_dc, fminf(cost_planar, 3.40282347e+38f)));
+    int mode;
+    if (cost_planar == min_cost)
+        mode = 0;
+    else if (cost_dc == min_cost)
+        mode = 1;
+    else
+        mode = cur_mode;
+    // luma re-run with the winner (:989-1037)
+    code_component(c, 0, bx, by, lg, mode, overflow);
+    LeafResult r;
+    r.luma_mode = mode;
+    r.chroma_mode = mode;
+    if (tree != TREE_DUAL_LUMA) {
+        const float cur = chroma_full_cost(c, bx, by, lg, mode, overflow);
+        const float lt = chroma_aux_cost(c, bx, by, lg, LT_CCLM);
+        const float t = chroma_aux_cost(c, bx, by, lg, T_CCLM);
+        const float l = chroma_aux_cost(c, bx, by, lg, L_CCLM);
+        const int cclm_mode = pick_cclm(lt, t, l);
+        const float cclm_cost = chroma_full_cost(c, bx, by, lg, cclm_mode, overflow);
+        const float mn = fminf(cclm_cost, fminf(cur, 3.40282347e+38f));
+        if (cur == mn) {
+            min_cost = full_cost(c, tree, bx, by, lg, mode, mode, overflow);
+        } else {
+            r.chroma_mode = cclm_mode;
+            min_cost = full_cost(c, tree, bx, by, lg, mode, cclm_mode, overflow);
+        }
+    } else if (mode <= 1) {
+        min_cost = full_cost(c, tree, bx, by, lg, mode, mode, overflow);
+    }
+    r.cost = min_cost;
+    return r;
+}
+
+// ---------------------------------------------------------------------------
+// Decision maps and recon save/restore
+// ---------------------------------------------------------------------------
+__device__ void fill_maps(const Ctx& c, int bx, int by, int lg, int luma_mode, int chroma_mode,
+                          bool luma, bool chroma) {
+    Lds* s = c.s;
+    const int n4 = (1 << lg) >> 2;
+    if (luma)
+        for (int i = c.lane; i < n4 * n4; i += 64) {
+            const int idx = ((by >> 2) + i / n4) * 8 + (bx >> 2) + i % n4;
+            s->cu_log2[idx] = (uint8_t)lg;
+            s->luma_mode[idx] = (uint8_t)luma_mode;
+        }
+    if (chroma) {
+        const int n8 = max(n4 >> 1, 1);
+        for (int i = c.lane; i < n8 * n8; i += 64)
+            s->chroma_mode[((by >> 3) + i / n8) * 4 + (bx >> 3) + i % n8] = (uint8_t)chroma_mode;
+    }
+    WSYNC();
+}
+
+__device__ __forceinline__ int save_off_y(int lg) { return lg == 5 ? 0 : (lg == 4 ? 1024 : 1280); }
+__device__ __forceinline__ int save_off_c(int lg) { return lg == 5 ? 0 : (lg == 4 ? 256 : 320); }
+
+__device__ void save_recon(const Ctx& c, int bx, int by, int lg) {
+    Lds* s = c.s;
+    const int n = 1 << lg;
+    uint8_t* dy = s->saveY + save_off_y(lg);
+    for (int i = c.lane; i < n * n; i += 64) dy[i] = (uint8_t)rec_get(s, 0, bx + (i & (n - 1)), by + (i >> lg));
+    const int nc = n >> 1;
+    for (int comp = 1; comp < 3; ++comp) {
+        uint8_t* dc = s->saveC[comp - 1] + save_off_c(lg);
+        for (int i = c.lane; i < nc * nc; i += 64)
+            dc[i] = (uint8_t)rec_get(s, comp, (bx >> 1) + (i & (nc - 1)), (by >> 1) + (i >> (lg - 1)));
+    }
+    WSYNC();
+}
+__device__ void restore_recon(const Ctx& c, int bx, int by, int lg) {
+    Lds* s = c.s;
+    const int n = 1 << lg;
+    const uint8_t* dy = s->saveY + save_off_y(lg);
+    for (int i = c.lane; i < n * n; i += 64) rec_put(s, 0, bx + (i & (n - 1)), by + (i >> lg), dy[i]);
+    const int nc = n >> 1;
+    for (int comp = 1; comp < 3; ++comp) {
+        const uint8_t* dc = s->saveC[comp - 1] + save_off_c(lg);
+        for (int i = c.lane; i < nc * nc; i += 64)
+            rec_put(s, comp, (bx >> 1) + (i & (nc - 1)), (by >> 1) + (i >> (lg - 1)), dc[i]);
+    }
+    WSYNC();
+}
+
+// ---------------------------------------------------------------------------
+// split_ct (block_splitter.rs:782-1154) for SINGLE_TREE nodes, LG = log2 size
+// ---------------------------------------------------------------------------
+template <int LG>
+__device__ float split_ct(Ctx& c, int bx, int by, int depth_left, int* overflow) {
+    const LeafResult ns = leaf_luma(c, TREE_SINGLE, bx, by, LG, overflow);
+    fill_maps(c, bx, by, LG, ns.luma_mode, ns.chroma_mode, true, true);
+    if (LG == 5) c.cu32_mode = ns.luma_mode;
+    if (depth_left == 0) return ns.cost;
+    save_recon(c, bx, by, LG);
+    float split_cost = 0.0f;
+    if constexpr (LG > 3) {
+        constexpr int H = 1 << (LG - 1);
+        for (int i = 0; i < 4; ++i)
+            split_cost = split_cost + split_ct<LG - 1>(c, bx + (i & 1) * H, by + (i >> 1) * H, depth_left - 1, overflow);
+    } else {
+        // 8x8 -> four DUAL_TREE_LUMA 4x4 + one DUAL_TREE_CHROMA 4x4 (ctu.rs:1990-2063)
+        for (int i = 0; i < 4; ++i) {
+            const int cxx = bx + (i & 1) * 4, cyy = by + (i >> 1) * 4;
+            const LeafResult r = leaf_luma(c, TREE_DUAL_LUMA, cxx, cyy, 2, overflow);
+            fill_maps(c, cxx, cyy, 2, r.luma_mode, 0, true, false);
+            split_cost = split_cost + r.cost;
+        }
+        // DM = luma mode of the CU covering the parent's centre (block_splitter.rs:795-805)
+        const int dm = c.s->luma_mode[((by + 4) >> 2) * 8 + ((bx + 4) >> 2)];
+        const LeafResult r = leaf_chroma(c, bx, by, 3, dm, overflow);
+        fill_maps(c, bx, by, 3, 0, r.chroma_mode, false, true);
+        split_cost = split_cost + r.cost;
+    }
+    if (split_cost > ns.cost) { // :1125-1145
+        restore_recon(c, bx, by, LG);
+        fill_maps(c, bx, by, LG, ns.luma_mode, ns.chroma_mode, true, true);
+        return ns.cost;
+    }
+    return split_cost;
+}
+
+// ---------------------------------------------------------------------------
+// Final pass (ctu_encoder.rs:1421-1461) in coding order; writes levels to HBM
+// ---------------------------------------------------------------------------
+__device__ void final_component(const Ctx& c, const PicBufs& pb, int comp, int tx, int ty, int tlg,
+                                int mode, int* overflow) {
+    Lds* s = c.s;
+    const int cs = comp ? 1 : 0;
+    const int lg = tlg - cs;
+    const int n = 1 << lg;
+    const int cx = tx >> cs, cy = ty >> cs;
+    // remember what the search left, to count mismatches
+    unsigned int diff = 0;
+    uint8_t* before = s->saveY; // the save stack is idle during the final pass
+    for (int i = c.lane; i < n * n; i += 64)
+        before[i] = (uint8_t)rec_get(s, comp, cx + (i & (n - 1)), cy + (i >> lg));
+    WSYNC();
+    code_component(c, comp, tx, ty, tlg, mode, overflow);
+    const int stride = c.k->W >> cs;
+    const int gx = (c.ctu_x >> cs) + cx, gy = (c.ctu_y >> cs) + cy;
+    int16_t* lev = pb.lev[comp];
+    for (int i = c.lane; i < n * n; i += 64) {
+        const int x = i & (n - 1), y = i >> lg;
+        lev[(size_t)(gy + y) * stride + gx + x] = s->bufC[i];
+        if (before[i] != (uint8_t)rec_get(s, comp, cx + x, cy + y)) ++diff;
+    }
+    const int total = wave_sum_i32((int)diff);
+    if (total && c.lane == 0) atomicAdd(c.mismatch, (unsigned long long)total);
+    WSYNC();
+}
+
+template <int LG>
+__device__ void final_pass(const Ctx& c, const PicBufs& pb, int bx, int by, int* overflow) {
+    Lds* s = c.s;
+    const int sz = s->cu_log2[(by >> 2) * 8 + (bx >> 2)];
+    if (sz == LG) {
+        const int ml = s->luma_mode[(by >> 2) * 8 + (bx >> 2)];
+        const int mc = s->chroma_mode[(by >> 3) * 4 + (bx >> 3)];
+        final_component(c, pb, 0, bx, by, LG, ml, overflow);
+        if constexpr (LG >= 3) {
+            final_component(c, pb, 1, bx, by, LG, mc, overflow);
+            final_component(c, pb, 2, bx, by, LG, mc, overflow);
+        }
+        return;
+    }
+    if constexpr (LG > 3) {
+        constexpr int H = 1 << (LG - 1);
+        for (int i = 0; i < 4; ++i) final_pass<LG - 1>(c, pb, bx + (i & 1) * H, by + (i >> 1) * H, overflow);
+    } else if constexpr (LG == 3) {
+        for (int i = 0; i < 4; ++i) {
+            const int cxx = bx + (i & 1) * 4, cyy = by + (i >> 1) * 4;
+            final_component(c, pb, 0, cxx, cyy, 2, s->luma_mode[(cyy >> 2) * 8 + (cxx >> 2)], overflow);
+        }
+        const int mc = s->chroma_mode[(by >> 3) * 4 + (bx >> 3)];
+        final_component(c, pb, 1, bx, by, 3, mc, overflow);
+        final_component(c, pb, 2, bx, by, 3, mc, overflow);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// CTU entry: load, search, final pass, store
+// ---------------------------------------------------------------------------
+__device__ void load_tables(const Ctx& c) {
+    Lds* s = c.s;
+    for (int i = c.lane; i < 256; i += 64) {
+        s->ldq[i] = (int32_t)c.k->ldq[i];
+        s->lv[i] = (int32_t)c.k->lv[i];
+    }
+}
+
+__device__ void encode_ctu(Ctx& c, const PicBufs& pb, int ctu_col, int ctu_row, int* overflow) {
+    Lds* s = c.s;
+    const DevConst* k = c.k;
+    const int W = k->W, H = k->H;
+    const int Wc = W >> 1;
+    c.ctu_x = ctu_col * 32;
+    c.ctu_y = ctu_row * 32;
+    c.cu32_mode = PLANAR;
+    load_tables(c);
+    // originals
+    for (int i = c.lane; i < 1024 / 4; i += 64) {
+        const int y = i >> 3, x4 = (i & 7) * 4;
+        *(uint32_t*)&s->orgY[y * 32 + x4] = *(const uint32_t*)&pb.org[0][(size_t)(c.ctu_y + y) * W + c.ctu_x + x4];
+    }
+    for (int comp = 1; comp < 3; ++comp)
+        for (int i = c.lane; i < 256 / 4; i += 64) {
+            const int y = i >> 2, x4 = (i & 3) * 4;
+            *(uint32_t*)&s->orgC[comp - 1][y * 16 + x4] =
+                *(const uint32_t*)&pb.org[comp][(size_t)((c.ctu_y >> 1) + y) * Wc + (c.ctu_x >> 1) + x4];
+        }
+    // neighbour border of the reconstruction: row -1 (x = -4..67) and columns -4..-1
+    for (int i = c.lane; i < 72; i += 64) {
+        const int gx = c.ctu_x - 4 + i, gy = c.ctu_y - 1;
+        s->recYtop[i] = (gx >= 0 && gx < W && gy >= 0) ? pb.rec[0][(size_t)gy * W + gx] : 0;
+    }
+    for (int i = c.lane; i < 32 * 4; i += 64) {
+        const int y = i >> 2, x = (i & 3) - 4;
+        const int gx = c.ctu_x + x, gy = c.ctu_y + y;
+        s->recY[y * 36 + x + 4] = gx >= 0 ? pb.rec[0][(size_t)gy * W + gx] : 0;
+    }
+    for (int comp = 1; comp < 3; ++comp) {
+        for (int i = c.lane; i < 40; i += 64) {
+            const int gx = (c.ctu_x >> 1) - 4 + i, gy = (c.ctu_y >> 1) - 1;
+            s->recCtop[comp - 1][i] = (gx >= 0 && gx < Wc && gy >= 0) ? pb.rec[comp][(size_t)gy * Wc + gx] : 0;
+        }
+        for (int i = c.lane; i < 16 * 4; i += 64) {
+            const int y = i >> 2, x = (i & 3) - 4;
+            const int gx = (c.ctu_x >> 1) + x, gy = (c.ctu_y >> 1) + y;
+            s->recC[comp - 1][y * 20 + x + 4] = gx >= 0 ? pb.rec[comp][(size_t)gy * Wc + gx] : 0;
+        }
+    }
+    // tile.rs:49-58: planes start at zero
+    for (int i = c.lane; i < 32 * 32; i += 64) s->recY[(i >> 5) * 36 + (i & 31) + 4] = 0;
+    for (int comp = 1; comp < 3; ++comp)
+        for (int i = c.lane; i < 256; i += 64) s->recC[comp - 1][(i >> 4) * 20 + (i & 15) + 4] = 0;
+    if (c.lane < 8)
+        s->left_mode[c.lane] =
+            c.ctu_x > 0 ? pb.luma_mode[(size_t)((c.ctu_y >> 2) + c.lane) * (W >> 2) + (c.ctu_x >> 2) - 1] : 0;
+    WSYNC();
+    (void)H;
+    const float cost = split_ct<5>(c, 0, 0, k->max_depth, overflow);
+    final_pass<5>(c, pb, 0, 0, overflow);
+    // store recon + decisions
+    for (int i = c.lane; i < 1024 / 4; i += 64) {
+        const int y = i >> 3, x4 = (i & 7) * 4;
+        *(uint32_t*)&pb.rec[0][(size_t)(c.ctu_y + y) * W + c.ctu_x + x4] = *(const uint32_t*)&s->recY[y * 36 + x4 + 4];
+    }
+    for (int comp = 1; comp < 3; ++comp)
+        for (int i = c.lane; i < 256 / 4; i += 64) {
+            const int y = i >> 2, x4 = (i & 3) * 4;
+            *(uint32_t*)&pb.rec[comp][(size_t)((c.ctu_y >> 1) + y) * Wc + (c.ctu_x >> 1) + x4] =
+                *(const uint32_t*)&s->recC[comp - 1][y * 20 + x4 + 4];
+        }
+    {
+        const int i = c.lane; // 64 4x4 units
+        const size_t o = (size_t)((c.ctu_y >> 2) + (i >> 3)) * (W >> 2) + (c.ctu_x >> 2) + (i & 7);
+        pb.cu_log2[o] = s->cu_log2[i];
+        pb.luma_mode[o] = s->luma_mode[i];
+        if (i < 16) {
+            const size_t oc = (size_t)((c.ctu_y >> 3) + (i >> 2)) * (W >> 3) + (c.ctu_x >> 3) + (i & 3);
+            pb.chroma_mode[oc] = s->chroma_mode[i];
+        }
+        if (i == 0) pb.ctu_cost[ctu_row * k->ctu_cols + ctu_col] = cost;
+    }
+}
+
+} // namespace wrenc

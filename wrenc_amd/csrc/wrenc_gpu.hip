@@ -1,0 +1,591 @@
+// wrenc_gpu.hip -- kernels + C ABI (include/wrenc_gpu.h) of the MI355X all-intra
+// RD-search path.  Built for gfx950 only:
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -shared -o libwrenc_gpu.so wrenc_gpu.hip
+//
+// Scheduling: a picture's CTUs depend on their left, above-left, above and
+// above-right neighbours (encoder_context.rs:934-948), so CTU (r, c) can run once
+// every CTU on anti-diagonal c + 2r - 1 is done.  One launch processes one
+// anti-diagonal of every picture of the batch (one wave per CTU); stream order
+// between launches is the only synchronisation, no in-kernel spinning.
+#include "../../include/wrenc_gpu.h"
+#include "wrenc_dev.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+using namespace wrenc;
+
+// ---------------------------------------------------------------------------
+// kernels
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void ctu_search_kernel(const DevConst* __restrict__ k,
+                                                        const PicBufs* __restrict__ slots,
+                                                        int first_slot, int diag, int r_min, int count,
+                                                        unsigned long long* mismatch, int* overflow) {
+    __shared__ Lds lds;
+    const int pic = blockIdx.x / count;
+    const int j = blockIdx.x - pic * count;
+    const int row = r_min + j;
+    const int col = diag - 2 * row;
+    Ctx c;
+    c.k = k;
+    c.s = &lds;
+    c.lane = threadIdx.x;
+    c.mismatch = mismatch;
+    const PicBufs pb = slots[first_slot + pic];
+    int ovf = 0;
+    encode_ctu(c, pb, col, row, &ovf);
+    if (ovf && threadIdx.x == 0) atomicOr(overflow, 1);
+}
+
+// building-block kernels: one wave per block of side 1 << lg
+__global__ __launch_bounds__(64) void test_fwd_dct_kernel(const DevConst* __restrict__ k,
+                                                          const int16_t* in, int lg, int16_t* out) {
+    __shared__ Lds lds;
+    Ctx c;
+    c.k = k;
+    c.s = &lds;
+    c.lane = threadIdx.x;
+    const int nn = 1 << (2 * lg);
+    for (int i = threadIdx.x; i < nn; i += 64) lds.bufA[i] = in[(size_t)blockIdx.x * nn + i];
+    WSYNC();
+    fwd_dct_lg(c, lg);
+    for (int i = threadIdx.x; i < nn; i += 64) out[(size_t)blockIdx.x * nn + i] = lds.bufB[i];
+}
+
+__global__ __launch_bounds__(64) void test_inv_dct_kernel(const DevConst* __restrict__ k,
+                                                          const int16_t* in, int lg, int16_t* out) {
+    __shared__ Lds lds;
+    Ctx c;
+    c.k = k;
+    c.s = &lds;
+    c.lane = threadIdx.x;
+    const int n = 1 << lg, nn = n * n;
+    for (int i = threadIdx.x; i < nn; i += 64) // transposed load: dT[x][i] = d[i][x]
+        lds.bufA[(i & (n - 1)) * n + (i >> lg)] = in[(size_t)blockIdx.x * nn + i];
+    WSYNC();
+    inv_dct_lg(c, lg);
+    for (int i = threadIdx.x; i < nn; i += 64) out[(size_t)blockIdx.x * nn + i] = lds.bufA[i];
+}
+
+__global__ __launch_bounds__(64) void test_quantize_kernel(const DevConst* __restrict__ k,
+                                                           const int16_t* in, int lg, int16_t* out,
+                                                           long long* cost, int* overflow) {
+    __shared__ Lds lds;
+    Ctx c;
+    c.k = k;
+    c.s = &lds;
+    c.lane = threadIdx.x;
+    load_tables(c);
+    const int nn = 1 << (2 * lg);
+    for (int i = threadIdx.x; i < nn; i += 64) lds.bufB[i] = in[(size_t)blockIdx.x * nn + i];
+    WSYNC();
+    int ovf = 0;
+    const long long lc = quantize(c, lg, &ovf);
+    for (int i = threadIdx.x; i < nn; i += 64) out[(size_t)blockIdx.x * nn + i] = lds.bufC[i];
+    if (threadIdx.x == 0) {
+        cost[blockIdx.x] = lc;
+        if (ovf) atomicOr(overflow, 1);
+    }
+}
+
+__global__ __launch_bounds__(64) void test_dequantize_kernel(const DevConst* __restrict__ k,
+                                                             const int16_t* in, int lg, int16_t* out) {
+    __shared__ Lds lds;
+    Ctx c;
+    c.k = k;
+    c.s = &lds;
+    c.lane = threadIdx.x;
+    const int n = 1 << lg, nn = n * n;
+    for (int i = threadIdx.x; i < nn; i += 64) lds.bufC[i] = in[(size_t)blockIdx.x * nn + i];
+    WSYNC();
+    dequantize_t(c, lg);
+    for (int i = threadIdx.x; i < nn; i += 64) // undo the transpose
+        out[(size_t)blockIdx.x * nn + i] = lds.bufA[(i & (n - 1)) * n + (i >> lg)];
+}
+
+// ---------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------
+namespace {
+
+thread_local std::string g_create_error;
+
+// DCT-2 integer cosines c[j] ~ 64*sqrt(2)*cos(j*pi/128), H.266 8.7.4.5
+// (the reference's 64-point matrix, transformer.rs:934-1191, is row k = c[(2n+1)k])
+const int kCos[65] = {64, 91, 90, 90, 90, 90, 90, 90, 89, 88, 88, 87, 87, 86, 85, 84, 83, 83, 82, 81, 80, 79,
+                      78, 77, 75, 73, 73, 71, 70, 69, 67, 65, 64, 62, 61, 59, 57, 56, 54, 52, 50, 48, 46, 44,
+                      43, 41, 38, 37, 36, 33, 31, 28, 25, 24, 22, 20, 18, 15, 13, 11, 9,  7,  4,  2,  0};
+
+int dct64(int k, int n) {
+    int t = ((2 * n + 1) * k) % 256;
+    if (t > 128) t = 256 - t;
+    return t > 64 ? -kCos[128 - t] : kCos[t];
+}
+
+// H.266 Table 24 (common.rs:145) and Table 25 fC (common.rs:153)
+const int16_t kIntraAngle[95] = {
+    512, 341, 256, 171, 128, 102, 86,  73,  64,  57,  51,  45,  39,  35,  0,   0,   32,  29,  26,
+    23,  20,  18,  16,  14,  12,  10,  8,   6,   4,   3,   2,   1,   0,   -1,  -2,  -3,  -4,  -6,
+    -8,  -10, -12, -14, -16, -18, -20, -23, -26, -29, -32, -29, -26, -23, -20, -18, -16, -14, -12,
+    -10, -8,  -6,  -4,  -3,  -2,  -1,  0,   1,   2,   3,   4,   6,   8,   10,  12,  14,  16,  18,
+    20,  23,  26,  29,  32,  35,  39,  45,  51,  57,  64,  73,  86,  102, 128, 171, 256, 341, 512};
+const int8_t kFC[32][4] = {
+    {0, 64, 0, 0},    {-1, 63, 2, 0},   {-2, 62, 4, 0},   {-2, 60, 7, -1},  {-2, 58, 10, -2}, {-3, 57, 12, -2},
+    {-4, 56, 14, -2}, {-4, 55, 15, -2}, {-4, 54, 16, -2}, {-5, 53, 18, -2}, {-6, 52, 20, -2}, {-6, 49, 24, -3},
+    {-6, 46, 28, -4}, {-5, 44, 29, -4}, {-4, 42, 30, -4}, {-4, 39, 33, -4}, {-4, 36, 36, -4}, {-4, 33, 39, -4},
+    {-4, 30, 42, -4}, {-4, 29, 44, -5}, {-4, 28, 46, -6}, {-3, 24, 49, -6}, {-2, 20, 52, -6}, {-2, 18, 53, -5},
+    {-2, 16, 54, -4}, {-2, 15, 55, -4}, {-2, 14, 56, -4}, {-2, 12, 57, -3}, {-2, 10, 58, -2}, {-1, 7, 60, -2},
+    {0, 4, 62, -2},   {0, 2, 63, -1}};
+
+void diag_scan(int lw, int lh, uint8_t (*out)[2]) { // ctu.rs:54-77
+    const int bw = 1 << lw, bh = 1 << lh;
+    int i = 0, x = 0, y = 0;
+    bool stop = false;
+    while (!stop) {
+        while (y >= 0) {
+            if (x < bw && y < bh) {
+                out[i][0] = (uint8_t)x;
+                out[i][1] = (uint8_t)y;
+                ++i;
+            }
+            --y;
+            ++x;
+        }
+        y = x;
+        x = 0;
+        if (i >= bw * bh) stop = true;
+    }
+}
+
+} // namespace
+
+struct wrenc_gpu_ctx {
+    wrenc_gpu_config cfg;
+    hipStream_t stream = nullptr;
+    DevConst* d_const = nullptr;
+    PicBufs* d_slots = nullptr;
+    std::vector<PicBufs> slots;
+    std::vector<int> state; // 0 empty, 1 uploaded, 2 encoded
+    unsigned long long* d_mismatch = nullptr;
+    int* d_overflow = nullptr;
+    hipEvent_t ev_begin = nullptr, ev_end = nullptr;
+    std::vector<hipEvent_t> ev_pool;
+    int last_launches = 0;
+    bool stats_valid = false;
+    std::string err;
+    int ctu_cols = 0, ctu_rows = 0;
+};
+
+namespace {
+
+int fail(wrenc_gpu_ctx* ctx, int code, const std::string& msg) {
+    if (ctx)
+        ctx->err = msg;
+    else
+        g_create_error = msg;
+    return code;
+}
+
+#define HIP_TRY(ctx, expr)                                                                        \
+    do {                                                                                          \
+        hipError_t e_ = (expr);                                                                   \
+        if (e_ != hipSuccess)                                                                     \
+            return fail(ctx, WRENC_GPU_EHIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+size_t plane_bytes(const wrenc_gpu_config& c, int comp, size_t elem) {
+    const size_t w = comp ? c.width / 2 : c.width, h = comp ? c.height / 2 : c.height;
+    return w * h * elem;
+}
+
+void fill_dev_const(const wrenc_gpu_config& cfg, DevConst& k) {
+    memset(&k, 0, sizeof(k));
+    k.W = cfg.width;
+    k.H = cfg.height;
+    k.qp = cfg.qp;
+    k.max_depth = cfg.max_split_depth;
+    k.ctu_cols = cfg.width / 32;
+    k.ctu_rows = cfg.height / 32;
+    static const int level_scale[6] = {40, 45, 51, 57, 64, 72}; // quantizer.rs:8
+    k.lsc = (16 * level_scale[(cfg.qp + 1) % 6]) << ((cfg.qp + 1) / 6);
+    k.div_magic = ((1ULL << 47) / (uint64_t)k.lsc) + 1;
+    k.lambda_q = cfg.lambda_q;
+    k.lambda_rd = cfg.lambda_rd;
+    k.lambda_rd_chroma = cfg.lambda_rd_chroma;
+    for (int i = 0; i < 1024; ++i) {
+        k.ldq[i] = cfg.lambda_q * cfg.dq_table[i];
+        k.lv[i] = cfg.lv_table[i];
+    }
+    memcpy(k.hb_luma, cfg.header_bits_luma, sizeof(k.hb_luma));
+    memcpy(k.hb_chroma, cfg.header_bits_chroma, sizeof(k.hb_chroma));
+    for (int idx = 0; idx < 4; ++idx) {
+        const int n = 4 << idx, step = 64 / n;
+        for (int u = 0; u < n; ++u)
+            for (int x = 0; x < n; ++x) {
+                k.dct[idx][u][x] = (int16_t)dct64(u * step, x);
+                k.dct_t[idx][x][u] = (int16_t)dct64(u * step, x);
+            }
+    }
+    diag_scan(2, 2, k.diag4);
+    for (int idx = 0; idx < 4; ++idx) diag_scan(idx, idx, k.diag_sb[idx]);
+    memcpy(k.intra_angle, kIntraAngle, sizeof(kIntraAngle));
+    memcpy(k.fc, kFC, sizeof(kFC));
+}
+
+} // namespace
+
+namespace {
+template <class Launch>
+int run_block_test(wrenc_gpu_ctx* ctx, const int16_t* in, int log2n, int count, int16_t* out, Launch launch) {
+    if (!ctx || !in || !out) return WRENC_GPU_EINVAL;
+    if (log2n < 2 || log2n > 5 || count < 1) return fail(ctx, WRENC_GPU_EINVAL, "log2n must be 2..5 and count >= 1");
+    HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
+    const size_t bytes = (size_t)count * sizeof(int16_t) << (2 * log2n);
+    int16_t *d_in = nullptr, *d_out = nullptr;
+    HIP_TRY(ctx, hipMalloc((void**)&d_in, bytes));
+    hipError_t e = hipMalloc((void**)&d_out, bytes);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_in, in, bytes, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) {
+        launch(d_in, d_out);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(out, d_out, bytes, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    (void)hipFree(d_in);
+    if (d_out) (void)hipFree(d_out);
+    if (e != hipSuccess) return fail(ctx, WRENC_GPU_EHIP, hipGetErrorString(e));
+    return WRENC_GPU_OK;
+}
+} // namespace
+
+extern "C" {
+
+int wrenc_gpu_default_config(wrenc_gpu_config* cfg, int width, int height, int qp, int max_split_depth) {
+    if (!cfg) return WRENC_GPU_EINVAL;
+    memset(cfg, 0, sizeof(*cfg));
+    cfg->width = width;
+    cfg->height = height;
+    cfg->qp = qp;
+    cfg->max_split_depth = max_split_depth;
+    cfg->device = 0;
+    cfg->n_slots = 1;
+    // block_splitter.rs:29-53 (lv_dq_trellis), quantizer.rs:16-25
+    for (int i = 0; i < 1024; ++i) {
+        cfg->lv_table[i] = (int64_t)(std::pow((double)i + 0.15150746310196822, 0.48592678233563835) * 16384.0);
+        cfg->dq_table[i] = (int64_t)std::pow((double)(i * 16384), 0.5004010166085378);
+    }
+    // quantizer.rs:650-683
+    cfg->lambda_q = (int64_t)(std::pow(2.0, (double)qp / 5.218413785332902) * 1.2709404305806742) + 11;
+    // block_splitter.rs:289-309,472
+    const float qp_div = 4.4043665f, lambda_mul = 1.1282581f;
+    cfg->lambda_rd = std::pow(2.0f, (float)qp / qp_div) * lambda_mul;
+    cfg->lambda_rd_chroma = cfg->lambda_rd; // block_splitter.rs:775-778 without extra-param "a"
+    // block_splitter.rs:187-406 (dep-quant + trellis defaults)
+    const float non_planar_offset = 2.2153597f, mpm_idx_offset = 1.3660221f, mpm_remainder_mult = 0.5007182f,
+                mpm_remainder_offset = 2.2973304f, planar_offset = 0.9626864f, header_bits = 1.1772872f,
+                chroma_header_bits = 1.309252f, cclm_pow = 0.4587651f, mpm_idx_pow = 0.40271285f,
+                mpm_remainder_pow = 0.34385094f, cclm_mode_idx_offset = 2.1f, non_cclm_offset = 0.89f,
+                cclm_offset = 0.53f;
+    for (int tree = 0; tree < 2; ++tree)
+        for (int cc = 0; cc < 4; ++cc)
+            for (int cls = 0; cls < 67; ++cls) {
+                float cclm_bits;
+                if (cc > 0)
+                    cclm_bits = cclm_offset + std::pow((float)(cc - 1) + cclm_mode_idx_offset, cclm_pow);
+                else if (tree == 1)
+                    cclm_bits = 0.0f;
+                else
+                    cclm_bits = non_cclm_offset;
+                float mode_bits;
+                if (cls == 0) {
+                    mode_bits = planar_offset;
+                } else {
+                    float t;
+                    if (cls <= 5)
+                        t = std::pow((float)(cls - 1) + mpm_idx_offset, mpm_idx_pow);
+                    else
+                        t = mpm_remainder_mult * std::pow((float)(cls - 6) + mpm_remainder_offset, mpm_remainder_pow);
+                    mode_bits = non_planar_offset + t;
+                }
+                mode_bits = mode_bits + cclm_bits;
+                const float hb = tree == 0 ? header_bits + mode_bits : header_bits / 3.0f + mode_bits;
+                cfg->header_bits_luma[tree][cc][cls] = (int64_t)(hb * 16384.0f);
+            }
+    for (int cc = 0; cc < 4; ++cc) {
+        const float mode_bits =
+            cc > 0 ? cclm_offset + std::pow((float)(cc - 1) + cclm_mode_idx_offset, cclm_pow) : non_cclm_offset;
+        cfg->header_bits_chroma[cc] = (int64_t)((chroma_header_bits + mode_bits) * 16384.0f);
+    }
+    return WRENC_GPU_OK;
+}
+
+const char* wrenc_gpu_last_error(const wrenc_gpu_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+void wrenc_gpu_destroy(wrenc_gpu_ctx* ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->cfg.device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    for (PicBufs& b : ctx->slots) {
+        for (int c = 0; c < 3; ++c) {
+            if (b.org[c]) (void)hipFree((void*)b.org[c]);
+            if (b.rec[c]) (void)hipFree(b.rec[c]);
+            if (b.lev[c]) (void)hipFree(b.lev[c]);
+        }
+        if (b.cu_log2) (void)hipFree(b.cu_log2);
+        if (b.luma_mode) (void)hipFree(b.luma_mode);
+        if (b.chroma_mode) (void)hipFree(b.chroma_mode);
+        if (b.ctu_cost) (void)hipFree(b.ctu_cost);
+    }
+    if (ctx->d_const) (void)hipFree(ctx->d_const);
+    if (ctx->d_slots) (void)hipFree(ctx->d_slots);
+    if (ctx->d_mismatch) (void)hipFree(ctx->d_mismatch);
+    if (ctx->d_overflow) (void)hipFree(ctx->d_overflow);
+    if (ctx->ev_begin) (void)hipEventDestroy(ctx->ev_begin);
+    if (ctx->ev_end) (void)hipEventDestroy(ctx->ev_end);
+    for (hipEvent_t e : ctx->ev_pool) (void)hipEventDestroy(e);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+int wrenc_gpu_create(const wrenc_gpu_config* cfg, wrenc_gpu_ctx** out) {
+    if (!cfg || !out) return fail(nullptr, WRENC_GPU_EINVAL, "null argument");
+    *out = nullptr;
+    if (cfg->width <= 0 || cfg->height <= 0 || (cfg->width & 31) || (cfg->height & 31))
+        return fail(nullptr, WRENC_GPU_EINVAL, "width and height must be positive multiples of 32");
+    if (cfg->qp < 0 || cfg->qp > 63) return fail(nullptr, WRENC_GPU_EINVAL, "qp out of range 0..63");
+    if (cfg->max_split_depth < 0 || cfg->max_split_depth > 3)
+        return fail(nullptr, WRENC_GPU_EINVAL, "max_split_depth out of range 0..3");
+    if (cfg->n_slots < 1) return fail(nullptr, WRENC_GPU_EINVAL, "n_slots must be >= 1");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(nullptr, WRENC_GPU_ENODEV, "no HIP device available");
+    if (cfg->device < 0 || cfg->device >= ndev) return fail(nullptr, WRENC_GPU_ENODEV, "device ordinal out of range");
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, cfg->device) != hipSuccess)
+        return fail(nullptr, WRENC_GPU_ENODEV, "hipGetDeviceProperties failed");
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(nullptr, WRENC_GPU_ENODEV, std::string("built for gfx950, device is ") + prop.gcnArchName);
+    wrenc_gpu_ctx* ctx = new (std::nothrow) wrenc_gpu_ctx();
+    if (!ctx) return fail(nullptr, WRENC_GPU_ENOMEM, "out of host memory");
+    ctx->cfg = *cfg;
+    ctx->ctu_cols = cfg->width / 32;
+    ctx->ctu_rows = cfg->height / 32;
+    auto bail = [&](int code, const std::string& msg) {
+        g_create_error = msg;
+        wrenc_gpu_destroy(ctx);
+        return code;
+    };
+#define CREATE_TRY(expr)                                                                            \
+    do {                                                                                            \
+        hipError_t e_ = (expr);                                                                     \
+        if (e_ != hipSuccess)                                                                       \
+            return bail(e_ == hipErrorOutOfMemory ? WRENC_GPU_ENOMEM : WRENC_GPU_EHIP,              \
+                        std::string(#expr) + ": " + hipGetErrorString(e_));                        \
+    } while (0)
+    CREATE_TRY(hipSetDevice(cfg->device));
+    CREATE_TRY(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+    CREATE_TRY(hipEventCreate(&ctx->ev_begin));
+    CREATE_TRY(hipEventCreate(&ctx->ev_end));
+    {
+        DevConst* hk = new (std::nothrow) DevConst();
+        if (!hk) return bail(WRENC_GPU_ENOMEM, "out of host memory");
+        fill_dev_const(*cfg, *hk);
+        hipError_t e = hipMalloc((void**)&ctx->d_const, sizeof(DevConst));
+        if (e == hipSuccess) e = hipMemcpy(ctx->d_const, hk, sizeof(DevConst), hipMemcpyHostToDevice);
+        delete hk;
+        CREATE_TRY(e);
+    }
+    CREATE_TRY(hipMalloc((void**)&ctx->d_mismatch, sizeof(unsigned long long)));
+    CREATE_TRY(hipMemset(ctx->d_mismatch, 0, sizeof(unsigned long long)));
+    CREATE_TRY(hipMalloc((void**)&ctx->d_overflow, sizeof(int)));
+    CREATE_TRY(hipMemset(ctx->d_overflow, 0, sizeof(int)));
+    ctx->slots.assign(cfg->n_slots, PicBufs{});
+    ctx->state.assign(cfg->n_slots, 0);
+    for (int s = 0; s < cfg->n_slots; ++s) {
+        PicBufs& b = ctx->slots[s];
+        for (int c = 0; c < 3; ++c) {
+            CREATE_TRY(hipMalloc((void**)&b.org[c], plane_bytes(*cfg, c, 1)));
+            CREATE_TRY(hipMalloc((void**)&b.rec[c], plane_bytes(*cfg, c, 1)));
+            CREATE_TRY(hipMalloc((void**)&b.lev[c], plane_bytes(*cfg, c, 2)));
+        }
+        CREATE_TRY(hipMalloc((void**)&b.cu_log2, (size_t)(cfg->width / 4) * (cfg->height / 4)));
+        CREATE_TRY(hipMalloc((void**)&b.luma_mode, (size_t)(cfg->width / 4) * (cfg->height / 4)));
+        CREATE_TRY(hipMalloc((void**)&b.chroma_mode, (size_t)(cfg->width / 8) * (cfg->height / 8)));
+        CREATE_TRY(hipMalloc((void**)&b.ctu_cost, sizeof(float) * ctx->ctu_cols * ctx->ctu_rows));
+    }
+    CREATE_TRY(hipMalloc((void**)&ctx->d_slots, sizeof(PicBufs) * cfg->n_slots));
+    CREATE_TRY(hipMemcpy(ctx->d_slots, ctx->slots.data(), sizeof(PicBufs) * cfg->n_slots, hipMemcpyHostToDevice));
+#undef CREATE_TRY
+    *out = ctx;
+    return WRENC_GPU_OK;
+}
+
+int wrenc_gpu_upload(wrenc_gpu_ctx* ctx, int slot, const uint8_t* y, const uint8_t* cb, const uint8_t* cr,
+                     size_t stride_y, size_t stride_c) {
+    if (!ctx) return WRENC_GPU_EINVAL;
+    if (slot < 0 || slot >= ctx->cfg.n_slots || !y || !cb || !cr) return fail(ctx, WRENC_GPU_EINVAL, "bad slot or null plane");
+    const size_t w = ctx->cfg.width, h = ctx->cfg.height;
+    if (stride_y < w || stride_c < w / 2) return fail(ctx, WRENC_GPU_EINVAL, "stride smaller than row");
+    HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
+    PicBufs& b = ctx->slots[slot];
+    HIP_TRY(ctx, hipMemcpy2DAsync((void*)b.org[0], w, y, stride_y, w, h, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpy2DAsync((void*)b.org[1], w / 2, cb, stride_c, w / 2, h / 2, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpy2DAsync((void*)b.org[2], w / 2, cr, stride_c, w / 2, h / 2, hipMemcpyHostToDevice, ctx->stream));
+    ctx->state[slot] = 1;
+    return WRENC_GPU_OK;
+}
+
+int wrenc_gpu_encode(wrenc_gpu_ctx* ctx, int first_slot, int n_pictures) {
+    if (!ctx) return WRENC_GPU_EINVAL;
+    if (first_slot < 0 || n_pictures < 1 || first_slot + n_pictures > ctx->cfg.n_slots)
+        return fail(ctx, WRENC_GPU_EINVAL, "slot range out of bounds");
+    for (int s = first_slot; s < first_slot + n_pictures; ++s)
+        if (ctx->state[s] == 0) return fail(ctx, WRENC_GPU_ESTATE, "slot has no uploaded picture");
+    HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
+    const int cols = ctx->ctu_cols, rows = ctx->ctu_rows;
+    const int ndiag = cols + 2 * (rows - 1);
+    while ((int)ctx->ev_pool.size() < 2 * ndiag) {
+        hipEvent_t e;
+        HIP_TRY(ctx, hipEventCreate(&e));
+        ctx->ev_pool.push_back(e);
+    }
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_begin, ctx->stream));
+    int launches = 0;
+    for (int d = 0; d < ndiag; ++d) {
+        // rows r with 0 <= d - 2r < cols
+        int r_min = d - (cols - 1);
+        r_min = r_min <= 0 ? 0 : (r_min + 1) / 2;
+        int r_max = d / 2;
+        if (r_max > rows - 1) r_max = rows - 1;
+        const int count = r_max - r_min + 1;
+        if (count <= 0) continue;
+        HIP_TRY(ctx, hipEventRecord(ctx->ev_pool[2 * launches], ctx->stream));
+        hipLaunchKernelGGL(ctu_search_kernel, dim3(count * n_pictures), dim3(64), 0, ctx->stream, ctx->d_const,
+                           ctx->d_slots, first_slot, d, r_min, count, ctx->d_mismatch, ctx->d_overflow);
+        HIP_TRY(ctx, hipGetLastError());
+        HIP_TRY(ctx, hipEventRecord(ctx->ev_pool[2 * launches + 1], ctx->stream));
+        ++launches;
+    }
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_end, ctx->stream));
+    ctx->last_launches = launches;
+    ctx->stats_valid = true;
+    for (int s = first_slot; s < first_slot + n_pictures; ++s) ctx->state[s] = 2;
+    return WRENC_GPU_OK;
+}
+
+int wrenc_gpu_sync(wrenc_gpu_ctx* ctx) {
+    if (!ctx) return WRENC_GPU_EINVAL;
+    HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    int ovf = 0;
+    HIP_TRY(ctx, hipMemcpy(&ovf, ctx->d_overflow, sizeof(int), hipMemcpyDeviceToHost));
+    if (ovf) return fail(ctx, WRENC_GPU_ELEVEL, "a quantised level reached 1024 (reference panics: block_splitter.rs:453)");
+    return WRENC_GPU_OK;
+}
+
+int wrenc_gpu_download(wrenc_gpu_ctx* ctx, int slot, wrenc_gpu_picture* out) {
+    if (!ctx || !out) return WRENC_GPU_EINVAL;
+    if (slot < 0 || slot >= ctx->cfg.n_slots) return fail(ctx, WRENC_GPU_EINVAL, "bad slot");
+    if (ctx->state[slot] != 2) return fail(ctx, WRENC_GPU_ESTATE, "slot has not been encoded");
+    HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
+    const PicBufs& b = ctx->slots[slot];
+    const wrenc_gpu_config& c = ctx->cfg;
+    uint8_t* rec[3] = {out->rec_y, out->rec_cb, out->rec_cr};
+    int16_t* lev[3] = {out->lev_y, out->lev_cb, out->lev_cr};
+    for (int k = 0; k < 3; ++k) {
+        if (rec[k]) HIP_TRY(ctx, hipMemcpyAsync(rec[k], b.rec[k], plane_bytes(c, k, 1), hipMemcpyDeviceToHost, ctx->stream));
+        if (lev[k]) HIP_TRY(ctx, hipMemcpyAsync(lev[k], b.lev[k], plane_bytes(c, k, 2), hipMemcpyDeviceToHost, ctx->stream));
+    }
+    const size_t n4 = (size_t)(c.width / 4) * (c.height / 4), n8 = (size_t)(c.width / 8) * (c.height / 8);
+    if (out->cu_log2_size) HIP_TRY(ctx, hipMemcpyAsync(out->cu_log2_size, b.cu_log2, n4, hipMemcpyDeviceToHost, ctx->stream));
+    if (out->luma_mode) HIP_TRY(ctx, hipMemcpyAsync(out->luma_mode, b.luma_mode, n4, hipMemcpyDeviceToHost, ctx->stream));
+    if (out->chroma_mode) HIP_TRY(ctx, hipMemcpyAsync(out->chroma_mode, b.chroma_mode, n8, hipMemcpyDeviceToHost, ctx->stream));
+    if (out->ctu_cost)
+        HIP_TRY(ctx, hipMemcpyAsync(out->ctu_cost, b.ctu_cost, sizeof(float) * ctx->ctu_cols * ctx->ctu_rows,
+                                    hipMemcpyDeviceToHost, ctx->stream));
+    return wrenc_gpu_sync(ctx);
+}
+
+int wrenc_gpu_encode_picture(wrenc_gpu_ctx* ctx, const uint8_t* y, const uint8_t* cb, const uint8_t* cr,
+                             wrenc_gpu_picture* out) {
+    if (!ctx) return WRENC_GPU_EINVAL;
+    int rc = wrenc_gpu_upload(ctx, 0, y, cb, cr, ctx->cfg.width, ctx->cfg.width / 2);
+    if (rc) return rc;
+    rc = wrenc_gpu_encode(ctx, 0, 1);
+    if (rc) return rc;
+    return wrenc_gpu_download(ctx, 0, out);
+}
+
+int wrenc_gpu_last_encode_stats(wrenc_gpu_ctx* ctx, float* total_ms, float* kernel_ms_sum, int* n_launches) {
+    if (!ctx) return WRENC_GPU_EINVAL;
+    if (!ctx->stats_valid) return fail(ctx, WRENC_GPU_ESTATE, "no encode has been queued");
+    HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
+    HIP_TRY(ctx, hipEventSynchronize(ctx->ev_end));
+    float t = 0.f;
+    HIP_TRY(ctx, hipEventElapsedTime(&t, ctx->ev_begin, ctx->ev_end));
+    float sum = 0.f;
+    for (int i = 0; i < ctx->last_launches; ++i) {
+        float k = 0.f;
+        HIP_TRY(ctx, hipEventElapsedTime(&k, ctx->ev_pool[2 * i], ctx->ev_pool[2 * i + 1]));
+        sum += k;
+    }
+    if (total_ms) *total_ms = t;
+    if (kernel_ms_sum) *kernel_ms_sum = sum;
+    if (n_launches) *n_launches = ctx->last_launches;
+    return WRENC_GPU_OK;
+}
+
+int wrenc_gpu_final_pass_mismatches(wrenc_gpu_ctx* ctx, long long* count) {
+    if (!ctx || !count) return WRENC_GPU_EINVAL;
+    HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    unsigned long long v = 0;
+    HIP_TRY(ctx, hipMemcpy(&v, ctx->d_mismatch, sizeof(v), hipMemcpyDeviceToHost));
+    *count = (long long)v;
+    return WRENC_GPU_OK;
+}
+
+// ---- building-block entry points ----
+
+int wrenc_gpu_test_fwd_dct(wrenc_gpu_ctx* ctx, const int16_t* res, int log2n, int count, int16_t* coef) {
+    return run_block_test(ctx, res, log2n, count, coef, [&](int16_t* i, int16_t* o) {
+        hipLaunchKernelGGL(test_fwd_dct_kernel, dim3(count), dim3(64), 0, ctx->stream, ctx->d_const, i, log2n, o);
+    });
+}
+int wrenc_gpu_test_inv_dct(wrenc_gpu_ctx* ctx, const int16_t* deq, int log2n, int count, int16_t* res) {
+    return run_block_test(ctx, deq, log2n, count, res, [&](int16_t* i, int16_t* o) {
+        hipLaunchKernelGGL(test_inv_dct_kernel, dim3(count), dim3(64), 0, ctx->stream, ctx->d_const, i, log2n, o);
+    });
+}
+int wrenc_gpu_test_dequantize(wrenc_gpu_ctx* ctx, const int16_t* levels, int log2n, int count, int16_t* deq) {
+    return run_block_test(ctx, levels, log2n, count, deq, [&](int16_t* i, int16_t* o) {
+        hipLaunchKernelGGL(test_dequantize_kernel, dim3(count), dim3(64), 0, ctx->stream, ctx->d_const, i, log2n, o);
+    });
+}
+int wrenc_gpu_test_quantize(wrenc_gpu_ctx* ctx, const int16_t* coef, int log2n, int count, int16_t* levels,
+                            int64_t* level_cost) {
+    if (!ctx || !level_cost) return WRENC_GPU_EINVAL;
+    if (count < 1) return fail(ctx, WRENC_GPU_EINVAL, "count must be >= 1");
+    HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
+    long long* d_cost = nullptr;
+    HIP_TRY(ctx, hipMalloc((void**)&d_cost, sizeof(long long) * count));
+    int rc = run_block_test(ctx, coef, log2n, count, levels, [&](int16_t* i, int16_t* o) {
+        hipLaunchKernelGGL(test_quantize_kernel, dim3(count), dim3(64), 0, ctx->stream, ctx->d_const, i, log2n, o,
+                           d_cost, ctx->d_overflow);
+    });
+    if (rc == WRENC_GPU_OK) {
+        hipError_t e = hipMemcpy(level_cost, d_cost, sizeof(long long) * count, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) rc = fail(ctx, WRENC_GPU_EHIP, hipGetErrorString(e));
+    }
+    (void)hipFree(d_cost);
+    return rc;
+}
+
+} // extern "C"

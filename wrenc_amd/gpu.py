@@ -1,0 +1,207 @@
+"""ctypes binding of the C ABI in include/wrenc_gpu.h (libwrenc_gpu.so).
+
+This is the Python-side mirror used by tests and bench.py; a C++/Rust host binds
+the same symbols.  There is no CPU fallback: if the HIP
+library is missing or no gfx950 device is present, creation fails loudly.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libwrenc_gpu.so")
+
+EXPORTED_SYMBOLS = [
+    "wrenc_gpu_default_config", "wrenc_gpu_create", "wrenc_gpu_destroy", "wrenc_gpu_last_error",
+    "wrenc_gpu_upload", "wrenc_gpu_encode", "wrenc_gpu_sync", "wrenc_gpu_download",
+    "wrenc_gpu_encode_picture", "wrenc_gpu_last_encode_stats", "wrenc_gpu_final_pass_mismatches",
+    "wrenc_gpu_test_fwd_dct", "wrenc_gpu_test_inv_dct", "wrenc_gpu_test_quantize",
+    "wrenc_gpu_test_dequantize",
+]
+
+
+class Config(C.Structure):
+    _fields_ = [
+        ("width", C.c_int32), ("height", C.c_int32), ("qp", C.c_int32), ("max_split_depth", C.c_int32),
+        ("device", C.c_int32), ("n_slots", C.c_int32),
+        ("lv_table", C.c_int64 * 1024), ("dq_table", C.c_int64 * 1024),
+        ("lambda_q", C.c_int64), ("lambda_rd", C.c_float), ("lambda_rd_chroma", C.c_float),
+        ("header_bits_luma", C.c_int64 * 67 * 4 * 2),
+        ("header_bits_chroma", C.c_int64 * 4),
+    ]
+
+
+class Picture(C.Structure):
+    _fields_ = [
+        ("rec_y", C.c_void_p), ("rec_cb", C.c_void_p), ("rec_cr", C.c_void_p),
+        ("lev_y", C.c_void_p), ("lev_cb", C.c_void_p), ("lev_cr", C.c_void_p),
+        ("cu_log2_size", C.c_void_p), ("luma_mode", C.c_void_p), ("chroma_mode", C.c_void_p),
+        ("ctu_cost", C.c_void_p),
+    ]
+
+
+class WrencGpuError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("wrenc_gpu error %d: %s" % (code, msg))
+        self.code = code
+
+
+_lib = None
+
+
+def load_library():
+    """Load libwrenc_gpu.so; raises if it has not been built (no fallback)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise FileNotFoundError(
+                "%s not built: run `python -c 'import __graft_entry__ as g; g.build()'`" % LIB_PATH)
+        lib = C.CDLL(LIB_PATH)
+        lib.wrenc_gpu_last_error.restype = C.c_char_p
+        lib.wrenc_gpu_last_error.argtypes = [C.c_void_p]
+        lib.wrenc_gpu_create.argtypes = [C.POINTER(Config), C.POINTER(C.c_void_p)]
+        lib.wrenc_gpu_destroy.argtypes = [C.c_void_p]
+        lib.wrenc_gpu_destroy.restype = None
+        lib.wrenc_gpu_upload.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                         C.c_size_t, C.c_size_t]
+        lib.wrenc_gpu_encode.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        lib.wrenc_gpu_sync.argtypes = [C.c_void_p]
+        lib.wrenc_gpu_download.argtypes = [C.c_void_p, C.c_int, C.POINTER(Picture)]
+        lib.wrenc_gpu_encode_picture.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                 C.POINTER(Picture)]
+        lib.wrenc_gpu_last_encode_stats.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float),
+                                                    C.POINTER(C.c_int)]
+        lib.wrenc_gpu_final_pass_mismatches.argtypes = [C.c_void_p, C.POINTER(C.c_longlong)]
+        for name in ("fwd_dct", "inv_dct", "dequantize"):
+            getattr(lib, "wrenc_gpu_test_" + name).argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+                                                               C.c_void_p]
+        lib.wrenc_gpu_test_quantize.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p,
+                                                C.c_void_p]
+        _lib = lib
+    return _lib
+
+
+def default_config(width, height, qp, max_split_depth, device=0, n_slots=1):
+    cfg = Config()
+    rc = load_library().wrenc_gpu_default_config(C.byref(cfg), width, height, qp, max_split_depth)
+    if rc:
+        raise WrencGpuError(rc, "default_config")
+    cfg.device = device
+    cfg.n_slots = n_slots
+    return cfg
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def alloc_picture(width, height):
+    return {
+        "rec_y": np.zeros((height, width), np.uint8),
+        "rec_cb": np.zeros((height // 2, width // 2), np.uint8),
+        "rec_cr": np.zeros((height // 2, width // 2), np.uint8),
+        "lev_y": np.zeros((height, width), np.int16),
+        "lev_cb": np.zeros((height // 2, width // 2), np.int16),
+        "lev_cr": np.zeros((height // 2, width // 2), np.int16),
+        "cu_log2_size": np.zeros((height // 4, width // 4), np.uint8),
+        "luma_mode": np.zeros((height // 4, width // 4), np.uint8),
+        "chroma_mode": np.zeros((height // 8, width // 8), np.uint8),
+        "ctu_cost": np.zeros(((height // 32) * (width // 32),), np.float32),
+    }
+
+
+_PIC_KEYS = ("rec_y", "rec_cb", "rec_cr", "lev_y", "lev_cb", "lev_cr", "cu_log2_size", "luma_mode",
+             "chroma_mode", "ctu_cost")
+
+
+class Encoder:
+    """One context = one GPU.  Mirrors the picture-granular call surface a C++
+    SliceEncoder::encode uses in place of the per-CTU split_ct loop."""
+
+    def __init__(self, width, height, qp=26, max_split_depth=3, device=0, n_slots=1, config=None):
+        self.lib = load_library()
+        self.cfg = config if config is not None else default_config(width, height, qp, max_split_depth,
+                                                                     device, n_slots)
+        self.width, self.height = self.cfg.width, self.cfg.height
+        self.ctx = C.c_void_p()
+        rc = self.lib.wrenc_gpu_create(C.byref(self.cfg), C.byref(self.ctx))
+        if rc:
+            raise WrencGpuError(rc, self.lib.wrenc_gpu_last_error(None).decode())
+        self._keep = {}
+
+    def _check(self, rc):
+        if rc:
+            raise WrencGpuError(rc, self.lib.wrenc_gpu_last_error(self.ctx).decode())
+
+    def close(self):
+        if self.ctx:
+            self.lib.wrenc_gpu_destroy(self.ctx)
+            self.ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def upload(self, slot, y, cb, cr):
+        y = np.ascontiguousarray(y, np.uint8)
+        cb = np.ascontiguousarray(cb, np.uint8)
+        cr = np.ascontiguousarray(cr, np.uint8)
+        assert y.shape == (self.height, self.width)
+        self._keep[slot] = (y, cb, cr)  # host buffers must outlive the async copy
+        self._check(self.lib.wrenc_gpu_upload(self.ctx, slot, _p(y), _p(cb), _p(cr), self.width, self.width // 2))
+
+    def encode(self, first_slot=0, n_pictures=1):
+        self._check(self.lib.wrenc_gpu_encode(self.ctx, first_slot, n_pictures))
+
+    def sync(self):
+        self._check(self.lib.wrenc_gpu_sync(self.ctx))
+
+    def download(self, slot):
+        out = alloc_picture(self.width, self.height)
+        pic = Picture(*[_p(out[k]) for k in _PIC_KEYS])
+        self._check(self.lib.wrenc_gpu_download(self.ctx, slot, C.byref(pic)))
+        return out
+
+    def encode_picture(self, y, cb, cr):
+        self.upload(0, y, cb, cr)
+        self.encode(0, 1)
+        return self.download(0)
+
+    def last_encode_stats(self):
+        t, k, n = C.c_float(), C.c_float(), C.c_int()
+        self._check(self.lib.wrenc_gpu_last_encode_stats(self.ctx, C.byref(t), C.byref(k), C.byref(n)))
+        return {"total_ms": t.value, "kernel_ms_sum": k.value, "n_launches": n.value}
+
+    def final_pass_mismatches(self):
+        v = C.c_longlong()
+        self._check(self.lib.wrenc_gpu_final_pass_mismatches(self.ctx, C.byref(v)))
+        return v.value
+
+    # ---- building blocks ----
+    def _blocks(self, fn, arr):
+        arr = np.ascontiguousarray(arr, np.int16)
+        count, n, _ = arr.shape
+        out = np.zeros_like(arr)
+        self._check(fn(self.ctx, _p(arr), int(n).bit_length() - 1, count, _p(out)))
+        return out
+
+    def fwd_dct(self, blocks):
+        return self._blocks(self.lib.wrenc_gpu_test_fwd_dct, blocks)
+
+    def inv_dct(self, blocks):
+        return self._blocks(self.lib.wrenc_gpu_test_inv_dct, blocks)
+
+    def dequantize(self, blocks):
+        return self._blocks(self.lib.wrenc_gpu_test_dequantize, blocks)
+
+    def quantize(self, blocks):
+        arr = np.ascontiguousarray(blocks, np.int16)
+        count, n, _ = arr.shape
+        out = np.zeros_like(arr)
+        cost = np.zeros(count, np.int64)
+        self._check(self.lib.wrenc_gpu_test_quantize(self.ctx, _p(arr), int(n).bit_length() - 1, count,
+                                                     _p(out), _p(cost)))
+        return out, cost
