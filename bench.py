@@ -1,0 +1,138 @@
+#!/usr/bin/env python3
+"""bench.py -- all-intra encode throughput of the MI355X RD-search path.
+
+Contract (driver): python bench.py --gpus N --steps K --warmup W ; for N > 1 it is
+launched by torch.distributed.run with one rank per GPU.  One "step" is one pass of
+the hot path (CTU search + final pass of every CTU) over one batch of pictures that
+is already resident in HBM.  Workload: BASELINE.json configs[1] -- 1920x1088
+(1080p padded to a multiple of 32, README.md:37 of the reference) synthetic
+YUV420, QP32, --max-split-depth 2.  Pictures are independent I-slices, so with N
+GPUs every rank runs its own batch (weak scaling, no data-path collective).
+
+Rank 0 prints ONE JSON line.  `value` is frames/s over all ranks; the roofline
+object prices the search kernel against HBM with the algorithmic 6 bytes per luma
+pixel, using the kernel's own HIP-event durations; cpu_baseline is
+the CPU oracle (a port of the reference algorithm: the Rust reference cannot be
+built here) timed on one host core on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+WIDTH, HEIGHT, QP, DEPTH = 1920, 1088, 32, 2
+ALGO_BYTES_PER_PIXEL = 6.0      # 1.5 B read + 1.5 B recon + 3.0 B levels
+HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: 8 TB/s spec
+
+
+def cpu_baseline(width, height, qp, depth, rows=None):
+    """Oracle on one host core over a bounded sample of the same workload."""
+    import numpy as np
+    from oracle import pyoracle as po
+    from wrenc_amd import synth
+    y, cb, cr = synth.synth_frame(width, height, 0)
+    if rows is not None:
+        y, cb, cr = y[:rows], cb[:rows // 2], cr[:rows // 2]
+    t0 = time.perf_counter()
+    po.encode_picture(np.ascontiguousarray(y), np.ascontiguousarray(cb), np.ascontiguousarray(cr), qp, depth)
+    dt = time.perf_counter() - t0
+    frac = y.shape[0] / float(height)
+    return {"value": frac / dt, "unit": "frames/s", "cores": 1, "kind": "port",
+            "sample": "%dx%d rows of one %dx%d frame, QP%d depth %d, %.1f s on 1 core"
+                      % (width, y.shape[0], width, height, qp, depth, dt),
+            "mpix_per_s": width * y.shape[0] / dt / 1e6}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=int(os.environ.get("WRENC_BENCH_BATCH", "64")),
+                    help="pictures resident per GPU and encoded per step")
+    ap.add_argument("--width", type=int, default=WIDTH)
+    ap.add_argument("--height", type=int, default=HEIGHT)
+    ap.add_argument("--qp", type=int, default=QP)
+    ap.add_argument("--depth", type=int, default=DEPTH)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    from wrenc_amd import gpu, sharding, synth
+
+    rank, local_rank, world = sharding.world_from_env()
+    if world != args.gpus and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    grp = sharding.Group(backend="nccl", device="cuda:%d" % local_rank)
+
+    w, h, B = args.width, args.height, args.batch
+    enc = gpu.Encoder(w, h, qp=args.qp, max_split_depth=args.depth, device=local_rank, n_slots=B)
+    # synthetic pictures, resident in HBM before the timed region; each rank owns the POCs
+    # p with p mod world == rank of a (world * B)-picture sequence
+    distinct = min(B, 8)
+    frames = {}
+    for s, poc in enumerate(sharding.picture_shard(world * B, rank, world)):
+        f = poc % (distinct * world)
+        if f not in frames:
+            frames[f] = synth.synth_frame(w, h, f)
+        enc.upload(s, *frames[f])
+    enc.sync()
+
+    kernel_ms, launches = 0.0, 0
+    for _ in range(args.warmup):
+        enc.encode(0, B)
+        enc.sync()
+    grp.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        enc.encode(0, B)
+        enc.sync()
+        st = enc.last_encode_stats()
+        kernel_ms += st["kernel_ms_sum"]
+        launches += st["n_launches"]
+    torch.cuda.synchronize()
+    grp.barrier()
+    dt = grp.max(time.perf_counter() - t0)
+    mism = enc.final_pass_mismatches()
+    enc.close()
+
+    total_frames = world * B * args.steps
+    fps = total_frames / dt
+    result = None
+    if rank == 0:
+        pix = float(w) * h
+        per_launch_bytes = ALGO_BYTES_PER_PIXEL * pix * B * args.steps / max(launches, 1)
+        avg_launch_s = kernel_ms / 1e3 / max(launches, 1)
+        achieved = per_launch_bytes / avg_launch_s / 1e9
+        result = {
+            "metric": "all-intra encode fps at fixed QP (CTU RD search + final pass, bit-exact vs CPU oracle)",
+            "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u8/i16/i32 (+i64 trellis costs, f32 RD cost)", "data": "synthetic",
+            "mpix_per_s": fps * pix / 1e6,
+            "config": {"workload": "%dx%d synthetic YUV420 QP%d max-split-depth %d" % (w, h, args.qp, args.depth),
+                       "pictures_per_step_per_gpu": B, "parallelism": "picture-sharded x%d, no collective" % world,
+                       "final_pass_mismatches": mism},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "ctu_search_kernel", "avg_launch_ms": avg_launch_s * 1e3,
+                         "algorithmic_bytes_per_launch": per_launch_bytes},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline(w, h, args.qp, args.depth)   # one full frame, ~15 s
+    grp.close()
+    if rank == 0:
+        print(json.dumps(result))
+
+
+if __name__ == "__main__":
+    main()

@@ -35,6 +35,16 @@ static const int kCos[65] = {
     2,  0};
 
 static int16_t g_dct64[64][64];
+// set when a table index reaches 1024: the reference panics there (block_splitter.rs:453,
+// quantizer.rs:30); the oracle clamps the index and reports failure
+static bool g_table_overflow = false;
+static inline size_t tbl(size_t i) {
+    if (i >= 1024) {
+        g_table_overflow = true;
+        return 1023;
+    }
+    return i;
+}
 static bool g_tables_ready = false;
 
 // intraPredAngle for predModeIntra -14..80 (H.266 Table 24; common.rs:145)
@@ -328,7 +338,7 @@ struct Trellis {
         table.assign((size_t)g.num_sb * 16 * 4, TrellisEntry{0, 0, INT64_MIN});
     }
     inline int64_t dq_cost(int64_t dist, int64_t bits) const { // quantizer.rs:29-31
-        return 128 * dist + lambda * rd.dq[bits];
+        return 128 * dist + lambda * rd.dq[tbl((size_t)bits)];
     }
     // quantizer.rs:338-517 (memo key omits is_trailing_zeros: first visit wins)
     TrellisEntry search(int q_state, int last_scan_pos, int last_sub_block, size_t depth,
@@ -502,7 +512,7 @@ static void quantize_viterbi(const RdConst& rd, const int16_t* coef, int log2n, 
         }
     }
     auto trailing = [&](int i, int s) { return s == 0 && i <= istar; };
-    auto dqc = [&](int64_t dist, int64_t bits) { return 128 * dist + lambda * rd.dq[bits]; };
+    auto dqc = [&](int64_t dist, int64_t bits) { return 128 * dist + lambda * rd.dq[tbl((size_t)bits)]; };
     std::vector<int64_t> C((size_t)(N + 1) * 4, 0);
     std::vector<uint32_t> A((size_t)N * 4);
     std::vector<int16_t> Q((size_t)N * 4);
@@ -619,7 +629,7 @@ static int64_t level_cost(const RdConst& rd, const int16_t* levels, int log2n) {
             q_state = kQStateTrans[q_state][0];
         } else {
             const size_t a = (qc + (q_state > 1 ? 1 : 0)) / 2;
-            sum += rd.lv[a];
+            sum += rd.lv[tbl(a)];
             q_state = kQStateTrans[q_state][a & 1];
         }
         is_trailing_zeros = is_trailing_zeros && (qc == 0);
@@ -1823,6 +1833,7 @@ int wro_encode_picture(const wro_params* prm, const uint8_t* y, const uint8_t* c
         return -1;
     if (prm->max_split_depth < 0 || prm->max_split_depth > 3) return -2;
     if (prm->qp < 0 || prm->qp > 63) return -3;
+    g_table_overflow = false;
     Picture p;
     p.W = prm->width;
     p.H = prm->height;
@@ -1852,6 +1863,7 @@ int wro_encode_picture(const wro_params* prm, const uint8_t* y, const uint8_t* c
         sp.final_pass(p.ctu_root[i]);
     }
     g_last_final_mismatch = p.final_mismatch;
+    if (g_table_overflow) return -4; // a level reached 1024: the reference would have panicked
     if (out) {
         for (int c = 0; c < 3; ++c) {
             uint8_t* dst = c == 0 ? out->rec_y : (c == 1 ? out->rec_cb : out->rec_cr);

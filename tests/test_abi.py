@@ -1,0 +1,92 @@
+"""CPU tests of the product's host side: the C-ABI library loads, exports every
+symbol the header declares, resolves the same constant tables as the oracle, and
+fails loudly (never falls back) when no gfx950 device is present."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    txt = open(os.path.join(ROOT, "include", "wrenc_gpu.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(wrenc_gpu_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_library_exports_every_declared_symbol(built):
+    from wrenc_amd import gpu
+    lib = C.CDLL(gpu.LIB_PATH)
+    declared = _declared_symbols()
+    assert len(declared) >= 14
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert sorted(gpu.EXPORTED_SYMBOLS) == declared
+
+
+def test_default_config_matches_oracle_tables(built):
+    from wrenc_amd import gpu
+    from oracle import pyoracle as po
+    for qp in (0, 12, 22, 26, 27, 32, 37, 45, 51, 63):
+        cfg = gpu.default_config(64, 64, qp, 2)
+        lv, dq, lq, lr = po.tables(qp)
+        assert np.array_equal(np.array(cfg.lv_table), lv)
+        assert np.array_equal(np.array(cfg.dq_table), dq)
+        assert cfg.lambda_q == lq
+        assert cfg.lambda_rd == lr and cfg.lambda_rd_chroma == lr
+    cfg = gpu.default_config(64, 64, 32, 2)
+    hb = np.array(cfg.header_bits_luma).reshape(2, 4, 67)
+    for tree in range(2):
+        for cc in range(4):
+            if tree == 1 and cc > 0:
+                continue
+            for cls in range(67):
+                want = po.header_bits(tree, int(cls > 0), int(cls <= 5), cls - 1 if 1 <= cls <= 5 else 0,
+                                      cls - 6 if cls > 5 else 0, int(cc > 0), max(cc - 1, 0))
+                assert hb[tree, cc, cls] == want, (tree, cc, cls)
+    hc = np.array(cfg.header_bits_chroma)
+    for cc in range(4):
+        assert hc[cc] == po.chroma_header_bits(int(cc > 0), max(cc - 1, 0))
+
+
+def test_create_rejects_bad_arguments_and_never_falls_back(built):
+    from wrenc_amd import gpu
+    lib = gpu.load_library()
+    for (w, h, qp, d) in [(100, 64, 32, 2), (64, 60, 32, 2), (64, 64, 64, 2), (64, 64, 32, 4), (0, 0, 32, 0)]:
+        cfg = gpu.default_config(w, h, qp, d)
+        ctx = C.c_void_p()
+        rc = lib.wrenc_gpu_create(C.byref(cfg), C.byref(ctx))
+        assert rc == -1 and not ctx.value           # WRENC_GPU_EINVAL
+        assert lib.wrenc_gpu_last_error(None)
+    import torch
+    if not torch.cuda.is_available():
+        cfg = gpu.default_config(64, 64, 32, 2)
+        ctx = C.c_void_p()
+        rc = lib.wrenc_gpu_create(C.byref(cfg), C.byref(ctx))
+        assert rc == -2 and not ctx.value           # WRENC_GPU_ENODEV: loud failure, no CPU path
+        with pytest.raises(gpu.WrencGpuError):
+            gpu.Encoder(64, 64, qp=32, max_split_depth=2)
+
+
+def test_product_does_not_import_oracle():
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "wrenc_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                txt = open(os.path.join(dirpath, f)).read()
+                assert "pyoracle" not in txt and "wrenc_oracle" not in txt and "libwrenc_oracle" not in txt, f
+
+
+def test_synth_is_deterministic():
+    import hashlib
+    from wrenc_amd import synth
+    y, cb, cr = synth.synth_frame(64, 64, 3)
+    h = hashlib.sha256(y.tobytes() + cb.tobytes() + cr.tobytes()).hexdigest()
+    y2, cb2, cr2 = synth.synth_frame(64, 64, 3)
+    assert np.array_equal(y, y2) and np.array_equal(cb, cb2) and np.array_equal(cr, cr2)
+    g = np.load(os.path.join(ROOT, "tests", "golden", "smooth64_qp37_d1.npz"))
+    y0, cb0, cr0 = synth.synth_frame(64, 64, 0)
+    assert np.array_equal(g["y"], y0) and np.array_equal(g["cb"], cb0) and np.array_equal(g["cr"], cr0)
+    assert len(h) == 64
