@@ -40,6 +40,7 @@ struct DevConst {
     int16_t dct_t[4][32][32]; // transposed: dct_t[idx][y][i] = T_N[i][y]
     uint8_t diag4[16][2];     // 4x4 up-right diagonal scan (x, y)   (ctu.rs:14-81)
     uint8_t diag_sb[4][64][2]; // sub-block scan for 1, 4, 16, 64 sub-blocks
+    uint16_t scan_idx[4][1024]; // raster index y*n+x of reverse-scan position p (p = 0: last in scan)
     int16_t intra_angle[95];  // common.rs:145
     int8_t fc[32][4];         // common.rs:153
 };
@@ -82,6 +83,9 @@ struct __attribute__((aligned(16))) Lds {
     uint8_t luma_mode[64];
     uint8_t chroma_mode[16];   // per 8x8 luma unit
     uint8_t left_mode[8];      // luma mode of the CU left of the CTU, per 4 rows
+    float ns_cost[4];          // per tree level: no-split cost, running split cost
+    float split_cost[4];
+    uint8_t ns_luma[4], ns_chroma[4], child[4];
 };
 
 // Per-wave uniform context.
@@ -184,7 +188,7 @@ __device__ __forceinline__ int pdpc_w(int n_scale, int i) {
     return sh > 5 ? 0 : (32 >> sh);
 }
 
-__device__ void build_refs(const Ctx& c, int comp, int tx, int ty, int tlg, int mode) {
+__device__ __noinline__ void build_refs(const Ctx& c, int comp, int tx, int ty, int tlg, int mode) {
     Lds* s = c.s;
     const int cs = comp ? 1 : 0;
     const int n = 1 << (tlg - cs);
@@ -194,14 +198,14 @@ __device__ void build_refs(const Ctx& c, int comp, int tx, int ty, int tlg, int 
     const bool ar = above_right_avail(c, tx, ty, tlg);
     const bool bl = below_left_avail(c, tx, ty, tlg);
     const int st = 1 << cs;
-    // segment availabilities in substitution-scan order: BL, L, corner, A, AR
-    bool av[5];
-    av[0] = nb_avail(c, gx, gy, tn, gx - st, gy + tn, ar, bl);
-    av[1] = nb_avail(c, gx, gy, tn, gx - st, gy, ar, bl);
-    av[2] = nb_avail(c, gx, gy, tn, gx - st, gy - st, ar, bl);
-    av[3] = nb_avail(c, gx, gy, tn, gx, gy - st, ar, bl);
-    av[4] = nb_avail(c, gx, gy, tn, gx + tn, gy - st, ar, bl);
-    const bool any = av[0] || av[1] || av[2] || av[3] || av[4];
+    // segment availabilities in substitution-scan order: BL, L, corner, A, AR (bit j = segment j)
+    int avm = 0;
+    avm |= nb_avail(c, gx, gy, tn, gx - st, gy + tn, ar, bl) ? 1 : 0;
+    avm |= nb_avail(c, gx, gy, tn, gx - st, gy, ar, bl) ? 2 : 0;
+    avm |= nb_avail(c, gx, gy, tn, gx - st, gy - st, ar, bl) ? 4 : 0;
+    avm |= nb_avail(c, gx, gy, tn, gx, gy - st, ar, bl) ? 8 : 0;
+    avm |= nb_avail(c, gx, gy, tn, gx + tn, gy - st, ar, bl) ? 16 : 0;
+    const bool any = avm != 0;
     const int total = 4 * n + 1;
     for (int t = c.lane; t < total; t += 64) {
         // unified item: t <= 2n -> left index li = t (li 0 = corner, li k -> y = k-1); else above
@@ -219,17 +223,17 @@ __device__ void build_refs(const Ctx& c, int comp, int tx, int ty, int tlg, int 
             // source sample: own position if available, else nearest available in scan order
             int sli = li, sai = ai;
             bool src_left = is_left;
-            if (!av[seg]) {
-                int j = seg - 1;
-                while (j >= 0 && !av[j]) --j;
-                if (j >= 0) { // last sample (in scan order) of the nearest earlier available segment
+            if (!((avm >> seg) & 1)) {
+                const int below = avm & ((1 << seg) - 1);
+                int j;
+                if (below) { // last sample (in scan order) of the nearest earlier available segment
+                    j = 31 - __clz(below);
                     if (j == 0) { src_left = true; sli = n + 1; }
                     else if (j == 1) { src_left = true; sli = 1; }
                     else if (j == 2) { src_left = true; sli = 0; }
                     else { src_left = false; sai = n - 1; }
                 } else { // first sample of the first available later segment
-                    j = seg + 1;
-                    while (!av[j]) ++j;
+                    j = __ffs(avm) - 1;
                     if (j == 1) { src_left = true; sli = n; }
                     else if (j == 2) { src_left = true; sli = 0; }
                     else if (j == 3) { src_left = false; sai = 0; }
@@ -291,7 +295,7 @@ __device__ __forceinline__ int cclm_ds6(const Ctx& c, int tx, int ty, int sy, in
             cclm_w(c, tx, ty, sy, sx + 1, avail_l) + cclm_w(c, tx, ty, sy + 1, sx + 1, avail_l) + 4) >> 3;
 }
 
-__device__ CclmParams cclm_params(const Ctx& c, int comp, int tx, int ty, int tlg, int mode) {
+__device__ __noinline__ CclmParams cclm_params(const Ctx& c, int comp, int tx, int ty, int tlg, int mode) {
     CclmParams r;
     const int tn = 1 << tlg;
     const int tw = tn >> 1, th = tw;
@@ -333,22 +337,30 @@ __device__ CclmParams cclm_params(const Ctx& c, int comp, int tx, int ty, int tl
     const bool b_ctu_boundary = ((c.ctu_y + ty) & 31) == 0;
     const int num_is_4 = !(avail_t && avail_l && mode == LT_CCLM) ? 1 : 0;
     int cnt_t = 0, cnt_l = 0;
-    int sel_y[4] = {0, 0, 0, 0}, sel_c[4] = {0, 0, 0, 0};
+    int y0 = 0, y1 = 0, y2 = 0, y3 = 0, c0 = 0, c1 = 0, c2 = 0, c3 = 0; // p_sel_ds_y / p_sel_c
+    auto put = [&](int i, int yy, int cc_) {
+        if (i == 0) { y0 = yy; c0 = cc_; }
+        else if (i == 1) { y1 = yy; c1 = cc_; }
+        else if (i == 2) { y2 = yy; c2 = cc_; }
+        else { y3 = yy; c3 = cc_; }
+    };
     if (avail_t && (mode == LT_CCLM || mode == T_CCLM)) {
         const int start = num_samp_t >> (2 + num_is_4);
         const int step = max(num_samp_t >> (1 + num_is_4), 1);
         cnt_t = min((1 + num_is_4) << 1, num_samp_t);
         for (int i = 0; i < cnt_t; ++i) {
             const int pos = start + i * step;
-            sel_c[i] = rec_get(c.s, comp, cx + pos, cy - 1);
+            const int sc = rec_get(c.s, comp, cx + pos, cy - 1);
             const int sx = 2 * pos;
+            int sy;
             if (!b_ctu_boundary)
-                sel_y[i] = (cclm_w(c, tx, ty, -1, sx - 1, avail_l) + cclm_w(c, tx, ty, -2, sx - 1, avail_l) +
-                            cclm_w(c, tx, ty, -1, sx, avail_l) * 2 + cclm_w(c, tx, ty, -2, sx, avail_l) * 2 +
-                            cclm_w(c, tx, ty, -1, sx + 1, avail_l) + cclm_w(c, tx, ty, -2, sx + 1, avail_l) + 4) >> 3;
+                sy = (cclm_w(c, tx, ty, -1, sx - 1, avail_l) + cclm_w(c, tx, ty, -2, sx - 1, avail_l) +
+                      cclm_w(c, tx, ty, -1, sx, avail_l) * 2 + cclm_w(c, tx, ty, -2, sx, avail_l) * 2 +
+                      cclm_w(c, tx, ty, -1, sx + 1, avail_l) + cclm_w(c, tx, ty, -2, sx + 1, avail_l) + 4) >> 3;
             else
-                sel_y[i] = (cclm_w(c, tx, ty, -1, sx - 1, avail_l) + cclm_w(c, tx, ty, -1, sx, avail_l) * 2 +
-                            cclm_w(c, tx, ty, -1, sx + 1, avail_l) + 2) >> 2;
+                sy = (cclm_w(c, tx, ty, -1, sx - 1, avail_l) + cclm_w(c, tx, ty, -1, sx, avail_l) * 2 +
+                      cclm_w(c, tx, ty, -1, sx + 1, avail_l) + 2) >> 2;
+            put(i, sy, sc);
         }
     }
     if (avail_l && (mode == LT_CCLM || mode == L_CCLM)) {
@@ -357,20 +369,23 @@ __device__ CclmParams cclm_params(const Ctx& c, int comp, int tx, int ty, int tl
         cnt_l = min((1 + num_is_4) << 1, num_samp_l);
         for (int i = 0; i < cnt_l; ++i) {
             const int pos = start + i * step;
-            sel_c[cnt_t + i] = rec_get(c.s, comp, cx - 1, cy + pos);
-            sel_y[cnt_t + i] = cclm_ds6(c, tx, ty, 2 * pos, -2, avail_l);
+            put(cnt_t + i, cclm_ds6(c, tx, ty, 2 * pos, -2, avail_l), rec_get(c.s, comp, cx - 1, cy + pos));
         }
     }
-    int mn0 = 0, mn1 = 2, mx0 = 1, mx1 = 3;
-    int t;
-    if (sel_y[mn0] > sel_y[mn1]) { t = mn0; mn0 = mn1; mn1 = t; }
-    if (sel_y[mx0] > sel_y[mx1]) { t = mx0; mx0 = mx1; mx1 = t; }
-    if (sel_y[mn0] > sel_y[mx1]) { t = mn0; mn0 = mx0; mx0 = t; t = mn1; mn1 = mx1; mx1 = t; }
-    if (sel_y[mn1] > sel_y[mx0]) { t = mn1; mn1 = mx0; mx0 = t; }
-    const int max_y = (sel_y[mx0] + sel_y[mx1] + 1) >> 1;
-    const int max_c = (sel_c[mx0] + sel_c[mx1] + 1) >> 1;
-    const int min_y = (sel_y[mn0] + sel_y[mn1] + 1) >> 1;
-    const int min_c = (sel_c[mn0] + sel_c[mn1] + 1) >> 1;
+    // min group {0,2}, max group {1,3} and the four compare-exchanges of :1973-1986,
+    // carried out on (luma, chroma) value pairs instead of indices
+    int mnAy = y0, mnAc = c0, mnBy = y2, mnBc = c2, mxAy = y1, mxAc = c1, mxBy = y3, mxBc = c3, t;
+    if (mnAy > mnBy) { t = mnAy; mnAy = mnBy; mnBy = t; t = mnAc; mnAc = mnBc; mnBc = t; }
+    if (mxAy > mxBy) { t = mxAy; mxAy = mxBy; mxBy = t; t = mxAc; mxAc = mxBc; mxBc = t; }
+    if (mnAy > mxBy) {
+        t = mnAy; mnAy = mxAy; mxAy = t; t = mnAc; mnAc = mxAc; mxAc = t;
+        t = mnBy; mnBy = mxBy; mxBy = t; t = mnBc; mnBc = mxBc; mxBc = t;
+    }
+    if (mnBy > mxAy) { t = mnBy; mnBy = mxAy; mxAy = t; t = mnBc; mnBc = mxAc; mxAc = t; }
+    const int max_y = (mxAy + mxBy + 1) >> 1;
+    const int max_c = (mxAc + mxBc + 1) >> 1;
+    const int min_y = (mnAy + mnBy + 1) >> 1;
+    const int min_c = (mnAc + mnBc + 1) >> 1;
     const int diff = max_y - min_y;
     if (diff != 0) {
         const int diff_c = max_c - min_c;
@@ -399,7 +414,7 @@ __device__ CclmParams cclm_params(const Ctx& c, int comp, int tx, int ty, int tl
     return r;
 }
 
-__device__ void predict(const Ctx& c, int comp, int tx, int ty, int tlg, int mode) {
+__device__ __noinline__ void predict(const Ctx& c, int comp, int tx, int ty, int tlg, int mode) {
     Lds* s = c.s;
     const int cs = comp ? 1 : 0;
     const int lg = tlg - cs;
@@ -589,6 +604,7 @@ __device__ void fwd_dct(const Ctx& c) {
         for (int k = 0; k < N / 2; ++k) t[k] = src[k];
     }
     // stage 1: H[u][y] = (sum_x T[u][x] r[y][x] + d) >> (LG-1)   (:2139-2209)
+#pragma unroll 1
     for (int y = g; y < N; y += G) {
         const uint32_t* row = (const uint32_t*)&s->bufA[y * N];
         int acc = 0;
@@ -598,13 +614,15 @@ __device__ void fwd_dct(const Ctx& c) {
     }
     WSYNC();
     // stage 2: C[v][x] = (sum_y T[v][y] H[x][y] + d) >> (LG+6)  (:2246-2316); lane v = u
+#pragma unroll 1
     for (int x = g; x < N; x += G) {
         const int32_t* col = &s->bufH[x * HS];
         int acc = 0;
 #pragma unroll
         for (int k = 0; k < N / 2; ++k) {
-            acc += (int)(short)(t[k] & 0xFFFF) * col[2 * k];
-            acc += ((int)t[k] >> 16) * col[2 * k + 1];
+            // |T| <= 90 and |H| <= 46410: 24-bit multiplies are exact (v_mad_i32_i24)
+            acc += __mul24((int)(short)(t[k] & 0xFFFF), col[2 * k]);
+            acc += __mul24((int)t[k] >> 16, col[2 * k + 1]);
         }
         s->bufB[u * N + x] = (int16_t)((acc + (1 << (LG + 5))) >> (LG + 6));
     }
@@ -627,6 +645,7 @@ __device__ void inv_dct(const Ctx& c) {
         for (int k = 0; k < N / 2; ++k) t[k] = src[k];
     }
     // stage 1 (vertical): V[y][x] = clamp16((sum_i T[i][y] d[i][x] + 64) >> 7); lane y = u
+#pragma unroll 1
     for (int x = g; x < N; x += G) {
         const uint32_t* col = (const uint32_t*)&s->bufA[x * N]; // dT[x][.]
         int acc = 0;
@@ -638,6 +657,7 @@ __device__ void inv_dct(const Ctx& c) {
     }
     WSYNC();
     // stage 2 (horizontal): r[y][x] = (sum_i T[i][x] V[y][i] + 2048) >> 12; lane x = u
+#pragma unroll 1
     for (int y = g; y < N; y += G) {
         const uint32_t* row = (const uint32_t*)&s->bufB[y * N];
         int acc = 0;
@@ -648,7 +668,7 @@ __device__ void inv_dct(const Ctx& c) {
     WSYNC();
 }
 
-__device__ void fwd_dct_lg(const Ctx& c, int lg) {
+__device__ __noinline__ void fwd_dct_lg(const Ctx& c, int lg) {
     switch (lg) {
     case 2: fwd_dct<2>(c); break;
     case 3: fwd_dct<3>(c); break;
@@ -656,7 +676,7 @@ __device__ void fwd_dct_lg(const Ctx& c, int lg) {
     default: fwd_dct<5>(c); break;
     }
 }
-__device__ void inv_dct_lg(const Ctx& c, int lg) {
+__device__ __noinline__ void inv_dct_lg(const Ctx& c, int lg) {
     switch (lg) {
     case 2: inv_dct<2>(c); break;
     case 3: inv_dct<3>(c); break;
@@ -674,16 +694,6 @@ __device__ __forceinline__ long long ldq_at(const Ctx& c, int bits) {
 __device__ __forceinline__ long long lv_at(const Ctx& c, int a) {
     return a < 256 ? (long long)c.s->lv[a] : c.k->lv[a];
 }
-__device__ __forceinline__ void scan_pos(const DevConst* k, int lg, int p, int& x, int& y) {
-    // p = reverse-scan index (0 = last coefficient of the scan, P-1 = DC)
-    const int nsb = 1 << (2 * lg - 4);
-    const int sb = nsb - 1 - (p >> 4);
-    const int sp = 15 - (p & 15);
-    const uint8_t* sbp = k->diag_sb[lg - 2][sb];
-    x = (sbp[0] << 2) + k->diag4[sp][0];
-    y = (sbp[1] << 2) + k->diag4[sp][1];
-}
-
 template <int CTRL>
 __device__ __forceinline__ long long dpp_quad64(long long v) {
     int lo = (int)(v & 0xFFFFFFFFLL), hi = (int)(v >> 32);
@@ -692,10 +702,25 @@ __device__ __forceinline__ long long dpp_quad64(long long v) {
     return ((long long)hi << 32) | (unsigned int)lo;
 }
 
+__device__ __forceinline__ int compose_map(int g2, int g1) {
+    // (g2 o g1)(s) = g2[g1[s]]; maps {0..3}->{0..3} packed 2 bits per entry
+    int r = 0;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) r |= ((g2 >> (2 * ((g1 >> (2 * s)) & 3))) & 3) << (2 * s);
+    return r;
+}
+
 // coefficients bufB (n*n row-major) -> levels bufC (n*n row-major).  Returns the
-// level cost of the TB (block_splitter.rs:436-458).  Uses bufH and decn as scratch.
+// level cost of the TB (block_splitter.rs:436-458).  Scratch: bufA, bufH, decn.
 // `*overflow` is set when a level needs a table entry >= 1024 (reference panics).
-__device__ long long quantize(const Ctx& c, int lg, int* overflow) {
+//
+// Backward pass = 4-state Viterbi equivalent of the memoised DFS (SURVEY.md Q3,
+// proven equal to the literal DFS in tests/test_oracle.py): per chunk of 64
+// positions all lanes precompute the two branch costs for both values of
+// delta = (state > 1); then lanes 0..3 (one per state) walk the chunk, exchanging
+// path costs with two DPP quad permutes.  Forward trace = composition of per-position
+// state maps (prefix scan over lanes), then every lane emits its own positions.
+__device__ __noinline__ long long quantize(const Ctx& c, int lg, int* overflow) {
     Lds* s = c.s;
     const DevConst* k = c.k;
     const int n = 1 << lg;
@@ -703,13 +728,14 @@ __device__ long long quantize(const Ctx& c, int lg, int* overflow) {
     const int sh = 8 + lg - 5 + 1; // quantizer.rs:558-569
     const int off = (1 << sh) >> 1;
     const int lsc = k->lsc;
+    const uint16_t* scan = k->scan_idx[lg - 2];
     int16_t* tcs = (int16_t*)s->bufH;        // coefficient in reverse-scan order
     int16_t* qds = (int16_t*)s->bufH + 1024; // |(tc << sh) - off| / lsc
+    int32_t* cc = (int32_t*)s->bufA;         // chunk: [64][4] = c0/c1 for delta 0, c0/c1 for delta 1
+    uint8_t* cf = (uint8_t*)(s->bufA + 512); // chunk flags
     int first = P;
     for (int p = c.lane; p < P; p += 64) {
-        int x, y;
-        scan_pos(k, lg, p, x, y);
-        const int tc = s->bufB[y * n + x];
+        const int tc = s->bufB[scan[p]];
         int S = (int)((unsigned)tc << sh) - off;
         if (tc < 0) S = -S;
         const int qd = tc == 0 ? 0 : (int)(((unsigned long long)(unsigned)S * k->div_magic) >> 47);
@@ -718,117 +744,139 @@ __device__ long long quantize(const Ctx& c, int lg, int* overflow) {
         if (tc != 0 && (qd >> 1) > 0) first = min(first, p);
     }
     const int istar = wave_min_i32(first);
-    WSYNC();
     const long long ldq1 = ldq_at(c, 1);
-    // backward Viterbi: lane s (0..3) carries C(p, s); lanes >= 4 mirror lane&3 (harmless)
     const int st = c.lane & 3;
     const int delta = st > 1 ? 1 : 0;
-    long long C;
+    long long C = 0;
     int ovf = 0;
-    {
-        const int p = P - 1;
-        const int tc = tcs[p];
-        const int qd = qds[p];
-        const bool tz = st == 0 && p <= istar;
-        bool pick1 = false;
-        if (tc == 0) {
-            C = tz ? 0 : ldq1;
-            if (tz) C -= ldq1; // last_scan_pos == 0 && trailing && a == 0 (quantizer.rs:512-514)
-        } else {
-            const int a0 = qd >> 1; // quantizer.rs:378 (no delta at the DC node)
-            int q0 = (int)(int16_t)(2 * a0 - delta);
-            if (tc < 0) q0 = (int)(int16_t)(-q0);
-            const int d0 = abs(tc - ((q0 * lsc + off) >> sh));
-            const int bits0 = (a0 + 1) * ((a0 != 0 || !tz) ? 1 : 0);
-            const int a1 = a0 + 1;
-            int q1 = (int)(int16_t)(2 * a1 - delta);
-            if (tc < 0) q1 = (int)(int16_t)(-q1);
-            const int d1 = abs(tc - ((q1 * lsc + off) >> sh));
-            if (a1 + 1 >= 1024) ovf = 1;
-            const long long c0 = 128LL * d0 + ldq_at(c, min(bits0, 1023));
-            const long long c1 = 128LL * d1 + ldq_at(c, min(a1 + 1, 1023));
-            if (c0 <= c1) {
-                C = c0;
-                if (a0 == 0 && tz) C -= ldq1;
-            } else {
-                C = c1;
-                pick1 = true;
+    const int CH = P < 64 ? P : 64;
+    for (int base = P - CH; base >= 0; base -= CH) {
+        WSYNC();
+        if (c.lane < CH) {
+            const int p = base + c.lane;
+            const int tc = tcs[p];
+            const int qd = qds[p];
+            const bool dcn = p == P - 1;
+            int flags = tc == 0 ? 1 : 0;
+#pragma unroll
+            for (int d = 0; d < 2; ++d) {
+                int c0 = 0, c1 = 0;
+                if (tc != 0) {
+                    const int a0 = dcn ? (qd >> 1) : ((qd + d) >> 1); // quantizer.rs:378 / :441
+                    int q0 = dcn ? (int)(int16_t)(2 * a0 - d) : (a0 > 0 ? 2 * a0 - d : 0);
+                    const int a1 = a0 + 1;
+                    int q1 = dcn ? (int)(int16_t)(2 * a1 - d) : 2 * a1 - d;
+                    if (tc < 0) {
+                        q0 = dcn ? (int)(int16_t)(-q0) : -q0;
+                        q1 = dcn ? (int)(int16_t)(-q1) : -q1;
+                    }
+                    const int d0 = abs(tc - ((q0 * lsc + off) >> sh));
+                    const int d1 = abs(tc - ((q1 * lsc + off) >> sh));
+                    if (a1 + 1 >= 1024) ovf = 1;
+                    c0 = (int)(128LL * d0 + ldq_at(c, min(a0 + 1, 1023)));
+                    c1 = (int)(128LL * d1 + ldq_at(c, min(a1 + 1, 1023)));
+                    flags |= (a0 & 1) << (1 + 2 * d);
+                    flags |= (a0 == 0 ? 1 : 0) << (2 + 2 * d);
+                } else {
+                    c0 = (int)ldq1; // zero coefficient outside the trailing run: dq_table[1]
+                    flags |= 1 << (2 + 2 * d);
+                }
+                cc[c.lane * 4 + 2 * d] = c0;
+                cc[c.lane * 4 + 2 * d + 1] = c1;
             }
+            cf[c.lane] = (uint8_t)flags;
         }
-        const unsigned nib = (unsigned)(__ballot(pick1) & 0xFULL);
-        if (c.lane == 0) s->decn[p] = (uint8_t)nib;
-    }
-    for (int p = P - 2; p >= 0; --p) {
-        const int tc = tcs[p];
-        const int qd = qds[p];
-        const bool tz = st == 0 && p <= istar;
-        const bool first_in_sb = (p & 15) == 15;
-        const long long CA = dpp_quad64<0xD8>(C); // C[trans[s][0]]: quad_perm [0,2,1,3]
-        const long long CB = dpp_quad64<0x72>(C); // C[trans[s][1]]: quad_perm [2,0,3,1]
-        bool pick1 = false;
-        if (tc == 0) {
-            C = CA + (tz ? 0 : ldq1);
-            if (first_in_sb && tz) C -= ldq1;
-        } else {
-            const int a0 = (qd + delta) >> 1;
-            int q0 = a0 > 0 ? 2 * a0 - delta : 0;
-            if (tc < 0) q0 = -q0;
-            const int d0 = abs(tc - ((q0 * lsc + off) >> sh));
-            const int bits0 = (a0 == 0 && tz) ? 0 : a0 + 1;
-            const int a1 = a0 + 1;
-            int q1 = 2 * a1 - delta;
-            if (tc < 0) q1 = -q1;
-            const int d1 = abs(tc - ((q1 * lsc + off) >> sh));
-            if (a1 + 1 >= 1024) ovf = 1;
-            const long long c0 = 128LL * d0 + ldq_at(c, min(bits0, 1023));
-            const long long c1 = 128LL * d1 + ldq_at(c, min(a1 + 1, 1023));
-            const long long K0 = c0 + ((a0 & 1) ? CB : CA);
-            const long long K1 = c1 + ((a0 & 1) ? CA : CB);
-            if (K0 <= K1) {
-                C = K0;
-                if (a0 == 0 && tz && first_in_sb) C -= ldq1;
-            } else {
-                C = K1;
-                pick1 = true;
-            }
+        WSYNC();
+        for (int i = CH - 1; i >= 0; --i) {
+            const int p = base + i;
+            const int f = cf[i];
+            const int2 cv = *(const int2*)&cc[i * 4 + 2 * delta];
+            const bool tz = st == 0 && p <= istar;
+            const bool zero = f & 1;
+            const bool par = (f >> (1 + 2 * delta)) & 1;
+            const bool a0z = (f >> (2 + 2 * delta)) & 1;
+            const long long CA = dpp_quad64<0xD8>(C); // C[trans[s][0]]: quad_perm [0,2,1,3]
+            const long long CB = dpp_quad64<0x72>(C); // C[trans[s][1]]: quad_perm [2,0,3,1]
+            // branch 0 keeps a0 (bits 0 instead of 1 inside the trailing run), branch 1 takes a0+1
+            long long K0 = (long long)cv.x + (par ? CB : CA);
+            if (tz && a0z) K0 -= ldq1;
+            const long long K1 = (long long)cv.y + (par ? CA : CB);
+            const bool pick1 = !zero && K1 < K0;
+            C = pick1 ? K1 : K0;
+            if (!pick1 && a0z && tz && (p & 15) == 15) C -= ldq1; // quantizer.rs:512-514
+            const unsigned nib = (unsigned)(__ballot(pick1) & 0xFULL);
+            if (c.lane == 0) s->decn[p] = (uint8_t)nib;
         }
-        const unsigned nib = (unsigned)(__ballot(pick1) & 0xFULL);
-        if (c.lane == 0) s->decn[p] = (uint8_t)nib;
     }
     WSYNC();
-    // forward trace from state 0 (quantizer.rs:686-721) fused with the level-cost walk
-    int state = 0;
-    long long sum = 0;
-    bool trailing = true;
-    for (int p = 0; p < P; ++p) {
-        const int tc = tcs[p];
-        const int qd = qds[p];
-        const int nib = s->decn[p];
-        int q = 0, a = 0;
-        const int dl = state > 1 ? 1 : 0;
-        if (tc != 0) {
-            const int a0 = (p == P - 1) ? (qd >> 1) : ((qd + dl) >> 1);
-            a = a0 + ((nib >> state) & 1);
-            if (p == P - 1)
-                q = (int)(int16_t)(2 * a - dl); // usize wrap + `as i16` (quantizer.rs:379,391)
-            else
-                q = a > 0 ? 2 * a - dl : 0;
-            if (tc < 0) q = -q;
+    // ---- forward trace from state 0 (quantizer.rs:686-721) + level-cost walk ----
+    const int per = P >= 64 ? (P >> 6) : 1; // consecutive positions per lane
+    const int p0 = c.lane * per;
+    const bool active = p0 < P;
+    int fmap = 0xE4; // identity map
+    if (active) {
+        for (int j = 0; j < per; ++j) {
+            const int p = p0 + j;
+            const int tc = tcs[p], qd = qds[p], nib = s->decn[p];
+            int g = 0;
+#pragma unroll
+            for (int sidx = 0; sidx < 4; ++sidx) {
+                const int dl = sidx > 1 ? 1 : 0;
+                int a = 0;
+                if (tc != 0) a = ((p == P - 1) ? (qd >> 1) : ((qd + dl) >> 1)) + ((nib >> sidx) & 1);
+                g |= ((0x7D28 >> (2 * (2 * sidx + (a & 1)))) & 3) << (2 * sidx);
+            }
+            fmap = compose_map(g, fmap);
         }
-        int x, y;
-        scan_pos(k, lg, p, x, y);
-        if (c.lane == 0) s->bufC[y * n + x] = (int16_t)q;
-        const int qc = abs(q);
-        if (qc == 0) {
-            if (!trailing) sum += lv_at(c, 0);
-        } else {
-            const int aw = (qc + dl) >> 1;
-            if (aw >= 1024) ovf = 1;
-            sum += lv_at(c, min(aw, 1023));
-        }
-        trailing = trailing && qc == 0;
-        state = (0x7D28 >> (2 * (2 * state + (a & 1)))) & 3; // {{0,2},{2,0},{1,3},{3,1}}, 2 bits each
     }
+    // inclusive prefix composition across lanes
+    int pre = fmap;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int other = __shfl_up(pre, d, 64);
+        if (c.lane >= d) pre = compose_map(pre, other);
+    }
+    int entry = __shfl_up(pre, 1, 64) & 3; // state after all previous lanes, starting from 0
+    if (c.lane == 0) entry = 0;
+    long long sum_nz = 0;
+    unsigned zmask = 0;
+    int fnz = P;
+    if (active) {
+        int state = entry;
+        for (int j = 0; j < per; ++j) {
+            const int p = p0 + j;
+            const int tc = tcs[p], qd = qds[p], nib = s->decn[p];
+            const int dl = state > 1 ? 1 : 0;
+            int q = 0, a = 0;
+            if (tc != 0) {
+                a = ((p == P - 1) ? (qd >> 1) : ((qd + dl) >> 1)) + ((nib >> state) & 1);
+                if (p == P - 1)
+                    q = (int)(int16_t)(2 * a - dl); // usize wrap + `as i16` (quantizer.rs:379,391)
+                else
+                    q = a > 0 ? 2 * a - dl : 0;
+                if (tc < 0) q = -q;
+            }
+            s->bufC[scan[p]] = (int16_t)q;
+            const int qc = abs(q);
+            if (qc == 0) {
+                zmask |= 1u << j;
+            } else {
+                const int aw = (qc + dl) >> 1;
+                if (aw >= 1024) ovf = 1;
+                sum_nz += lv_at(c, min(aw, 1023));
+                fnz = min(fnz, p);
+            }
+            state = (0x7D28 >> (2 * (2 * state + (a & 1)))) & 3;
+        }
+    }
+    const int pf = wave_min_i32(fnz); // zeros before the first non-zero level cost nothing
+    if (active) {
+        int nz_after = 0;
+        for (int j = 0; j < per; ++j)
+            if (((zmask >> j) & 1) && p0 + j > pf) ++nz_after;
+        sum_nz += (long long)nz_after * lv_at(c, 0);
+    }
+    const long long sum = (long long)wave_sum_u64((unsigned long long)sum_nz);
     if (__ballot(ovf != 0) != 0ULL) *overflow = 1;
     WSYNC();
     return sum;
@@ -836,7 +884,7 @@ __device__ long long quantize(const Ctx& c, int lg, int* overflow) {
 
 // levels bufC (row-major) -> transposed dequantised coefficients bufA (dT[x][i] = d[i][x]);
 // quantizer.rs:761-1079
-__device__ void dequantize_t(const Ctx& c, int lg) {
+__device__ __noinline__ void dequantize_t(const Ctx& c, int lg) {
     Lds* s = c.s;
     const int n = 1 << lg;
     const int sh = 8 + lg - 5 + 1;
@@ -861,7 +909,7 @@ struct CompCost {
 
 // predict -> T -> Q -> DQ -> IT -> recon (+SSD) of one component
 // (block_splitter.rs:146-185); levels stay in bufC.
-__device__ CompCost code_component(const Ctx& c, int comp, int tx, int ty, int tlg, int mode,
+__device__ __noinline__ CompCost code_component(const Ctx& c, int comp, int tx, int ty, int tlg, int mode,
                                    int* overflow) {
     Lds* s = c.s;
     const int cs = comp ? 1 : 0;
@@ -889,7 +937,7 @@ __device__ CompCost code_component(const Ctx& c, int comp, int tx, int ty, int t
 }
 
 // predict + SAD (block_splitter.rs:64-108)
-__device__ unsigned int sad_component(const Ctx& c, int comp, int tx, int ty, int tlg, int mode) {
+__device__ __noinline__ unsigned int sad_component(const Ctx& c, int comp, int tx, int ty, int tlg, int mode) {
     Lds* s = c.s;
     const int cs = comp ? 1 : 0;
     const int n = 1 << (tlg - cs);
@@ -918,7 +966,7 @@ __device__ __forceinline__ int nb_luma_mode(const Ctx& c, int x, int y, bool* ex
 
 // mode class index for the header-bit table: 0 planar, 1..5 mpm_idx, 6..66 remainder
 // (ctu.rs:1498-1635)
-__device__ int mpm_class(const Ctx& c, int bx, int by, int lg, int mode) {
+__device__ __noinline__ int mpm_class(const Ctx& c, int bx, int by, int lg, int mode) {
     if (mode == PLANAR) return 0;
     const int n = 1 << lg;
     bool le, ae;
@@ -932,55 +980,58 @@ __device__ int mpm_class(const Ctx& c, int bx, int by, int lg, int mode) {
         above = nb_luma_mode(c, bx + n - 1, by - 1, &ae);
         if (!ae) above = PLANAR;
     }
-    int cand[5];
+    int k0, k1, k2, k3, k4;
     if (left == above && left > DC) {
         const int m = left;
-        cand[0] = m;
-        cand[1] = 2 + (m + 61) % 64;
-        cand[2] = 2 + (m - 1) % 64;
-        cand[3] = 2 + (m + 60) % 64;
-        cand[4] = 2 + m % 64;
+        k0 = m;
+        k1 = 2 + (m + 61) % 64;
+        k2 = 2 + (m - 1) % 64;
+        k3 = 2 + (m + 60) % 64;
+        k4 = 2 + m % 64;
     } else if (left != above && (left > DC || above > DC)) {
         const int mn = min(left, above), mx = max(left, above);
         if (mn > DC) {
             const int d = mx - mn;
-            cand[0] = left;
-            cand[1] = above;
+            k0 = left;
+            k1 = above;
             if (d == 1) {
-                cand[2] = 2 + (mn + 61) % 64;
-                cand[3] = 2 + (mx - 1) % 64;
-                cand[4] = 2 + (mn + 60) % 64;
+                k2 = 2 + (mn + 61) % 64;
+                k3 = 2 + (mx - 1) % 64;
+                k4 = 2 + (mn + 60) % 64;
             } else if (d >= 62) {
-                cand[2] = 2 + (mn - 1) % 64;
-                cand[3] = 2 + (mx + 61) % 64;
-                cand[4] = 2 + mn % 64;
+                k2 = 2 + (mn - 1) % 64;
+                k3 = 2 + (mx + 61) % 64;
+                k4 = 2 + mn % 64;
             } else if (d == 2) {
-                cand[2] = 2 + (mn - 1) % 64;
-                cand[3] = 2 + (mn + 61) % 64;
-                cand[4] = 2 + (mx - 1) % 64;
+                k2 = 2 + (mn - 1) % 64;
+                k3 = 2 + (mn + 61) % 64;
+                k4 = 2 + (mx - 1) % 64;
             } else {
-                cand[2] = 2 + (mn + 61) % 64;
-                cand[3] = 2 + (mn - 1) % 64;
-                cand[4] = 2 + (mx + 61) % 64;
+                k2 = 2 + (mn + 61) % 64;
+                k3 = 2 + (mn - 1) % 64;
+                k4 = 2 + (mx + 61) % 64;
             }
         } else {
-            cand[0] = mx;
-            cand[1] = 2 + (mx + 61) % 64;
-            cand[2] = 2 + (mx - 1) % 64;
-            cand[3] = 2 + (mx + 60) % 64;
-            cand[4] = 2 + mx % 64;
+            k0 = mx;
+            k1 = 2 + (mx + 61) % 64;
+            k2 = 2 + (mx - 1) % 64;
+            k3 = 2 + (mx + 60) % 64;
+            k4 = 2 + mx % 64;
         }
     } else {
-        cand[0] = DC;
-        cand[1] = 50;
-        cand[2] = 18;
-        cand[3] = 46;
-        cand[4] = 54;
+        k0 = DC;
+        k1 = 50;
+        k2 = 18;
+        k3 = 46;
+        k4 = 54;
     }
-    for (int i = 0; i < 5; ++i)
-        if (cand[i] == mode) return 1 + i;
-    int smaller = 0; // remainder = mode - 1 - #(candidates below mode) after sorting (:1613-1628)
-    for (int i = 0; i < 5; ++i) smaller += cand[i] < mode ? 1 : 0;
+    if (k0 == mode) return 1;
+    if (k1 == mode) return 2;
+    if (k2 == mode) return 3;
+    if (k3 == mode) return 4;
+    if (k4 == mode) return 5;
+    // remainder = mode - 1 - #(candidates below mode) after sorting (:1613-1628)
+    const int smaller = (k0 < mode) + (k1 < mode) + (k2 < mode) + (k3 < mode) + (k4 < mode);
     return 6 + (mode - 1 - smaller);
 }
 
@@ -1001,7 +1052,7 @@ struct LeafResult {
 };
 
 // get_intra_pred_cost (block_splitter.rs:110-474) for modes [ml, mc, mc]
-__device__ float full_cost(const Ctx& c, int tree, int bx, int by, int lg, int ml, int mc,
+__device__ __noinline__ float full_cost(const Ctx& c, int tree, int bx, int by, int lg, int ml, int mc,
                            int* overflow) {
     const int cls = mpm_class(c, bx, by, lg, ml);
     const bool cclm = mc >= LT_CCLM;
@@ -1025,7 +1076,7 @@ __device__ float full_cost(const Ctx& c, int tree, int bx, int by, int lg, int m
 }
 
 // get_intra_pred_aux_cost (block_splitter.rs:64-108) for modes [m; 3]
-__device__ float aux_cost(const Ctx& c, int tree, int bx, int by, int lg, int m) {
+__device__ __noinline__ float aux_cost(const Ctx& c, int tree, int bx, int by, int lg, int m) {
     unsigned long long sad = sad_component(c, 0, bx, by, lg, m);
     if (tree == TREE_SINGLE) {
         sad += sad_component(c, 1, bx, by, lg, m);
@@ -1035,7 +1086,7 @@ __device__ float aux_cost(const Ctx& c, int tree, int bx, int by, int lg, int m)
 }
 
 // get_chroma_intra_pred_cost (block_splitter.rs:524-780)
-__device__ float chroma_full_cost(const Ctx& c, int bx, int by, int lg, int mc, int* overflow) {
+__device__ __noinline__ float chroma_full_cost(const Ctx& c, int bx, int by, int lg, int mc, int* overflow) {
     unsigned long long ssd = 0;
     long long level = 0;
     for (int comp = 1; comp < 3; ++comp) {
@@ -1048,7 +1099,7 @@ __device__ float chroma_full_cost(const Ctx& c, int bx, int by, int lg, int mc, 
 }
 
 // get_chroma_intra_pred_aux_cost (block_splitter.rs:476-522)
-__device__ float chroma_aux_cost(const Ctx& c, int bx, int by, int lg, int mc) {
+__device__ __noinline__ float chroma_aux_cost(const Ctx& c, int bx, int by, int lg, int mc) {
     unsigned long long sad = sad_component(c, 1, bx, by, lg, mc);
     sad += sad_component(c, 2, bx, by, lg, mc);
     return (float)sad;
@@ -1077,7 +1128,7 @@ __device__ __forceinline__ int pick_cclm(float lt, float t, float l) {
 }
 
 // leaf search of a DUAL_TREE_CHROMA block (block_splitter.rs:794-885); lg = luma log2 (3)
-__device__ LeafResult leaf_chroma(const Ctx& c, int bx, int by, int lg, int dm_mode, int* overflow) {
+__device__ __noinline__ LeafResult leaf_chroma(const Ctx& c, int bx, int by, int lg, int dm_mode, int* overflow) {
     const float lt = chroma_aux_cost(c, bx, by, lg, LT_CCLM);
     const float t = chroma_aux_cost(c, bx, by, lg, T_CCLM);
     const float l = chroma_aux_cost(c, bx, by, lg, L_CCLM);
@@ -1100,13 +1151,13 @@ __device__ LeafResult leaf_chroma(const Ctx& c, int bx, int by, int lg, int dm_m
 }
 
 // leaf search of a SINGLE_TREE / DUAL_TREE_LUMA block (block_splitter.rs:886-1078)
-__device__ LeafResult leaf_luma(const Ctx& c, int tree, int bx, int by, int lg, int* overflow) {
-    const int cand_modes[15] = {0, 1, 2, 7, 13, 18, 23, 29, 34, 39, 45, 50, 55, 60, 66};
+__device__ __noinline__ LeafResult leaf_luma(const Ctx& c, int tree, int bx, int by, int lg, int* overflow) {
     float cost_planar = 0.f, cost_dc = 0.f;
     float min_dir_cost = 3.40282347e+38f;
     int min_dir_mode = 2;
     for (int i = 0; i < 15; ++i) {
-        const int m = cand_modes[i];
+        // {0,1,2,7,13,18,23,29,34,39,45,50,55,60,66} (:887), 7 bits each
+        const int m = i < 8 ? (int)((0x3A5C90D0E08080ULL >> (7 * i)) & 127) : (int)((0x109E3764B53A2ULL >> (7 * (i - 8))) & 127);
         if (m <= 1) {
             const float v = full_cost(c, tree, bx, by, lg, m, m, overflow);
             if (m == 0) cost_planar = v; else cost_dc = v;
@@ -1189,7 +1240,7 @@ __device__ LeafResult leaf_luma(const Ctx& c, int tree, int bx, int by, int lg, 
 // ---------------------------------------------------------------------------
 // Decision maps and recon save/restore
 // ---------------------------------------------------------------------------
-__device__ void fill_maps(const Ctx& c, int bx, int by, int lg, int luma_mode, int chroma_mode,
+__device__ __noinline__ void fill_maps(const Ctx& c, int bx, int by, int lg, int luma_mode, int chroma_mode,
                           bool luma, bool chroma) {
     Lds* s = c.s;
     const int n4 = (1 << lg) >> 2;
@@ -1210,7 +1261,7 @@ __device__ void fill_maps(const Ctx& c, int bx, int by, int lg, int luma_mode, i
 __device__ __forceinline__ int save_off_y(int lg) { return lg == 5 ? 0 : (lg == 4 ? 1024 : 1280); }
 __device__ __forceinline__ int save_off_c(int lg) { return lg == 5 ? 0 : (lg == 4 ? 256 : 320); }
 
-__device__ void save_recon(const Ctx& c, int bx, int by, int lg) {
+__device__ __noinline__ void save_recon(const Ctx& c, int bx, int by, int lg) {
     Lds* s = c.s;
     const int n = 1 << lg;
     uint8_t* dy = s->saveY + save_off_y(lg);
@@ -1223,7 +1274,7 @@ __device__ void save_recon(const Ctx& c, int bx, int by, int lg) {
     }
     WSYNC();
 }
-__device__ void restore_recon(const Ctx& c, int bx, int by, int lg) {
+__device__ __noinline__ void restore_recon(const Ctx& c, int bx, int by, int lg) {
     Lds* s = c.s;
     const int n = 1 << lg;
     const uint8_t* dy = s->saveY + save_off_y(lg);
@@ -1238,46 +1289,104 @@ __device__ void restore_recon(const Ctx& c, int bx, int by, int lg) {
 }
 
 // ---------------------------------------------------------------------------
-// split_ct (block_splitter.rs:782-1154) for SINGLE_TREE nodes, LG = log2 size
+// split_ct (block_splitter.rs:782-1154): exhaustive quad-tree search of one CTU as an
+// explicit depth-first walk (level 0 = 32x32 ... level 2 = 8x8; an 8x8 node's split is
+// four DUAL_TREE_LUMA 4x4 leaves + one DUAL_TREE_CHROMA 4x4 leaf, ctu.rs:1990-2063).
+// Per-level state lives in LDS (wave-uniform).
 // ---------------------------------------------------------------------------
-template <int LG>
-__device__ float split_ct(Ctx& c, int bx, int by, int depth_left, int* overflow) {
-    const LeafResult ns = leaf_luma(c, TREE_SINGLE, bx, by, LG, overflow);
-    fill_maps(c, bx, by, LG, ns.luma_mode, ns.chroma_mode, true, true);
-    if (LG == 5) c.cu32_mode = ns.luma_mode;
-    if (depth_left == 0) return ns.cost;
-    save_recon(c, bx, by, LG);
+__device__ __noinline__ float split_node8(const Ctx& c, int bx, int by, int* overflow) {
     float split_cost = 0.0f;
-    if constexpr (LG > 3) {
-        constexpr int H = 1 << (LG - 1);
-        for (int i = 0; i < 4; ++i)
-            split_cost = split_cost + split_ct<LG - 1>(c, bx + (i & 1) * H, by + (i >> 1) * H, depth_left - 1, overflow);
-    } else {
-        // 8x8 -> four DUAL_TREE_LUMA 4x4 + one DUAL_TREE_CHROMA 4x4 (ctu.rs:1990-2063)
-        for (int i = 0; i < 4; ++i) {
-            const int cxx = bx + (i & 1) * 4, cyy = by + (i >> 1) * 4;
-            const LeafResult r = leaf_luma(c, TREE_DUAL_LUMA, cxx, cyy, 2, overflow);
-            fill_maps(c, cxx, cyy, 2, r.luma_mode, 0, true, false);
-            split_cost = split_cost + r.cost;
-        }
-        // DM = luma mode of the CU covering the parent's centre (block_splitter.rs:795-805)
-        const int dm = c.s->luma_mode[((by + 4) >> 2) * 8 + ((bx + 4) >> 2)];
-        const LeafResult r = leaf_chroma(c, bx, by, 3, dm, overflow);
-        fill_maps(c, bx, by, 3, 0, r.chroma_mode, false, true);
+    for (int i = 0; i < 4; ++i) {
+        const int cxx = bx + (i & 1) * 4, cyy = by + (i >> 1) * 4;
+        const LeafResult r = leaf_luma(c, TREE_DUAL_LUMA, cxx, cyy, 2, overflow);
+        fill_maps(c, cxx, cyy, 2, r.luma_mode, 0, true, false);
         split_cost = split_cost + r.cost;
     }
-    if (split_cost > ns.cost) { // :1125-1145
-        restore_recon(c, bx, by, LG);
-        fill_maps(c, bx, by, LG, ns.luma_mode, ns.chroma_mode, true, true);
-        return ns.cost;
+    // DM = luma mode of the CU covering the parent's centre (block_splitter.rs:795-805)
+    const int dm = c.s->luma_mode[((by + 4) >> 2) * 8 + ((bx + 4) >> 2)];
+    const LeafResult r = leaf_chroma(c, bx, by, 3, dm, overflow);
+    fill_maps(c, bx, by, 3, 0, r.chroma_mode, false, true);
+    return split_cost + r.cost;
+}
+
+__device__ float split_ct_ctu(Ctx& c, int max_depth, int* overflow) {
+    Lds* s = c.s;
+    int level = 0;
+    int bx = 0, by = 0;
+    float ret = 0.0f;
+    for (;;) {
+        // ---- enter node (bx, by) at `level` ----
+        const int lg = 5 - level;
+        const LeafResult ns = leaf_luma(c, TREE_SINGLE, bx, by, lg, overflow);
+        fill_maps(c, bx, by, lg, ns.luma_mode, ns.chroma_mode, true, true);
+        if (level == 0) c.cu32_mode = ns.luma_mode;
+        bool done;
+        if (max_depth - level == 0) {
+            ret = ns.cost;
+            done = true;
+        } else {
+            save_recon(c, bx, by, lg);
+            if (c.lane == 0) {
+                s->ns_cost[level] = ns.cost;
+                s->ns_luma[level] = (uint8_t)ns.luma_mode;
+                s->ns_chroma[level] = (uint8_t)ns.chroma_mode;
+                s->split_cost[level] = 0.0f;
+                s->child[level] = 0;
+            }
+            WSYNC();
+            if (lg > 3) {
+                level += 1; // descend into child 0 (same top-left corner)
+                continue;
+            }
+            const float sc = split_node8(c, bx, by, overflow);
+            if (sc > ns.cost) { // :1125-1145
+                restore_recon(c, bx, by, lg);
+                fill_maps(c, bx, by, lg, ns.luma_mode, ns.chroma_mode, true, true);
+                ret = ns.cost;
+            } else {
+                ret = sc;
+            }
+            done = true;
+        }
+        // ---- return `ret` from a finished node to its ancestors ----
+        while (done) {
+            if (level == 0) return ret;
+            const int pl = level - 1;
+            const int psz = 1 << (5 - pl);
+            const int pbx = bx & ~(psz - 1), pby = by & ~(psz - 1);
+            const float acc = s->split_cost[pl] + ret; // children in z-order, f32 (:1116-1123)
+            const int ch = s->child[pl] + 1;
+            WSYNC();
+            if (c.lane == 0) {
+                s->split_cost[pl] = acc;
+                s->child[pl] = (uint8_t)ch;
+            }
+            WSYNC();
+            if (ch < 4) { // next sibling
+                bx = pbx + (ch & 1) * (psz >> 1);
+                by = pby + (ch >> 1) * (psz >> 1);
+                done = false;
+            } else { // parent complete
+                const float nsc = s->ns_cost[pl];
+                bx = pbx;
+                by = pby;
+                level = pl;
+                if (acc > nsc) {
+                    restore_recon(c, bx, by, 5 - pl);
+                    fill_maps(c, bx, by, 5 - pl, s->ns_luma[pl], s->ns_chroma[pl], true, true);
+                    ret = nsc;
+                } else {
+                    ret = acc;
+                }
+            }
+        }
     }
-    return split_cost;
 }
 
 // ---------------------------------------------------------------------------
 // Final pass (ctu_encoder.rs:1421-1461) in coding order; writes levels to HBM
 // ---------------------------------------------------------------------------
-__device__ void final_component(const Ctx& c, const PicBufs& pb, int comp, int tx, int ty, int tlg,
+__device__ __noinline__ void final_component(const Ctx& c, const PicBufs& pb, int comp, int tx, int ty, int tlg,
                                 int mode, int* overflow) {
     Lds* s = c.s;
     const int cs = comp ? 1 : 0;
@@ -1304,31 +1413,30 @@ __device__ void final_component(const Ctx& c, const PicBufs& pb, int comp, int t
     WSYNC();
 }
 
-template <int LG>
-__device__ void final_pass(const Ctx& c, const PicBufs& pb, int bx, int by, int* overflow) {
+// coding order = z-order over the 4x4 units; a CU is emitted at its top-left unit
+__device__ void final_pass_ctu(const Ctx& c, const PicBufs& pb, int* overflow) {
     Lds* s = c.s;
-    const int sz = s->cu_log2[(by >> 2) * 8 + (bx >> 2)];
-    if (sz == LG) {
-        const int ml = s->luma_mode[(by >> 2) * 8 + (bx >> 2)];
-        const int mc = s->chroma_mode[(by >> 3) * 4 + (bx >> 3)];
-        final_component(c, pb, 0, bx, by, LG, ml, overflow);
-        if constexpr (LG >= 3) {
-            final_component(c, pb, 1, bx, by, LG, mc, overflow);
-            final_component(c, pb, 2, bx, by, LG, mc, overflow);
+    for (int z = 0; z < 64; ++z) {
+        const int x4 = (z & 1) | ((z >> 1) & 2) | ((z >> 2) & 4);
+        const int y4 = ((z >> 1) & 1) | ((z >> 2) & 2) | ((z >> 3) & 4);
+        const int lg = s->cu_log2[y4 * 8 + x4];
+        const int bx = x4 * 4, by = y4 * 4;
+        const int sz = 1 << lg;
+        if ((bx & (sz - 1)) == 0 && (by & (sz - 1)) == 0) {
+            const int ml = s->luma_mode[y4 * 8 + x4];
+            final_component(c, pb, 0, bx, by, lg, ml, overflow);
+            if (lg >= 3) {
+                const int mc = s->chroma_mode[(by >> 3) * 4 + (bx >> 3)];
+                final_component(c, pb, 1, bx, by, lg, mc, overflow);
+                final_component(c, pb, 2, bx, by, lg, mc, overflow);
+            }
         }
-        return;
-    }
-    if constexpr (LG > 3) {
-        constexpr int H = 1 << (LG - 1);
-        for (int i = 0; i < 4; ++i) final_pass<LG - 1>(c, pb, bx + (i & 1) * H, by + (i >> 1) * H, overflow);
-    } else if constexpr (LG == 3) {
-        for (int i = 0; i < 4; ++i) {
-            const int cxx = bx + (i & 1) * 4, cyy = by + (i >> 1) * 4;
-            final_component(c, pb, 0, cxx, cyy, 2, s->luma_mode[(cyy >> 2) * 8 + (cxx >> 2)], overflow);
+        if (lg == 2 && (z & 3) == 3) { // after the fourth 4x4 luma CU: the 8x8's chroma CU
+            const int pbx = bx & ~7, pby = by & ~7;
+            const int mc = s->chroma_mode[(pby >> 3) * 4 + (pbx >> 3)];
+            final_component(c, pb, 1, pbx, pby, 3, mc, overflow);
+            final_component(c, pb, 2, pbx, pby, 3, mc, overflow);
         }
-        const int mc = s->chroma_mode[(by >> 3) * 4 + (bx >> 3)];
-        final_component(c, pb, 1, bx, by, 3, mc, overflow);
-        final_component(c, pb, 2, bx, by, 3, mc, overflow);
     }
 }
 
@@ -1393,8 +1501,8 @@ __device__ void encode_ctu(Ctx& c, const PicBufs& pb, int ctu_col, int ctu_row, 
             c.ctu_x > 0 ? pb.luma_mode[(size_t)((c.ctu_y >> 2) + c.lane) * (W >> 2) + (c.ctu_x >> 2) - 1] : 0;
     WSYNC();
     (void)H;
-    const float cost = split_ct<5>(c, 0, 0, k->max_depth, overflow);
-    final_pass<5>(c, pb, 0, 0, overflow);
+    const float cost = split_ct_ctu(c, k->max_depth, overflow);
+    final_pass_ctu(c, pb, overflow);
     // store recon + decisions
     for (int i = c.lane; i < 1024 / 4; i += 64) {
         const int y = i >> 3, x4 = (i & 7) * 4;

@@ -24,7 +24,7 @@ using namespace wrenc;
 // ---------------------------------------------------------------------------
 // kernels
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void ctu_search_kernel(const DevConst* __restrict__ k,
+__global__ __launch_bounds__(64, 4) void ctu_search_kernel(const DevConst* __restrict__ k,
                                                         const PicBufs* __restrict__ slots,
                                                         int first_slot, int diag, int r_min, int count,
                                                         unsigned long long* mismatch, int* overflow) {
@@ -45,7 +45,7 @@ __global__ __launch_bounds__(64) void ctu_search_kernel(const DevConst* __restri
 }
 
 // building-block kernels: one wave per block of side 1 << lg
-__global__ __launch_bounds__(64) void test_fwd_dct_kernel(const DevConst* __restrict__ k,
+__global__ __launch_bounds__(64, 4) void test_fwd_dct_kernel(const DevConst* __restrict__ k,
                                                           const int16_t* in, int lg, int16_t* out) {
     __shared__ Lds lds;
     Ctx c;
@@ -59,7 +59,7 @@ __global__ __launch_bounds__(64) void test_fwd_dct_kernel(const DevConst* __rest
     for (int i = threadIdx.x; i < nn; i += 64) out[(size_t)blockIdx.x * nn + i] = lds.bufB[i];
 }
 
-__global__ __launch_bounds__(64) void test_inv_dct_kernel(const DevConst* __restrict__ k,
+__global__ __launch_bounds__(64, 4) void test_inv_dct_kernel(const DevConst* __restrict__ k,
                                                           const int16_t* in, int lg, int16_t* out) {
     __shared__ Lds lds;
     Ctx c;
@@ -74,7 +74,7 @@ __global__ __launch_bounds__(64) void test_inv_dct_kernel(const DevConst* __rest
     for (int i = threadIdx.x; i < nn; i += 64) out[(size_t)blockIdx.x * nn + i] = lds.bufA[i];
 }
 
-__global__ __launch_bounds__(64) void test_quantize_kernel(const DevConst* __restrict__ k,
+__global__ __launch_bounds__(64, 4) void test_quantize_kernel(const DevConst* __restrict__ k,
                                                            const int16_t* in, int lg, int16_t* out,
                                                            long long* cost, int* overflow) {
     __shared__ Lds lds;
@@ -95,7 +95,7 @@ __global__ __launch_bounds__(64) void test_quantize_kernel(const DevConst* __res
     }
 }
 
-__global__ __launch_bounds__(64) void test_dequantize_kernel(const DevConst* __restrict__ k,
+__global__ __launch_bounds__(64, 4) void test_dequantize_kernel(const DevConst* __restrict__ k,
                                                              const int16_t* in, int lg, int16_t* out) {
     __shared__ Lds lds;
     Ctx c;
@@ -235,6 +235,15 @@ void fill_dev_const(const wrenc_gpu_config& cfg, DevConst& k) {
     }
     diag_scan(2, 2, k.diag4);
     for (int idx = 0; idx < 4; ++idx) diag_scan(idx, idx, k.diag_sb[idx]);
+    for (int idx = 0; idx < 4; ++idx) { // reverse-scan position -> raster index (ctu.rs:827-845: 4x4 sub-blocks)
+        const int lg = idx + 2, n = 1 << lg, nsb = 1 << (2 * lg - 4);
+        for (int p = 0; p < n * n; ++p) {
+            const int sb = nsb - 1 - (p >> 4), sp = 15 - (p & 15);
+            const int x = (k.diag_sb[idx][sb][0] << 2) + k.diag4[sp][0];
+            const int y = (k.diag_sb[idx][sb][1] << 2) + k.diag4[sp][1];
+            k.scan_idx[idx][p] = (uint16_t)(y * n + x);
+        }
+    }
     memcpy(k.intra_angle, kIntraAngle, sizeof(kIntraAngle));
     memcpy(k.fc, kFC, sizeof(kFC));
 }
