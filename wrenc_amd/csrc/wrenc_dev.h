@@ -64,6 +64,7 @@ struct __attribute__((aligned(16))) Lds {
     int32_t bufH[33 * 32];
     int32_t ldq[256];
     int32_t lv[256];
+    int8_t fc[32][4];          // common.rs:153 (copied from the constant block)
     int16_t refL[136];
     int16_t refA[136];
     int16_t refLf[136];
@@ -89,16 +90,63 @@ struct __attribute__((aligned(16))) Lds {
 };
 
 // Per-wave uniform context.
+// Per-wave uniform context, passed BY VALUE (a few registers) so that the out-of-line
+// stage functions never reload it from memory.
 struct Ctx {
-    const DevConst* k;
-    Lds* s;
+    const DevConst* __restrict__ k;
     int ctu_x, ctu_y; // luma, picture coordinates
-    int lane;
     int cu32_mode;    // in-CTU neighbour lookups during search resolve to the root CU
     unsigned long long* mismatch;
 };
 
-#define WSYNC() __syncthreads()
+// The one LDS object of every kernel in this translation unit (one wave per block).
+// File scope so that every access is a DS instruction (no generic-pointer FLAT ops).
+__shared__ Lds SH;
+#define LANE ((int)threadIdx.x)
+
+// Everything in Ctx and every block-geometry argument is wave-uniform.  Out-of-line
+// functions receive arguments in VGPRs; re-deriving them through readfirstlane lets the
+// compiler keep them in SGPRs (scalar ALU, scalar branches, s_load from the constant block).
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ Ctx uni(Ctx c) {
+    const unsigned long long kp = (unsigned long long)c.k, mp = (unsigned long long)c.mismatch;
+    const unsigned long long ku = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(kp >> 32)) << 32) |
+                                  (unsigned)__builtin_amdgcn_readfirstlane((int)kp);
+    const unsigned long long mu = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(mp >> 32)) << 32) |
+                                  (unsigned)__builtin_amdgcn_readfirstlane((int)mp);
+    Ctx r;
+    r.k = (const DevConst*)ku;
+    r.mismatch = (unsigned long long*)mu;
+    r.ctu_x = __builtin_amdgcn_readfirstlane(c.ctu_x);
+    r.ctu_y = __builtin_amdgcn_readfirstlane(c.ctu_y);
+    r.cu32_mode = __builtin_amdgcn_readfirstlane(c.cu32_mode);
+    return r;
+}
+
+// One wave per block: LDS operations of a wave are issued and serviced in program order,
+// so "synchronising" only has to stop the compiler from reordering LDS accesses.
+#define WSYNC()                                                  \
+    do {                                                         \
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   \
+        __builtin_amdgcn_wave_barrier();                         \
+    } while (0)
+
+// Diagnostic build only (-DWRENC_PROFILE): per-phase cycle counters, summed per wave and
+// added to a global table at CTU end.  Never compiled into the product library.
+#ifdef WRENC_PROFILE
+enum { PH_PREDICT, PH_FDCT, PH_QPRE, PH_QBACK, PH_QTRACE, PH_DEQ, PH_IDCT, PH_RECON, PH_TOTAL, PH_COUNT };
+__device__ unsigned long long g_prof[PH_COUNT];
+__shared__ unsigned long long s_prof[PH_COUNT];
+#define PROF_T0() const unsigned long long prof_t0_ = __builtin_readcyclecounter()
+#define PROF_ADD(ph) do { if (threadIdx.x == 0) s_prof[ph] += __builtin_readcyclecounter() - prof_t0_; } while (0)
+#define PROF_MARK(var) const unsigned long long var = __builtin_readcyclecounter()
+#define PROF_ADD2(ph, a, b) do { if (threadIdx.x == 0) s_prof[ph] += (b) - (a); } while (0)
+#else
+#define PROF_T0()
+#define PROF_ADD(ph)
+#define PROF_MARK(var)
+#define PROF_ADD2(ph, a, b)
+#endif
 
 // ---------------------------------------------------------------------------
 // wave helpers
@@ -123,25 +171,25 @@ __device__ __forceinline__ int ilog2i(int v) { return 31 - __clz(v); }
 // ---------------------------------------------------------------------------
 // recon tile access (CTU-local component coordinates)
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ int rec_get(const Lds* s, int c, int x, int y) {
-    if (c == 0) return y < 0 ? s->recYtop[x + 4] : s->recY[y * 36 + x + 4];
-    return y < 0 ? s->recCtop[c - 1][x + 4] : s->recC[c - 1][y * 20 + x + 4];
+__device__ __forceinline__ int rec_get(int c, int x, int y) {
+    if (c == 0) return y < 0 ? SH.recYtop[x + 4] : SH.recY[y * 36 + x + 4];
+    return y < 0 ? SH.recCtop[c - 1][x + 4] : SH.recC[c - 1][y * 20 + x + 4];
 }
-__device__ __forceinline__ void rec_put(Lds* s, int c, int x, int y, int v) {
+__device__ __forceinline__ void rec_put(int c, int x, int y, int v) {
     if (c == 0)
-        s->recY[y * 36 + x + 4] = (uint8_t)v;
+        SH.recY[y * 36 + x + 4] = (uint8_t)v;
     else
-        s->recC[c - 1][y * 20 + x + 4] = (uint8_t)v;
+        SH.recC[c - 1][y * 20 + x + 4] = (uint8_t)v;
 }
-__device__ __forceinline__ int org_get(const Lds* s, int c, int x, int y) {
-    return c == 0 ? s->orgY[y * 32 + x] : s->orgC[c - 1][y * 16 + x];
+__device__ __forceinline__ int org_get(int c, int x, int y) {
+    return c == 0 ? SH.orgY[y * 32 + x] : SH.orgC[c - 1][y * 16 + x];
 }
 
 // ---------------------------------------------------------------------------
 // availability (ctu.rs:2083-2188, encoder_context.rs:918-956)
 // bx, by: CTU-local luma position, lg: log2 luma size
 // ---------------------------------------------------------------------------
-__device__ inline bool above_right_avail(const Ctx& c, int bx, int by, int lg) {
+__device__ inline bool above_right_avail(Ctx c, int bx, int by, int lg) {
     for (;;) {
         const int n = 1 << lg;
         if (c.ctu_x + bx + n >= c.k->W) return false;
@@ -158,7 +206,7 @@ __device__ inline bool above_right_avail(const Ctx& c, int bx, int by, int lg) {
         return false;
     }
 }
-__device__ inline bool below_left_avail(const Ctx& c, int bx, int by, int lg) {
+__device__ inline bool below_left_avail(Ctx c, int bx, int by, int lg) {
     for (;;) {
         const int n = 1 << lg;
         if (c.ctu_y + by + n >= c.k->H) return false;
@@ -171,7 +219,7 @@ __device__ inline bool below_left_avail(const Ctx& c, int bx, int by, int lg) {
         lg += 1;
     }
 }
-__device__ __forceinline__ bool nb_avail(const Ctx& c, int gx, int gy, int tn, int xn, int yn,
+__device__ __forceinline__ bool nb_avail(Ctx c, int gx, int gy, int tn, int xn, int yn,
                                          bool ar, bool bl) {
     return xn >= 0 && yn >= 0 && xn < c.k->W && yn < c.k->H &&
            ((xn >> 5) <= (gx >> 5) || (yn >> 5) < (gy >> 5)) && (yn >> 5) < (gy >> 5) + 1 &&
@@ -181,15 +229,20 @@ __device__ __forceinline__ bool nb_avail(const Ctx& c, int gx, int gy, int tn, i
 // ---------------------------------------------------------------------------
 // Intra prediction.  tx, ty: CTU-local luma position of the TU, tlg: log2 luma
 // size, comp: component, mode: TU-array prediction mode.
-// Writes s->pred (compact n*n) and the residual org - pred into s->bufA.
+// Writes SH.pred (compact n*n) and the residual org - pred into SH.bufA.
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ int pdpc_w(int n_scale, int i) {
     const int sh = (i << 1) >> n_scale;
     return sh > 5 ? 0 : (32 >> sh);
 }
 
-__device__ __noinline__ void build_refs(const Ctx& c, int comp, int tx, int ty, int tlg, int mode) {
-    Lds* s = c.s;
+__device__ __forceinline__ void build_refs(Ctx c, int comp, int tx, int ty, int tlg, int mode) {
+    c = uni(c);
+    comp = uni(comp);
+    tx = uni(tx);
+    ty = uni(ty);
+    tlg = uni(tlg);
+    mode = uni(mode);
     const int cs = comp ? 1 : 0;
     const int n = 1 << (tlg - cs);
     const int tn = 1 << tlg;
@@ -207,7 +260,7 @@ __device__ __noinline__ void build_refs(const Ctx& c, int comp, int tx, int ty, 
     avm |= nb_avail(c, gx, gy, tn, gx + tn, gy - st, ar, bl) ? 16 : 0;
     const bool any = avm != 0;
     const int total = 4 * n + 1;
-    for (int t = c.lane; t < total; t += 64) {
+    for (int t = LANE; t < total; t += 64) {
         // unified item: t <= 2n -> left index li = t (li 0 = corner, li k -> y = k-1); else above
         int seg;
         const bool is_left = t <= 2 * n;
@@ -240,37 +293,37 @@ __device__ __noinline__ void build_refs(const Ctx& c, int comp, int tx, int ty, 
                     else { src_left = false; sai = n; }
                 }
             }
-            v = src_left ? rec_get(s, comp, cx - 1, cy + sli - 1) : rec_get(s, comp, cx + sai, cy - 1);
+            v = src_left ? rec_get(comp, cx - 1, cy + sli - 1) : rec_get(comp, cx + sai, cy - 1);
         }
         if (is_left)
-            s->refL[li] = (int16_t)v;
+            SH.refL[li] = (int16_t)v;
         else
-            s->refA[ai] = (int16_t)v;
+            SH.refA[ai] = (int16_t)v;
     }
     WSYNC();
     // [1 2 1] filter, intra_predictor.rs:304-352
     const bool filt = comp == 0 && n * n > 32 && (mode == 0 || mode == 2 || mode == 34 || mode == 66);
-    for (int t = c.lane; t < total; t += 64) {
+    for (int t = LANE; t < total; t += 64) {
         if (t <= 2 * n) {
             const int li = t;
             int v;
             if (!filt || li == 2 * n)
-                v = s->refL[li];
+                v = SH.refL[li];
             else if (li == 0)
-                v = (s->refL[1] + 2 * s->refL[0] + s->refA[0] + 2) >> 2;
+                v = (SH.refL[1] + 2 * SH.refL[0] + SH.refA[0] + 2) >> 2;
             else
-                v = (s->refL[li + 1] + 2 * s->refL[li] + s->refL[li - 1] + 2) >> 2;
-            s->refLf[li] = (int16_t)v;
+                v = (SH.refL[li + 1] + 2 * SH.refL[li] + SH.refL[li - 1] + 2) >> 2;
+            SH.refLf[li] = (int16_t)v;
         } else {
             const int ai = t - (2 * n + 1);
             int v;
             if (!filt || ai == 2 * n - 1)
-                v = s->refA[ai];
+                v = SH.refA[ai];
             else if (ai == 0)
-                v = (s->refL[0] + 2 * s->refA[0] + s->refA[1] + 2) >> 2;
+                v = (SH.refL[0] + 2 * SH.refA[0] + SH.refA[1] + 2) >> 2;
             else
-                v = (s->refA[ai - 1] + 2 * s->refA[ai] + s->refA[ai + 1] + 2) >> 2;
-            s->refAf[ai] = (int16_t)v;
+                v = (SH.refA[ai - 1] + 2 * SH.refA[ai] + SH.refA[ai + 1] + 2) >> 2;
+            SH.refAf[ai] = (int16_t)v;
         }
     }
     WSYNC();
@@ -283,19 +336,25 @@ struct CclmParams {
     bool avail_l;
 };
 
-__device__ __forceinline__ int cclm_w(const Ctx& c, int tx, int ty, int y, int x, bool avail_l) {
+__device__ __forceinline__ int cclm_w(Ctx c, int tx, int ty, int y, int x, bool avail_l) {
     // padded luma window p_y_xm3_ym3 (:1766-1818): column -1 repeats column 0 when the left
     // neighbour is unavailable; every other read hits reconstructed luma
     if (x < 0 && !avail_l) x = 0;
-    return rec_get(c.s, 0, tx + x, ty + y);
+    return rec_get(0, tx + x, ty + y);
 }
-__device__ __forceinline__ int cclm_ds6(const Ctx& c, int tx, int ty, int sy, int sx, bool avail_l) {
+__device__ __forceinline__ int cclm_ds6(Ctx c, int tx, int ty, int sy, int sx, bool avail_l) {
     return (cclm_w(c, tx, ty, sy, sx - 1, avail_l) + cclm_w(c, tx, ty, sy + 1, sx - 1, avail_l) +
             cclm_w(c, tx, ty, sy, sx, avail_l) * 2 + cclm_w(c, tx, ty, sy + 1, sx, avail_l) * 2 +
             cclm_w(c, tx, ty, sy, sx + 1, avail_l) + cclm_w(c, tx, ty, sy + 1, sx + 1, avail_l) + 4) >> 3;
 }
 
-__device__ __noinline__ CclmParams cclm_params(const Ctx& c, int comp, int tx, int ty, int tlg, int mode) {
+__device__ __forceinline__ CclmParams cclm_params(Ctx c, int comp, int tx, int ty, int tlg, int mode) {
+    c = uni(c);
+    comp = uni(comp);
+    tx = uni(tx);
+    ty = uni(ty);
+    tlg = uni(tlg);
+    mode = uni(mode);
     CclmParams r;
     const int tn = 1 << tlg;
     const int tw = tn >> 1, th = tw;
@@ -350,7 +409,7 @@ __device__ __noinline__ CclmParams cclm_params(const Ctx& c, int comp, int tx, i
         cnt_t = min((1 + num_is_4) << 1, num_samp_t);
         for (int i = 0; i < cnt_t; ++i) {
             const int pos = start + i * step;
-            const int sc = rec_get(c.s, comp, cx + pos, cy - 1);
+            const int sc = rec_get(comp, cx + pos, cy - 1);
             const int sx = 2 * pos;
             int sy;
             if (!b_ctu_boundary)
@@ -369,7 +428,7 @@ __device__ __noinline__ CclmParams cclm_params(const Ctx& c, int comp, int tx, i
         cnt_l = min((1 + num_is_4) << 1, num_samp_l);
         for (int i = 0; i < cnt_l; ++i) {
             const int pos = start + i * step;
-            put(cnt_t + i, cclm_ds6(c, tx, ty, 2 * pos, -2, avail_l), rec_get(c.s, comp, cx - 1, cy + pos));
+            put(cnt_t + i, cclm_ds6(c, tx, ty, 2 * pos, -2, avail_l), rec_get(comp, cx - 1, cy + pos));
         }
     }
     // min group {0,2}, max group {1,3} and the four compare-exchanges of :1973-1986,
@@ -414,8 +473,13 @@ __device__ __noinline__ CclmParams cclm_params(const Ctx& c, int comp, int tx, i
     return r;
 }
 
-__device__ __noinline__ void predict(const Ctx& c, int comp, int tx, int ty, int tlg, int mode) {
-    Lds* s = c.s;
+__device__ __forceinline__ void predict(Ctx c, int comp, int tx, int ty, int tlg, int mode) {
+    c = uni(c);
+    comp = uni(comp);
+    tx = uni(tx);
+    ty = uni(ty);
+    tlg = uni(tlg);
+    mode = uni(mode);
     const int cs = comp ? 1 : 0;
     const int lg = tlg - cs;
     const int n = 1 << lg;
@@ -423,7 +487,7 @@ __device__ __noinline__ void predict(const Ctx& c, int comp, int tx, int ty, int
     const int nn = n * n;
     if (mode >= LT_CCLM) {
         const CclmParams cp = cclm_params(c, comp, tx, ty, tlg, mode);
-        for (int i = c.lane; i < nn; i += 64) {
+        for (int i = LANE; i < nn; i += 64) {
             const int x = i & (n - 1), y = i >> lg;
             int v;
             if (cp.flat128) {
@@ -433,26 +497,26 @@ __device__ __noinline__ void predict(const Ctx& c, int comp, int tx, int ty, int
                 v = ((ds * cp.a) >> cp.k) + cp.b;
                 v = min(max(v, 0), 255);
             }
-            s->pred[i] = (uint8_t)v;
-            s->bufA[i] = (int16_t)(org_get(s, comp, cx + x, cy + y) - v);
+            SH.pred[i] = (uint8_t)v;
+            SH.bufA[i] = (int16_t)(org_get(comp, cx + x, cy + y) - v);
         }
         WSYNC();
         return;
     }
     build_refs(c, comp, tx, ty, tlg, mode);
-    const int16_t* L = s->refLf; // index 0 = corner
-    const int16_t* A = s->refAf;
+    const int16_t* L = SH.refLf; // index 0 = corner
+    const int16_t* A = SH.refAf;
     const int alrs = L[0];
     if (mode == PLANAR || mode == DC) {
         int dcv = 0;
         if (mode == DC) {
             int part = 0;
-            for (int t = c.lane; t < 2 * n; t += 64) part += t < n ? A[t] : L[t - n + 1];
+            for (int t = LANE; t < 2 * n; t += 64) part += t < n ? A[t] : L[t - n + 1];
             dcv = (wave_sum_i32(part) + n) >> (lg + 1);
             dcv &= 0xFF; // `as u8`
         }
         const int n_scale = (2 * lg - 2) >> 2;
-        for (int i = c.lane; i < nn; i += 64) {
+        for (int i = LANE; i < nn; i += 64) {
             const int x = i & (n - 1), y = i >> lg;
             int v;
             if (mode == PLANAR) {
@@ -465,8 +529,8 @@ __device__ __noinline__ void predict(const Ctx& c, int comp, int tx, int ty, int
             const int wl = pdpc_w(n_scale, x), wt = pdpc_w(n_scale, y);
             v = (int16_t)(L[y + 1] * wl + A[x] * wt + (64 - wt - wl) * v + 32) >> 6;
             v = min(max(v, 0), 255);
-            s->pred[i] = (uint8_t)v;
-            s->bufA[i] = (int16_t)(org_get(s, comp, cx + x, cy + y) - v);
+            SH.pred[i] = (uint8_t)v;
+            SH.bufA[i] = (int16_t)(org_get(comp, cx + x, cy + y) - v);
         }
         WSYNC();
         return;
@@ -490,7 +554,7 @@ __device__ __noinline__ void predict(const Ctx& c, int comp, int tx, int ty, int
         n_scale = min(lg - ilog2i(3 * inv_angle - 2) + 8, 2);
     else
         n_scale = (2 * lg - 2) >> 2;
-    for (int i = c.lane; i < nn; i += 64) {
+    for (int i = LANE; i < nn; i += 64) {
         const int x = i & (n - 1), y = i >> lg;
         int v;
         if (mode >= 34) {
@@ -508,7 +572,7 @@ __device__ __noinline__ void predict(const Ctx& c, int comp, int tx, int ty, int
                     const int f = filter_flag ? (t == 0 ? 16 - (i_fact >> 1)
                                                         : t == 1 ? 32 - (i_fact >> 1)
                                                                  : t == 2 ? 16 + (i_fact >> 1) : (i_fact >> 1))
-                                              : (int)c.k->fc[i_fact][t];
+                                              : (int)SH.fc[i_fact][t];
                     acc += f * ref(x + i_idx + t);
                 }
                 v = min(max((acc + 32) >> 6, 0), 255);
@@ -533,7 +597,7 @@ __device__ __noinline__ void predict(const Ctx& c, int comp, int tx, int ty, int
                     const int f = filter_flag ? (t == 0 ? 16 - (i_fact >> 1)
                                                         : t == 1 ? 32 - (i_fact >> 1)
                                                                  : t == 2 ? 16 + (i_fact >> 1) : (i_fact >> 1))
-                                              : (int)c.k->fc[i_fact][t];
+                                              : (int)SH.fc[i_fact][t];
                     acc += f * ref(y + i_idx + t);
                 }
                 v = min(max((acc + 32) >> 6, 0), 255);
@@ -563,8 +627,8 @@ __device__ __noinline__ void predict(const Ctx& c, int comp, int tx, int ty, int
             v = (int16_t)(rl * wl + rt * wt + (64 - wt - wl) * v + 32) >> 6;
             v = min(max(v, 0), 255);
         }
-        s->pred[i] = (uint8_t)v;
-        s->bufA[i] = (int16_t)(org_get(s, comp, cx + x, cy + y) - v);
+        SH.pred[i] = (uint8_t)v;
+        SH.bufA[i] = (int16_t)(org_get(comp, cx + x, cy + y) - v);
     }
     WSYNC();
 }
@@ -590,13 +654,12 @@ __device__ __forceinline__ int dot2(uint32_t a, uint32_t b, int acc) {
 
 // forward: residual bufA (n*n i16) -> coefficients bufB (n*n i16); transformer.rs:2040-2378
 template <int LG>
-__device__ void fwd_dct(const Ctx& c) {
+__device__ void fwd_dct(Ctx c) {
     constexpr int N = 1 << LG;
     constexpr int G = 64 / N;
     constexpr int HS = N + 1; // bufH row stride
-    Lds* s = c.s;
-    const int u = c.lane & (N - 1);
-    const int g = c.lane >> LG;
+    const int u = LANE & (N - 1);
+    const int g = LANE >> LG;
     uint32_t t[N / 2];
     {
         const uint32_t* src = (const uint32_t*)&c.k->dct[LG - 2][u][0];
@@ -606,17 +669,17 @@ __device__ void fwd_dct(const Ctx& c) {
     // stage 1: H[u][y] = (sum_x T[u][x] r[y][x] + d) >> (LG-1)   (:2139-2209)
 #pragma unroll 1
     for (int y = g; y < N; y += G) {
-        const uint32_t* row = (const uint32_t*)&s->bufA[y * N];
+        const uint32_t* row = (const uint32_t*)&SH.bufA[y * N];
         int acc = 0;
 #pragma unroll
         for (int k = 0; k < N / 2; ++k) acc = dot2(row[k], t[k], acc);
-        s->bufH[u * HS + y] = (acc + (1 << (LG - 2))) >> (LG - 1);
+        SH.bufH[u * HS + y] = (acc + (1 << (LG - 2))) >> (LG - 1);
     }
     WSYNC();
     // stage 2: C[v][x] = (sum_y T[v][y] H[x][y] + d) >> (LG+6)  (:2246-2316); lane v = u
 #pragma unroll 1
     for (int x = g; x < N; x += G) {
-        const int32_t* col = &s->bufH[x * HS];
+        const int32_t* col = &SH.bufH[x * HS];
         int acc = 0;
 #pragma unroll
         for (int k = 0; k < N / 2; ++k) {
@@ -624,7 +687,7 @@ __device__ void fwd_dct(const Ctx& c) {
             acc += __mul24((int)(short)(t[k] & 0xFFFF), col[2 * k]);
             acc += __mul24((int)t[k] >> 16, col[2 * k + 1]);
         }
-        s->bufB[u * N + x] = (int16_t)((acc + (1 << (LG + 5))) >> (LG + 6));
+        SH.bufB[u * N + x] = (int16_t)((acc + (1 << (LG + 5))) >> (LG + 6));
     }
     WSYNC();
 }
@@ -632,12 +695,11 @@ __device__ void fwd_dct(const Ctx& c) {
 // inverse: transposed dequantised coefficients bufA (dT[x][i]) -> residual bufA (r[y][x]);
 // uses bufB for the intermediate.  transformer.rs:2380-2737
 template <int LG>
-__device__ void inv_dct(const Ctx& c) {
+__device__ void inv_dct(Ctx c) {
     constexpr int N = 1 << LG;
     constexpr int G = 64 / N;
-    Lds* s = c.s;
-    const int u = c.lane & (N - 1);
-    const int g = c.lane >> LG;
+    const int u = LANE & (N - 1);
+    const int g = LANE >> LG;
     uint32_t t[N / 2]; // Tt[u][i] = T_N[i][u]
     {
         const uint32_t* src = (const uint32_t*)&c.k->dct_t[LG - 2][u][0];
@@ -647,28 +709,30 @@ __device__ void inv_dct(const Ctx& c) {
     // stage 1 (vertical): V[y][x] = clamp16((sum_i T[i][y] d[i][x] + 64) >> 7); lane y = u
 #pragma unroll 1
     for (int x = g; x < N; x += G) {
-        const uint32_t* col = (const uint32_t*)&s->bufA[x * N]; // dT[x][.]
+        const uint32_t* col = (const uint32_t*)&SH.bufA[x * N]; // dT[x][.]
         int acc = 0;
 #pragma unroll
         for (int k = 0; k < N / 2; ++k) acc = dot2(col[k], t[k], acc);
         int v = (acc + 64) >> 7;
         v = min(max(v, -32768), 32767);
-        s->bufB[u * N + x] = (int16_t)v;
+        SH.bufB[u * N + x] = (int16_t)v;
     }
     WSYNC();
     // stage 2 (horizontal): r[y][x] = (sum_i T[i][x] V[y][i] + 2048) >> 12; lane x = u
 #pragma unroll 1
     for (int y = g; y < N; y += G) {
-        const uint32_t* row = (const uint32_t*)&s->bufB[y * N];
+        const uint32_t* row = (const uint32_t*)&SH.bufB[y * N];
         int acc = 0;
 #pragma unroll
         for (int k = 0; k < N / 2; ++k) acc = dot2(row[k], t[k], acc);
-        s->bufA[y * N + u] = (int16_t)((acc + 2048) >> 12);
+        SH.bufA[y * N + u] = (int16_t)((acc + 2048) >> 12);
     }
     WSYNC();
 }
 
-__device__ __noinline__ void fwd_dct_lg(const Ctx& c, int lg) {
+__device__ __forceinline__ void fwd_dct_lg(Ctx c, int lg) {
+    c = uni(c);
+    lg = uni(lg);
     switch (lg) {
     case 2: fwd_dct<2>(c); break;
     case 3: fwd_dct<3>(c); break;
@@ -676,7 +740,9 @@ __device__ __noinline__ void fwd_dct_lg(const Ctx& c, int lg) {
     default: fwd_dct<5>(c); break;
     }
 }
-__device__ __noinline__ void inv_dct_lg(const Ctx& c, int lg) {
+__device__ __forceinline__ void inv_dct_lg(Ctx c, int lg) {
+    c = uni(c);
+    lg = uni(lg);
     switch (lg) {
     case 2: inv_dct<2>(c); break;
     case 3: inv_dct<3>(c); break;
@@ -688,11 +754,11 @@ __device__ __noinline__ void inv_dct_lg(const Ctx& c, int lg) {
 // ---------------------------------------------------------------------------
 // Dependent quantisation (quantizer.rs:338-759) + level cost (block_splitter.rs:415-460)
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ long long ldq_at(const Ctx& c, int bits) {
-    return bits < 256 ? (long long)c.s->ldq[bits] : c.k->ldq[bits];
+__device__ __forceinline__ long long ldq_at(Ctx c, int bits) {
+    return bits < 256 ? (long long)SH.ldq[bits] : c.k->ldq[bits];
 }
-__device__ __forceinline__ long long lv_at(const Ctx& c, int a) {
-    return a < 256 ? (long long)c.s->lv[a] : c.k->lv[a];
+__device__ __forceinline__ long long lv_at(Ctx c, int a) {
+    return a < 256 ? (long long)SH.lv[a] : c.k->lv[a];
 }
 template <int CTRL>
 __device__ __forceinline__ long long dpp_quad64(long long v) {
@@ -720,8 +786,9 @@ __device__ __forceinline__ int compose_map(int g2, int g1) {
 // delta = (state > 1); then lanes 0..3 (one per state) walk the chunk, exchanging
 // path costs with two DPP quad permutes.  Forward trace = composition of per-position
 // state maps (prefix scan over lanes), then every lane emits its own positions.
-__device__ __noinline__ long long quantize(const Ctx& c, int lg, int* overflow) {
-    Lds* s = c.s;
+__device__ __forceinline__ long long quantize(Ctx c, int lg, int* overflow) {
+    c = uni(c);
+    lg = uni(lg);
     const DevConst* k = c.k;
     const int n = 1 << lg;
     const int P = n * n;
@@ -729,13 +796,15 @@ __device__ __noinline__ long long quantize(const Ctx& c, int lg, int* overflow) 
     const int off = (1 << sh) >> 1;
     const int lsc = k->lsc;
     const uint16_t* scan = k->scan_idx[lg - 2];
-    int16_t* tcs = (int16_t*)s->bufH;        // coefficient in reverse-scan order
-    int16_t* qds = (int16_t*)s->bufH + 1024; // |(tc << sh) - off| / lsc
-    int32_t* cc = (int32_t*)s->bufA;         // chunk: [64][4] = c0/c1 for delta 0, c0/c1 for delta 1
-    uint8_t* cf = (uint8_t*)(s->bufA + 512); // chunk flags
+    int16_t* tcs = (int16_t*)SH.bufH;        // coefficient in reverse-scan order
+    int16_t* qds = (int16_t*)SH.bufH + 1024; // |(tc << sh) - off| / lsc
+    int32_t* cc = (int32_t*)SH.bufA;         // chunk: [64][4] = c0/c1 for delta 0, c0/c1 for delta 1
+    uint8_t* cf = (uint8_t*)(SH.bufA + 512); // chunk flags
+    uint32_t* decw = (uint32_t*)SH.decn;      // decisions: 4 bits per position, 8 positions per word
+    PROF_MARK(q0_);
     int first = P;
-    for (int p = c.lane; p < P; p += 64) {
-        const int tc = s->bufB[scan[p]];
+    for (int p = LANE; p < P; p += 64) {
+        const int tc = SH.bufB[scan[p]];
         int S = (int)((unsigned)tc << sh) - off;
         if (tc < 0) S = -S;
         const int qd = tc == 0 ? 0 : (int)(((unsigned long long)(unsigned)S * k->div_magic) >> 47);
@@ -744,16 +813,18 @@ __device__ __noinline__ long long quantize(const Ctx& c, int lg, int* overflow) 
         if (tc != 0 && (qd >> 1) > 0) first = min(first, p);
     }
     const int istar = wave_min_i32(first);
+    PROF_MARK(q1_);
+    PROF_ADD2(PH_QPRE, q0_, q1_);
     const long long ldq1 = ldq_at(c, 1);
-    const int st = c.lane & 3;
+    const int st = LANE & 3;
     const int delta = st > 1 ? 1 : 0;
     long long C = 0;
     int ovf = 0;
     const int CH = P < 64 ? P : 64;
     for (int base = P - CH; base >= 0; base -= CH) {
         WSYNC();
-        if (c.lane < CH) {
-            const int p = base + c.lane;
+        if (LANE < CH) {
+            const int p = base + LANE;
             const int tc = tcs[p];
             const int qd = qds[p];
             const bool dcn = p == P - 1;
@@ -781,16 +852,23 @@ __device__ __noinline__ long long quantize(const Ctx& c, int lg, int* overflow) 
                     c0 = (int)ldq1; // zero coefficient outside the trailing run: dq_table[1]
                     flags |= 1 << (2 + 2 * d);
                 }
-                cc[c.lane * 4 + 2 * d] = c0;
-                cc[c.lane * 4 + 2 * d + 1] = c1;
+                cc[LANE * 4 + 2 * d] = c0;
+                cc[LANE * 4 + 2 * d + 1] = c1;
             }
-            cf[c.lane] = (uint8_t)flags;
+            cf[LANE] = (uint8_t)flags;
         }
         WSYNC();
+        int f_n = cf[CH - 1];
+        int2 cv_n = *(const int2*)&cc[(CH - 1) * 4 + 2 * delta];
+        unsigned word = 0;
         for (int i = CH - 1; i >= 0; --i) {
             const int p = base + i;
-            const int f = cf[i];
-            const int2 cv = *(const int2*)&cc[i * 4 + 2 * delta];
+            const int f = f_n;
+            const int2 cv = cv_n;
+            if (i > 0) { // prefetch the next position while this one is evaluated
+                f_n = cf[i - 1];
+                cv_n = *(const int2*)&cc[(i - 1) * 4 + 2 * delta];
+            }
             const bool tz = st == 0 && p <= istar;
             const bool zero = f & 1;
             const bool par = (f >> (1 + 2 * delta)) & 1;
@@ -804,20 +882,25 @@ __device__ __noinline__ long long quantize(const Ctx& c, int lg, int* overflow) 
             const bool pick1 = !zero && K1 < K0;
             C = pick1 ? K1 : K0;
             if (!pick1 && a0z && tz && (p & 15) == 15) C -= ldq1; // quantizer.rs:512-514
-            const unsigned nib = (unsigned)(__ballot(pick1) & 0xFULL);
-            if (c.lane == 0) s->decn[p] = (uint8_t)nib;
+            word |= ((unsigned)__ballot(pick1) & 0xFu) << (4 * (p & 7));
+            if ((p & 7) == 0) { // eight positions per 32-bit word
+                if (LANE == 0) decw[p >> 3] = word;
+                word = 0;
+            }
         }
     }
     WSYNC();
+    PROF_MARK(q2_);
+    PROF_ADD2(PH_QBACK, q1_, q2_);
     // ---- forward trace from state 0 (quantizer.rs:686-721) + level-cost walk ----
     const int per = P >= 64 ? (P >> 6) : 1; // consecutive positions per lane
-    const int p0 = c.lane * per;
+    const int p0 = LANE * per;
     const bool active = p0 < P;
     int fmap = 0xE4; // identity map
     if (active) {
         for (int j = 0; j < per; ++j) {
             const int p = p0 + j;
-            const int tc = tcs[p], qd = qds[p], nib = s->decn[p];
+            const int tc = tcs[p], qd = qds[p], nib = (decw[p >> 3] >> (4 * (p & 7))) & 15;
             int g = 0;
 #pragma unroll
             for (int sidx = 0; sidx < 4; ++sidx) {
@@ -834,10 +917,10 @@ __device__ __noinline__ long long quantize(const Ctx& c, int lg, int* overflow) 
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
         const int other = __shfl_up(pre, d, 64);
-        if (c.lane >= d) pre = compose_map(pre, other);
+        if (LANE >= d) pre = compose_map(pre, other);
     }
     int entry = __shfl_up(pre, 1, 64) & 3; // state after all previous lanes, starting from 0
-    if (c.lane == 0) entry = 0;
+    if (LANE == 0) entry = 0;
     long long sum_nz = 0;
     unsigned zmask = 0;
     int fnz = P;
@@ -845,7 +928,7 @@ __device__ __noinline__ long long quantize(const Ctx& c, int lg, int* overflow) 
         int state = entry;
         for (int j = 0; j < per; ++j) {
             const int p = p0 + j;
-            const int tc = tcs[p], qd = qds[p], nib = s->decn[p];
+            const int tc = tcs[p], qd = qds[p], nib = (decw[p >> 3] >> (4 * (p & 7))) & 15;
             const int dl = state > 1 ? 1 : 0;
             int q = 0, a = 0;
             if (tc != 0) {
@@ -856,7 +939,7 @@ __device__ __noinline__ long long quantize(const Ctx& c, int lg, int* overflow) 
                     q = a > 0 ? 2 * a - dl : 0;
                 if (tc < 0) q = -q;
             }
-            s->bufC[scan[p]] = (int16_t)q;
+            SH.bufC[scan[p]] = (int16_t)q;
             const int qc = abs(q);
             if (qc == 0) {
                 zmask |= 1u << j;
@@ -879,22 +962,25 @@ __device__ __noinline__ long long quantize(const Ctx& c, int lg, int* overflow) 
     const long long sum = (long long)wave_sum_u64((unsigned long long)sum_nz);
     if (__ballot(ovf != 0) != 0ULL) *overflow = 1;
     WSYNC();
+    PROF_MARK(q3_);
+    PROF_ADD2(PH_QTRACE, q2_, q3_);
     return sum;
 }
 
 // levels bufC (row-major) -> transposed dequantised coefficients bufA (dT[x][i] = d[i][x]);
 // quantizer.rs:761-1079
-__device__ __noinline__ void dequantize_t(const Ctx& c, int lg) {
-    Lds* s = c.s;
+__device__ __forceinline__ void dequantize_t(Ctx c, int lg) {
+    c = uni(c);
+    lg = uni(lg);
     const int n = 1 << lg;
     const int sh = 8 + lg - 5 + 1;
     const int off = (1 << sh) >> 1;
     const int lsc = c.k->lsc;
-    for (int i = c.lane; i < n * n; i += 64) {
+    for (int i = LANE; i < n * n; i += 64) {
         const int x = i & (n - 1), y = i >> lg;
-        int v = ((int)s->bufC[i] * lsc + off) >> sh;
+        int v = ((int)SH.bufC[i] * lsc + off) >> sh;
         v = min(max(v, -32768), 32767);
-        s->bufA[x * n + y] = (int16_t)v;
+        SH.bufA[x * n + y] = (int16_t)v;
     }
     WSYNC();
 }
@@ -909,41 +995,66 @@ struct CompCost {
 
 // predict -> T -> Q -> DQ -> IT -> recon (+SSD) of one component
 // (block_splitter.rs:146-185); levels stay in bufC.
-__device__ __noinline__ CompCost code_component(const Ctx& c, int comp, int tx, int ty, int tlg, int mode,
+__device__ __noinline__ CompCost code_component(Ctx c, int comp, int tx, int ty, int tlg, int mode,
                                    int* overflow) {
-    Lds* s = c.s;
+    c = uni(c);
+    comp = uni(comp);
+    tx = uni(tx);
+    ty = uni(ty);
+    tlg = uni(tlg);
+    mode = uni(mode);
     const int cs = comp ? 1 : 0;
     const int lg = tlg - cs;
     const int n = 1 << lg;
     const int cx = tx >> cs, cy = ty >> cs;
+    PROF_MARK(t0_);
     predict(c, comp, tx, ty, tlg, mode);
+    PROF_MARK(t1_);
     fwd_dct_lg(c, lg);
+    PROF_MARK(t2_);
     CompCost r;
     r.level = quantize(c, lg, overflow);
+    PROF_MARK(t3_);
     dequantize_t(c, lg);
+    PROF_MARK(t4_);
     inv_dct_lg(c, lg);
+    PROF_MARK(t5_);
+    PROF_ADD2(PH_PREDICT, t0_, t1_);
+    PROF_ADD2(PH_FDCT, t1_, t2_);
+    PROF_ADD2(PH_DEQ, t3_, t4_);
+    PROF_ADD2(PH_IDCT, t4_, t5_);
     unsigned int part = 0;
-    for (int i = c.lane; i < n * n; i += 64) {
+    for (int i = LANE; i < n * n; i += 64) {
         const int x = i & (n - 1), y = i >> lg;
-        int v = (int16_t)((int)s->pred[i] + (int)s->bufA[i]);
+        int v = (int16_t)((int)SH.pred[i] + (int)SH.bufA[i]);
         v = min(max(v, 0), 255);
-        rec_put(s, comp, cx + x, cy + y, v);
-        const int d = v - org_get(s, comp, cx + x, cy + y);
+        rec_put(comp, cx + x, cy + y, v);
+        const int d = v - org_get(comp, cx + x, cy + y);
         part += (unsigned)(d * d);
     }
     r.ssd = wave_sum_u64((unsigned long long)part);
     WSYNC();
+    PROF_MARK(t6_);
+    PROF_ADD2(PH_RECON, t5_, t6_);
     return r;
 }
 
 // predict + SAD (block_splitter.rs:64-108)
-__device__ __noinline__ unsigned int sad_component(const Ctx& c, int comp, int tx, int ty, int tlg, int mode) {
-    Lds* s = c.s;
+__device__ __noinline__ unsigned int sad_component(Ctx c, int comp, int tx, int ty, int tlg, int mode) {
+    c = uni(c);
+    comp = uni(comp);
+    tx = uni(tx);
+    ty = uni(ty);
+    tlg = uni(tlg);
+    mode = uni(mode);
     const int cs = comp ? 1 : 0;
     const int n = 1 << (tlg - cs);
+    PROF_MARK(t0_);
     predict(c, comp, tx, ty, tlg, mode);
+    PROF_MARK(t1_);
+    PROF_ADD2(PH_PREDICT, t0_, t1_);
     int part = 0;
-    for (int i = c.lane; i < n * n; i += 64) part += abs((int)s->bufA[i]);
+    for (int i = LANE; i < n * n; i += 64) part += abs((int)SH.bufA[i]);
     const int total = wave_sum_i32(part);
     WSYNC();
     return (unsigned)total;
@@ -951,14 +1062,14 @@ __device__ __noinline__ unsigned int sad_component(const Ctx& c, int comp, int t
 
 // luma mode of the CU covering picture position (CTU-local x, y), as the search sees it
 // (SURVEY.md Q7): inside the CTU -> root CU's mode; left CTU -> its final map; else none.
-__device__ __forceinline__ int nb_luma_mode(const Ctx& c, int x, int y, bool* exists) {
+__device__ __forceinline__ int nb_luma_mode(Ctx c, int x, int y, bool* exists) {
     if (x >= 0 && y >= 0) {
         *exists = true;
         return c.cu32_mode;
     }
     if (y >= 0 && x < 0 && c.ctu_x > 0) {
         *exists = true;
-        return c.s->left_mode[y >> 2];
+        return SH.left_mode[y >> 2];
     }
     *exists = false;
     return PLANAR;
@@ -966,7 +1077,12 @@ __device__ __forceinline__ int nb_luma_mode(const Ctx& c, int x, int y, bool* ex
 
 // mode class index for the header-bit table: 0 planar, 1..5 mpm_idx, 6..66 remainder
 // (ctu.rs:1498-1635)
-__device__ __noinline__ int mpm_class(const Ctx& c, int bx, int by, int lg, int mode) {
+__device__ __noinline__ int mpm_class(Ctx c, int bx, int by, int lg, int mode) {
+    c = uni(c);
+    bx = uni(bx);
+    by = uni(by);
+    lg = uni(lg);
+    mode = uni(mode);
     if (mode == PLANAR) return 0;
     const int n = 1 << lg;
     bool le, ae;
@@ -1052,8 +1168,15 @@ struct LeafResult {
 };
 
 // get_intra_pred_cost (block_splitter.rs:110-474) for modes [ml, mc, mc]
-__device__ __noinline__ float full_cost(const Ctx& c, int tree, int bx, int by, int lg, int ml, int mc,
+__device__ __noinline__ float full_cost(Ctx c, int tree, int bx, int by, int lg, int ml, int mc,
                            int* overflow) {
+    c = uni(c);
+    tree = uni(tree);
+    bx = uni(bx);
+    by = uni(by);
+    lg = uni(lg);
+    ml = uni(ml);
+    mc = uni(mc);
     const int cls = mpm_class(c, bx, by, lg, ml);
     const bool cclm = mc >= LT_CCLM;
     unsigned long long ssd = 0;
@@ -1076,7 +1199,13 @@ __device__ __noinline__ float full_cost(const Ctx& c, int tree, int bx, int by, 
 }
 
 // get_intra_pred_aux_cost (block_splitter.rs:64-108) for modes [m; 3]
-__device__ __noinline__ float aux_cost(const Ctx& c, int tree, int bx, int by, int lg, int m) {
+__device__ __noinline__ float aux_cost(Ctx c, int tree, int bx, int by, int lg, int m) {
+    c = uni(c);
+    tree = uni(tree);
+    bx = uni(bx);
+    by = uni(by);
+    lg = uni(lg);
+    m = uni(m);
     unsigned long long sad = sad_component(c, 0, bx, by, lg, m);
     if (tree == TREE_SINGLE) {
         sad += sad_component(c, 1, bx, by, lg, m);
@@ -1086,7 +1215,12 @@ __device__ __noinline__ float aux_cost(const Ctx& c, int tree, int bx, int by, i
 }
 
 // get_chroma_intra_pred_cost (block_splitter.rs:524-780)
-__device__ __noinline__ float chroma_full_cost(const Ctx& c, int bx, int by, int lg, int mc, int* overflow) {
+__device__ __noinline__ float chroma_full_cost(Ctx c, int bx, int by, int lg, int mc, int* overflow) {
+    c = uni(c);
+    bx = uni(bx);
+    by = uni(by);
+    lg = uni(lg);
+    mc = uni(mc);
     unsigned long long ssd = 0;
     long long level = 0;
     for (int comp = 1; comp < 3; ++comp) {
@@ -1099,24 +1233,29 @@ __device__ __noinline__ float chroma_full_cost(const Ctx& c, int bx, int by, int
 }
 
 // get_chroma_intra_pred_aux_cost (block_splitter.rs:476-522)
-__device__ __noinline__ float chroma_aux_cost(const Ctx& c, int bx, int by, int lg, int mc) {
+__device__ __noinline__ float chroma_aux_cost(Ctx c, int bx, int by, int lg, int mc) {
+    c = uni(c);
+    bx = uni(bx);
+    by = uni(by);
+    lg = uni(lg);
+    mc = uni(mc);
     unsigned long long sad = sad_component(c, 1, bx, by, lg, mc);
     sad += sad_component(c, 2, bx, by, lg, mc);
     return (float)sad;
 }
 
-__device__ void save_chroma(const Ctx& c, int bx, int by, int lg, uint8_t (*dst)[256]) {
+__device__ void save_chroma(Ctx c, int bx, int by, int lg, uint8_t (*dst)[256]) {
     const int n = 1 << (lg - 1);
     for (int comp = 1; comp < 3; ++comp)
-        for (int i = c.lane; i < n * n; i += 64)
-            dst[comp - 1][i] = (uint8_t)rec_get(c.s, comp, (bx >> 1) + (i & (n - 1)), (by >> 1) + (i >> (lg - 1)));
+        for (int i = LANE; i < n * n; i += 64)
+            dst[comp - 1][i] = (uint8_t)rec_get(comp, (bx >> 1) + (i & (n - 1)), (by >> 1) + (i >> (lg - 1)));
     WSYNC();
 }
-__device__ void restore_chroma(const Ctx& c, int bx, int by, int lg, const uint8_t (*src)[256]) {
+__device__ void restore_chroma(Ctx c, int bx, int by, int lg, const uint8_t (*src)[256]) {
     const int n = 1 << (lg - 1);
     for (int comp = 1; comp < 3; ++comp)
-        for (int i = c.lane; i < n * n; i += 64)
-            rec_put(c.s, comp, (bx >> 1) + (i & (n - 1)), (by >> 1) + (i >> (lg - 1)), src[comp - 1][i]);
+        for (int i = LANE; i < n * n; i += 64)
+            rec_put(comp, (bx >> 1) + (i & (n - 1)), (by >> 1) + (i >> (lg - 1)), src[comp - 1][i]);
     WSYNC();
 }
 
@@ -1128,13 +1267,18 @@ __device__ __forceinline__ int pick_cclm(float lt, float t, float l) {
 }
 
 // leaf search of a DUAL_TREE_CHROMA block (block_splitter.rs:794-885); lg = luma log2 (3)
-__device__ __noinline__ LeafResult leaf_chroma(const Ctx& c, int bx, int by, int lg, int dm_mode, int* overflow) {
+__device__ __noinline__ LeafResult leaf_chroma(Ctx c, int bx, int by, int lg, int dm_mode, int* overflow) {
+    c = uni(c);
+    bx = uni(bx);
+    by = uni(by);
+    lg = uni(lg);
+    dm_mode = uni(dm_mode);
     const float lt = chroma_aux_cost(c, bx, by, lg, LT_CCLM);
     const float t = chroma_aux_cost(c, bx, by, lg, T_CCLM);
     const float l = chroma_aux_cost(c, bx, by, lg, L_CCLM);
     const int cclm_mode = pick_cclm(lt, t, l);
     const float cclm_cost = chroma_full_cost(c, bx, by, lg, cclm_mode, overflow);
-    save_chroma(c, bx, by, lg, c.s->saveCclm);
+    save_chroma(c, bx, by, lg, SH.saveCclm);
     const float cur = chroma_full_cost(c, bx, by, lg, dm_mode, overflow);
     LeafResult r;
     r.luma_mode = 0;
@@ -1145,13 +1289,18 @@ __device__ __noinline__ LeafResult leaf_chroma(const Ctx& c, int bx, int by, int
     } else {
         r.cost = mn;
         r.chroma_mode = cclm_mode;
-        restore_chroma(c, bx, by, lg, c.s->saveCclm);
+        restore_chroma(c, bx, by, lg, SH.saveCclm);
     }
     return r;
 }
 
 // leaf search of a SINGLE_TREE / DUAL_TREE_LUMA block (block_splitter.rs:886-1078)
-__device__ __noinline__ LeafResult leaf_luma(const Ctx& c, int tree, int bx, int by, int lg, int* overflow) {
+__device__ __noinline__ LeafResult leaf_luma(Ctx c, int tree, int bx, int by, int lg, int* overflow) {
+    c = uni(c);
+    tree = uni(tree);
+    bx = uni(bx);
+    by = uni(by);
+    lg = uni(lg);
     float cost_planar = 0.f, cost_dc = 0.f;
     float min_dir_cost = 3.40282347e+38f;
     int min_dir_mode = 2;
@@ -1240,20 +1389,25 @@ __device__ __noinline__ LeafResult leaf_luma(const Ctx& c, int tree, int bx, int
 // ---------------------------------------------------------------------------
 // Decision maps and recon save/restore
 // ---------------------------------------------------------------------------
-__device__ __noinline__ void fill_maps(const Ctx& c, int bx, int by, int lg, int luma_mode, int chroma_mode,
+__device__ __noinline__ void fill_maps(Ctx c, int bx, int by, int lg, int luma_mode, int chroma_mode,
                           bool luma, bool chroma) {
-    Lds* s = c.s;
+    c = uni(c);
+    bx = uni(bx);
+    by = uni(by);
+    lg = uni(lg);
+    luma_mode = uni(luma_mode);
+    chroma_mode = uni(chroma_mode);
     const int n4 = (1 << lg) >> 2;
     if (luma)
-        for (int i = c.lane; i < n4 * n4; i += 64) {
+        for (int i = LANE; i < n4 * n4; i += 64) {
             const int idx = ((by >> 2) + i / n4) * 8 + (bx >> 2) + i % n4;
-            s->cu_log2[idx] = (uint8_t)lg;
-            s->luma_mode[idx] = (uint8_t)luma_mode;
+            SH.cu_log2[idx] = (uint8_t)lg;
+            SH.luma_mode[idx] = (uint8_t)luma_mode;
         }
     if (chroma) {
         const int n8 = max(n4 >> 1, 1);
-        for (int i = c.lane; i < n8 * n8; i += 64)
-            s->chroma_mode[((by >> 3) + i / n8) * 4 + (bx >> 3) + i % n8] = (uint8_t)chroma_mode;
+        for (int i = LANE; i < n8 * n8; i += 64)
+            SH.chroma_mode[((by >> 3) + i / n8) * 4 + (bx >> 3) + i % n8] = (uint8_t)chroma_mode;
     }
     WSYNC();
 }
@@ -1261,29 +1415,35 @@ __device__ __noinline__ void fill_maps(const Ctx& c, int bx, int by, int lg, int
 __device__ __forceinline__ int save_off_y(int lg) { return lg == 5 ? 0 : (lg == 4 ? 1024 : 1280); }
 __device__ __forceinline__ int save_off_c(int lg) { return lg == 5 ? 0 : (lg == 4 ? 256 : 320); }
 
-__device__ __noinline__ void save_recon(const Ctx& c, int bx, int by, int lg) {
-    Lds* s = c.s;
+__device__ __noinline__ void save_recon(Ctx c, int bx, int by, int lg) {
+    c = uni(c);
+    bx = uni(bx);
+    by = uni(by);
+    lg = uni(lg);
     const int n = 1 << lg;
-    uint8_t* dy = s->saveY + save_off_y(lg);
-    for (int i = c.lane; i < n * n; i += 64) dy[i] = (uint8_t)rec_get(s, 0, bx + (i & (n - 1)), by + (i >> lg));
+    uint8_t* dy = SH.saveY + save_off_y(lg);
+    for (int i = LANE; i < n * n; i += 64) dy[i] = (uint8_t)rec_get(0, bx + (i & (n - 1)), by + (i >> lg));
     const int nc = n >> 1;
     for (int comp = 1; comp < 3; ++comp) {
-        uint8_t* dc = s->saveC[comp - 1] + save_off_c(lg);
-        for (int i = c.lane; i < nc * nc; i += 64)
-            dc[i] = (uint8_t)rec_get(s, comp, (bx >> 1) + (i & (nc - 1)), (by >> 1) + (i >> (lg - 1)));
+        uint8_t* dc = SH.saveC[comp - 1] + save_off_c(lg);
+        for (int i = LANE; i < nc * nc; i += 64)
+            dc[i] = (uint8_t)rec_get(comp, (bx >> 1) + (i & (nc - 1)), (by >> 1) + (i >> (lg - 1)));
     }
     WSYNC();
 }
-__device__ __noinline__ void restore_recon(const Ctx& c, int bx, int by, int lg) {
-    Lds* s = c.s;
+__device__ __noinline__ void restore_recon(Ctx c, int bx, int by, int lg) {
+    c = uni(c);
+    bx = uni(bx);
+    by = uni(by);
+    lg = uni(lg);
     const int n = 1 << lg;
-    const uint8_t* dy = s->saveY + save_off_y(lg);
-    for (int i = c.lane; i < n * n; i += 64) rec_put(s, 0, bx + (i & (n - 1)), by + (i >> lg), dy[i]);
+    const uint8_t* dy = SH.saveY + save_off_y(lg);
+    for (int i = LANE; i < n * n; i += 64) rec_put(0, bx + (i & (n - 1)), by + (i >> lg), dy[i]);
     const int nc = n >> 1;
     for (int comp = 1; comp < 3; ++comp) {
-        const uint8_t* dc = s->saveC[comp - 1] + save_off_c(lg);
-        for (int i = c.lane; i < nc * nc; i += 64)
-            rec_put(s, comp, (bx >> 1) + (i & (nc - 1)), (by >> 1) + (i >> (lg - 1)), dc[i]);
+        const uint8_t* dc = SH.saveC[comp - 1] + save_off_c(lg);
+        for (int i = LANE; i < nc * nc; i += 64)
+            rec_put(comp, (bx >> 1) + (i & (nc - 1)), (by >> 1) + (i >> (lg - 1)), dc[i]);
     }
     WSYNC();
 }
@@ -1294,7 +1454,10 @@ __device__ __noinline__ void restore_recon(const Ctx& c, int bx, int by, int lg)
 // four DUAL_TREE_LUMA 4x4 leaves + one DUAL_TREE_CHROMA 4x4 leaf, ctu.rs:1990-2063).
 // Per-level state lives in LDS (wave-uniform).
 // ---------------------------------------------------------------------------
-__device__ __noinline__ float split_node8(const Ctx& c, int bx, int by, int* overflow) {
+__device__ __noinline__ float split_node8(Ctx c, int bx, int by, int* overflow) {
+    c = uni(c);
+    bx = uni(bx);
+    by = uni(by);
     float split_cost = 0.0f;
     for (int i = 0; i < 4; ++i) {
         const int cxx = bx + (i & 1) * 4, cyy = by + (i >> 1) * 4;
@@ -1303,14 +1466,13 @@ __device__ __noinline__ float split_node8(const Ctx& c, int bx, int by, int* ove
         split_cost = split_cost + r.cost;
     }
     // DM = luma mode of the CU covering the parent's centre (block_splitter.rs:795-805)
-    const int dm = c.s->luma_mode[((by + 4) >> 2) * 8 + ((bx + 4) >> 2)];
+    const int dm = SH.luma_mode[((by + 4) >> 2) * 8 + ((bx + 4) >> 2)];
     const LeafResult r = leaf_chroma(c, bx, by, 3, dm, overflow);
     fill_maps(c, bx, by, 3, 0, r.chroma_mode, false, true);
     return split_cost + r.cost;
 }
 
 __device__ float split_ct_ctu(Ctx& c, int max_depth, int* overflow) {
-    Lds* s = c.s;
     int level = 0;
     int bx = 0, by = 0;
     float ret = 0.0f;
@@ -1326,12 +1488,12 @@ __device__ float split_ct_ctu(Ctx& c, int max_depth, int* overflow) {
             done = true;
         } else {
             save_recon(c, bx, by, lg);
-            if (c.lane == 0) {
-                s->ns_cost[level] = ns.cost;
-                s->ns_luma[level] = (uint8_t)ns.luma_mode;
-                s->ns_chroma[level] = (uint8_t)ns.chroma_mode;
-                s->split_cost[level] = 0.0f;
-                s->child[level] = 0;
+            if (LANE == 0) {
+                SH.ns_cost[level] = ns.cost;
+                SH.ns_luma[level] = (uint8_t)ns.luma_mode;
+                SH.ns_chroma[level] = (uint8_t)ns.chroma_mode;
+                SH.split_cost[level] = 0.0f;
+                SH.child[level] = 0;
             }
             WSYNC();
             if (lg > 3) {
@@ -1354,12 +1516,12 @@ __device__ float split_ct_ctu(Ctx& c, int max_depth, int* overflow) {
             const int pl = level - 1;
             const int psz = 1 << (5 - pl);
             const int pbx = bx & ~(psz - 1), pby = by & ~(psz - 1);
-            const float acc = s->split_cost[pl] + ret; // children in z-order, f32 (:1116-1123)
-            const int ch = s->child[pl] + 1;
+            const float acc = SH.split_cost[pl] + ret; // children in z-order, f32 (:1116-1123)
+            const int ch = SH.child[pl] + 1;
             WSYNC();
-            if (c.lane == 0) {
-                s->split_cost[pl] = acc;
-                s->child[pl] = (uint8_t)ch;
+            if (LANE == 0) {
+                SH.split_cost[pl] = acc;
+                SH.child[pl] = (uint8_t)ch;
             }
             WSYNC();
             if (ch < 4) { // next sibling
@@ -1367,13 +1529,13 @@ __device__ float split_ct_ctu(Ctx& c, int max_depth, int* overflow) {
                 by = pby + (ch >> 1) * (psz >> 1);
                 done = false;
             } else { // parent complete
-                const float nsc = s->ns_cost[pl];
+                const float nsc = SH.ns_cost[pl];
                 bx = pbx;
                 by = pby;
                 level = pl;
                 if (acc > nsc) {
                     restore_recon(c, bx, by, 5 - pl);
-                    fill_maps(c, bx, by, 5 - pl, s->ns_luma[pl], s->ns_chroma[pl], true, true);
+                    fill_maps(c, bx, by, 5 - pl, SH.ns_luma[pl], SH.ns_chroma[pl], true, true);
                     ret = nsc;
                 } else {
                     ret = acc;
@@ -1386,54 +1548,58 @@ __device__ float split_ct_ctu(Ctx& c, int max_depth, int* overflow) {
 // ---------------------------------------------------------------------------
 // Final pass (ctu_encoder.rs:1421-1461) in coding order; writes levels to HBM
 // ---------------------------------------------------------------------------
-__device__ __noinline__ void final_component(const Ctx& c, const PicBufs& pb, int comp, int tx, int ty, int tlg,
+__device__ __noinline__ void final_component(Ctx c, const PicBufs& pb, int comp, int tx, int ty, int tlg,
                                 int mode, int* overflow) {
-    Lds* s = c.s;
+    c = uni(c);
+    comp = uni(comp);
+    tx = uni(tx);
+    ty = uni(ty);
+    tlg = uni(tlg);
+    mode = uni(mode);
     const int cs = comp ? 1 : 0;
     const int lg = tlg - cs;
     const int n = 1 << lg;
     const int cx = tx >> cs, cy = ty >> cs;
     // remember what the search left, to count mismatches
     unsigned int diff = 0;
-    uint8_t* before = s->saveY; // the save stack is idle during the final pass
-    for (int i = c.lane; i < n * n; i += 64)
-        before[i] = (uint8_t)rec_get(s, comp, cx + (i & (n - 1)), cy + (i >> lg));
+    uint8_t* before = SH.saveY; // the save stack is idle during the final pass
+    for (int i = LANE; i < n * n; i += 64)
+        before[i] = (uint8_t)rec_get(comp, cx + (i & (n - 1)), cy + (i >> lg));
     WSYNC();
     code_component(c, comp, tx, ty, tlg, mode, overflow);
     const int stride = c.k->W >> cs;
     const int gx = (c.ctu_x >> cs) + cx, gy = (c.ctu_y >> cs) + cy;
     int16_t* lev = pb.lev[comp];
-    for (int i = c.lane; i < n * n; i += 64) {
+    for (int i = LANE; i < n * n; i += 64) {
         const int x = i & (n - 1), y = i >> lg;
-        lev[(size_t)(gy + y) * stride + gx + x] = s->bufC[i];
-        if (before[i] != (uint8_t)rec_get(s, comp, cx + x, cy + y)) ++diff;
+        lev[(size_t)(gy + y) * stride + gx + x] = SH.bufC[i];
+        if (before[i] != (uint8_t)rec_get(comp, cx + x, cy + y)) ++diff;
     }
     const int total = wave_sum_i32((int)diff);
-    if (total && c.lane == 0) atomicAdd(c.mismatch, (unsigned long long)total);
+    if (total && LANE == 0) atomicAdd(c.mismatch, (unsigned long long)total);
     WSYNC();
 }
 
 // coding order = z-order over the 4x4 units; a CU is emitted at its top-left unit
-__device__ void final_pass_ctu(const Ctx& c, const PicBufs& pb, int* overflow) {
-    Lds* s = c.s;
+__device__ void final_pass_ctu(Ctx c, const PicBufs& pb, int* overflow) {
     for (int z = 0; z < 64; ++z) {
         const int x4 = (z & 1) | ((z >> 1) & 2) | ((z >> 2) & 4);
         const int y4 = ((z >> 1) & 1) | ((z >> 2) & 2) | ((z >> 3) & 4);
-        const int lg = s->cu_log2[y4 * 8 + x4];
+        const int lg = SH.cu_log2[y4 * 8 + x4];
         const int bx = x4 * 4, by = y4 * 4;
         const int sz = 1 << lg;
         if ((bx & (sz - 1)) == 0 && (by & (sz - 1)) == 0) {
-            const int ml = s->luma_mode[y4 * 8 + x4];
+            const int ml = SH.luma_mode[y4 * 8 + x4];
             final_component(c, pb, 0, bx, by, lg, ml, overflow);
             if (lg >= 3) {
-                const int mc = s->chroma_mode[(by >> 3) * 4 + (bx >> 3)];
+                const int mc = SH.chroma_mode[(by >> 3) * 4 + (bx >> 3)];
                 final_component(c, pb, 1, bx, by, lg, mc, overflow);
                 final_component(c, pb, 2, bx, by, lg, mc, overflow);
             }
         }
         if (lg == 2 && (z & 3) == 3) { // after the fourth 4x4 luma CU: the 8x8's chroma CU
             const int pbx = bx & ~7, pby = by & ~7;
-            const int mc = s->chroma_mode[(pby >> 3) * 4 + (pbx >> 3)];
+            const int mc = SH.chroma_mode[(pby >> 3) * 4 + (pbx >> 3)];
             final_component(c, pb, 1, pbx, pby, 3, mc, overflow);
             final_component(c, pb, 2, pbx, pby, 3, mc, overflow);
         }
@@ -1443,88 +1609,98 @@ __device__ void final_pass_ctu(const Ctx& c, const PicBufs& pb, int* overflow) {
 // ---------------------------------------------------------------------------
 // CTU entry: load, search, final pass, store
 // ---------------------------------------------------------------------------
-__device__ void load_tables(const Ctx& c) {
-    Lds* s = c.s;
-    for (int i = c.lane; i < 256; i += 64) {
-        s->ldq[i] = (int32_t)c.k->ldq[i];
-        s->lv[i] = (int32_t)c.k->lv[i];
+__device__ void load_tables(Ctx c) {
+    for (int i = LANE; i < 256; i += 64) {
+        SH.ldq[i] = (int32_t)c.k->ldq[i];
+        SH.lv[i] = (int32_t)c.k->lv[i];
     }
+    for (int i = LANE; i < 128; i += 64) ((int8_t*)SH.fc)[i] = ((const int8_t*)c.k->fc)[i];
 }
 
 __device__ void encode_ctu(Ctx& c, const PicBufs& pb, int ctu_col, int ctu_row, int* overflow) {
-    Lds* s = c.s;
     const DevConst* k = c.k;
     const int W = k->W, H = k->H;
     const int Wc = W >> 1;
     c.ctu_x = ctu_col * 32;
     c.ctu_y = ctu_row * 32;
     c.cu32_mode = PLANAR;
+#ifdef WRENC_PROFILE
+    if (threadIdx.x < PH_COUNT) s_prof[threadIdx.x] = 0;
+    __syncthreads();
+#endif
+    PROF_MARK(tt0_);
     load_tables(c);
     // originals
-    for (int i = c.lane; i < 1024 / 4; i += 64) {
+    for (int i = LANE; i < 1024 / 4; i += 64) {
         const int y = i >> 3, x4 = (i & 7) * 4;
-        *(uint32_t*)&s->orgY[y * 32 + x4] = *(const uint32_t*)&pb.org[0][(size_t)(c.ctu_y + y) * W + c.ctu_x + x4];
+        *(uint32_t*)&SH.orgY[y * 32 + x4] = *(const uint32_t*)&pb.org[0][(size_t)(c.ctu_y + y) * W + c.ctu_x + x4];
     }
     for (int comp = 1; comp < 3; ++comp)
-        for (int i = c.lane; i < 256 / 4; i += 64) {
+        for (int i = LANE; i < 256 / 4; i += 64) {
             const int y = i >> 2, x4 = (i & 3) * 4;
-            *(uint32_t*)&s->orgC[comp - 1][y * 16 + x4] =
+            *(uint32_t*)&SH.orgC[comp - 1][y * 16 + x4] =
                 *(const uint32_t*)&pb.org[comp][(size_t)((c.ctu_y >> 1) + y) * Wc + (c.ctu_x >> 1) + x4];
         }
     // neighbour border of the reconstruction: row -1 (x = -4..67) and columns -4..-1
-    for (int i = c.lane; i < 72; i += 64) {
+    for (int i = LANE; i < 72; i += 64) {
         const int gx = c.ctu_x - 4 + i, gy = c.ctu_y - 1;
-        s->recYtop[i] = (gx >= 0 && gx < W && gy >= 0) ? pb.rec[0][(size_t)gy * W + gx] : 0;
+        SH.recYtop[i] = (gx >= 0 && gx < W && gy >= 0) ? pb.rec[0][(size_t)gy * W + gx] : 0;
     }
-    for (int i = c.lane; i < 32 * 4; i += 64) {
+    for (int i = LANE; i < 32 * 4; i += 64) {
         const int y = i >> 2, x = (i & 3) - 4;
         const int gx = c.ctu_x + x, gy = c.ctu_y + y;
-        s->recY[y * 36 + x + 4] = gx >= 0 ? pb.rec[0][(size_t)gy * W + gx] : 0;
+        SH.recY[y * 36 + x + 4] = gx >= 0 ? pb.rec[0][(size_t)gy * W + gx] : 0;
     }
     for (int comp = 1; comp < 3; ++comp) {
-        for (int i = c.lane; i < 40; i += 64) {
+        for (int i = LANE; i < 40; i += 64) {
             const int gx = (c.ctu_x >> 1) - 4 + i, gy = (c.ctu_y >> 1) - 1;
-            s->recCtop[comp - 1][i] = (gx >= 0 && gx < Wc && gy >= 0) ? pb.rec[comp][(size_t)gy * Wc + gx] : 0;
+            SH.recCtop[comp - 1][i] = (gx >= 0 && gx < Wc && gy >= 0) ? pb.rec[comp][(size_t)gy * Wc + gx] : 0;
         }
-        for (int i = c.lane; i < 16 * 4; i += 64) {
+        for (int i = LANE; i < 16 * 4; i += 64) {
             const int y = i >> 2, x = (i & 3) - 4;
             const int gx = (c.ctu_x >> 1) + x, gy = (c.ctu_y >> 1) + y;
-            s->recC[comp - 1][y * 20 + x + 4] = gx >= 0 ? pb.rec[comp][(size_t)gy * Wc + gx] : 0;
+            SH.recC[comp - 1][y * 20 + x + 4] = gx >= 0 ? pb.rec[comp][(size_t)gy * Wc + gx] : 0;
         }
     }
     // tile.rs:49-58: planes start at zero
-    for (int i = c.lane; i < 32 * 32; i += 64) s->recY[(i >> 5) * 36 + (i & 31) + 4] = 0;
+    for (int i = LANE; i < 32 * 32; i += 64) SH.recY[(i >> 5) * 36 + (i & 31) + 4] = 0;
     for (int comp = 1; comp < 3; ++comp)
-        for (int i = c.lane; i < 256; i += 64) s->recC[comp - 1][(i >> 4) * 20 + (i & 15) + 4] = 0;
-    if (c.lane < 8)
-        s->left_mode[c.lane] =
-            c.ctu_x > 0 ? pb.luma_mode[(size_t)((c.ctu_y >> 2) + c.lane) * (W >> 2) + (c.ctu_x >> 2) - 1] : 0;
+        for (int i = LANE; i < 256; i += 64) SH.recC[comp - 1][(i >> 4) * 20 + (i & 15) + 4] = 0;
+    if (LANE < 8)
+        SH.left_mode[LANE] =
+            c.ctu_x > 0 ? pb.luma_mode[(size_t)((c.ctu_y >> 2) + LANE) * (W >> 2) + (c.ctu_x >> 2) - 1] : 0;
     WSYNC();
     (void)H;
     const float cost = split_ct_ctu(c, k->max_depth, overflow);
     final_pass_ctu(c, pb, overflow);
     // store recon + decisions
-    for (int i = c.lane; i < 1024 / 4; i += 64) {
+    for (int i = LANE; i < 1024 / 4; i += 64) {
         const int y = i >> 3, x4 = (i & 7) * 4;
-        *(uint32_t*)&pb.rec[0][(size_t)(c.ctu_y + y) * W + c.ctu_x + x4] = *(const uint32_t*)&s->recY[y * 36 + x4 + 4];
+        *(uint32_t*)&pb.rec[0][(size_t)(c.ctu_y + y) * W + c.ctu_x + x4] = *(const uint32_t*)&SH.recY[y * 36 + x4 + 4];
     }
     for (int comp = 1; comp < 3; ++comp)
-        for (int i = c.lane; i < 256 / 4; i += 64) {
+        for (int i = LANE; i < 256 / 4; i += 64) {
             const int y = i >> 2, x4 = (i & 3) * 4;
             *(uint32_t*)&pb.rec[comp][(size_t)((c.ctu_y >> 1) + y) * Wc + (c.ctu_x >> 1) + x4] =
-                *(const uint32_t*)&s->recC[comp - 1][y * 20 + x4 + 4];
+                *(const uint32_t*)&SH.recC[comp - 1][y * 20 + x4 + 4];
         }
     {
-        const int i = c.lane; // 64 4x4 units
+        const int i = LANE; // 64 4x4 units
         const size_t o = (size_t)((c.ctu_y >> 2) + (i >> 3)) * (W >> 2) + (c.ctu_x >> 2) + (i & 7);
-        pb.cu_log2[o] = s->cu_log2[i];
-        pb.luma_mode[o] = s->luma_mode[i];
+        pb.cu_log2[o] = SH.cu_log2[i];
+        pb.luma_mode[o] = SH.luma_mode[i];
         if (i < 16) {
             const size_t oc = (size_t)((c.ctu_y >> 3) + (i >> 2)) * (W >> 3) + (c.ctu_x >> 3) + (i & 3);
-            pb.chroma_mode[oc] = s->chroma_mode[i];
+            pb.chroma_mode[oc] = SH.chroma_mode[i];
         }
         if (i == 0) pb.ctu_cost[ctu_row * k->ctu_cols + ctu_col] = cost;
     }
+#ifdef WRENC_PROFILE
+    PROF_MARK(tt1_);
+    PROF_ADD2(PH_TOTAL, tt0_, tt1_);
+    __syncthreads();
+    if (threadIdx.x < PH_COUNT) atomicAdd(&g_prof[threadIdx.x], s_prof[threadIdx.x]);
+#endif
 }
 
 } // namespace wrenc

@@ -28,15 +28,12 @@ __global__ __launch_bounds__(64, 4) void ctu_search_kernel(const DevConst* __res
                                                         const PicBufs* __restrict__ slots,
                                                         int first_slot, int diag, int r_min, int count,
                                                         unsigned long long* mismatch, int* overflow) {
-    __shared__ Lds lds;
     const int pic = blockIdx.x / count;
     const int j = blockIdx.x - pic * count;
     const int row = r_min + j;
     const int col = diag - 2 * row;
     Ctx c;
     c.k = k;
-    c.s = &lds;
-    c.lane = threadIdx.x;
     c.mismatch = mismatch;
     const PicBufs pb = slots[first_slot + pic];
     int ovf = 0;
@@ -47,48 +44,39 @@ __global__ __launch_bounds__(64, 4) void ctu_search_kernel(const DevConst* __res
 // building-block kernels: one wave per block of side 1 << lg
 __global__ __launch_bounds__(64, 4) void test_fwd_dct_kernel(const DevConst* __restrict__ k,
                                                           const int16_t* in, int lg, int16_t* out) {
-    __shared__ Lds lds;
     Ctx c;
     c.k = k;
-    c.s = &lds;
-    c.lane = threadIdx.x;
     const int nn = 1 << (2 * lg);
-    for (int i = threadIdx.x; i < nn; i += 64) lds.bufA[i] = in[(size_t)blockIdx.x * nn + i];
+    for (int i = threadIdx.x; i < nn; i += 64) SH.bufA[i] = in[(size_t)blockIdx.x * nn + i];
     WSYNC();
     fwd_dct_lg(c, lg);
-    for (int i = threadIdx.x; i < nn; i += 64) out[(size_t)blockIdx.x * nn + i] = lds.bufB[i];
+    for (int i = threadIdx.x; i < nn; i += 64) out[(size_t)blockIdx.x * nn + i] = SH.bufB[i];
 }
 
 __global__ __launch_bounds__(64, 4) void test_inv_dct_kernel(const DevConst* __restrict__ k,
                                                           const int16_t* in, int lg, int16_t* out) {
-    __shared__ Lds lds;
     Ctx c;
     c.k = k;
-    c.s = &lds;
-    c.lane = threadIdx.x;
     const int n = 1 << lg, nn = n * n;
     for (int i = threadIdx.x; i < nn; i += 64) // transposed load: dT[x][i] = d[i][x]
-        lds.bufA[(i & (n - 1)) * n + (i >> lg)] = in[(size_t)blockIdx.x * nn + i];
+        SH.bufA[(i & (n - 1)) * n + (i >> lg)] = in[(size_t)blockIdx.x * nn + i];
     WSYNC();
     inv_dct_lg(c, lg);
-    for (int i = threadIdx.x; i < nn; i += 64) out[(size_t)blockIdx.x * nn + i] = lds.bufA[i];
+    for (int i = threadIdx.x; i < nn; i += 64) out[(size_t)blockIdx.x * nn + i] = SH.bufA[i];
 }
 
 __global__ __launch_bounds__(64, 4) void test_quantize_kernel(const DevConst* __restrict__ k,
                                                            const int16_t* in, int lg, int16_t* out,
                                                            long long* cost, int* overflow) {
-    __shared__ Lds lds;
     Ctx c;
     c.k = k;
-    c.s = &lds;
-    c.lane = threadIdx.x;
     load_tables(c);
     const int nn = 1 << (2 * lg);
-    for (int i = threadIdx.x; i < nn; i += 64) lds.bufB[i] = in[(size_t)blockIdx.x * nn + i];
+    for (int i = threadIdx.x; i < nn; i += 64) SH.bufB[i] = in[(size_t)blockIdx.x * nn + i];
     WSYNC();
     int ovf = 0;
     const long long lc = quantize(c, lg, &ovf);
-    for (int i = threadIdx.x; i < nn; i += 64) out[(size_t)blockIdx.x * nn + i] = lds.bufC[i];
+    for (int i = threadIdx.x; i < nn; i += 64) out[(size_t)blockIdx.x * nn + i] = SH.bufC[i];
     if (threadIdx.x == 0) {
         cost[blockIdx.x] = lc;
         if (ovf) atomicOr(overflow, 1);
@@ -97,17 +85,14 @@ __global__ __launch_bounds__(64, 4) void test_quantize_kernel(const DevConst* __
 
 __global__ __launch_bounds__(64, 4) void test_dequantize_kernel(const DevConst* __restrict__ k,
                                                              const int16_t* in, int lg, int16_t* out) {
-    __shared__ Lds lds;
     Ctx c;
     c.k = k;
-    c.s = &lds;
-    c.lane = threadIdx.x;
     const int n = 1 << lg, nn = n * n;
-    for (int i = threadIdx.x; i < nn; i += 64) lds.bufC[i] = in[(size_t)blockIdx.x * nn + i];
+    for (int i = threadIdx.x; i < nn; i += 64) SH.bufC[i] = in[(size_t)blockIdx.x * nn + i];
     WSYNC();
     dequantize_t(c, lg);
     for (int i = threadIdx.x; i < nn; i += 64) // undo the transpose
-        out[(size_t)blockIdx.x * nn + i] = lds.bufA[(i & (n - 1)) * n + (i >> lg)];
+        out[(size_t)blockIdx.x * nn + i] = SH.bufA[(i & (n - 1)) * n + (i >> lg)];
 }
 
 // ---------------------------------------------------------------------------
@@ -560,6 +545,20 @@ int wrenc_gpu_final_pass_mismatches(wrenc_gpu_ctx* ctx, long long* count) {
     *count = (long long)v;
     return WRENC_GPU_OK;
 }
+
+#ifdef WRENC_PROFILE
+// diagnostic build only: read and clear the per-phase cycle counters
+int wrenc_gpu_prof_read(wrenc_gpu_ctx* ctx, unsigned long long* out, int n) {
+    if (!ctx || !out) return WRENC_GPU_EINVAL;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    unsigned long long host[PH_COUNT];
+    HIP_TRY(ctx, hipMemcpyFromSymbol(host, HIP_SYMBOL(g_prof), sizeof(host)));
+    for (int i = 0; i < n && i < PH_COUNT; ++i) out[i] = host[i];
+    memset(host, 0, sizeof(host));
+    HIP_TRY(ctx, hipMemcpyToSymbol(HIP_SYMBOL(g_prof), host, sizeof(host)));
+    return WRENC_GPU_OK;
+}
+#endif
 
 // ---- building-block entry points ----
 

@@ -10,7 +10,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libwrenc_gpu.so")
+LIB_PATH = os.environ.get("WRENC_GPU_LIB", os.path.join(_HERE, "csrc", "libwrenc_gpu.so"))
 
 EXPORTED_SYMBOLS = [
     "wrenc_gpu_default_config", "wrenc_gpu_create", "wrenc_gpu_destroy", "wrenc_gpu_last_error",
