@@ -62,9 +62,6 @@ struct __attribute__((aligned(16))) Lds {
     int16_t bufB[1024];
     int16_t bufC[1024];
     int32_t bufH[33 * 32];
-    int32_t ldq[256];
-    int32_t lv[256];
-    int8_t fc[32][4];          // common.rs:153 (copied from the constant block)
     int16_t refL[136];
     int16_t refA[136];
     int16_t refLf[136];
@@ -79,7 +76,9 @@ struct __attribute__((aligned(16))) Lds {
     uint8_t saveY[1024 + 256 + 64];
     uint8_t saveC[2][256 + 64 + 16];
     uint8_t saveCclm[2][256];
-    uint8_t decn[1024];        // trellis decisions: 4 bits per position
+    uint32_t decw[128];        // trellis decisions: 4 bits per position, 8 positions per word
+    int32_t q_istar;           // shared-Viterbi hand-off: first position with a non-zero state-0 level
+    int32_t q_active;          // this wave's TB takes part in the shared Viterbi
     uint8_t cu_log2[64];       // per 4x4 luma unit
     uint8_t luma_mode[64];
     uint8_t chroma_mode[16];   // per 8x8 luma unit
@@ -96,13 +95,29 @@ struct Ctx {
     const DevConst* __restrict__ k;
     int ctu_x, ctu_y; // luma, picture coordinates
     int cu32_mode;    // in-CTU neighbour lookups during search resolve to the root CU
+    int write;        // 0 for a padding wave (batch not a multiple of WPB): compute, never store
     unsigned long long* mismatch;
 };
 
-// The one LDS object of every kernel in this translation unit (one wave per block).
-// File scope so that every access is a DS instruction (no generic-pointer FLAT ops).
-__shared__ Lds SH;
-#define LANE ((int)threadIdx.x)
+// LDS: one working set per wave (= per CTU), WPB waves per workgroup, plus tables shared
+// by the workgroup.  File scope so that every access is a DS instruction (no FLAT ops).
+// The waves of a workgroup process the SAME CTU position of WPB different pictures, so
+// they execute the same schedule; the 4-lane Viterbi of all WPB transform blocks is run by
+// wave 0 in WPB quads at once (see quantize()).
+#ifndef WRENC_WPB
+#define WRENC_WPB 8
+#endif
+constexpr int WPB = WRENC_WPB;
+struct LdsTab {
+    int32_t ldq[256];
+    int32_t lv[256];
+    int8_t fc[32][4]; // common.rs:153 (copied from the constant block)
+};
+__shared__ Lds SHW[WPB];
+__shared__ LdsTab SHT;
+#define LANE ((int)(threadIdx.x & 63))
+#define WAVE (__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)))
+#define SH (SHW[WAVE])
 
 // Everything in Ctx and every block-geometry argument is wave-uniform.  Out-of-line
 // functions receive arguments in VGPRs; re-deriving them through readfirstlane lets the
@@ -120,6 +135,7 @@ __device__ __forceinline__ Ctx uni(Ctx c) {
     r.ctu_x = __builtin_amdgcn_readfirstlane(c.ctu_x);
     r.ctu_y = __builtin_amdgcn_readfirstlane(c.ctu_y);
     r.cu32_mode = __builtin_amdgcn_readfirstlane(c.cu32_mode);
+    r.write = __builtin_amdgcn_readfirstlane(c.write);
     return r;
 }
 
@@ -572,7 +588,7 @@ __device__ __forceinline__ void predict(Ctx c, int comp, int tx, int ty, int tlg
                     const int f = filter_flag ? (t == 0 ? 16 - (i_fact >> 1)
                                                         : t == 1 ? 32 - (i_fact >> 1)
                                                                  : t == 2 ? 16 + (i_fact >> 1) : (i_fact >> 1))
-                                              : (int)SH.fc[i_fact][t];
+                                              : (int)SHT.fc[i_fact][t];
                     acc += f * ref(x + i_idx + t);
                 }
                 v = min(max((acc + 32) >> 6, 0), 255);
@@ -597,7 +613,7 @@ __device__ __forceinline__ void predict(Ctx c, int comp, int tx, int ty, int tlg
                     const int f = filter_flag ? (t == 0 ? 16 - (i_fact >> 1)
                                                         : t == 1 ? 32 - (i_fact >> 1)
                                                                  : t == 2 ? 16 + (i_fact >> 1) : (i_fact >> 1))
-                                              : (int)SH.fc[i_fact][t];
+                                              : (int)SHT.fc[i_fact][t];
                     acc += f * ref(y + i_idx + t);
                 }
                 v = min(max((acc + 32) >> 6, 0), 255);
@@ -755,10 +771,10 @@ __device__ __forceinline__ void inv_dct_lg(Ctx c, int lg) {
 // Dependent quantisation (quantizer.rs:338-759) + level cost (block_splitter.rs:415-460)
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ long long ldq_at(Ctx c, int bits) {
-    return bits < 256 ? (long long)SH.ldq[bits] : c.k->ldq[bits];
+    return bits < 256 ? (long long)SHT.ldq[bits] : c.k->ldq[bits];
 }
 __device__ __forceinline__ long long lv_at(Ctx c, int a) {
-    return a < 256 ? (long long)SH.lv[a] : c.k->lv[a];
+    return a < 256 ? (long long)SHT.lv[a] : c.k->lv[a];
 }
 template <int CTRL>
 __device__ __forceinline__ long long dpp_quad64(long long v) {
@@ -776,17 +792,42 @@ __device__ __forceinline__ int compose_map(int g2, int g1) {
     return r;
 }
 
-// coefficients bufB (n*n row-major) -> levels bufC (n*n row-major).  Returns the
-// level cost of the TB (block_splitter.rs:436-458).  Scratch: bufA, bufH, decn.
-// `*overflow` is set when a level needs a table entry >= 1024 (reference panics).
+// One Viterbi step for the lane's state (st = lane & 3) of its quad's transform block.
+// cv = (cost of keeping a0, cost of a0+1) for this state's delta; f = chunk flags.
+__device__ __forceinline__ bool viterbi_step(long long& C, int f, int2 cv, int delta, bool tz, bool first_in_sb,
+                                             long long ldq1) {
+    const bool zero = f & 1;
+    const bool par = (f >> (1 + 2 * delta)) & 1;
+    const bool a0z = (f >> (2 + 2 * delta)) & 1;
+    const long long CA = dpp_quad64<0xD8>(C); // C[trans[s][0]]: quad_perm [0,2,1,3]
+    const long long CB = dpp_quad64<0x72>(C); // C[trans[s][1]]: quad_perm [2,0,3,1]
+    // branch 0 keeps a0 (bits 0 instead of 1 inside the trailing run), branch 1 takes a0+1
+    long long K0 = (long long)cv.x + (par ? CB : CA);
+    if (tz && a0z) K0 -= ldq1;
+    const long long K1 = (long long)cv.y + (par ? CA : CB);
+    const bool pick1 = !zero && K1 < K0;
+    C = pick1 ? K1 : K0;
+    if (!pick1 && a0z && tz && first_in_sb) C -= ldq1; // quantizer.rs:512-514
+    return pick1;
+}
+
+// Dependent quantisation of one transform block: coefficients bufB (n*n row-major) ->
+// levels bufC (n*n row-major); returns the level cost (block_splitter.rs:436-458).
+// Scratch: bufA, bufH, decw.  `*overflow` is set when a level needs a table entry >= 1024
+// (the reference panics there).
 //
-// Backward pass = 4-state Viterbi equivalent of the memoised DFS (SURVEY.md Q3,
-// proven equal to the literal DFS in tests/test_oracle.py): per chunk of 64
-// positions all lanes precompute the two branch costs for both values of
-// delta = (state > 1); then lanes 0..3 (one per state) walk the chunk, exchanging
-// path costs with two DPP quad permutes.  Forward trace = composition of per-position
-// state maps (prefix scan over lanes), then every lane emits its own positions.
-__device__ __forceinline__ long long quantize(Ctx c, int lg, int* overflow) {
+// Backward pass = 4-state Viterbi equivalent of the reference's memoised DFS (SURVEY.md Q3,
+// proven equal to the literal DFS in tests/test_oracle.py).  Per chunk of 64 positions all
+// lanes precompute the two branch costs for both values of delta = (state > 1); then ONE lane
+// per state walks the chunk, exchanging path costs with two DPP quad permutes.
+//   shared == true : every wave of the workgroup is in this call with a block of the same size
+//                    (same schedule, see SHW above); wave 0 walks all WPB blocks at once, one
+//                    quad of lanes per block, between two workgroup barriers per chunk.
+//                    `active == false` = this wave only keeps the barriers company.
+//   shared == false: the wave walks its own block in lanes 0..3 (final pass, tests).
+// Forward trace = composition of per-position state maps (prefix scan over lanes), then every
+// lane emits its own positions and their level costs.
+__device__ __forceinline__ long long quantize(Ctx c, int lg, bool shared, bool active, int* overflow) {
     c = uni(c);
     lg = uni(lg);
     const DevConst* k = c.k;
@@ -800,30 +841,43 @@ __device__ __forceinline__ long long quantize(Ctx c, int lg, int* overflow) {
     int16_t* qds = (int16_t*)SH.bufH + 1024; // |(tc << sh) - off| / lsc
     int32_t* cc = (int32_t*)SH.bufA;         // chunk: [64][4] = c0/c1 for delta 0, c0/c1 for delta 1
     uint8_t* cf = (uint8_t*)(SH.bufA + 512); // chunk flags
-    uint32_t* decw = (uint32_t*)SH.decn;      // decisions: 4 bits per position, 8 positions per word
+    uint32_t* decw = SH.decw;                 // decisions: 4 bits per position, 8 positions per word
     PROF_MARK(q0_);
-    int first = P;
-    for (int p = LANE; p < P; p += 64) {
-        const int tc = SH.bufB[scan[p]];
-        int S = (int)((unsigned)tc << sh) - off;
-        if (tc < 0) S = -S;
-        const int qd = tc == 0 ? 0 : (int)(((unsigned long long)(unsigned)S * k->div_magic) >> 47);
-        tcs[p] = (int16_t)tc;
-        qds[p] = (int16_t)qd;
-        if (tc != 0 && (qd >> 1) > 0) first = min(first, p);
+    int istar = P;
+    if (active) {
+        int first = P;
+        for (int p = LANE; p < P; p += 64) {
+            const int tc = SH.bufB[scan[p]];
+            int S = (int)((unsigned)tc << sh) - off;
+            if (tc < 0) S = -S;
+            const int qd = tc == 0 ? 0 : (int)(((unsigned long long)(unsigned)S * k->div_magic) >> 47);
+            tcs[p] = (int16_t)tc;
+            qds[p] = (int16_t)qd;
+            if (tc != 0 && (qd >> 1) > 0) first = min(first, p);
+        }
+        istar = wave_min_i32(first);
     }
-    const int istar = wave_min_i32(first);
+    if (LANE == 0) {
+        SH.q_istar = istar;
+        SH.q_active = active ? 1 : 0;
+    }
     PROF_MARK(q1_);
     PROF_ADD2(PH_QPRE, q0_, q1_);
     const long long ldq1 = ldq_at(c, 1);
     const int st = LANE & 3;
     const int delta = st > 1 ? 1 : 0;
+    // which block this lane's quad walks: own block (solo) or block of wave `quad` (shared, wave 0)
+    const int quad = LANE >> 2;
+    const bool walker = shared ? (WAVE == 0 && quad < WPB) : (quad == 0);
+    const Lds* tb = shared ? &SHW[quad < WPB ? quad : 0] : &SH;
+    const int32_t* wcc = (const int32_t*)tb->bufA;
+    const uint8_t* wcf = (const uint8_t*)(tb->bufA + 512);
     long long C = 0;
     int ovf = 0;
     const int CH = P < 64 ? P : 64;
     for (int base = P - CH; base >= 0; base -= CH) {
         WSYNC();
-        if (LANE < CH) {
+        if (active && LANE < CH) {
             const int p = base + LANE;
             const int tc = tcs[p];
             const int qd = qds[p];
@@ -857,47 +911,45 @@ __device__ __forceinline__ long long quantize(Ctx c, int lg, int* overflow) {
             }
             cf[LANE] = (uint8_t)flags;
         }
-        WSYNC();
-        int f_n = cf[CH - 1];
-        int2 cv_n = *(const int2*)&cc[(CH - 1) * 4 + 2 * delta];
-        unsigned word = 0;
-        for (int i = CH - 1; i >= 0; --i) {
-            const int p = base + i;
-            const int f = f_n;
-            const int2 cv = cv_n;
-            if (i > 0) { // prefetch the next position while this one is evaluated
-                f_n = cf[i - 1];
-                cv_n = *(const int2*)&cc[(i - 1) * 4 + 2 * delta];
-            }
-            const bool tz = st == 0 && p <= istar;
-            const bool zero = f & 1;
-            const bool par = (f >> (1 + 2 * delta)) & 1;
-            const bool a0z = (f >> (2 + 2 * delta)) & 1;
-            const long long CA = dpp_quad64<0xD8>(C); // C[trans[s][0]]: quad_perm [0,2,1,3]
-            const long long CB = dpp_quad64<0x72>(C); // C[trans[s][1]]: quad_perm [2,0,3,1]
-            // branch 0 keeps a0 (bits 0 instead of 1 inside the trailing run), branch 1 takes a0+1
-            long long K0 = (long long)cv.x + (par ? CB : CA);
-            if (tz && a0z) K0 -= ldq1;
-            const long long K1 = (long long)cv.y + (par ? CA : CB);
-            const bool pick1 = !zero && K1 < K0;
-            C = pick1 ? K1 : K0;
-            if (!pick1 && a0z && tz && (p & 15) == 15) C -= ldq1; // quantizer.rs:512-514
-            word |= ((unsigned)__ballot(pick1) & 0xFu) << (4 * (p & 7));
-            if ((p & 7) == 0) { // eight positions per 32-bit word
-                if (LANE == 0) decw[p >> 3] = word;
-                word = 0;
+        if (shared)
+            __syncthreads();
+        else
+            WSYNC();
+        if (walker && (!shared || tb->q_active)) {
+            const int wistar = shared ? tb->q_istar : istar;
+            uint32_t* wdec = const_cast<uint32_t*>(tb->decw);
+            int f_n = wcf[CH - 1];
+            int2 cv_n = *(const int2*)&wcc[(CH - 1) * 4 + 2 * delta];
+            unsigned word = 0;
+            for (int i = CH - 1; i >= 0; --i) {
+                const int p = base + i;
+                const int f = f_n;
+                const int2 cv = cv_n;
+                if (i > 0) { // prefetch the next position while this one is evaluated
+                    f_n = wcf[i - 1];
+                    cv_n = *(const int2*)&wcc[(i - 1) * 4 + 2 * delta];
+                }
+                const bool pick1 = viterbi_step(C, f, cv, delta, st == 0 && p <= wistar, (p & 15) == 15, ldq1);
+                const unsigned nib = (unsigned)(__ballot(pick1) >> (LANE & ~3)) & 0xFu;
+                word |= nib << (4 * (p & 7));
+                if ((p & 7) == 0) { // eight positions per 32-bit word
+                    if (st == 0) wdec[p >> 3] = word;
+                    word = 0;
+                }
             }
         }
+        if (shared) __syncthreads();
     }
     WSYNC();
     PROF_MARK(q2_);
     PROF_ADD2(PH_QBACK, q1_, q2_);
+    if (!active) return 0;
     // ---- forward trace from state 0 (quantizer.rs:686-721) + level-cost walk ----
     const int per = P >= 64 ? (P >> 6) : 1; // consecutive positions per lane
     const int p0 = LANE * per;
-    const bool active = p0 < P;
+    const bool act = p0 < P;
     int fmap = 0xE4; // identity map
-    if (active) {
+    if (act) {
         for (int j = 0; j < per; ++j) {
             const int p = p0 + j;
             const int tc = tcs[p], qd = qds[p], nib = (decw[p >> 3] >> (4 * (p & 7))) & 15;
@@ -924,7 +976,7 @@ __device__ __forceinline__ long long quantize(Ctx c, int lg, int* overflow) {
     long long sum_nz = 0;
     unsigned zmask = 0;
     int fnz = P;
-    if (active) {
+    if (act) {
         int state = entry;
         for (int j = 0; j < per; ++j) {
             const int p = p0 + j;
@@ -953,7 +1005,7 @@ __device__ __forceinline__ long long quantize(Ctx c, int lg, int* overflow) {
         }
     }
     const int pf = wave_min_i32(fnz); // zeros before the first non-zero level cost nothing
-    if (active) {
+    if (act) {
         int nz_after = 0;
         for (int j = 0; j < per; ++j)
             if (((zmask >> j) & 1) && p0 + j > pf) ++nz_after;
@@ -995,8 +1047,8 @@ struct CompCost {
 
 // predict -> T -> Q -> DQ -> IT -> recon (+SSD) of one component
 // (block_splitter.rs:146-185); levels stay in bufC.
-__device__ __noinline__ CompCost code_component(Ctx c, int comp, int tx, int ty, int tlg, int mode,
-                                   int* overflow) {
+__device__ __noinline__ CompCost code_component(Ctx c, int comp, int tx, int ty, int tlg, int mode, bool shared,
+                                                bool active, int* overflow) {
     c = uni(c);
     comp = uni(comp);
     tx = uni(tx);
@@ -1007,13 +1059,18 @@ __device__ __noinline__ CompCost code_component(Ctx c, int comp, int tx, int ty,
     const int lg = tlg - cs;
     const int n = 1 << lg;
     const int cx = tx >> cs, cy = ty >> cs;
+    CompCost r;
+    if (!active) { // keep the shared-Viterbi barriers company (all waves run the same schedule)
+        r.level = quantize(c, lg, shared, false, overflow);
+        r.ssd = 0;
+        return r;
+    }
     PROF_MARK(t0_);
     predict(c, comp, tx, ty, tlg, mode);
     PROF_MARK(t1_);
     fwd_dct_lg(c, lg);
     PROF_MARK(t2_);
-    CompCost r;
-    r.level = quantize(c, lg, overflow);
+    r.level = quantize(c, lg, shared, true, overflow);
     PROF_MARK(t3_);
     dequantize_t(c, lg);
     PROF_MARK(t4_);
@@ -1168,8 +1225,8 @@ struct LeafResult {
 };
 
 // get_intra_pred_cost (block_splitter.rs:110-474) for modes [ml, mc, mc]
-__device__ __noinline__ float full_cost(Ctx c, int tree, int bx, int by, int lg, int ml, int mc,
-                           int* overflow) {
+__device__ __noinline__ float full_cost(Ctx c, int tree, int bx, int by, int lg, int ml, int mc, bool active,
+                                       int* overflow) {
     c = uni(c);
     tree = uni(tree);
     bx = uni(bx);
@@ -1182,17 +1239,18 @@ __device__ __noinline__ float full_cost(Ctx c, int tree, int bx, int by, int lg,
     unsigned long long ssd = 0;
     long long level = 0;
     {
-        const CompCost r = code_component(c, 0, bx, by, lg, ml, overflow);
+        const CompCost r = code_component(c, 0, bx, by, lg, ml, true, active, overflow);
         ssd += r.ssd;
         level += r.level;
     }
     if (tree == TREE_SINGLE) {
         for (int comp = 1; comp < 3; ++comp) {
-            const CompCost r = code_component(c, comp, bx, by, lg, mc, overflow);
+            const CompCost r = code_component(c, comp, bx, by, lg, mc, true, active, overflow);
             ssd += r.ssd;
             level += r.level;
         }
     }
+    if (!active) return 3.40282347e+38f; // skipped evaluation (f32::MAX in the reference)
     const int cc = (tree == TREE_SINGLE && cclm) ? 1 + (mc - LT_CCLM) : 0;
     level += c.k->hb_luma[tree == TREE_SINGLE ? 0 : 1][cc][cls];
     return rd_cost(ssd, level, c.k->lambda_rd);
@@ -1224,7 +1282,7 @@ __device__ __noinline__ float chroma_full_cost(Ctx c, int bx, int by, int lg, in
     unsigned long long ssd = 0;
     long long level = 0;
     for (int comp = 1; comp < 3; ++comp) {
-        const CompCost r = code_component(c, comp, bx, by, lg, mc, overflow);
+        const CompCost r = code_component(c, comp, bx, by, lg, mc, true, true, overflow);
         ssd += r.ssd;
         level += r.level;
     }
@@ -1308,7 +1366,7 @@ __device__ __noinline__ LeafResult leaf_luma(Ctx c, int tree, int bx, int by, in
         // {0,1,2,7,13,18,23,29,34,39,45,50,55,60,66} (:887), 7 bits each
         const int m = i < 8 ? (int)((0x3A5C90D0E08080ULL >> (7 * i)) & 127) : (int)((0x109E3764B53A2ULL >> (7 * (i - 8))) & 127);
         if (m <= 1) {
-            const float v = full_cost(c, tree, bx, by, lg, m, m, overflow);
+            const float v = full_cost(c, tree, bx, by, lg, m, m, true, overflow);
             if (m == 0) cost_planar = v; else cost_dc = v;
         } else {
             const float v = aux_cost(c, tree, bx, by, lg, m);
@@ -1336,11 +1394,11 @@ __device__ __noinline__ LeafResult leaf_luma(Ctx c, int tree, int bx, int by, in
     }
     // step_search(mode, 1, _, aux=false) (:974)
     {
-        cur_cost = full_cost(c, tree, bx, by, lg, cur_mode, cur_mode, overflow);
-        const float c0 = cur_mode < 3 ? 3.40282347e+38f
-                                      : full_cost(c, tree, bx, by, lg, cur_mode - 1, cur_mode - 1, overflow);
-        const float c1 = cur_mode + 1 > 66 ? 3.40282347e+38f
-                                           : full_cost(c, tree, bx, by, lg, cur_mode + 1, cur_mode + 1, overflow);
+        // out-of-range neighbours are "evaluated" inactive: the wave still walks the schedule so
+        // that the workgroup's shared Viterbi barriers stay aligned; the result is f32::MAX
+        cur_cost = full_cost(c, tree, bx, by, lg, cur_mode, cur_mode, true, overflow);
+        const float c0 = full_cost(c, tree, bx, by, lg, cur_mode - 1, cur_mode - 1, !(cur_mode < 3), overflow);
+        const float c1 = full_cost(c, tree, bx, by, lg, cur_mode + 1, cur_mode + 1, !(cur_mode + 1 > 66), overflow);
         const float mn = fminf(fminf(cur_cost, c0), c1);
         if (cur_cost == mn) {
         } else if (c0 == mn) {
@@ -1361,7 +1419,7 @@ __device__ __noinline__ LeafResult leaf_luma(Ctx c, int tree, int bx, int by, in
     else
         mode = cur_mode;
     // luma re-run with the winner (:989-1037)
-    code_component(c, 0, bx, by, lg, mode, overflow);
+    code_component(c, 0, bx, by, lg, mode, true, true, overflow);
     LeafResult r;
     r.luma_mode = mode;
     r.chroma_mode = mode;
@@ -1374,13 +1432,15 @@ __device__ __noinline__ LeafResult leaf_luma(Ctx c, int tree, int bx, int by, in
         const float cclm_cost = chroma_full_cost(c, bx, by, lg, cclm_mode, overflow);
         const float mn = fminf(cclm_cost, fminf(cur, 3.40282347e+38f));
         if (cur == mn) {
-            min_cost = full_cost(c, tree, bx, by, lg, mode, mode, overflow);
+            min_cost = full_cost(c, tree, bx, by, lg, mode, mode, true, overflow);
         } else {
             r.chroma_mode = cclm_mode;
-            min_cost = full_cost(c, tree, bx, by, lg, mode, cclm_mode, overflow);
+            min_cost = full_cost(c, tree, bx, by, lg, mode, cclm_mode, true, overflow);
         }
-    } else if (mode <= 1) {
-        min_cost = full_cost(c, tree, bx, by, lg, mode, mode, overflow);
+    } else {
+        const bool need = mode <= 1; // :1073-1076; otherwise an inactive walk of the schedule
+        const float v = full_cost(c, tree, bx, by, lg, mode, mode, need, overflow);
+        if (need) min_cost = v;
     }
     r.cost = min_cost;
     return r;
@@ -1566,17 +1626,17 @@ __device__ __noinline__ void final_component(Ctx c, const PicBufs& pb, int comp,
     for (int i = LANE; i < n * n; i += 64)
         before[i] = (uint8_t)rec_get(comp, cx + (i & (n - 1)), cy + (i >> lg));
     WSYNC();
-    code_component(c, comp, tx, ty, tlg, mode, overflow);
+    code_component(c, comp, tx, ty, tlg, mode, false, true, overflow);
     const int stride = c.k->W >> cs;
     const int gx = (c.ctu_x >> cs) + cx, gy = (c.ctu_y >> cs) + cy;
     int16_t* lev = pb.lev[comp];
     for (int i = LANE; i < n * n; i += 64) {
         const int x = i & (n - 1), y = i >> lg;
-        lev[(size_t)(gy + y) * stride + gx + x] = SH.bufC[i];
+        if (c.write) lev[(size_t)(gy + y) * stride + gx + x] = SH.bufC[i];
         if (before[i] != (uint8_t)rec_get(comp, cx + x, cy + y)) ++diff;
     }
     const int total = wave_sum_i32((int)diff);
-    if (total && LANE == 0) atomicAdd(c.mismatch, (unsigned long long)total);
+    if (total && LANE == 0 && c.write) atomicAdd(c.mismatch, (unsigned long long)total);
     WSYNC();
 }
 
@@ -1610,11 +1670,12 @@ __device__ void final_pass_ctu(Ctx c, const PicBufs& pb, int* overflow) {
 // CTU entry: load, search, final pass, store
 // ---------------------------------------------------------------------------
 __device__ void load_tables(Ctx c) {
-    for (int i = LANE; i < 256; i += 64) {
-        SH.ldq[i] = (int32_t)c.k->ldq[i];
-        SH.lv[i] = (int32_t)c.k->lv[i];
+    for (int i = threadIdx.x; i < 256; i += blockDim.x) {
+        SHT.ldq[i] = (int32_t)c.k->ldq[i];
+        SHT.lv[i] = (int32_t)c.k->lv[i];
     }
-    for (int i = LANE; i < 128; i += 64) ((int8_t*)SH.fc)[i] = ((const int8_t*)c.k->fc)[i];
+    for (int i = threadIdx.x; i < 128; i += blockDim.x) ((int8_t*)SHT.fc)[i] = ((const int8_t*)c.k->fc)[i];
+    __syncthreads();
 }
 
 __device__ void encode_ctu(Ctx& c, const PicBufs& pb, int ctu_col, int ctu_row, int* overflow) {
@@ -1674,6 +1735,7 @@ __device__ void encode_ctu(Ctx& c, const PicBufs& pb, int ctu_col, int ctu_row, 
     const float cost = split_ct_ctu(c, k->max_depth, overflow);
     final_pass_ctu(c, pb, overflow);
     // store recon + decisions
+    if (c.write) {
     for (int i = LANE; i < 1024 / 4; i += 64) {
         const int y = i >> 3, x4 = (i & 7) * 4;
         *(uint32_t*)&pb.rec[0][(size_t)(c.ctu_y + y) * W + c.ctu_x + x4] = *(const uint32_t*)&SH.recY[y * 36 + x4 + 4];
@@ -1694,6 +1756,7 @@ __device__ void encode_ctu(Ctx& c, const PicBufs& pb, int ctu_col, int ctu_row, 
             pb.chroma_mode[oc] = SH.chroma_mode[i];
         }
         if (i == 0) pb.ctu_cost[ctu_row * k->ctu_cols + ctu_col] = cost;
+    }
     }
 #ifdef WRENC_PROFILE
     PROF_MARK(tt1_);

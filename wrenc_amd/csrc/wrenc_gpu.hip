@@ -24,27 +24,31 @@ using namespace wrenc;
 // ---------------------------------------------------------------------------
 // kernels
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(64, 4) void ctu_search_kernel(const DevConst* __restrict__ k,
-                                                        const PicBufs* __restrict__ slots,
-                                                        int first_slot, int diag, int r_min, int count,
-                                                        unsigned long long* mismatch, int* overflow) {
-    const int pic = blockIdx.x / count;
-    const int j = blockIdx.x - pic * count;
+__global__ __launch_bounds__(64 * WPB) void ctu_search_kernel(const DevConst* __restrict__ k,
+                                                              const PicBufs* __restrict__ slots, int first_slot,
+                                                              int n_pictures, int diag, int r_min, int count,
+                                                              unsigned long long* mismatch, int* overflow) {
+    // one workgroup = the same CTU of WPB consecutive pictures, one wave each
+    const int group = blockIdx.x / count;
+    const int j = blockIdx.x - group * count;
     const int row = r_min + j;
     const int col = diag - 2 * row;
+    int pic = group * WPB + WAVE;
     Ctx c;
     c.k = k;
     c.mismatch = mismatch;
+    c.write = pic < n_pictures ? 1 : 0;
+    if (pic >= n_pictures) pic = n_pictures - 1; // padding wave: same work, no stores
     const PicBufs pb = slots[first_slot + pic];
     int ovf = 0;
     encode_ctu(c, pb, col, row, &ovf);
-    if (ovf && threadIdx.x == 0) atomicOr(overflow, 1);
+    if (ovf && LANE == 0) atomicOr(overflow, 1);
 }
 
 // building-block kernels: one wave per block of side 1 << lg
-__global__ __launch_bounds__(64, 4) void test_fwd_dct_kernel(const DevConst* __restrict__ k,
+__global__ __launch_bounds__(64) void test_fwd_dct_kernel(const DevConst* __restrict__ k,
                                                           const int16_t* in, int lg, int16_t* out) {
-    Ctx c;
+    Ctx c = {};
     c.k = k;
     const int nn = 1 << (2 * lg);
     for (int i = threadIdx.x; i < nn; i += 64) SH.bufA[i] = in[(size_t)blockIdx.x * nn + i];
@@ -53,9 +57,9 @@ __global__ __launch_bounds__(64, 4) void test_fwd_dct_kernel(const DevConst* __r
     for (int i = threadIdx.x; i < nn; i += 64) out[(size_t)blockIdx.x * nn + i] = SH.bufB[i];
 }
 
-__global__ __launch_bounds__(64, 4) void test_inv_dct_kernel(const DevConst* __restrict__ k,
+__global__ __launch_bounds__(64) void test_inv_dct_kernel(const DevConst* __restrict__ k,
                                                           const int16_t* in, int lg, int16_t* out) {
-    Ctx c;
+    Ctx c = {};
     c.k = k;
     const int n = 1 << lg, nn = n * n;
     for (int i = threadIdx.x; i < nn; i += 64) // transposed load: dT[x][i] = d[i][x]
@@ -65,17 +69,17 @@ __global__ __launch_bounds__(64, 4) void test_inv_dct_kernel(const DevConst* __r
     for (int i = threadIdx.x; i < nn; i += 64) out[(size_t)blockIdx.x * nn + i] = SH.bufA[i];
 }
 
-__global__ __launch_bounds__(64, 4) void test_quantize_kernel(const DevConst* __restrict__ k,
+__global__ __launch_bounds__(64) void test_quantize_kernel(const DevConst* __restrict__ k,
                                                            const int16_t* in, int lg, int16_t* out,
                                                            long long* cost, int* overflow) {
-    Ctx c;
+    Ctx c = {};
     c.k = k;
     load_tables(c);
     const int nn = 1 << (2 * lg);
     for (int i = threadIdx.x; i < nn; i += 64) SH.bufB[i] = in[(size_t)blockIdx.x * nn + i];
     WSYNC();
     int ovf = 0;
-    const long long lc = quantize(c, lg, &ovf);
+    const long long lc = quantize(c, lg, false, true, &ovf);
     for (int i = threadIdx.x; i < nn; i += 64) out[(size_t)blockIdx.x * nn + i] = SH.bufC[i];
     if (threadIdx.x == 0) {
         cost[blockIdx.x] = lc;
@@ -83,9 +87,9 @@ __global__ __launch_bounds__(64, 4) void test_quantize_kernel(const DevConst* __
     }
 }
 
-__global__ __launch_bounds__(64, 4) void test_dequantize_kernel(const DevConst* __restrict__ k,
+__global__ __launch_bounds__(64) void test_dequantize_kernel(const DevConst* __restrict__ k,
                                                              const int16_t* in, int lg, int16_t* out) {
-    Ctx c;
+    Ctx c = {};
     c.k = k;
     const int n = 1 << lg, nn = n * n;
     for (int i = threadIdx.x; i < nn; i += 64) SH.bufC[i] = in[(size_t)blockIdx.x * nn + i];
@@ -461,8 +465,9 @@ int wrenc_gpu_encode(wrenc_gpu_ctx* ctx, int first_slot, int n_pictures) {
         const int count = r_max - r_min + 1;
         if (count <= 0) continue;
         HIP_TRY(ctx, hipEventRecord(ctx->ev_pool[2 * launches], ctx->stream));
-        hipLaunchKernelGGL(ctu_search_kernel, dim3(count * n_pictures), dim3(64), 0, ctx->stream, ctx->d_const,
-                           ctx->d_slots, first_slot, d, r_min, count, ctx->d_mismatch, ctx->d_overflow);
+        const int groups = (n_pictures + WPB - 1) / WPB;
+        hipLaunchKernelGGL(ctu_search_kernel, dim3(count * groups), dim3(64 * WPB), 0, ctx->stream, ctx->d_const,
+                           ctx->d_slots, first_slot, n_pictures, d, r_min, count, ctx->d_mismatch, ctx->d_overflow);
         HIP_TRY(ctx, hipGetLastError());
         HIP_TRY(ctx, hipEventRecord(ctx->ev_pool[2 * launches + 1], ctx->stream));
         ++launches;
