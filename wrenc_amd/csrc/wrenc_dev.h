@@ -58,24 +58,19 @@ struct PicBufs {
 
 // LDS working set of one wave / one CTU.
 struct __attribute__((aligned(16))) Lds {
-    int16_t bufA[1024];
-    int16_t bufB[1024];
-    int16_t bufC[1024];
-    int32_t bufH[33 * 32];
-    int16_t refL[136];
-    int16_t refA[136];
-    int16_t refLf[136];
-    int16_t refAf[136];
-    uint8_t pred[1024];
-    uint8_t orgY[32 * 32];
-    uint8_t orgC[2][16 * 16];
+    // Transform working set, time-multiplexed (see code_component):
+    //   r1: residual -> coefficients -> Viterbi chunk costs / levels -> reconstructed residual
+    //   r2: stage-1 DCT output (i32) -> scan-order coefficients + quotients -> dequantised^T + V
+    int16_t r1[1024];
+    int32_t r2[33 * 32];
+    // reference samples of the current block, built once per (block, component) and reused by
+    // every candidate mode: luma unfiltered + [1 2 1]-filtered, chroma unfiltered
+    int16_t refL0[66], refA0[64], refLf0[66], refAf0[64];
+    int16_t refLc[2][34], refAc[2][32];
     uint8_t recYtop[72];       // y = -1, x = -4..67 (index x+4)
     uint8_t recY[32 * 36];     // x = -4..31 (index x+4), stride 36
     uint8_t recCtop[2][40];    // y = -1, x = -4..35
     uint8_t recC[2][16 * 20];  // x = -4..15, stride 20
-    uint8_t saveY[1024 + 256 + 64];
-    uint8_t saveC[2][256 + 64 + 16];
-    uint8_t saveCclm[2][256];
     uint32_t decw[128];        // trellis decisions: 4 bits per position, 8 positions per word
     int32_t q_istar;           // shared-Viterbi hand-off: first position with a non-zero state-0 level
     int32_t q_active;          // this wave's TB takes part in the shared Viterbi
@@ -93,10 +88,12 @@ struct __attribute__((aligned(16))) Lds {
 // stage functions never reload it from memory.
 struct Ctx {
     const DevConst* __restrict__ k;
+    const uint8_t* org[3];              // original planes of this wave's picture (read-only, L2-resident)
+    uint8_t* pred_scratch;              // 1 KB per wave in HBM: prediction bytes between predict and recon
+    unsigned long long* mismatch;
     int ctu_x, ctu_y; // luma, picture coordinates
     int cu32_mode;    // in-CTU neighbour lookups during search resolve to the root CU
     int write;        // 0 for a padding wave (batch not a multiple of WPB): compute, never store
-    unsigned long long* mismatch;
 };
 
 // LDS: one working set per wave (= per CTU), WPB waves per workgroup, plus tables shared
@@ -124,18 +121,13 @@ __shared__ LdsTab SHT;
 // compiler keep them in SGPRs (scalar ALU, scalar branches, s_load from the constant block).
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 __device__ __forceinline__ Ctx uni(Ctx c) {
-    const unsigned long long kp = (unsigned long long)c.k, mp = (unsigned long long)c.mismatch;
-    const unsigned long long ku = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(kp >> 32)) << 32) |
-                                  (unsigned)__builtin_amdgcn_readfirstlane((int)kp);
-    const unsigned long long mu = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(mp >> 32)) << 32) |
-                                  (unsigned)__builtin_amdgcn_readfirstlane((int)mp);
+    static_assert(sizeof(Ctx) % 4 == 0, "Ctx must be a whole number of dwords");
+    int w[sizeof(Ctx) / 4];
+    __builtin_memcpy(w, &c, sizeof(Ctx));
+#pragma unroll
+    for (unsigned i = 0; i < sizeof(Ctx) / 4; ++i) w[i] = __builtin_amdgcn_readfirstlane(w[i]);
     Ctx r;
-    r.k = (const DevConst*)ku;
-    r.mismatch = (unsigned long long*)mu;
-    r.ctu_x = __builtin_amdgcn_readfirstlane(c.ctu_x);
-    r.ctu_y = __builtin_amdgcn_readfirstlane(c.ctu_y);
-    r.cu32_mode = __builtin_amdgcn_readfirstlane(c.cu32_mode);
-    r.write = __builtin_amdgcn_readfirstlane(c.write);
+    __builtin_memcpy(&r, w, sizeof(Ctx));
     return r;
 }
 
@@ -197,8 +189,12 @@ __device__ __forceinline__ void rec_put(int c, int x, int y, int v) {
     else
         SH.recC[c - 1][y * 20 + x + 4] = (uint8_t)v;
 }
-__device__ __forceinline__ int org_get(int c, int x, int y) {
-    return c == 0 ? SH.orgY[y * 32 + x] : SH.orgC[c - 1][y * 16 + x];
+// original sample at CTU-local component coordinates (global load; the planes are read-only
+// for the whole launch, so the loads are cacheable and need no ordering)
+__device__ __forceinline__ int org_get(const Ctx& c, int comp, int x, int y) {
+    const int cs = comp ? 1 : 0;
+    const int stride = c.k->W >> cs;
+    return c.org[comp][(size_t)((c.ctu_y >> cs) + y) * stride + (c.ctu_x >> cs) + x];
 }
 
 // ---------------------------------------------------------------------------
@@ -245,20 +241,23 @@ __device__ __forceinline__ bool nb_avail(Ctx c, int gx, int gy, int tn, int xn, 
 // ---------------------------------------------------------------------------
 // Intra prediction.  tx, ty: CTU-local luma position of the TU, tlg: log2 luma
 // size, comp: component, mode: TU-array prediction mode.
-// Writes SH.pred (compact n*n) and the residual org - pred into SH.bufA.
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ int pdpc_w(int n_scale, int i) {
     const int sh = (i << 1) >> n_scale;
     return sh > 5 ? 0 : (32 >> sh);
 }
 
-__device__ __forceinline__ void build_refs(Ctx c, int comp, int tx, int ty, int tlg, int mode) {
+// Reference samples of one (block, component) into the per-component LDS arrays: unfiltered
+// always, plus the [1 2 1]-filtered version for luma blocks of more than 32 samples
+// (intra_predictor.rs:146-353).  The neighbourhood of a block does not change while its
+// candidate modes are evaluated (evaluations only write inside the block), so this runs once per
+// block and component instead of once per mode.
+__device__ __noinline__ void build_refs(Ctx c, int comp, int tx, int ty, int tlg) {
     c = uni(c);
     comp = uni(comp);
     tx = uni(tx);
     ty = uni(ty);
     tlg = uni(tlg);
-    mode = uni(mode);
     const int cs = comp ? 1 : 0;
     const int n = 1 << (tlg - cs);
     const int tn = 1 << tlg;
@@ -267,6 +266,8 @@ __device__ __forceinline__ void build_refs(Ctx c, int comp, int tx, int ty, int 
     const bool ar = above_right_avail(c, tx, ty, tlg);
     const bool bl = below_left_avail(c, tx, ty, tlg);
     const int st = 1 << cs;
+    int16_t* refL = comp == 0 ? SH.refL0 : SH.refLc[comp - 1];
+    int16_t* refA = comp == 0 ? SH.refA0 : SH.refAc[comp - 1];
     // segment availabilities in substitution-scan order: BL, L, corner, A, AR (bit j = segment j)
     int avm = 0;
     avm |= nb_avail(c, gx, gy, tn, gx - st, gy + tn, ar, bl) ? 1 : 0;
@@ -312,37 +313,38 @@ __device__ __forceinline__ void build_refs(Ctx c, int comp, int tx, int ty, int 
             v = src_left ? rec_get(comp, cx - 1, cy + sli - 1) : rec_get(comp, cx + sai, cy - 1);
         }
         if (is_left)
-            SH.refL[li] = (int16_t)v;
+            refL[li] = (int16_t)v;
         else
-            SH.refA[ai] = (int16_t)v;
+            refA[ai] = (int16_t)v;
     }
     WSYNC();
-    // [1 2 1] filter, intra_predictor.rs:304-352
-    const bool filt = comp == 0 && n * n > 32 && (mode == 0 || mode == 2 || mode == 34 || mode == 66);
-    for (int t = LANE; t < total; t += 64) {
-        if (t <= 2 * n) {
-            const int li = t;
-            int v;
-            if (!filt || li == 2 * n)
-                v = SH.refL[li];
-            else if (li == 0)
-                v = (SH.refL[1] + 2 * SH.refL[0] + SH.refA[0] + 2) >> 2;
-            else
-                v = (SH.refL[li + 1] + 2 * SH.refL[li] + SH.refL[li - 1] + 2) >> 2;
-            SH.refLf[li] = (int16_t)v;
-        } else {
-            const int ai = t - (2 * n + 1);
-            int v;
-            if (!filt || ai == 2 * n - 1)
-                v = SH.refA[ai];
-            else if (ai == 0)
-                v = (SH.refL[0] + 2 * SH.refA[0] + SH.refA[1] + 2) >> 2;
-            else
-                v = (SH.refA[ai - 1] + 2 * SH.refA[ai] + SH.refA[ai + 1] + 2) >> 2;
-            SH.refAf[ai] = (int16_t)v;
+    // [1 2 1] filter, intra_predictor.rs:304-352 (used by modes 0, 2, 34, 66 only)
+    if (comp == 0 && n * n > 32) {
+        for (int t = LANE; t < total; t += 64) {
+            if (t <= 2 * n) {
+                const int li = t;
+                int v;
+                if (li == 2 * n)
+                    v = refL[li];
+                else if (li == 0)
+                    v = (refL[1] + 2 * refL[0] + refA[0] + 2) >> 2;
+                else
+                    v = (refL[li + 1] + 2 * refL[li] + refL[li - 1] + 2) >> 2;
+                SH.refLf0[li] = (int16_t)v;
+            } else {
+                const int ai = t - (2 * n + 1);
+                int v;
+                if (ai == 2 * n - 1)
+                    v = refA[ai];
+                else if (ai == 0)
+                    v = (refL[0] + 2 * refA[0] + refA[1] + 2) >> 2;
+                else
+                    v = (refA[ai - 1] + 2 * refA[ai] + refA[ai + 1] + 2) >> 2;
+                SH.refAf0[ai] = (int16_t)v;
+            }
         }
+        WSYNC();
     }
-    WSYNC();
 }
 
 // CCLM model parameters (intra_predictor.rs:1604-2031); uniform across the wave
@@ -489,7 +491,24 @@ __device__ __forceinline__ CclmParams cclm_params(Ctx c, int comp, int tx, int t
     return r;
 }
 
-__device__ __forceinline__ void predict(Ctx c, int comp, int tx, int ty, int tlg, int mode) {
+// one predicted sample: accumulate |org - pred|; FULL also stores residual and prediction
+template <bool FULL>
+__device__ __forceinline__ int emit_sample(const Ctx& c, int comp, int x, int y, int i, int v) {
+    const int d = org_get(c, comp, x, y) - v;
+    if (FULL) {
+        SH.r1[i] = (int16_t)d;
+        c.pred_scratch[i] = (uint8_t)v;
+    }
+    return d < 0 ? -d : d;
+}
+
+// Prediction of one component block from the cached reference samples (build_refs must have
+// run for this block and component; CCLM reads the reconstructed luma instead).
+// FULL: the residual org - pred goes to r1 (compact n*n) and the prediction bytes to this
+//       wave's scratch (each lane later re-reads exactly the bytes it wrote).
+// Returns the lane's partial sum of |org - pred| (the SAD of block_splitter.rs:96-104).
+template <bool FULL>
+__device__ __forceinline__ int predict(Ctx c, int comp, int tx, int ty, int tlg, int mode) {
     c = uni(c);
     comp = uni(comp);
     tx = uni(tx);
@@ -501,6 +520,7 @@ __device__ __forceinline__ void predict(Ctx c, int comp, int tx, int ty, int tlg
     const int n = 1 << lg;
     const int cx = tx >> cs, cy = ty >> cs;
     const int nn = n * n;
+    int sad = 0;
     if (mode >= LT_CCLM) {
         const CclmParams cp = cclm_params(c, comp, tx, ty, tlg, mode);
         for (int i = LANE; i < nn; i += 64) {
@@ -513,15 +533,15 @@ __device__ __forceinline__ void predict(Ctx c, int comp, int tx, int ty, int tlg
                 v = ((ds * cp.a) >> cp.k) + cp.b;
                 v = min(max(v, 0), 255);
             }
-            SH.pred[i] = (uint8_t)v;
-            SH.bufA[i] = (int16_t)(org_get(comp, cx + x, cy + y) - v);
+            sad += emit_sample<FULL>(c, comp, cx + x, cy + y, i, v);
         }
         WSYNC();
-        return;
+        return sad;
     }
-    build_refs(c, comp, tx, ty, tlg, mode);
-    const int16_t* L = SH.refLf; // index 0 = corner
-    const int16_t* A = SH.refAf;
+    // luma blocks of more than 32 samples use the filtered references for modes 0, 2, 34, 66
+    const bool filt = comp == 0 && nn > 32 && (mode == 0 || mode == 2 || mode == 34 || mode == 66);
+    const int16_t* L = comp == 0 ? (filt ? SH.refLf0 : SH.refL0) : SH.refLc[comp - 1]; // index 0 = corner
+    const int16_t* A = comp == 0 ? (filt ? SH.refAf0 : SH.refA0) : SH.refAc[comp - 1];
     const int alrs = L[0];
     if (mode == PLANAR || mode == DC) {
         int dcv = 0;
@@ -545,11 +565,10 @@ __device__ __forceinline__ void predict(Ctx c, int comp, int tx, int ty, int tlg
             const int wl = pdpc_w(n_scale, x), wt = pdpc_w(n_scale, y);
             v = (int16_t)(L[y + 1] * wl + A[x] * wt + (64 - wt - wl) * v + 32) >> 6;
             v = min(max(v, 0), 255);
-            SH.pred[i] = (uint8_t)v;
-            SH.bufA[i] = (int16_t)(org_get(comp, cx + x, cy + y) - v);
+            sad += emit_sample<FULL>(c, comp, cx + x, cy + y, i, v);
         }
         WSYNC();
-        return;
+        return sad;
     }
     // angular 2..66 (intra_predictor.rs:1287-1602), square blocks
     const int angle = c.k->intra_angle[14 + mode];
@@ -643,10 +662,10 @@ __device__ __forceinline__ void predict(Ctx c, int comp, int tx, int ty, int tlg
             v = (int16_t)(rl * wl + rt * wt + (64 - wt - wl) * v + 32) >> 6;
             v = min(max(v, 0), 255);
         }
-        SH.pred[i] = (uint8_t)v;
-        SH.bufA[i] = (int16_t)(org_get(comp, cx + x, cy + y) - v);
+        sad += emit_sample<FULL>(c, comp, cx + x, cy + y, i, v);
     }
     WSYNC();
+    return sad;
 }
 
 // ---------------------------------------------------------------------------
@@ -668,12 +687,12 @@ __device__ __forceinline__ int dot2(uint32_t a, uint32_t b, int acc) {
 #endif
 }
 
-// forward: residual bufA (n*n i16) -> coefficients bufB (n*n i16); transformer.rs:2040-2378
+// forward: residual r1 (n*n i16) -> coefficients r1 (n*n i16), via r2; transformer.rs:2040-2378
 template <int LG>
 __device__ void fwd_dct(Ctx c) {
     constexpr int N = 1 << LG;
     constexpr int G = 64 / N;
-    constexpr int HS = N + 1; // bufH row stride
+    constexpr int HS = N + 1; // r2 row stride
     const int u = LANE & (N - 1);
     const int g = LANE >> LG;
     uint32_t t[N / 2];
@@ -685,17 +704,17 @@ __device__ void fwd_dct(Ctx c) {
     // stage 1: H[u][y] = (sum_x T[u][x] r[y][x] + d) >> (LG-1)   (:2139-2209)
 #pragma unroll 1
     for (int y = g; y < N; y += G) {
-        const uint32_t* row = (const uint32_t*)&SH.bufA[y * N];
+        const uint32_t* row = (const uint32_t*)&SH.r1[y * N];
         int acc = 0;
 #pragma unroll
         for (int k = 0; k < N / 2; ++k) acc = dot2(row[k], t[k], acc);
-        SH.bufH[u * HS + y] = (acc + (1 << (LG - 2))) >> (LG - 1);
+        SH.r2[u * HS + y] = (acc + (1 << (LG - 2))) >> (LG - 1);
     }
     WSYNC();
     // stage 2: C[v][x] = (sum_y T[v][y] H[x][y] + d) >> (LG+6)  (:2246-2316); lane v = u
 #pragma unroll 1
     for (int x = g; x < N; x += G) {
-        const int32_t* col = &SH.bufH[x * HS];
+        const int32_t* col = &SH.r2[x * HS];
         int acc = 0;
 #pragma unroll
         for (int k = 0; k < N / 2; ++k) {
@@ -703,19 +722,21 @@ __device__ void fwd_dct(Ctx c) {
             acc += __mul24((int)(short)(t[k] & 0xFFFF), col[2 * k]);
             acc += __mul24((int)t[k] >> 16, col[2 * k + 1]);
         }
-        SH.bufB[u * N + x] = (int16_t)((acc + (1 << (LG + 5))) >> (LG + 6));
+        SH.r1[u * N + x] = (int16_t)((acc + (1 << (LG + 5))) >> (LG + 6));
     }
     WSYNC();
 }
 
-// inverse: transposed dequantised coefficients bufA (dT[x][i]) -> residual bufA (r[y][x]);
-// uses bufB for the intermediate.  transformer.rs:2380-2737
+// inverse: transposed dequantised coefficients in the lower half of r2 (dT[x][i], i16) ->
+// residual r1 (r[y][x]); the intermediate lives in the upper half of r2.  transformer.rs:2380-2737
 template <int LG>
 __device__ void inv_dct(Ctx c) {
     constexpr int N = 1 << LG;
     constexpr int G = 64 / N;
     const int u = LANE & (N - 1);
     const int g = LANE >> LG;
+    const int16_t* dqt = (const int16_t*)SH.r2;
+    int16_t* vbuf = (int16_t*)SH.r2 + 1024;
     uint32_t t[N / 2]; // Tt[u][i] = T_N[i][u]
     {
         const uint32_t* src = (const uint32_t*)&c.k->dct_t[LG - 2][u][0];
@@ -725,23 +746,23 @@ __device__ void inv_dct(Ctx c) {
     // stage 1 (vertical): V[y][x] = clamp16((sum_i T[i][y] d[i][x] + 64) >> 7); lane y = u
 #pragma unroll 1
     for (int x = g; x < N; x += G) {
-        const uint32_t* col = (const uint32_t*)&SH.bufA[x * N]; // dT[x][.]
+        const uint32_t* col = (const uint32_t*)&dqt[x * N]; // dT[x][.]
         int acc = 0;
 #pragma unroll
         for (int k = 0; k < N / 2; ++k) acc = dot2(col[k], t[k], acc);
         int v = (acc + 64) >> 7;
         v = min(max(v, -32768), 32767);
-        SH.bufB[u * N + x] = (int16_t)v;
+        vbuf[u * N + x] = (int16_t)v;
     }
     WSYNC();
     // stage 2 (horizontal): r[y][x] = (sum_i T[i][x] V[y][i] + 2048) >> 12; lane x = u
 #pragma unroll 1
     for (int y = g; y < N; y += G) {
-        const uint32_t* row = (const uint32_t*)&SH.bufB[y * N];
+        const uint32_t* row = (const uint32_t*)&vbuf[y * N];
         int acc = 0;
 #pragma unroll
         for (int k = 0; k < N / 2; ++k) acc = dot2(row[k], t[k], acc);
-        SH.bufA[y * N + u] = (int16_t)((acc + 2048) >> 12);
+        SH.r1[y * N + u] = (int16_t)((acc + 2048) >> 12);
     }
     WSYNC();
 }
@@ -811,9 +832,9 @@ __device__ __forceinline__ bool viterbi_step(long long& C, int f, int2 cv, int d
     return pick1;
 }
 
-// Dependent quantisation of one transform block: coefficients bufB (n*n row-major) ->
-// levels bufC (n*n row-major); returns the level cost (block_splitter.rs:436-458).
-// Scratch: bufA, bufH, decw.  `*overflow` is set when a level needs a table entry >= 1024
+// Dependent quantisation of one transform block: coefficients r1 (n*n row-major) ->
+// levels r1 (n*n row-major); returns the level cost (block_splitter.rs:436-458).
+// Scratch: r2, decw.  `*overflow` is set when a level needs a table entry >= 1024
 // (the reference panics there).
 //
 // Backward pass = 4-state Viterbi equivalent of the reference's memoised DFS (SURVEY.md Q3,
@@ -837,17 +858,17 @@ __device__ __forceinline__ long long quantize(Ctx c, int lg, bool shared, bool a
     const int off = (1 << sh) >> 1;
     const int lsc = k->lsc;
     const uint16_t* scan = k->scan_idx[lg - 2];
-    int16_t* tcs = (int16_t*)SH.bufH;        // coefficient in reverse-scan order
-    int16_t* qds = (int16_t*)SH.bufH + 1024; // |(tc << sh) - off| / lsc
-    int32_t* cc = (int32_t*)SH.bufA;         // chunk: [64][4] = c0/c1 for delta 0, c0/c1 for delta 1
-    uint8_t* cf = (uint8_t*)(SH.bufA + 512); // chunk flags
+    int16_t* tcs = (int16_t*)SH.r2;          // coefficient in reverse-scan order
+    int16_t* qds = (int16_t*)SH.r2 + 1024;   // |(tc << sh) - off| / lsc
+    int32_t* cc = (int32_t*)SH.r1;           // chunk: [64][4] = c0/c1 for delta 0, c0/c1 for delta 1
+    uint8_t* cf = (uint8_t*)(SH.r1 + 512);   // chunk flags (coefficients are dead after the gather)
     uint32_t* decw = SH.decw;                 // decisions: 4 bits per position, 8 positions per word
     PROF_MARK(q0_);
     int istar = P;
     if (active) {
         int first = P;
         for (int p = LANE; p < P; p += 64) {
-            const int tc = SH.bufB[scan[p]];
+            const int tc = SH.r1[scan[p]];
             int S = (int)((unsigned)tc << sh) - off;
             if (tc < 0) S = -S;
             const int qd = tc == 0 ? 0 : (int)(((unsigned long long)(unsigned)S * k->div_magic) >> 47);
@@ -870,8 +891,8 @@ __device__ __forceinline__ long long quantize(Ctx c, int lg, bool shared, bool a
     const int quad = LANE >> 2;
     const bool walker = shared ? (WAVE == 0 && quad < WPB) : (quad == 0);
     const Lds* tb = shared ? &SHW[quad < WPB ? quad : 0] : &SH;
-    const int32_t* wcc = (const int32_t*)tb->bufA;
-    const uint8_t* wcf = (const uint8_t*)(tb->bufA + 512);
+    const int32_t* wcc = (const int32_t*)tb->r1;
+    const uint8_t* wcf = (const uint8_t*)(tb->r1 + 512);
     long long C = 0;
     int ovf = 0;
     const int CH = P < 64 ? P : 64;
@@ -991,7 +1012,7 @@ __device__ __forceinline__ long long quantize(Ctx c, int lg, bool shared, bool a
                     q = a > 0 ? 2 * a - dl : 0;
                 if (tc < 0) q = -q;
             }
-            SH.bufC[scan[p]] = (int16_t)q;
+            SH.r1[scan[p]] = (int16_t)q;
             const int qc = abs(q);
             if (qc == 0) {
                 zmask |= 1u << j;
@@ -1019,7 +1040,7 @@ __device__ __forceinline__ long long quantize(Ctx c, int lg, bool shared, bool a
     return sum;
 }
 
-// levels bufC (row-major) -> transposed dequantised coefficients bufA (dT[x][i] = d[i][x]);
+// levels r1 (row-major) -> transposed dequantised coefficients in r2 (dT[x][i] = d[i][x]);
 // quantizer.rs:761-1079
 __device__ __forceinline__ void dequantize_t(Ctx c, int lg) {
     c = uni(c);
@@ -1030,9 +1051,9 @@ __device__ __forceinline__ void dequantize_t(Ctx c, int lg) {
     const int lsc = c.k->lsc;
     for (int i = LANE; i < n * n; i += 64) {
         const int x = i & (n - 1), y = i >> lg;
-        int v = ((int)SH.bufC[i] * lsc + off) >> sh;
+        int v = ((int)SH.r1[i] * lsc + off) >> sh;
         v = min(max(v, -32768), 32767);
-        SH.bufA[x * n + y] = (int16_t)v;
+        ((int16_t*)SH.r2)[x * n + y] = (int16_t)v;
     }
     WSYNC();
 }
@@ -1045,10 +1066,13 @@ struct CompCost {
     long long level;
 };
 
-// predict -> T -> Q -> DQ -> IT -> recon (+SSD) of one component
-// (block_splitter.rs:146-185); levels stay in bufC.
+// predict -> T -> Q -> DQ -> IT -> recon (+SSD) of one component (block_splitter.rs:146-185).
+// The block's reference samples must be current (build_refs).  lev_out != nullptr: the final
+// pass -- the levels are stored to that plane position (row stride lev_stride) and samples whose
+// reconstruction differs from what the search left in the tile are counted in *changed.
 __device__ __noinline__ CompCost code_component(Ctx c, int comp, int tx, int ty, int tlg, int mode, bool shared,
-                                                bool active, int* overflow) {
+                                                bool active, int16_t* lev_out, int lev_stride, int* changed,
+                                                int* overflow) {
     c = uni(c);
     comp = uni(comp);
     tx = uni(tx);
@@ -1066,12 +1090,14 @@ __device__ __noinline__ CompCost code_component(Ctx c, int comp, int tx, int ty,
         return r;
     }
     PROF_MARK(t0_);
-    predict(c, comp, tx, ty, tlg, mode);
+    predict<true>(c, comp, tx, ty, tlg, mode);
     PROF_MARK(t1_);
     fwd_dct_lg(c, lg);
     PROF_MARK(t2_);
     r.level = quantize(c, lg, shared, true, overflow);
     PROF_MARK(t3_);
+    if (lev_out != nullptr && c.write)
+        for (int i = LANE; i < n * n; i += 64) lev_out[(size_t)(i >> lg) * lev_stride + (i & (n - 1))] = SH.r1[i];
     dequantize_t(c, lg);
     PROF_MARK(t4_);
     inv_dct_lg(c, lg);
@@ -1081,22 +1107,25 @@ __device__ __noinline__ CompCost code_component(Ctx c, int comp, int tx, int ty,
     PROF_ADD2(PH_DEQ, t3_, t4_);
     PROF_ADD2(PH_IDCT, t4_, t5_);
     unsigned int part = 0;
+    int diff = 0;
     for (int i = LANE; i < n * n; i += 64) {
         const int x = i & (n - 1), y = i >> lg;
-        int v = (int16_t)((int)SH.pred[i] + (int)SH.bufA[i]);
+        int v = (int16_t)((int)c.pred_scratch[i] + (int)SH.r1[i]); // pred as i16 + res, clamp (:178)
         v = min(max(v, 0), 255);
+        if (changed != nullptr && v != rec_get(comp, cx + x, cy + y)) ++diff;
         rec_put(comp, cx + x, cy + y, v);
-        const int d = v - org_get(comp, cx + x, cy + y);
+        const int d = v - org_get(c, comp, cx + x, cy + y);
         part += (unsigned)(d * d);
     }
     r.ssd = wave_sum_u64((unsigned long long)part);
+    if (changed != nullptr) *changed += wave_sum_i32(diff);
     WSYNC();
     PROF_MARK(t6_);
     PROF_ADD2(PH_RECON, t5_, t6_);
     return r;
 }
 
-// predict + SAD (block_splitter.rs:64-108)
+// predict + SAD (block_splitter.rs:64-108); nothing is stored
 __device__ __noinline__ unsigned int sad_component(Ctx c, int comp, int tx, int ty, int tlg, int mode) {
     c = uni(c);
     comp = uni(comp);
@@ -1104,17 +1133,11 @@ __device__ __noinline__ unsigned int sad_component(Ctx c, int comp, int tx, int 
     ty = uni(ty);
     tlg = uni(tlg);
     mode = uni(mode);
-    const int cs = comp ? 1 : 0;
-    const int n = 1 << (tlg - cs);
     PROF_MARK(t0_);
-    predict(c, comp, tx, ty, tlg, mode);
+    const int part = predict<false>(c, comp, tx, ty, tlg, mode);
     PROF_MARK(t1_);
     PROF_ADD2(PH_PREDICT, t0_, t1_);
-    int part = 0;
-    for (int i = LANE; i < n * n; i += 64) part += abs((int)SH.bufA[i]);
-    const int total = wave_sum_i32(part);
-    WSYNC();
-    return (unsigned)total;
+    return (unsigned)wave_sum_i32(part);
 }
 
 // luma mode of the CU covering picture position (CTU-local x, y), as the search sees it
@@ -1239,13 +1262,13 @@ __device__ __noinline__ float full_cost(Ctx c, int tree, int bx, int by, int lg,
     unsigned long long ssd = 0;
     long long level = 0;
     {
-        const CompCost r = code_component(c, 0, bx, by, lg, ml, true, active, overflow);
+        const CompCost r = code_component(c, 0, bx, by, lg, ml, true, active, nullptr, 0, nullptr, overflow);
         ssd += r.ssd;
         level += r.level;
     }
     if (tree == TREE_SINGLE) {
         for (int comp = 1; comp < 3; ++comp) {
-            const CompCost r = code_component(c, comp, bx, by, lg, mc, true, active, overflow);
+            const CompCost r = code_component(c, comp, bx, by, lg, mc, true, active, nullptr, 0, nullptr, overflow);
             ssd += r.ssd;
             level += r.level;
         }
@@ -1282,7 +1305,7 @@ __device__ __noinline__ float chroma_full_cost(Ctx c, int bx, int by, int lg, in
     unsigned long long ssd = 0;
     long long level = 0;
     for (int comp = 1; comp < 3; ++comp) {
-        const CompCost r = code_component(c, comp, bx, by, lg, mc, true, true, overflow);
+        const CompCost r = code_component(c, comp, bx, by, lg, mc, true, true, nullptr, 0, nullptr, overflow);
         ssd += r.ssd;
         level += r.level;
     }
@@ -1302,26 +1325,35 @@ __device__ __noinline__ float chroma_aux_cost(Ctx c, int bx, int by, int lg, int
     return (float)sad;
 }
 
-__device__ void save_chroma(Ctx c, int bx, int by, int lg, uint8_t (*dst)[256]) {
-    const int n = 1 << (lg - 1);
-    for (int comp = 1; comp < 3; ++comp)
-        for (int i = LANE; i < n * n; i += 64)
-            dst[comp - 1][i] = (uint8_t)rec_get(comp, (bx >> 1) + (i & (n - 1)), (by >> 1) + (i >> (lg - 1)));
-    WSYNC();
-}
-__device__ void restore_chroma(Ctx c, int bx, int by, int lg, const uint8_t (*src)[256]) {
-    const int n = 1 << (lg - 1);
-    for (int comp = 1; comp < 3; ++comp)
-        for (int i = LANE; i < n * n; i += 64)
-            rec_put(comp, (bx >> 1) + (i & (n - 1)), (by >> 1) + (i >> (lg - 1)), src[comp - 1][i]);
-    WSYNC();
-}
-
 __device__ __forceinline__ int pick_cclm(float lt, float t, float l) {
     // block_splitter.rs:847-854
     if (lt <= t && lt <= l) return LT_CCLM;
     if (t <= l) return T_CCLM;
     return L_CCLM;
+}
+
+// Re-create the reconstruction of a decided block by running its evaluation again with the
+// solo Viterbi (no workgroup barriers: which blocks need this differs from wave to wave).  The
+// neighbourhood is unchanged, so the result equals what the evaluation produced the first time;
+// this replaces the reference's cache_reconsts / restore_reconsts copies (block_splitter.rs:
+// 807-840, 1085-1145) without keeping saved planes in LDS.
+__device__ __noinline__ void regen_block(Ctx c, int bx, int by, int lg, int luma_mode, int chroma_mode, bool luma,
+                                         bool chroma, int* overflow) {
+    c = uni(c);
+    bx = uni(bx);
+    by = uni(by);
+    lg = uni(lg);
+    luma_mode = uni(luma_mode);
+    chroma_mode = uni(chroma_mode);
+    if (luma) {
+        build_refs(c, 0, bx, by, lg);
+        code_component(c, 0, bx, by, lg, luma_mode, false, true, nullptr, 0, nullptr, overflow);
+    }
+    if (chroma)
+        for (int comp = 1; comp < 3; ++comp) {
+            if (chroma_mode < LT_CCLM) build_refs(c, comp, bx, by, lg);
+            code_component(c, comp, bx, by, lg, chroma_mode, false, true, nullptr, 0, nullptr, overflow);
+        }
 }
 
 // leaf search of a DUAL_TREE_CHROMA block (block_splitter.rs:794-885); lg = luma log2 (3)
@@ -1331,23 +1363,23 @@ __device__ __noinline__ LeafResult leaf_chroma(Ctx c, int bx, int by, int lg, in
     by = uni(by);
     lg = uni(lg);
     dm_mode = uni(dm_mode);
+    build_refs(c, 1, bx, by, lg);
+    build_refs(c, 2, bx, by, lg);
     const float lt = chroma_aux_cost(c, bx, by, lg, LT_CCLM);
     const float t = chroma_aux_cost(c, bx, by, lg, T_CCLM);
     const float l = chroma_aux_cost(c, bx, by, lg, L_CCLM);
     const int cclm_mode = pick_cclm(lt, t, l);
     const float cclm_cost = chroma_full_cost(c, bx, by, lg, cclm_mode, overflow);
-    save_chroma(c, bx, by, lg, SH.saveCclm);
     const float cur = chroma_full_cost(c, bx, by, lg, dm_mode, overflow);
     LeafResult r;
     r.luma_mode = 0;
     const float mn = fminf(cclm_cost, fminf(cur, 3.40282347e+38f));
+    r.cost = mn;
     if (cur == mn) {
-        r.cost = mn;
         r.chroma_mode = dm_mode;
     } else {
-        r.cost = mn;
         r.chroma_mode = cclm_mode;
-        restore_chroma(c, bx, by, lg, SH.saveCclm);
+        regen_block(c, bx, by, lg, 0, cclm_mode, false, true, overflow); // :869-873 restore_reconsts
     }
     return r;
 }
@@ -1359,6 +1391,11 @@ __device__ __noinline__ LeafResult leaf_luma(Ctx c, int tree, int bx, int by, in
     bx = uni(bx);
     by = uni(by);
     lg = uni(lg);
+    build_refs(c, 0, bx, by, lg);
+    if (tree == TREE_SINGLE) {
+        build_refs(c, 1, bx, by, lg);
+        build_refs(c, 2, bx, by, lg);
+    }
     float cost_planar = 0.f, cost_dc = 0.f;
     float min_dir_cost = 3.40282347e+38f;
     int min_dir_mode = 2;
@@ -1419,7 +1456,7 @@ __device__ __noinline__ LeafResult leaf_luma(Ctx c, int tree, int bx, int by, in
     else
         mode = cur_mode;
     // luma re-run with the winner (:989-1037)
-    code_component(c, 0, bx, by, lg, mode, true, true, overflow);
+    code_component(c, 0, bx, by, lg, mode, true, true, nullptr, 0, nullptr, overflow);
     LeafResult r;
     r.luma_mode = mode;
     r.chroma_mode = mode;
@@ -1472,42 +1509,6 @@ __device__ __noinline__ void fill_maps(Ctx c, int bx, int by, int lg, int luma_m
     WSYNC();
 }
 
-__device__ __forceinline__ int save_off_y(int lg) { return lg == 5 ? 0 : (lg == 4 ? 1024 : 1280); }
-__device__ __forceinline__ int save_off_c(int lg) { return lg == 5 ? 0 : (lg == 4 ? 256 : 320); }
-
-__device__ __noinline__ void save_recon(Ctx c, int bx, int by, int lg) {
-    c = uni(c);
-    bx = uni(bx);
-    by = uni(by);
-    lg = uni(lg);
-    const int n = 1 << lg;
-    uint8_t* dy = SH.saveY + save_off_y(lg);
-    for (int i = LANE; i < n * n; i += 64) dy[i] = (uint8_t)rec_get(0, bx + (i & (n - 1)), by + (i >> lg));
-    const int nc = n >> 1;
-    for (int comp = 1; comp < 3; ++comp) {
-        uint8_t* dc = SH.saveC[comp - 1] + save_off_c(lg);
-        for (int i = LANE; i < nc * nc; i += 64)
-            dc[i] = (uint8_t)rec_get(comp, (bx >> 1) + (i & (nc - 1)), (by >> 1) + (i >> (lg - 1)));
-    }
-    WSYNC();
-}
-__device__ __noinline__ void restore_recon(Ctx c, int bx, int by, int lg) {
-    c = uni(c);
-    bx = uni(bx);
-    by = uni(by);
-    lg = uni(lg);
-    const int n = 1 << lg;
-    const uint8_t* dy = SH.saveY + save_off_y(lg);
-    for (int i = LANE; i < n * n; i += 64) rec_put(0, bx + (i & (n - 1)), by + (i >> lg), dy[i]);
-    const int nc = n >> 1;
-    for (int comp = 1; comp < 3; ++comp) {
-        const uint8_t* dc = SH.saveC[comp - 1] + save_off_c(lg);
-        for (int i = LANE; i < nc * nc; i += 64)
-            rec_put(comp, (bx >> 1) + (i & (nc - 1)), (by >> 1) + (i >> (lg - 1)), dc[i]);
-    }
-    WSYNC();
-}
-
 // ---------------------------------------------------------------------------
 // split_ct (block_splitter.rs:782-1154): exhaustive quad-tree search of one CTU as an
 // explicit depth-first walk (level 0 = 32x32 ... level 2 = 8x8; an 8x8 node's split is
@@ -1547,7 +1548,6 @@ __device__ float split_ct_ctu(Ctx& c, int max_depth, int* overflow) {
             ret = ns.cost;
             done = true;
         } else {
-            save_recon(c, bx, by, lg);
             if (LANE == 0) {
                 SH.ns_cost[level] = ns.cost;
                 SH.ns_luma[level] = (uint8_t)ns.luma_mode;
@@ -1562,7 +1562,7 @@ __device__ float split_ct_ctu(Ctx& c, int max_depth, int* overflow) {
             }
             const float sc = split_node8(c, bx, by, overflow);
             if (sc > ns.cost) { // :1125-1145
-                restore_recon(c, bx, by, lg);
+                regen_block(c, bx, by, lg, ns.luma_mode, ns.chroma_mode, true, true, overflow);
                 fill_maps(c, bx, by, lg, ns.luma_mode, ns.chroma_mode, true, true);
                 ret = ns.cost;
             } else {
@@ -1594,7 +1594,7 @@ __device__ float split_ct_ctu(Ctx& c, int max_depth, int* overflow) {
                 by = pby;
                 level = pl;
                 if (acc > nsc) {
-                    restore_recon(c, bx, by, 5 - pl);
+                    regen_block(c, bx, by, 5 - pl, SH.ns_luma[pl], SH.ns_chroma[pl], true, true, overflow);
                     fill_maps(c, bx, by, 5 - pl, SH.ns_luma[pl], SH.ns_chroma[pl], true, true);
                     ret = nsc;
                 } else {
@@ -1608,8 +1608,8 @@ __device__ float split_ct_ctu(Ctx& c, int max_depth, int* overflow) {
 // ---------------------------------------------------------------------------
 // Final pass (ctu_encoder.rs:1421-1461) in coding order; writes levels to HBM
 // ---------------------------------------------------------------------------
-__device__ __noinline__ void final_component(Ctx c, const PicBufs& pb, int comp, int tx, int ty, int tlg,
-                                int mode, int* overflow) {
+__device__ __noinline__ void final_component(Ctx c, const PicBufs& pb, int comp, int tx, int ty, int tlg, int mode,
+                                             int* overflow) {
     c = uni(c);
     comp = uni(comp);
     tx = uni(tx);
@@ -1617,27 +1617,13 @@ __device__ __noinline__ void final_component(Ctx c, const PicBufs& pb, int comp,
     tlg = uni(tlg);
     mode = uni(mode);
     const int cs = comp ? 1 : 0;
-    const int lg = tlg - cs;
-    const int n = 1 << lg;
-    const int cx = tx >> cs, cy = ty >> cs;
-    // remember what the search left, to count mismatches
-    unsigned int diff = 0;
-    uint8_t* before = SH.saveY; // the save stack is idle during the final pass
-    for (int i = LANE; i < n * n; i += 64)
-        before[i] = (uint8_t)rec_get(comp, cx + (i & (n - 1)), cy + (i >> lg));
-    WSYNC();
-    code_component(c, comp, tx, ty, tlg, mode, false, true, overflow);
     const int stride = c.k->W >> cs;
-    const int gx = (c.ctu_x >> cs) + cx, gy = (c.ctu_y >> cs) + cy;
-    int16_t* lev = pb.lev[comp];
-    for (int i = LANE; i < n * n; i += 64) {
-        const int x = i & (n - 1), y = i >> lg;
-        if (c.write) lev[(size_t)(gy + y) * stride + gx + x] = SH.bufC[i];
-        if (before[i] != (uint8_t)rec_get(comp, cx + x, cy + y)) ++diff;
-    }
-    const int total = wave_sum_i32((int)diff);
-    if (total && LANE == 0 && c.write) atomicAdd(c.mismatch, (unsigned long long)total);
-    WSYNC();
+    const int gx = (c.ctu_x + tx) >> cs, gy = (c.ctu_y + ty) >> cs;
+    if (mode < LT_CCLM) build_refs(c, comp, tx, ty, tlg);
+    int changed = 0;
+    code_component(c, comp, tx, ty, tlg, mode, false, true, pb.lev[comp] + (size_t)gy * stride + gx, stride, &changed,
+                   overflow);
+    if (changed && LANE == 0 && c.write) atomicAdd(c.mismatch, (unsigned long long)changed);
 }
 
 // coding order = z-order over the 4x4 units; a CU is emitted at its top-left unit
@@ -1691,17 +1677,6 @@ __device__ void encode_ctu(Ctx& c, const PicBufs& pb, int ctu_col, int ctu_row, 
 #endif
     PROF_MARK(tt0_);
     load_tables(c);
-    // originals
-    for (int i = LANE; i < 1024 / 4; i += 64) {
-        const int y = i >> 3, x4 = (i & 7) * 4;
-        *(uint32_t*)&SH.orgY[y * 32 + x4] = *(const uint32_t*)&pb.org[0][(size_t)(c.ctu_y + y) * W + c.ctu_x + x4];
-    }
-    for (int comp = 1; comp < 3; ++comp)
-        for (int i = LANE; i < 256 / 4; i += 64) {
-            const int y = i >> 2, x4 = (i & 3) * 4;
-            *(uint32_t*)&SH.orgC[comp - 1][y * 16 + x4] =
-                *(const uint32_t*)&pb.org[comp][(size_t)((c.ctu_y >> 1) + y) * Wc + (c.ctu_x >> 1) + x4];
-        }
     // neighbour border of the reconstruction: row -1 (x = -4..67) and columns -4..-1
     for (int i = LANE; i < 72; i += 64) {
         const int gx = c.ctu_x - 4 + i, gy = c.ctu_y - 1;

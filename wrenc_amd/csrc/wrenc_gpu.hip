@@ -24,22 +24,27 @@ using namespace wrenc;
 // ---------------------------------------------------------------------------
 // kernels
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(64 * WPB) void ctu_search_kernel(const DevConst* __restrict__ k,
+__global__ __launch_bounds__(64 * WPB, 4) void ctu_search_kernel(const DevConst* __restrict__ k,
                                                               const PicBufs* __restrict__ slots, int first_slot,
                                                               int n_pictures, int diag, int r_min, int count,
-                                                              unsigned long long* mismatch, int* overflow) {
+                                                              uint8_t* pred_scratch, unsigned long long* mismatch,
+                                                              int* overflow) {
     // one workgroup = the same CTU of WPB consecutive pictures, one wave each
     const int group = blockIdx.x / count;
     const int j = blockIdx.x - group * count;
     const int row = r_min + j;
     const int col = diag - 2 * row;
     int pic = group * WPB + WAVE;
-    Ctx c;
+    Ctx c = {};
     c.k = k;
     c.mismatch = mismatch;
     c.write = pic < n_pictures ? 1 : 0;
     if (pic >= n_pictures) pic = n_pictures - 1; // padding wave: same work, no stores
     const PicBufs pb = slots[first_slot + pic];
+    c.org[0] = pb.org[0];
+    c.org[1] = pb.org[1];
+    c.org[2] = pb.org[2];
+    c.pred_scratch = pred_scratch + ((size_t)blockIdx.x * WPB + WAVE) * 1024;
     int ovf = 0;
     encode_ctu(c, pb, col, row, &ovf);
     if (ovf && LANE == 0) atomicOr(overflow, 1);
@@ -51,10 +56,10 @@ __global__ __launch_bounds__(64) void test_fwd_dct_kernel(const DevConst* __rest
     Ctx c = {};
     c.k = k;
     const int nn = 1 << (2 * lg);
-    for (int i = threadIdx.x; i < nn; i += 64) SH.bufA[i] = in[(size_t)blockIdx.x * nn + i];
+    for (int i = threadIdx.x; i < nn; i += 64) SH.r1[i] = in[(size_t)blockIdx.x * nn + i];
     WSYNC();
     fwd_dct_lg(c, lg);
-    for (int i = threadIdx.x; i < nn; i += 64) out[(size_t)blockIdx.x * nn + i] = SH.bufB[i];
+    for (int i = threadIdx.x; i < nn; i += 64) out[(size_t)blockIdx.x * nn + i] = SH.r1[i];
 }
 
 __global__ __launch_bounds__(64) void test_inv_dct_kernel(const DevConst* __restrict__ k,
@@ -63,10 +68,10 @@ __global__ __launch_bounds__(64) void test_inv_dct_kernel(const DevConst* __rest
     c.k = k;
     const int n = 1 << lg, nn = n * n;
     for (int i = threadIdx.x; i < nn; i += 64) // transposed load: dT[x][i] = d[i][x]
-        SH.bufA[(i & (n - 1)) * n + (i >> lg)] = in[(size_t)blockIdx.x * nn + i];
+        ((int16_t*)SH.r2)[(i & (n - 1)) * n + (i >> lg)] = in[(size_t)blockIdx.x * nn + i];
     WSYNC();
     inv_dct_lg(c, lg);
-    for (int i = threadIdx.x; i < nn; i += 64) out[(size_t)blockIdx.x * nn + i] = SH.bufA[i];
+    for (int i = threadIdx.x; i < nn; i += 64) out[(size_t)blockIdx.x * nn + i] = SH.r1[i];
 }
 
 __global__ __launch_bounds__(64) void test_quantize_kernel(const DevConst* __restrict__ k,
@@ -76,11 +81,11 @@ __global__ __launch_bounds__(64) void test_quantize_kernel(const DevConst* __res
     c.k = k;
     load_tables(c);
     const int nn = 1 << (2 * lg);
-    for (int i = threadIdx.x; i < nn; i += 64) SH.bufB[i] = in[(size_t)blockIdx.x * nn + i];
+    for (int i = threadIdx.x; i < nn; i += 64) SH.r1[i] = in[(size_t)blockIdx.x * nn + i];
     WSYNC();
     int ovf = 0;
     const long long lc = quantize(c, lg, false, true, &ovf);
-    for (int i = threadIdx.x; i < nn; i += 64) out[(size_t)blockIdx.x * nn + i] = SH.bufC[i];
+    for (int i = threadIdx.x; i < nn; i += 64) out[(size_t)blockIdx.x * nn + i] = SH.r1[i];
     if (threadIdx.x == 0) {
         cost[blockIdx.x] = lc;
         if (ovf) atomicOr(overflow, 1);
@@ -92,11 +97,11 @@ __global__ __launch_bounds__(64) void test_dequantize_kernel(const DevConst* __r
     Ctx c = {};
     c.k = k;
     const int n = 1 << lg, nn = n * n;
-    for (int i = threadIdx.x; i < nn; i += 64) SH.bufC[i] = in[(size_t)blockIdx.x * nn + i];
+    for (int i = threadIdx.x; i < nn; i += 64) SH.r1[i] = in[(size_t)blockIdx.x * nn + i];
     WSYNC();
     dequantize_t(c, lg);
     for (int i = threadIdx.x; i < nn; i += 64) // undo the transpose
-        out[(size_t)blockIdx.x * nn + i] = SH.bufA[(i & (n - 1)) * n + (i >> lg)];
+        out[(size_t)blockIdx.x * nn + i] = ((const int16_t*)SH.r2)[(i & (n - 1)) * n + (i >> lg)];
 }
 
 // ---------------------------------------------------------------------------
@@ -164,6 +169,8 @@ struct wrenc_gpu_ctx {
     std::vector<int> state; // 0 empty, 1 uploaded, 2 encoded
     unsigned long long* d_mismatch = nullptr;
     int* d_overflow = nullptr;
+    uint8_t* d_pred_scratch = nullptr; // 1 KB per resident wave: prediction bytes between predict and recon
+    size_t pred_scratch_bytes = 0;
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;
     std::vector<hipEvent_t> ev_pool;
     int last_launches = 0;
@@ -345,6 +352,7 @@ void wrenc_gpu_destroy(wrenc_gpu_ctx* ctx) {
     if (ctx->d_slots) (void)hipFree(ctx->d_slots);
     if (ctx->d_mismatch) (void)hipFree(ctx->d_mismatch);
     if (ctx->d_overflow) (void)hipFree(ctx->d_overflow);
+    if (ctx->d_pred_scratch) (void)hipFree(ctx->d_pred_scratch);
     if (ctx->ev_begin) (void)hipEventDestroy(ctx->ev_begin);
     if (ctx->ev_end) (void)hipEventDestroy(ctx->ev_end);
     for (hipEvent_t e : ctx->ev_pool) (void)hipEventDestroy(e);
@@ -454,6 +462,19 @@ int wrenc_gpu_encode(wrenc_gpu_ctx* ctx, int first_slot, int n_pictures) {
         HIP_TRY(ctx, hipEventCreate(&e));
         ctx->ev_pool.push_back(e);
     }
+    {
+        // widest launch: the longest anti-diagonal times the picture groups
+        const int max_diag = (cols + 1) / 2 < rows ? (cols + 1) / 2 : rows;
+        const size_t need = (size_t)max_diag * ((n_pictures + WPB - 1) / WPB) * WPB * 1024;
+        if (need > ctx->pred_scratch_bytes) {
+            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+            if (ctx->d_pred_scratch) (void)hipFree(ctx->d_pred_scratch);
+            ctx->d_pred_scratch = nullptr;
+            ctx->pred_scratch_bytes = 0;
+            HIP_TRY(ctx, hipMalloc((void**)&ctx->d_pred_scratch, need));
+            ctx->pred_scratch_bytes = need;
+        }
+    }
     HIP_TRY(ctx, hipEventRecord(ctx->ev_begin, ctx->stream));
     int launches = 0;
     for (int d = 0; d < ndiag; ++d) {
@@ -467,7 +488,8 @@ int wrenc_gpu_encode(wrenc_gpu_ctx* ctx, int first_slot, int n_pictures) {
         HIP_TRY(ctx, hipEventRecord(ctx->ev_pool[2 * launches], ctx->stream));
         const int groups = (n_pictures + WPB - 1) / WPB;
         hipLaunchKernelGGL(ctu_search_kernel, dim3(count * groups), dim3(64 * WPB), 0, ctx->stream, ctx->d_const,
-                           ctx->d_slots, first_slot, n_pictures, d, r_min, count, ctx->d_mismatch, ctx->d_overflow);
+                           ctx->d_slots, first_slot, n_pictures, d, r_min, count, ctx->d_pred_scratch, ctx->d_mismatch,
+                           ctx->d_overflow);
         HIP_TRY(ctx, hipGetLastError());
         HIP_TRY(ctx, hipEventRecord(ctx->ev_pool[2 * launches + 1], ctx->stream));
         ++launches;
