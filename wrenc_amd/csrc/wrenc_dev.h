@@ -798,11 +798,14 @@ __device__ __forceinline__ long long lv_at(Ctx c, int a) {
     return a < 256 ? (long long)SHT.lv[a] : c.k->lv[a];
 }
 template <int CTRL>
-__device__ __forceinline__ long long dpp_quad64(long long v) {
-    int lo = (int)(v & 0xFFFFFFFFLL), hi = (int)(v >> 32);
-    lo = __builtin_amdgcn_mov_dpp(lo, CTRL, 0xF, 0xF, true);
-    hi = __builtin_amdgcn_mov_dpp(hi, CTRL, 0xF, 0xF, true);
-    return ((long long)hi << 32) | (unsigned int)lo;
+__device__ __forceinline__ int dpp_quad(int v) {
+    return __builtin_amdgcn_mov_dpp(v, CTRL, 0xF, 0xF, true);
+}
+
+__device__ __forceinline__ int dec_nib(const uint16_t* dec16, int p) {
+    const uint16_t* g = dec16 + (p >> 4) * 4;
+    const int k = p & 15;
+    return ((g[0] >> k) & 1) | (((g[1] >> k) & 1) << 1) | (((g[2] >> k) & 1) << 2) | (((g[3] >> k) & 1) << 3);
 }
 
 __device__ __forceinline__ int compose_map(int g2, int g1) {
@@ -813,24 +816,14 @@ __device__ __forceinline__ int compose_map(int g2, int g1) {
     return r;
 }
 
-// One Viterbi step for the lane's state (st = lane & 3) of its quad's transform block.
-// cv = (cost of keeping a0, cost of a0+1) for this state's delta; f = chunk flags.
-__device__ __forceinline__ bool viterbi_step(long long& C, int f, int2 cv, int delta, bool tz, bool first_in_sb,
-                                             long long ldq1) {
-    const bool zero = f & 1;
-    const bool par = (f >> (1 + 2 * delta)) & 1;
-    const bool a0z = (f >> (2 + 2 * delta)) & 1;
-    const long long CA = dpp_quad64<0xD8>(C); // C[trans[s][0]]: quad_perm [0,2,1,3]
-    const long long CB = dpp_quad64<0x72>(C); // C[trans[s][1]]: quad_perm [2,0,3,1]
-    // branch 0 keeps a0 (bits 0 instead of 1 inside the trailing run), branch 1 takes a0+1
-    long long K0 = (long long)cv.x + (par ? CB : CA);
-    if (tz && a0z) K0 -= ldq1;
-    const long long K1 = (long long)cv.y + (par ? CA : CB);
-    const bool pick1 = !zero && K1 < K0;
-    C = pick1 ? K1 : K0;
-    if (!pick1 && a0z && tz && first_in_sb) C -= ldq1; // quantizer.rs:512-514
-    return pick1;
-}
+// Path costs are kept in 32 bits.  Only cost DIFFERENCES between the four states decide the
+// path, and they are bounded: any state reaches any other state's continuation within two
+// steps (q_state_trans_table is 2-step complete), and one step costs at most
+// 128*65535 + lambda_q*dq_table[1023] < 2^25 (QP 63), so |C_s - C_s'| < 2^26.2.  Subtracting the
+// quad minimum every 16 positions therefore keeps every value below 2^26.2 + 16*2^25 < 2^30.
+// A zero coefficient has no second branch; it is given the cost 2^29, which can never win
+// against branch 0 (K0 <= n0 + 2^25 <= n1 + 2^26.2 + 2^25 < n1 + 2^29) and cannot overflow.
+constexpr int kNoBranch = 1 << 29;
 
 // Dependent quantisation of one transform block: coefficients r1 (n*n row-major) ->
 // levels r1 (n*n row-major); returns the level cost (block_splitter.rs:436-458).
@@ -860,9 +853,8 @@ __device__ __forceinline__ long long quantize(Ctx c, int lg, bool shared, bool a
     const uint16_t* scan = k->scan_idx[lg - 2];
     int16_t* tcs = (int16_t*)SH.r2;          // coefficient in reverse-scan order
     int16_t* qds = (int16_t*)SH.r2 + 1024;   // |(tc << sh) - off| / lsc
-    int32_t* cc = (int32_t*)SH.r1;           // chunk: [64][4] = c0/c1 for delta 0, c0/c1 for delta 1
-    uint8_t* cf = (uint8_t*)(SH.r1 + 512);   // chunk flags (coefficients are dead after the gather)
-    uint32_t* decw = SH.decw;                 // decisions: 4 bits per position, 8 positions per word
+    int32_t* cc = (int32_t*)SH.r1;           // chunk: [64][6] ints (the coefficients are dead after the gather)
+    const uint16_t* dec16 = (const uint16_t*)SH.decw; // decisions: [sub-block][state] 16-bit masks
     PROF_MARK(q0_);
     int istar = P;
     if (active) {
@@ -884,7 +876,7 @@ __device__ __forceinline__ long long quantize(Ctx c, int lg, bool shared, bool a
     }
     PROF_MARK(q1_);
     PROF_ADD2(PH_QPRE, q0_, q1_);
-    const long long ldq1 = ldq_at(c, 1);
+    const int ldq1 = (int)ldq_at(c, 1);
     const int st = LANE & 3;
     const int delta = st > 1 ? 1 : 0;
     // which block this lane's quad walks: own block (solo) or block of wave `quad` (shared, wave 0)
@@ -892,21 +884,22 @@ __device__ __forceinline__ long long quantize(Ctx c, int lg, bool shared, bool a
     const bool walker = shared ? (WAVE == 0 && quad < WPB) : (quad == 0);
     const Lds* tb = shared ? &SHW[quad < WPB ? quad : 0] : &SH;
     const int32_t* wcc = (const int32_t*)tb->r1;
-    const uint8_t* wcf = (const uint8_t*)(tb->r1 + 512);
-    long long C = 0;
+    int C = 0;
     int ovf = 0;
     const int CH = P < 64 ? P : 64;
     for (int base = P - CH; base >= 0; base -= CH) {
         WSYNC();
         if (active && LANE < CH) {
+            // per position: [c0 d0, c1 d0, c0 d1, c1 d1, c0 d0 inside the trailing run, flags]
             const int p = base + LANE;
             const int tc = tcs[p];
             const int qd = qds[p];
             const bool dcn = p == P - 1;
-            int flags = tc == 0 ? 1 : 0;
+            int flags = 0;
+            int c0tz = 0;
 #pragma unroll
             for (int d = 0; d < 2; ++d) {
-                int c0 = 0, c1 = 0;
+                int c0, c1;
                 if (tc != 0) {
                     const int a0 = dcn ? (qd >> 1) : ((qd + d) >> 1); // quantizer.rs:378 / :441
                     int q0 = dcn ? (int)(int16_t)(2 * a0 - d) : (a0 > 0 ? 2 * a0 - d : 0);
@@ -921,16 +914,24 @@ __device__ __forceinline__ long long quantize(Ctx c, int lg, bool shared, bool a
                     if (a1 + 1 >= 1024) ovf = 1;
                     c0 = (int)(128LL * d0 + ldq_at(c, min(a0 + 1, 1023)));
                     c1 = (int)(128LL * d1 + ldq_at(c, min(a1 + 1, 1023)));
-                    flags |= (a0 & 1) << (1 + 2 * d);
-                    flags |= (a0 == 0 ? 1 : 0) << (2 + 2 * d);
+                    flags |= (a0 & 1) << d;              // bit d: parity of a0 -> which successor state
+                    if (d == 0) {
+                        flags |= (a0 == 0 ? 1 : 0) << 2; // bit 2: a0 == 0 in state class delta 0
+                        c0tz = a0 == 0 ? c0 - ldq1 : c0; // bits 0 instead of 1 in the trailing run (:449-453)
+                    }
                 } else {
-                    c0 = (int)ldq1; // zero coefficient outside the trailing run: dq_table[1]
-                    flags |= 1 << (2 + 2 * d);
+                    c0 = ldq1; // zero coefficient outside the trailing run: dq_table[1] (:433)
+                    c1 = kNoBranch;
+                    if (d == 0) {
+                        flags |= 1 << 2;
+                        c0tz = 0;
+                    }
                 }
-                cc[LANE * 4 + 2 * d] = c0;
-                cc[LANE * 4 + 2 * d + 1] = c1;
+                cc[LANE * 6 + 2 * d] = c0;
+                cc[LANE * 6 + 2 * d + 1] = c1;
             }
-            cf[LANE] = (uint8_t)flags;
+            cc[LANE * 6 + 4] = c0tz;
+            cc[LANE * 6 + 5] = flags;
         }
         if (shared)
             __syncthreads();
@@ -938,25 +939,33 @@ __device__ __forceinline__ long long quantize(Ctx c, int lg, bool shared, bool a
             WSYNC();
         if (walker && (!shared || tb->q_active)) {
             const int wistar = shared ? tb->q_istar : istar;
-            uint32_t* wdec = const_cast<uint32_t*>(tb->decw);
-            int f_n = wcf[CH - 1];
-            int2 cv_n = *(const int2*)&wcc[(CH - 1) * 4 + 2 * delta];
-            unsigned word = 0;
-            for (int i = CH - 1; i >= 0; --i) {
-                const int p = base + i;
-                const int f = f_n;
-                const int2 cv = cv_n;
-                if (i > 0) { // prefetch the next position while this one is evaluated
-                    f_n = wcf[i - 1];
-                    cv_n = *(const int2*)&wcc[(i - 1) * 4 + 2 * delta];
+            uint16_t* wdec = (uint16_t*)const_cast<uint32_t*>(tb->decw);
+            for (int g16 = CH - 16; g16 >= 0; g16 -= 16) { // one 4x4 sub-block per iteration
+                unsigned bits = 0;
+#pragma unroll
+                for (int kk = 15; kk >= 0; --kk) {
+                    const int i = g16 + kk;
+                    const int p = base + i;
+                    const int2 cv = *(const int2*)&wcc[i * 6 + 2 * delta];
+                    const int2 ex = *(const int2*)&wcc[i * 6 + 4]; // (c0 in trailing run, flags)
+                    const bool tz = st == 0 && p <= wistar;
+                    const bool par = (ex.y >> delta) & 1;
+                    const int CA = dpp_quad<0xD8>(C); // C[trans[s][0]]: quad_perm [0,2,1,3]
+                    const int CB = dpp_quad<0x72>(C); // C[trans[s][1]]: quad_perm [2,0,3,1]
+                    const int K0 = (tz ? ex.x : cv.x) + (par ? CB : CA); // keep a0
+                    const int K1 = cv.y + (par ? CA : CB);               // take a0 + 1
+                    const bool pick1 = K1 < K0;                            // tie -> a0 (:505)
+                    C = pick1 ? K1 : K0;
+                    if (kk == 15) { // first position of a sub-block in coding order (:512-514)
+                        if (!pick1 && tz && ((ex.y >> 2) & 1)) C -= ldq1;
+                    }
+                    bits |= (pick1 ? 1u : 0u) << kk;
                 }
-                const bool pick1 = viterbi_step(C, f, cv, delta, st == 0 && p <= wistar, (p & 15) == 15, ldq1);
-                const unsigned nib = (unsigned)(__ballot(pick1) >> (LANE & ~3)) & 0xFu;
-                word |= nib << (4 * (p & 7));
-                if ((p & 7) == 0) { // eight positions per 32-bit word
-                    if (st == 0) wdec[p >> 3] = word;
-                    word = 0;
-                }
+                // renormalise: subtract the quad minimum (decisions depend on differences only)
+                int m = min(C, dpp_quad<0xB1>(C));  // quad_perm [1,0,3,2]
+                m = min(m, dpp_quad<0x4E>(m));      // quad_perm [2,3,0,1]
+                C -= m;
+                wdec[((base + g16) >> 4) * 4 + st] = (uint16_t)bits;
             }
         }
         if (shared) __syncthreads();
@@ -973,7 +982,7 @@ __device__ __forceinline__ long long quantize(Ctx c, int lg, bool shared, bool a
     if (act) {
         for (int j = 0; j < per; ++j) {
             const int p = p0 + j;
-            const int tc = tcs[p], qd = qds[p], nib = (decw[p >> 3] >> (4 * (p & 7))) & 15;
+            const int tc = tcs[p], qd = qds[p], nib = dec_nib(dec16, p);
             int g = 0;
 #pragma unroll
             for (int sidx = 0; sidx < 4; ++sidx) {
@@ -1001,7 +1010,7 @@ __device__ __forceinline__ long long quantize(Ctx c, int lg, bool shared, bool a
         int state = entry;
         for (int j = 0; j < per; ++j) {
             const int p = p0 + j;
-            const int tc = tcs[p], qd = qds[p], nib = (decw[p >> 3] >> (4 * (p & 7))) & 15;
+            const int tc = tcs[p], qd = qds[p], nib = dec_nib(dec16, p);
             const int dl = state > 1 ? 1 : 0;
             int q = 0, a = 0;
             if (tc != 0) {
