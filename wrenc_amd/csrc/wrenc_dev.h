@@ -1256,9 +1256,58 @@ struct LeafResult {
     int chroma_mode; // TU-array chroma prediction mode
 };
 
-// get_intra_pred_cost (block_splitter.rs:110-474) for modes [ml, mc, mc]
-__device__ __noinline__ float full_cost(Ctx c, int tree, int bx, int by, int lg, int ml, int mc, bool active,
-                                       int* overflow) {
+// SSD and level cost of the luma and of the chroma pair of one evaluated candidate.  Evaluations
+// are deterministic functions of (block, mode, neighbourhood[, luma recon for CCLM]), so where the
+// reference re-runs an evaluation it has already done (block_splitter.rs:1040,1068-1075) the
+// parts are re-used and only the cost is re-assembled.
+struct EvalParts {
+    unsigned long long ssd_y, ssd_c;
+    long long lvl_y, lvl_c;
+};
+
+// get_intra_pred_cost (block_splitter.rs:110-474) from already evaluated parts, modes [ml, mc, mc]
+__device__ __forceinline__ float assemble_cost(const Ctx& c, int tree, int cls, int mc, const EvalParts& e) {
+    const bool single = tree == TREE_SINGLE;
+    const int cc = (single && mc >= LT_CCLM) ? 1 + (mc - LT_CCLM) : 0;
+    const unsigned long long ssd = e.ssd_y + (single ? e.ssd_c : 0ULL);
+    const long long level = e.lvl_y + (single ? e.lvl_c : 0LL) + c.k->hb_luma[single ? 0 : 1][cc][cls];
+    return rd_cost(ssd, level, c.k->lambda_rd);
+}
+
+// get_chroma_intra_pred_cost (block_splitter.rs:524-780) from already evaluated parts
+__device__ __forceinline__ float assemble_chroma_cost(const Ctx& c, int mc, const EvalParts& e) {
+    const long long level = e.lvl_c + c.k->hb_chroma[mc >= LT_CCLM ? 1 + (mc - LT_CCLM) : 0];
+    return rd_cost(e.ssd_c, level, c.k->lambda_rd_chroma);
+}
+
+// evaluate the chroma pair with mode mc into e.ssd_c / e.lvl_c
+__device__ __noinline__ CompCost eval_chroma(Ctx c, int bx, int by, int lg, int mc, bool active, int* overflow) {
+    c = uni(c);
+    bx = uni(bx);
+    by = uni(by);
+    lg = uni(lg);
+    mc = uni(mc);
+    unsigned long long ssd = 0;
+    long long level = 0;
+    for (int comp = 1; comp < 3; ++comp) {
+        const CompCost r = code_component(c, comp, bx, by, lg, mc, true, active, nullptr, 0, nullptr, overflow);
+        ssd += r.ssd;
+        level += r.level;
+    }
+    CompCost out;
+    out.ssd = ssd;
+    out.level = level;
+    return out;
+}
+
+struct FullRes {
+    float cost;
+    EvalParts e;
+};
+
+// get_intra_pred_cost (block_splitter.rs:110-474) for modes [ml, mc, mc], with its parts
+__device__ __noinline__ FullRes full_cost(Ctx c, int tree, int bx, int by, int lg, int ml, int mc, bool active,
+                                         int* overflow) {
     c = uni(c);
     tree = uni(tree);
     bx = uni(bx);
@@ -1266,26 +1315,22 @@ __device__ __noinline__ float full_cost(Ctx c, int tree, int bx, int by, int lg,
     lg = uni(lg);
     ml = uni(ml);
     mc = uni(mc);
-    const int cls = mpm_class(c, bx, by, lg, ml);
-    const bool cclm = mc >= LT_CCLM;
-    unsigned long long ssd = 0;
-    long long level = 0;
+    EvalParts p = {0, 0, 0, 0};
     {
         const CompCost r = code_component(c, 0, bx, by, lg, ml, true, active, nullptr, 0, nullptr, overflow);
-        ssd += r.ssd;
-        level += r.level;
+        p.ssd_y = r.ssd;
+        p.lvl_y = r.level;
     }
     if (tree == TREE_SINGLE) {
-        for (int comp = 1; comp < 3; ++comp) {
-            const CompCost r = code_component(c, comp, bx, by, lg, mc, true, active, nullptr, 0, nullptr, overflow);
-            ssd += r.ssd;
-            level += r.level;
-        }
+        const CompCost cc = eval_chroma(c, bx, by, lg, mc, active, overflow);
+        p.ssd_c = cc.ssd;
+        p.lvl_c = cc.level;
     }
-    if (!active) return 3.40282347e+38f; // skipped evaluation (f32::MAX in the reference)
-    const int cc = (tree == TREE_SINGLE && cclm) ? 1 + (mc - LT_CCLM) : 0;
-    level += c.k->hb_luma[tree == TREE_SINGLE ? 0 : 1][cc][cls];
-    return rd_cost(ssd, level, c.k->lambda_rd);
+    FullRes out;
+    out.e = p;
+    // a skipped evaluation is f32::MAX in the reference
+    out.cost = active ? assemble_cost(c, tree, mpm_class(c, bx, by, lg, ml), mc, p) : 3.40282347e+38f;
+    return out;
 }
 
 // get_intra_pred_aux_cost (block_splitter.rs:64-108) for modes [m; 3]
@@ -1305,21 +1350,11 @@ __device__ __noinline__ float aux_cost(Ctx c, int tree, int bx, int by, int lg, 
 }
 
 // get_chroma_intra_pred_cost (block_splitter.rs:524-780)
-__device__ __noinline__ float chroma_full_cost(Ctx c, int bx, int by, int lg, int mc, int* overflow) {
-    c = uni(c);
-    bx = uni(bx);
-    by = uni(by);
-    lg = uni(lg);
-    mc = uni(mc);
-    unsigned long long ssd = 0;
-    long long level = 0;
-    for (int comp = 1; comp < 3; ++comp) {
-        const CompCost r = code_component(c, comp, bx, by, lg, mc, true, true, nullptr, 0, nullptr, overflow);
-        ssd += r.ssd;
-        level += r.level;
-    }
-    level += c.k->hb_chroma[mc >= LT_CCLM ? 1 + (mc - LT_CCLM) : 0];
-    return rd_cost(ssd, level, c.k->lambda_rd_chroma);
+__device__ __forceinline__ float chroma_full_cost(Ctx c, int bx, int by, int lg, int mc, EvalParts& e, int* overflow) {
+    const CompCost cc = eval_chroma(c, bx, by, lg, mc, true, overflow);
+    e.ssd_c = cc.ssd;
+    e.lvl_c = cc.level;
+    return assemble_chroma_cost(c, mc, e);
 }
 
 // get_chroma_intra_pred_aux_cost (block_splitter.rs:476-522)
@@ -1378,8 +1413,9 @@ __device__ __noinline__ LeafResult leaf_chroma(Ctx c, int bx, int by, int lg, in
     const float t = chroma_aux_cost(c, bx, by, lg, T_CCLM);
     const float l = chroma_aux_cost(c, bx, by, lg, L_CCLM);
     const int cclm_mode = pick_cclm(lt, t, l);
-    const float cclm_cost = chroma_full_cost(c, bx, by, lg, cclm_mode, overflow);
-    const float cur = chroma_full_cost(c, bx, by, lg, dm_mode, overflow);
+    EvalParts e_cclm = {0, 0, 0, 0}, e_dm = {0, 0, 0, 0};
+    const float cclm_cost = chroma_full_cost(c, bx, by, lg, cclm_mode, e_cclm, overflow);
+    const float cur = chroma_full_cost(c, bx, by, lg, dm_mode, e_dm, overflow);
     LeafResult r;
     r.luma_mode = 0;
     const float mn = fminf(cclm_cost, fminf(cur, 3.40282347e+38f));
@@ -1406,14 +1442,21 @@ __device__ __noinline__ LeafResult leaf_luma(Ctx c, int tree, int bx, int by, in
         build_refs(c, 2, bx, by, lg);
     }
     float cost_planar = 0.f, cost_dc = 0.f;
+    EvalParts e_planar = {0, 0, 0, 0}, e_dc = {0, 0, 0, 0};
     float min_dir_cost = 3.40282347e+38f;
     int min_dir_mode = 2;
     for (int i = 0; i < 15; ++i) {
         // {0,1,2,7,13,18,23,29,34,39,45,50,55,60,66} (:887), 7 bits each
         const int m = i < 8 ? (int)((0x3A5C90D0E08080ULL >> (7 * i)) & 127) : (int)((0x109E3764B53A2ULL >> (7 * (i - 8))) & 127);
         if (m <= 1) {
-            const float v = full_cost(c, tree, bx, by, lg, m, m, true, overflow);
-            if (m == 0) cost_planar = v; else cost_dc = v;
+            const FullRes fr = full_cost(c, tree, bx, by, lg, m, m, true, overflow);
+            if (m == 0) {
+                cost_planar = fr.cost;
+                e_planar = fr.e;
+            } else {
+                cost_dc = fr.cost;
+                e_dc = fr.e;
+            }
         } else {
             const float v = aux_cost(c, tree, bx, by, lg, m);
             if (v < min_dir_cost) { // first minimum (:899-904)
@@ -1439,54 +1482,72 @@ __device__ __noinline__ LeafResult leaf_luma(Ctx c, int tree, int bx, int by, in
         }
     }
     // step_search(mode, 1, _, aux=false) (:974)
+    EvalParts e_dir = {0, 0, 0, 0};
     {
         // out-of-range neighbours are "evaluated" inactive: the wave still walks the schedule so
         // that the workgroup's shared Viterbi barriers stay aligned; the result is f32::MAX
-        cur_cost = full_cost(c, tree, bx, by, lg, cur_mode, cur_mode, true, overflow);
-        const float c0 = full_cost(c, tree, bx, by, lg, cur_mode - 1, cur_mode - 1, !(cur_mode < 3), overflow);
-        const float c1 = full_cost(c, tree, bx, by, lg, cur_mode + 1, cur_mode + 1, !(cur_mode + 1 > 66), overflow);
+        const FullRes f = full_cost(c, tree, bx, by, lg, cur_mode, cur_mode, true, overflow);
+        const FullRes f0 = full_cost(c, tree, bx, by, lg, cur_mode - 1, cur_mode - 1, !(cur_mode < 3), overflow);
+        const FullRes f1 = full_cost(c, tree, bx, by, lg, cur_mode + 1, cur_mode + 1, !(cur_mode + 1 > 66), overflow);
+        cur_cost = f.cost;
+        e_dir = f.e;
+        const float c0 = f0.cost, c1 = f1.cost;
         const float mn = fminf(fminf(cur_cost, c0), c1);
         if (cur_cost == mn) {
         } else if (c0 == mn) {
             cur_mode -= 1;
             cur_cost = c0;
+            e_dir = f0.e;
         } else {
             cur_mode += 1;
             cur_cost = c1;
+            e_dir = f1.e;
         }
     }
     // min of {planar, DC, dir}, first index wins (:975-978)
     float min_cost = fminf(cur_cost, fminf(cost_dc, fminf(cost_planar, 3.40282347e+38f)));
     int mode;
-    if (cost_planar == min_cost)
+    EvalParts e_win;
+    if (cost_planar == min_cost) {
         mode = 0;
-    else if (cost_dc == min_cost)
+        e_win = e_planar;
+    } else if (cost_dc == min_cost) {
         mode = 1;
-    else
+        e_win = e_dc;
+    } else {
         mode = cur_mode;
-    // luma re-run with the winner (:989-1037)
+        e_win = e_dir;
+    }
+    // luma re-run with the winner (:989-1037): puts the winner's luma reconstruction into the tile
     code_component(c, 0, bx, by, lg, mode, true, true, nullptr, 0, nullptr, overflow);
     LeafResult r;
     r.luma_mode = mode;
     r.chroma_mode = mode;
     if (tree != TREE_DUAL_LUMA) {
-        const float cur = chroma_full_cost(c, bx, by, lg, mode, overflow);
+        // :1040 get_chroma_intra_pred_cost(mode) repeats the winner's chroma evaluation: re-use it
+        const float cur = assemble_chroma_cost(c, mode, e_win);
         const float lt = chroma_aux_cost(c, bx, by, lg, LT_CCLM);
         const float t = chroma_aux_cost(c, bx, by, lg, T_CCLM);
         const float l = chroma_aux_cost(c, bx, by, lg, L_CCLM);
         const int cclm_mode = pick_cclm(lt, t, l);
-        const float cclm_cost = chroma_full_cost(c, bx, by, lg, cclm_mode, overflow);
+        EvalParts e_cclm = e_win;
+        const float cclm_cost = chroma_full_cost(c, bx, by, lg, cclm_mode, e_cclm, overflow);
         const float mn = fminf(cclm_cost, fminf(cur, 3.40282347e+38f));
-        if (cur == mn) {
-            min_cost = full_cost(c, tree, bx, by, lg, mode, mode, true, overflow);
+        const bool dm_wins = cur == mn;
+        // :1062-1072 final get_intra_pred_cost: luma = the re-run above; the chroma pair is the DM
+        // evaluation (re-done only to put its reconstruction back when DM wins; an inactive walk of
+        // the schedule otherwise) or the CCLM evaluation just made
+        eval_chroma(c, bx, by, lg, mode, dm_wins, overflow);
+        const int cls = mpm_class(c, bx, by, lg, mode);
+        if (dm_wins) {
+            min_cost = assemble_cost(c, tree, cls, mode, e_win);
         } else {
             r.chroma_mode = cclm_mode;
-            min_cost = full_cost(c, tree, bx, by, lg, mode, cclm_mode, true, overflow);
+            min_cost = assemble_cost(c, tree, cls, cclm_mode, e_cclm);
         }
-    } else {
-        const bool need = mode <= 1; // :1073-1076; otherwise an inactive walk of the schedule
-        const float v = full_cost(c, tree, bx, by, lg, mode, mode, need, overflow);
-        if (need) min_cost = v;
+    } else if (mode <= 1) {
+        // :1073-1076 repeats the luma evaluation just re-run: same parts, same cost
+        min_cost = assemble_cost(c, tree, mpm_class(c, bx, by, lg, mode), mode, e_win);
     }
     r.cost = min_cost;
     return r;
