@@ -72,7 +72,7 @@ struct __attribute__((aligned(16))) Lds {
     uint8_t recCtop[2][40];    // y = -1, x = -4..35
     uint8_t recC[2][16 * 20];  // x = -4..15, stride 20
     uint32_t decw[128];        // trellis decisions: 4 bits per position, 8 positions per word
-    int32_t q_istar;           // shared-Viterbi hand-off: first position with a non-zero state-0 level
+    int32_t q_istar[2];        // shared-Viterbi hand-off, per block: first position with a non-zero state-0 level
     int32_t q_active;          // this wave's TB takes part in the shared Viterbi
     uint8_t cu_log2[64];       // per 4x4 luma unit
     uint8_t luma_mode[64];
@@ -174,6 +174,13 @@ __device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v)
     for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
     return v;
 }
+// minimum over aligned groups of `width` lanes (width = 64 or 32)
+__device__ __forceinline__ int group_min_i32(int v, int width) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1)
+        if (m < width) v = min(v, __shfl_xor(v, m, 64));
+    return v;
+}
 __device__ __forceinline__ int ilog2i(int v) { return 31 - __clz(v); }
 
 // ---------------------------------------------------------------------------
@@ -191,10 +198,11 @@ __device__ __forceinline__ void rec_put(int c, int x, int y, int v) {
 }
 // original sample at CTU-local component coordinates (global load; the planes are read-only
 // for the whole launch, so the loads are cacheable and need no ordering)
-__device__ __forceinline__ int org_get(const Ctx& c, int comp, int x, int y) {
-    const int cs = comp ? 1 : 0;
+__device__ __forceinline__ int org_get(const Ctx& c, int pc, int x, int y) {
+    const int cs = pc ? 1 : 0;
     const int stride = c.k->W >> cs;
-    return c.org[comp][(size_t)((c.ctu_y >> cs) + y) * stride + (c.ctu_x >> cs) + x];
+    const uint8_t* base = pc == 0 ? c.org[0] : (pc == 1 ? c.org[1] : c.org[2]); // pc may differ per lane
+    return base[(size_t)((c.ctu_y >> cs) + y) * stride + (c.ctu_x >> cs) + x];
 }
 
 // ---------------------------------------------------------------------------
@@ -247,11 +255,13 @@ __device__ __forceinline__ int pdpc_w(int n_scale, int i) {
     return sh > 5 ? 0 : (32 >> sh);
 }
 
-// Reference samples of one (block, component) into the per-component LDS arrays: unfiltered
-// always, plus the [1 2 1]-filtered version for luma blocks of more than 32 samples
-// (intra_predictor.rs:146-353).  The neighbourhood of a block does not change while its
-// candidate modes are evaluated (evaluations only write inside the block), so this runs once per
-// block and component instead of once per mode.
+// Component convention of every stage below: comp 0 = luma block, comp 1 = the chroma PAIR
+// (Cb and Cr blocks of the TU processed together: block index blk = 0/1, plane pc = comp + blk).
+//
+// Reference samples of one block into the per-plane LDS arrays: unfiltered always, plus the
+// [1 2 1]-filtered version for luma blocks of more than 32 samples (intra_predictor.rs:146-353).
+// The neighbourhood of a block does not change while its candidate modes are evaluated
+// (evaluations only write inside the block), so this runs once per block instead of once per mode.
 __device__ __noinline__ void build_refs(Ctx c, int comp, int tx, int ty, int tlg) {
     c = uni(c);
     comp = uni(comp);
@@ -259,6 +269,7 @@ __device__ __noinline__ void build_refs(Ctx c, int comp, int tx, int ty, int tlg
     ty = uni(ty);
     tlg = uni(tlg);
     const int cs = comp ? 1 : 0;
+    const int nb = comp ? 2 : 1;
     const int n = 1 << (tlg - cs);
     const int tn = 1 << tlg;
     const int cx = tx >> cs, cy = ty >> cs;
@@ -266,8 +277,6 @@ __device__ __noinline__ void build_refs(Ctx c, int comp, int tx, int ty, int tlg
     const bool ar = above_right_avail(c, tx, ty, tlg);
     const bool bl = below_left_avail(c, tx, ty, tlg);
     const int st = 1 << cs;
-    int16_t* refL = comp == 0 ? SH.refL0 : SH.refLc[comp - 1];
-    int16_t* refA = comp == 0 ? SH.refA0 : SH.refAc[comp - 1];
     // segment availabilities in substitution-scan order: BL, L, corner, A, AR (bit j = segment j)
     int avm = 0;
     avm |= nb_avail(c, gx, gy, tn, gx - st, gy + tn, ar, bl) ? 1 : 0;
@@ -277,7 +286,12 @@ __device__ __noinline__ void build_refs(Ctx c, int comp, int tx, int ty, int tlg
     avm |= nb_avail(c, gx, gy, tn, gx + tn, gy - st, ar, bl) ? 16 : 0;
     const bool any = avm != 0;
     const int total = 4 * n + 1;
-    for (int t = LANE; t < total; t += 64) {
+    for (int tt = LANE; tt < nb * total; tt += 64) {
+        const int blk = tt >= total ? 1 : 0;
+        const int t = tt - blk * total;
+        const int pc = comp + blk;
+        int16_t* refL = pc == 0 ? SH.refL0 : SH.refLc[pc - 1];
+        int16_t* refA = pc == 0 ? SH.refA0 : SH.refAc[pc - 1];
         // unified item: t <= 2n -> left index li = t (li 0 = corner, li k -> y = k-1); else above
         int seg;
         const bool is_left = t <= 2 * n;
@@ -310,7 +324,7 @@ __device__ __noinline__ void build_refs(Ctx c, int comp, int tx, int ty, int tlg
                     else { src_left = false; sai = n; }
                 }
             }
-            v = src_left ? rec_get(comp, cx - 1, cy + sli - 1) : rec_get(comp, cx + sai, cy - 1);
+            v = src_left ? rec_get(pc, cx - 1, cy + sli - 1) : rec_get(pc, cx + sai, cy - 1);
         }
         if (is_left)
             refL[li] = (int16_t)v;
@@ -320,6 +334,8 @@ __device__ __noinline__ void build_refs(Ctx c, int comp, int tx, int ty, int tlg
     WSYNC();
     // [1 2 1] filter, intra_predictor.rs:304-352 (used by modes 0, 2, 34, 66 only)
     if (comp == 0 && n * n > 32) {
+        const int16_t* refL = SH.refL0;
+        const int16_t* refA = SH.refA0;
         for (int t = LANE; t < total; t += 64) {
             if (t <= 2 * n) {
                 const int li = t;
@@ -366,9 +382,9 @@ __device__ __forceinline__ int cclm_ds6(Ctx c, int tx, int ty, int sy, int sx, b
             cclm_w(c, tx, ty, sy, sx + 1, avail_l) + cclm_w(c, tx, ty, sy + 1, sx + 1, avail_l) + 4) >> 3;
 }
 
+// `comp` (plane 1 or 2) may differ per lane: everything that depends on it is per-lane data
 __device__ __forceinline__ CclmParams cclm_params(Ctx c, int comp, int tx, int ty, int tlg, int mode) {
     c = uni(c);
-    comp = uni(comp);
     tx = uni(tx);
     ty = uni(ty);
     tlg = uni(tlg);
@@ -491,10 +507,10 @@ __device__ __forceinline__ CclmParams cclm_params(Ctx c, int comp, int tx, int t
     return r;
 }
 
-// one predicted sample: accumulate |org - pred|; FULL also stores residual and prediction
+// one predicted sample of plane pc: accumulate |org - pred|; FULL also stores residual and prediction
 template <bool FULL>
-__device__ __forceinline__ int emit_sample(const Ctx& c, int comp, int x, int y, int i, int v) {
-    const int d = org_get(c, comp, x, y) - v;
+__device__ __forceinline__ int emit_sample(const Ctx& c, int pc, int x, int y, int i, int v) {
+    const int d = org_get(c, pc, x, y) - v;
     if (FULL) {
         SH.r1[i] = (int16_t)d;
         c.pred_scratch[i] = (uint8_t)v;
@@ -502,10 +518,11 @@ __device__ __forceinline__ int emit_sample(const Ctx& c, int comp, int x, int y,
     return d < 0 ? -d : d;
 }
 
-// Prediction of one component block from the cached reference samples (build_refs must have
-// run for this block and component; CCLM reads the reconstructed luma instead).
-// FULL: the residual org - pred goes to r1 (compact n*n) and the prediction bytes to this
-//       wave's scratch (each lane later re-reads exactly the bytes it wrote).
+// Prediction of one luma block (comp 0) or of the Cb+Cr pair (comp 1) from the cached reference
+// samples (build_refs must have run for this block; CCLM reads the reconstructed luma instead).
+// Sample index i runs over nb*n*n: block blk = i / (n*n), then row-major inside the block.
+// FULL: the residual org - pred goes to r1[i] and the prediction byte to this wave's scratch
+//       (each lane later re-reads exactly the bytes it wrote).
 // Returns the lane's partial sum of |org - pred| (the SAD of block_splitter.rs:96-104).
 template <bool FULL>
 __device__ __forceinline__ int predict(Ctx c, int comp, int tx, int ty, int tlg, int mode) {
@@ -516,56 +533,71 @@ __device__ __forceinline__ int predict(Ctx c, int comp, int tx, int ty, int tlg,
     tlg = uni(tlg);
     mode = uni(mode);
     const int cs = comp ? 1 : 0;
+    const int nb = comp ? 2 : 1;
     const int lg = tlg - cs;
     const int n = 1 << lg;
     const int cx = tx >> cs, cy = ty >> cs;
     const int nn = n * n;
     int sad = 0;
     if (mode >= LT_CCLM) {
-        const CclmParams cp = cclm_params(c, comp, tx, ty, tlg, mode);
-        for (int i = LANE; i < nn; i += 64) {
-            const int x = i & (n - 1), y = i >> lg;
+        // model parameters of both planes in one pass: odd lanes derive Cr, even lanes Cb
+        const CclmParams cpv = cclm_params(c, 1 + (LANE & 1), tx, ty, tlg, mode);
+        const int a0 = __builtin_amdgcn_readlane(cpv.a, 0), a1 = __builtin_amdgcn_readlane(cpv.a, 1);
+        const int k0 = __builtin_amdgcn_readlane(cpv.k, 0), k1 = __builtin_amdgcn_readlane(cpv.k, 1);
+        const int b0 = __builtin_amdgcn_readlane(cpv.b, 0), b1 = __builtin_amdgcn_readlane(cpv.b, 1);
+        const bool flat128 = __builtin_amdgcn_readlane((int)cpv.flat128, 0) != 0;
+        const bool avail_l = __builtin_amdgcn_readlane((int)cpv.avail_l, 0) != 0;
+        for (int i = LANE; i < nb * nn; i += 64) {
+            const int blk = i >> (2 * lg);
+            const int ii = i & (nn - 1);
+            const int x = ii & (n - 1), y = ii >> lg;
             int v;
-            if (cp.flat128) {
+            if (flat128) {
                 v = 128;
             } else {
-                const int ds = cclm_ds6(c, tx, ty, 2 * y, 2 * x, cp.avail_l);
-                v = ((ds * cp.a) >> cp.k) + cp.b;
+                const int ds = cclm_ds6(c, tx, ty, 2 * y, 2 * x, avail_l);
+                v = ((ds * (blk ? a1 : a0)) >> (blk ? k1 : k0)) + (blk ? b1 : b0);
                 v = min(max(v, 0), 255);
             }
-            sad += emit_sample<FULL>(c, comp, cx + x, cy + y, i, v);
+            sad += emit_sample<FULL>(c, comp + blk, cx + x, cy + y, i, v);
         }
         WSYNC();
         return sad;
     }
     // luma blocks of more than 32 samples use the filtered references for modes 0, 2, 34, 66
     const bool filt = comp == 0 && nn > 32 && (mode == 0 || mode == 2 || mode == 34 || mode == 66);
-    const int16_t* L = comp == 0 ? (filt ? SH.refLf0 : SH.refL0) : SH.refLc[comp - 1]; // index 0 = corner
-    const int16_t* A = comp == 0 ? (filt ? SH.refAf0 : SH.refA0) : SH.refAc[comp - 1];
-    const int alrs = L[0];
+    const int16_t* L0 = comp == 0 ? (filt ? SH.refLf0 : SH.refL0) : SH.refLc[0]; // index 0 = corner
+    const int16_t* A0 = comp == 0 ? (filt ? SH.refAf0 : SH.refA0) : SH.refAc[0];
     if (mode == PLANAR || mode == DC) {
-        int dcv = 0;
+        int dcv0 = 0, dcv1 = 0;
         if (mode == DC) {
-            int part = 0;
-            for (int t = LANE; t < 2 * n; t += 64) part += t < n ? A[t] : L[t - n + 1];
-            dcv = (wave_sum_i32(part) + n) >> (lg + 1);
-            dcv &= 0xFF; // `as u8`
+            int part0 = 0, part1 = 0;
+            for (int t = LANE; t < 2 * n; t += 64) {
+                part0 += t < n ? A0[t] : L0[t - n + 1];
+                if (nb == 2) part1 += t < n ? SH.refAc[1][t] : SH.refLc[1][t - n + 1];
+            }
+            dcv0 = ((wave_sum_i32(part0) + n) >> (lg + 1)) & 0xFF; // `as u8`
+            if (nb == 2) dcv1 = ((wave_sum_i32(part1) + n) >> (lg + 1)) & 0xFF;
         }
         const int n_scale = (2 * lg - 2) >> 2;
-        for (int i = LANE; i < nn; i += 64) {
-            const int x = i & (n - 1), y = i >> lg;
+        for (int i = LANE; i < nb * nn; i += 64) {
+            const int blk = i >> (2 * lg);
+            const int ii = i & (nn - 1);
+            const int x = ii & (n - 1), y = ii >> lg;
+            const int16_t* L = blk ? SH.refLc[1] : L0;
+            const int16_t* A = blk ? SH.refAc[1] : A0;
             int v;
             if (mode == PLANAR) {
                 const int pv = (n - 1 - y) * A[x] + (y + 1) * L[n + 1];
                 const int ph = (n - 1 - x) * L[y + 1] + (x + 1) * A[n];
                 v = ((pv + ph + n) >> (lg + 1)) & 0xFF;
             } else {
-                v = dcv;
+                v = blk ? dcv1 : dcv0;
             }
             const int wl = pdpc_w(n_scale, x), wt = pdpc_w(n_scale, y);
             v = (int16_t)(L[y + 1] * wl + A[x] * wt + (64 - wt - wl) * v + 32) >> 6;
             v = min(max(v, 0), 255);
-            sad += emit_sample<FULL>(c, comp, cx + x, cy + y, i, v);
+            sad += emit_sample<FULL>(c, comp + blk, cx + x, cy + y, i, v);
         }
         WSYNC();
         return sad;
@@ -589,8 +621,13 @@ __device__ __forceinline__ int predict(Ctx c, int comp, int tx, int ty, int tlg,
         n_scale = min(lg - ilog2i(3 * inv_angle - 2) + 8, 2);
     else
         n_scale = (2 * lg - 2) >> 2;
-    for (int i = LANE; i < nn; i += 64) {
-        const int x = i & (n - 1), y = i >> lg;
+    for (int i = LANE; i < nb * nn; i += 64) {
+        const int blk = i >> (2 * lg);
+        const int ii = i & (nn - 1);
+        const int x = ii & (n - 1), y = ii >> lg;
+        const int16_t* L = blk ? SH.refLc[1] : L0;
+        const int16_t* A = blk ? SH.refAc[1] : A0;
+        const int alrs = L[0];
         int v;
         if (mode >= 34) {
             const int i_idx = ((y + 1) * angle) >> 5;
@@ -662,7 +699,7 @@ __device__ __forceinline__ int predict(Ctx c, int comp, int tx, int ty, int tlg,
             v = (int16_t)(rl * wl + rt * wt + (64 - wt - wl) * v + 32) >> 6;
             v = min(max(v, 0), 255);
         }
-        sad += emit_sample<FULL>(c, comp, cx + x, cy + y, i, v);
+        sad += emit_sample<FULL>(c, comp + blk, cx + x, cy + y, i, v);
     }
     WSYNC();
     return sad;
@@ -687,9 +724,10 @@ __device__ __forceinline__ int dot2(uint32_t a, uint32_t b, int acc) {
 #endif
 }
 
-// forward: residual r1 (n*n i16) -> coefficients r1 (n*n i16), via r2; transformer.rs:2040-2378
+// forward: nb residual blocks in r1 ([blk][y][x] i16) -> coefficients in place, via r2;
+// transformer.rs:2040-2378
 template <int LG>
-__device__ void fwd_dct(Ctx c) {
+__device__ void fwd_dct(Ctx c, int nb) {
     constexpr int N = 1 << LG;
     constexpr int G = 64 / N;
     constexpr int HS = N + 1; // r2 row stride
@@ -701,20 +739,22 @@ __device__ void fwd_dct(Ctx c) {
 #pragma unroll
         for (int k = 0; k < N / 2; ++k) t[k] = src[k];
     }
-    // stage 1: H[u][y] = (sum_x T[u][x] r[y][x] + d) >> (LG-1)   (:2139-2209)
+    // stage 1: H[u][y] = (sum_x T[u][x] r[y][x] + d) >> (LG-1)   (:2139-2209); rows of all blocks
 #pragma unroll 1
-    for (int y = g; y < N; y += G) {
-        const uint32_t* row = (const uint32_t*)&SH.r1[y * N];
+    for (int yy = g; yy < nb * N; yy += G) {
+        const uint32_t* row = (const uint32_t*)&SH.r1[yy * N];
         int acc = 0;
 #pragma unroll
         for (int k = 0; k < N / 2; ++k) acc = dot2(row[k], t[k], acc);
-        SH.r2[u * HS + y] = (acc + (1 << (LG - 2))) >> (LG - 1);
+        const int blk = yy >> LG, y = yy & (N - 1);
+        SH.r2[blk * (N * HS) + u * HS + y] = (acc + (1 << (LG - 2))) >> (LG - 1);
     }
     WSYNC();
     // stage 2: C[v][x] = (sum_y T[v][y] H[x][y] + d) >> (LG+6)  (:2246-2316); lane v = u
 #pragma unroll 1
-    for (int x = g; x < N; x += G) {
-        const int32_t* col = &SH.r2[x * HS];
+    for (int xx = g; xx < nb * N; xx += G) {
+        const int blk = xx >> LG, x = xx & (N - 1);
+        const int32_t* col = &SH.r2[blk * (N * HS) + x * HS];
         int acc = 0;
 #pragma unroll
         for (int k = 0; k < N / 2; ++k) {
@@ -722,15 +762,15 @@ __device__ void fwd_dct(Ctx c) {
             acc += __mul24((int)(short)(t[k] & 0xFFFF), col[2 * k]);
             acc += __mul24((int)t[k] >> 16, col[2 * k + 1]);
         }
-        SH.r1[u * N + x] = (int16_t)((acc + (1 << (LG + 5))) >> (LG + 6));
+        SH.r1[blk * (N * N) + u * N + x] = (int16_t)((acc + (1 << (LG + 5))) >> (LG + 6));
     }
     WSYNC();
 }
 
-// inverse: transposed dequantised coefficients in the lower half of r2 (dT[x][i], i16) ->
-// residual r1 (r[y][x]); the intermediate lives in the upper half of r2.  transformer.rs:2380-2737
+// inverse: nb transposed dequantised blocks in the lower half of r2 ([blk][x][i], i16) ->
+// residuals r1 ([blk][y][x]); the intermediate lives in the upper half of r2.  transformer.rs:2380-2737
 template <int LG>
-__device__ void inv_dct(Ctx c) {
+__device__ void inv_dct(Ctx c, int nb) {
     constexpr int N = 1 << LG;
     constexpr int G = 64 / N;
     const int u = LANE & (N - 1);
@@ -745,46 +785,49 @@ __device__ void inv_dct(Ctx c) {
     }
     // stage 1 (vertical): V[y][x] = clamp16((sum_i T[i][y] d[i][x] + 64) >> 7); lane y = u
 #pragma unroll 1
-    for (int x = g; x < N; x += G) {
-        const uint32_t* col = (const uint32_t*)&dqt[x * N]; // dT[x][.]
+    for (int xx = g; xx < nb * N; xx += G) {
+        const uint32_t* col = (const uint32_t*)&dqt[xx * N]; // dT[blk][x][.]
         int acc = 0;
 #pragma unroll
         for (int k = 0; k < N / 2; ++k) acc = dot2(col[k], t[k], acc);
         int v = (acc + 64) >> 7;
         v = min(max(v, -32768), 32767);
-        vbuf[u * N + x] = (int16_t)v;
+        const int blk = xx >> LG, x = xx & (N - 1);
+        vbuf[blk * (N * N) + u * N + x] = (int16_t)v;
     }
     WSYNC();
     // stage 2 (horizontal): r[y][x] = (sum_i T[i][x] V[y][i] + 2048) >> 12; lane x = u
 #pragma unroll 1
-    for (int y = g; y < N; y += G) {
-        const uint32_t* row = (const uint32_t*)&vbuf[y * N];
+    for (int yy = g; yy < nb * N; yy += G) {
+        const uint32_t* row = (const uint32_t*)&vbuf[yy * N];
         int acc = 0;
 #pragma unroll
         for (int k = 0; k < N / 2; ++k) acc = dot2(row[k], t[k], acc);
-        SH.r1[y * N + u] = (int16_t)((acc + 2048) >> 12);
+        SH.r1[yy * N + u] = (int16_t)((acc + 2048) >> 12);
     }
     WSYNC();
 }
 
-__device__ __forceinline__ void fwd_dct_lg(Ctx c, int lg) {
+__device__ __forceinline__ void fwd_dct_lg(Ctx c, int lg, int nb) {
     c = uni(c);
     lg = uni(lg);
+    nb = uni(nb);
     switch (lg) {
-    case 2: fwd_dct<2>(c); break;
-    case 3: fwd_dct<3>(c); break;
-    case 4: fwd_dct<4>(c); break;
-    default: fwd_dct<5>(c); break;
+    case 2: fwd_dct<2>(c, nb); break;
+    case 3: fwd_dct<3>(c, nb); break;
+    case 4: fwd_dct<4>(c, nb); break;
+    default: fwd_dct<5>(c, nb); break;
     }
 }
-__device__ __forceinline__ void inv_dct_lg(Ctx c, int lg) {
+__device__ __forceinline__ void inv_dct_lg(Ctx c, int lg, int nb) {
     c = uni(c);
     lg = uni(lg);
+    nb = uni(nb);
     switch (lg) {
-    case 2: inv_dct<2>(c); break;
-    case 3: inv_dct<3>(c); break;
-    case 4: inv_dct<4>(c); break;
-    default: inv_dct<5>(c); break;
+    case 2: inv_dct<2>(c, nb); break;
+    case 3: inv_dct<3>(c, nb); break;
+    case 4: inv_dct<4>(c, nb); break;
+    default: inv_dct<5>(c, nb); break;
     }
 }
 
@@ -825,53 +868,63 @@ __device__ __forceinline__ int compose_map(int g2, int g1) {
 // against branch 0 (K0 <= n0 + 2^25 <= n1 + 2^26.2 + 2^25 < n1 + 2^29) and cannot overflow.
 constexpr int kNoBranch = 1 << 29;
 
-// Dependent quantisation of one transform block: coefficients r1 (n*n row-major) ->
-// levels r1 (n*n row-major); returns the level cost (block_splitter.rs:436-458).
-// Scratch: r2, decw.  `*overflow` is set when a level needs a table entry >= 1024
-// (the reference panics there).
+// Dependent quantisation of nb transform blocks of side n (nb = 1 luma, 2 = Cb+Cr pair):
+// coefficients r1 ([blk][y][x]) -> levels in place; returns the summed level cost
+// (block_splitter.rs:436-458).  Scratch: r2, decw.  `*overflow` is set when a level needs a table
+// entry >= 1024 (the reference panics there).
 //
 // Backward pass = 4-state Viterbi equivalent of the reference's memoised DFS (SURVEY.md Q3,
-// proven equal to the literal DFS in tests/test_oracle.py).  Per chunk of 64 positions all
-// lanes precompute the two branch costs for both values of delta = (state > 1); then ONE lane
-// per state walks the chunk, exchanging path costs with two DPP quad permutes.
-//   shared == true : every wave of the workgroup is in this call with a block of the same size
-//                    (same schedule, see SHW above); wave 0 walks all WPB blocks at once, one
+// proven equal to the literal DFS in tests/test_oracle.py).  Per chunk of positions all lanes
+// precompute the two branch costs for both values of delta = (state > 1); then ONE lane per
+// state and block walks the chunk, exchanging path costs with two DPP quad permutes.
+//   shared == true : every wave of the workgroup is in this call with blocks of the same size
+//                    (same schedule, see SHW above); wave 0 walks all WPB*nb blocks at once, one
 //                    quad of lanes per block, between two workgroup barriers per chunk.
 //                    `active == false` = this wave only keeps the barriers company.
-//   shared == false: the wave walks its own block in lanes 0..3 (final pass, tests).
+//   shared == false: the wave walks its own blocks in quads 0..nb-1 (final pass, tests).
 // Forward trace = composition of per-position state maps (prefix scan over lanes), then every
 // lane emits its own positions and their level costs.
-__device__ __forceinline__ long long quantize(Ctx c, int lg, bool shared, bool active, int* overflow) {
+__device__ __forceinline__ long long quantize(Ctx c, int lg, int nb, bool shared, bool active, int* overflow) {
     c = uni(c);
     lg = uni(lg);
+    nb = uni(nb);
     const DevConst* k = c.k;
     const int n = 1 << lg;
     const int P = n * n;
+    const int lgP = 2 * lg;
     const int sh = 8 + lg - 5 + 1; // quantizer.rs:558-569
     const int off = (1 << sh) >> 1;
     const int lsc = k->lsc;
     const uint16_t* scan = k->scan_idx[lg - 2];
-    int16_t* tcs = (int16_t*)SH.r2;          // coefficient in reverse-scan order
-    int16_t* qds = (int16_t*)SH.r2 + 1024;   // |(tc << sh) - off| / lsc
-    int32_t* cc = (int32_t*)SH.r1;           // chunk: [64][6] ints (the coefficients are dead after the gather)
-    const uint16_t* dec16 = (const uint16_t*)SH.decw; // decisions: [sub-block][state] 16-bit masks
+    int16_t* tcs = (int16_t*)SH.r2;          // [blk][p]: coefficient in reverse-scan order
+    int16_t* qds = (int16_t*)SH.r2 + 1024;   // [blk][p]: |(tc << sh) - off| / lsc
+    int32_t* cc = (int32_t*)SH.r1;           // chunk: [blk][CH][6] ints (coefficients are dead after the gather)
+    const uint16_t* dec16 = (const uint16_t*)SH.decw; // decisions: [blk][sub-block][state] 16-bit masks
     PROF_MARK(q0_);
-    int istar = P;
+    int istar0 = P, istar1 = P;
     if (active) {
-        int first = P;
-        for (int p = LANE; p < P; p += 64) {
-            const int tc = SH.r1[scan[p]];
+        int first0 = P, first1 = P;
+        for (int idx = LANE; idx < nb * P; idx += 64) {
+            const int blk = idx >> lgP, p = idx & (P - 1);
+            const int tc = SH.r1[blk * P + scan[p]];
             int S = (int)((unsigned)tc << sh) - off;
             if (tc < 0) S = -S;
             const int qd = tc == 0 ? 0 : (int)(((unsigned long long)(unsigned)S * k->div_magic) >> 47);
-            tcs[p] = (int16_t)tc;
-            qds[p] = (int16_t)qd;
-            if (tc != 0 && (qd >> 1) > 0) first = min(first, p);
+            tcs[idx] = (int16_t)tc;
+            qds[idx] = (int16_t)qd;
+            if (tc != 0 && (qd >> 1) > 0) {
+                if (blk)
+                    first1 = min(first1, p);
+                else
+                    first0 = min(first0, p);
+            }
         }
-        istar = wave_min_i32(first);
+        istar0 = wave_min_i32(first0);
+        if (nb == 2) istar1 = wave_min_i32(first1);
     }
     if (LANE == 0) {
-        SH.q_istar = istar;
+        SH.q_istar[0] = istar0;
+        SH.q_istar[1] = istar1;
         SH.q_active = active ? 1 : 0;
     }
     PROF_MARK(q1_);
@@ -879,21 +932,24 @@ __device__ __forceinline__ long long quantize(Ctx c, int lg, bool shared, bool a
     const int ldq1 = (int)ldq_at(c, 1);
     const int st = LANE & 3;
     const int delta = st > 1 ? 1 : 0;
-    // which block this lane's quad walks: own block (solo) or block of wave `quad` (shared, wave 0)
+    const int CH = min(P, nb == 2 ? 32 : 64); // chunk positions per block
+    // which block this lane's quad walks: (wave, blk) = (quad / nb, quad % nb) in shared mode
     const int quad = LANE >> 2;
-    const bool walker = shared ? (WAVE == 0 && quad < WPB) : (quad == 0);
-    const Lds* tb = shared ? &SHW[quad < WPB ? quad : 0] : &SH;
-    const int32_t* wcc = (const int32_t*)tb->r1;
+    const int wblk = nb == 2 ? (quad & 1) : 0;
+    const int wwave = nb == 2 ? (quad >> 1) : quad;
+    const bool walker = shared ? (WAVE == 0 && wwave < WPB) : (quad < nb);
+    const Lds* tb = shared ? &SHW[wwave < WPB ? wwave : 0] : &SH;
+    const int32_t* wcc = (const int32_t*)tb->r1 + wblk * CH * 6;
     int C = 0;
     int ovf = 0;
-    const int CH = P < 64 ? P : 64;
     for (int base = P - CH; base >= 0; base -= CH) {
         WSYNC();
-        if (active && LANE < CH) {
+        if (active && LANE < nb * CH) {
             // per position: [c0 d0, c1 d0, c0 d1, c1 d1, c0 d0 inside the trailing run, flags]
-            const int p = base + LANE;
-            const int tc = tcs[p];
-            const int qd = qds[p];
+            const int blk = LANE >= CH ? 1 : 0;
+            const int p = base + LANE - blk * CH;
+            const int tc = tcs[blk * P + p];
+            const int qd = qds[blk * P + p];
             const bool dcn = p == P - 1;
             int flags = 0;
             int c0tz = 0;
@@ -938,8 +994,8 @@ __device__ __forceinline__ long long quantize(Ctx c, int lg, bool shared, bool a
         else
             WSYNC();
         if (walker && (!shared || tb->q_active)) {
-            const int wistar = shared ? tb->q_istar : istar;
-            uint16_t* wdec = (uint16_t*)const_cast<uint32_t*>(tb->decw);
+            const int wistar = shared ? tb->q_istar[wblk] : (wblk ? istar1 : istar0);
+            uint16_t* wdec = (uint16_t*)const_cast<uint32_t*>(tb->decw) + wblk * (P >> 2);
             for (int g16 = CH - 16; g16 >= 0; g16 -= 16) { // one 4x4 sub-block per iteration
                 unsigned bits = 0;
 #pragma unroll
@@ -975,14 +1031,21 @@ __device__ __forceinline__ long long quantize(Ctx c, int lg, bool shared, bool a
     PROF_ADD2(PH_QBACK, q1_, q2_);
     if (!active) return 0;
     // ---- forward trace from state 0 (quantizer.rs:686-721) + level-cost walk ----
-    const int per = P >= 64 ? (P >> 6) : 1; // consecutive positions per lane
-    const int p0 = LANE * per;
+    // lanes are split evenly between the blocks; each lane owns `per` consecutive positions
+    const int half = nb == 2 ? 32 : 64;
+    const int blk = nb == 2 ? (LANE >> 5) : 0;
+    const int lane_in = LANE & (half - 1);
+    const int per = P >= half ? P / half : 1;
+    const int p0 = lane_in * per;
     const bool act = p0 < P;
+    const int16_t* btcs = tcs + blk * P;
+    const int16_t* bqds = qds + blk * P;
+    const uint16_t* bdec = dec16 + blk * (P >> 2);
     int fmap = 0xE4; // identity map
     if (act) {
         for (int j = 0; j < per; ++j) {
             const int p = p0 + j;
-            const int tc = tcs[p], qd = qds[p], nib = dec_nib(dec16, p);
+            const int tc = btcs[p], qd = bqds[p], nib = dec_nib(bdec, p);
             int g = 0;
 #pragma unroll
             for (int sidx = 0; sidx < 4; ++sidx) {
@@ -994,15 +1057,15 @@ __device__ __forceinline__ long long quantize(Ctx c, int lg, bool shared, bool a
             fmap = compose_map(g, fmap);
         }
     }
-    // inclusive prefix composition across lanes
+    // inclusive prefix composition across the lanes of a block
     int pre = fmap;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
         const int other = __shfl_up(pre, d, 64);
-        if (LANE >= d) pre = compose_map(pre, other);
+        if (lane_in >= d) pre = compose_map(pre, other);
     }
-    int entry = __shfl_up(pre, 1, 64) & 3; // state after all previous lanes, starting from 0
-    if (LANE == 0) entry = 0;
+    int entry = __shfl_up(pre, 1, 64) & 3; // state after all previous lanes of the block, starting from 0
+    if (lane_in == 0) entry = 0;
     long long sum_nz = 0;
     unsigned zmask = 0;
     int fnz = P;
@@ -1010,7 +1073,7 @@ __device__ __forceinline__ long long quantize(Ctx c, int lg, bool shared, bool a
         int state = entry;
         for (int j = 0; j < per; ++j) {
             const int p = p0 + j;
-            const int tc = tcs[p], qd = qds[p], nib = dec_nib(dec16, p);
+            const int tc = btcs[p], qd = bqds[p], nib = dec_nib(bdec, p);
             const int dl = state > 1 ? 1 : 0;
             int q = 0, a = 0;
             if (tc != 0) {
@@ -1021,7 +1084,7 @@ __device__ __forceinline__ long long quantize(Ctx c, int lg, bool shared, bool a
                     q = a > 0 ? 2 * a - dl : 0;
                 if (tc < 0) q = -q;
             }
-            SH.r1[scan[p]] = (int16_t)q;
+            SH.r1[blk * P + scan[p]] = (int16_t)q;
             const int qc = abs(q);
             if (qc == 0) {
                 zmask |= 1u << j;
@@ -1034,7 +1097,7 @@ __device__ __forceinline__ long long quantize(Ctx c, int lg, bool shared, bool a
             state = (0x7D28 >> (2 * (2 * state + (a & 1)))) & 3;
         }
     }
-    const int pf = wave_min_i32(fnz); // zeros before the first non-zero level cost nothing
+    const int pf = group_min_i32(fnz, half); // zeros before a block's first non-zero level cost nothing
     if (act) {
         int nz_after = 0;
         for (int j = 0; j < per; ++j)
@@ -1051,18 +1114,22 @@ __device__ __forceinline__ long long quantize(Ctx c, int lg, bool shared, bool a
 
 // levels r1 (row-major) -> transposed dequantised coefficients in r2 (dT[x][i] = d[i][x]);
 // quantizer.rs:761-1079
-__device__ __forceinline__ void dequantize_t(Ctx c, int lg) {
+__device__ __forceinline__ void dequantize_t(Ctx c, int lg, int nb) {
     c = uni(c);
     lg = uni(lg);
+    nb = uni(nb);
     const int n = 1 << lg;
+    const int nn = n * n;
     const int sh = 8 + lg - 5 + 1;
     const int off = (1 << sh) >> 1;
     const int lsc = c.k->lsc;
-    for (int i = LANE; i < n * n; i += 64) {
-        const int x = i & (n - 1), y = i >> lg;
+    int16_t* out = (int16_t*)SH.r2;
+    for (int i = LANE; i < nb * nn; i += 64) {
+        const int blk = i >> (2 * lg), ii = i & (nn - 1);
+        const int x = ii & (n - 1), y = ii >> lg;
         int v = ((int)SH.r1[i] * lsc + off) >> sh;
         v = min(max(v, -32768), 32767);
-        ((int16_t*)SH.r2)[x * n + y] = (int16_t)v;
+        out[blk * nn + x * n + y] = (int16_t)v;
     }
     WSYNC();
 }
@@ -1075,13 +1142,14 @@ struct CompCost {
     long long level;
 };
 
-// predict -> T -> Q -> DQ -> IT -> recon (+SSD) of one component (block_splitter.rs:146-185).
-// The block's reference samples must be current (build_refs).  lev_out != nullptr: the final
-// pass -- the levels are stored to that plane position (row stride lev_stride) and samples whose
+// predict -> T -> Q -> DQ -> IT -> recon (+SSD) of the luma block (comp 0) or of the Cb+Cr pair
+// (comp 1) of a TU (block_splitter.rs:146-185); returns SSD and level cost summed over the blocks.
+// The TU's reference samples must be current (build_refs).  lev0 != nullptr: the final pass --
+// the levels go to plane position lev0 (and lev1 for Cr), row stride lev_stride, and samples whose
 // reconstruction differs from what the search left in the tile are counted in *changed.
 __device__ __noinline__ CompCost code_component(Ctx c, int comp, int tx, int ty, int tlg, int mode, bool shared,
-                                                bool active, int16_t* lev_out, int lev_stride, int* changed,
-                                                int* overflow) {
+                                                bool active, int16_t* lev0, int16_t* lev1, int lev_stride,
+                                                int* changed, int* overflow) {
     c = uni(c);
     comp = uni(comp);
     tx = uni(tx);
@@ -1089,27 +1157,32 @@ __device__ __noinline__ CompCost code_component(Ctx c, int comp, int tx, int ty,
     tlg = uni(tlg);
     mode = uni(mode);
     const int cs = comp ? 1 : 0;
+    const int nb = comp ? 2 : 1;
     const int lg = tlg - cs;
     const int n = 1 << lg;
+    const int nn = n * n;
     const int cx = tx >> cs, cy = ty >> cs;
     CompCost r;
     if (!active) { // keep the shared-Viterbi barriers company (all waves run the same schedule)
-        r.level = quantize(c, lg, shared, false, overflow);
+        r.level = quantize(c, lg, nb, shared, false, overflow);
         r.ssd = 0;
         return r;
     }
     PROF_MARK(t0_);
     predict<true>(c, comp, tx, ty, tlg, mode);
     PROF_MARK(t1_);
-    fwd_dct_lg(c, lg);
+    fwd_dct_lg(c, lg, nb);
     PROF_MARK(t2_);
-    r.level = quantize(c, lg, shared, true, overflow);
+    r.level = quantize(c, lg, nb, shared, true, overflow);
     PROF_MARK(t3_);
-    if (lev_out != nullptr && c.write)
-        for (int i = LANE; i < n * n; i += 64) lev_out[(size_t)(i >> lg) * lev_stride + (i & (n - 1))] = SH.r1[i];
-    dequantize_t(c, lg);
+    if (lev0 != nullptr && c.write)
+        for (int i = LANE; i < nb * nn; i += 64) {
+            const int blk = i >> (2 * lg), ii = i & (nn - 1);
+            (blk ? lev1 : lev0)[(size_t)(ii >> lg) * lev_stride + (ii & (n - 1))] = SH.r1[i];
+        }
+    dequantize_t(c, lg, nb);
     PROF_MARK(t4_);
-    inv_dct_lg(c, lg);
+    inv_dct_lg(c, lg, nb);
     PROF_MARK(t5_);
     PROF_ADD2(PH_PREDICT, t0_, t1_);
     PROF_ADD2(PH_FDCT, t1_, t2_);
@@ -1117,13 +1190,15 @@ __device__ __noinline__ CompCost code_component(Ctx c, int comp, int tx, int ty,
     PROF_ADD2(PH_IDCT, t4_, t5_);
     unsigned int part = 0;
     int diff = 0;
-    for (int i = LANE; i < n * n; i += 64) {
-        const int x = i & (n - 1), y = i >> lg;
+    for (int i = LANE; i < nb * nn; i += 64) {
+        const int blk = i >> (2 * lg), ii = i & (nn - 1);
+        const int x = ii & (n - 1), y = ii >> lg;
+        const int pc = comp + blk;
         int v = (int16_t)((int)c.pred_scratch[i] + (int)SH.r1[i]); // pred as i16 + res, clamp (:178)
         v = min(max(v, 0), 255);
-        if (changed != nullptr && v != rec_get(comp, cx + x, cy + y)) ++diff;
-        rec_put(comp, cx + x, cy + y, v);
-        const int d = v - org_get(c, comp, cx + x, cy + y);
+        if (changed != nullptr && v != rec_get(pc, cx + x, cy + y)) ++diff;
+        rec_put(pc, cx + x, cy + y, v);
+        const int d = v - org_get(c, pc, cx + x, cy + y);
         part += (unsigned)(d * d);
     }
     r.ssd = wave_sum_u64((unsigned long long)part);
@@ -1134,7 +1209,7 @@ __device__ __noinline__ CompCost code_component(Ctx c, int comp, int tx, int ty,
     return r;
 }
 
-// predict + SAD (block_splitter.rs:64-108); nothing is stored
+// predict + SAD of the luma block or the Cb+Cr pair (block_splitter.rs:64-108); nothing is stored
 __device__ __noinline__ unsigned int sad_component(Ctx c, int comp, int tx, int ty, int tlg, int mode) {
     c = uni(c);
     comp = uni(comp);
@@ -1281,23 +1356,8 @@ __device__ __forceinline__ float assemble_chroma_cost(const Ctx& c, int mc, cons
 }
 
 // evaluate the chroma pair with mode mc into e.ssd_c / e.lvl_c
-__device__ __noinline__ CompCost eval_chroma(Ctx c, int bx, int by, int lg, int mc, bool active, int* overflow) {
-    c = uni(c);
-    bx = uni(bx);
-    by = uni(by);
-    lg = uni(lg);
-    mc = uni(mc);
-    unsigned long long ssd = 0;
-    long long level = 0;
-    for (int comp = 1; comp < 3; ++comp) {
-        const CompCost r = code_component(c, comp, bx, by, lg, mc, true, active, nullptr, 0, nullptr, overflow);
-        ssd += r.ssd;
-        level += r.level;
-    }
-    CompCost out;
-    out.ssd = ssd;
-    out.level = level;
-    return out;
+__device__ __forceinline__ CompCost eval_chroma(Ctx c, int bx, int by, int lg, int mc, bool active, int* overflow) {
+    return code_component(c, 1, bx, by, lg, mc, true, active, nullptr, nullptr, 0, nullptr, overflow);
 }
 
 struct FullRes {
@@ -1317,7 +1377,7 @@ __device__ __noinline__ FullRes full_cost(Ctx c, int tree, int bx, int by, int l
     mc = uni(mc);
     EvalParts p = {0, 0, 0, 0};
     {
-        const CompCost r = code_component(c, 0, bx, by, lg, ml, true, active, nullptr, 0, nullptr, overflow);
+        const CompCost r = code_component(c, 0, bx, by, lg, ml, true, active, nullptr, nullptr, 0, nullptr, overflow);
         p.ssd_y = r.ssd;
         p.lvl_y = r.level;
     }
@@ -1334,18 +1394,9 @@ __device__ __noinline__ FullRes full_cost(Ctx c, int tree, int bx, int by, int l
 }
 
 // get_intra_pred_aux_cost (block_splitter.rs:64-108) for modes [m; 3]
-__device__ __noinline__ float aux_cost(Ctx c, int tree, int bx, int by, int lg, int m) {
-    c = uni(c);
-    tree = uni(tree);
-    bx = uni(bx);
-    by = uni(by);
-    lg = uni(lg);
-    m = uni(m);
+__device__ __forceinline__ float aux_cost(Ctx c, int tree, int bx, int by, int lg, int m) {
     unsigned long long sad = sad_component(c, 0, bx, by, lg, m);
-    if (tree == TREE_SINGLE) {
-        sad += sad_component(c, 1, bx, by, lg, m);
-        sad += sad_component(c, 2, bx, by, lg, m);
-    }
+    if (tree == TREE_SINGLE) sad += sad_component(c, 1, bx, by, lg, m);
     return (float)sad;
 }
 
@@ -1358,15 +1409,8 @@ __device__ __forceinline__ float chroma_full_cost(Ctx c, int bx, int by, int lg,
 }
 
 // get_chroma_intra_pred_aux_cost (block_splitter.rs:476-522)
-__device__ __noinline__ float chroma_aux_cost(Ctx c, int bx, int by, int lg, int mc) {
-    c = uni(c);
-    bx = uni(bx);
-    by = uni(by);
-    lg = uni(lg);
-    mc = uni(mc);
-    unsigned long long sad = sad_component(c, 1, bx, by, lg, mc);
-    sad += sad_component(c, 2, bx, by, lg, mc);
-    return (float)sad;
+__device__ __forceinline__ float chroma_aux_cost(Ctx c, int bx, int by, int lg, int mc) {
+    return (float)(unsigned long long)sad_component(c, 1, bx, by, lg, mc);
 }
 
 __device__ __forceinline__ int pick_cclm(float lt, float t, float l) {
@@ -1391,13 +1435,12 @@ __device__ __noinline__ void regen_block(Ctx c, int bx, int by, int lg, int luma
     chroma_mode = uni(chroma_mode);
     if (luma) {
         build_refs(c, 0, bx, by, lg);
-        code_component(c, 0, bx, by, lg, luma_mode, false, true, nullptr, 0, nullptr, overflow);
+        code_component(c, 0, bx, by, lg, luma_mode, false, true, nullptr, nullptr, 0, nullptr, overflow);
     }
-    if (chroma)
-        for (int comp = 1; comp < 3; ++comp) {
-            if (chroma_mode < LT_CCLM) build_refs(c, comp, bx, by, lg);
-            code_component(c, comp, bx, by, lg, chroma_mode, false, true, nullptr, 0, nullptr, overflow);
-        }
+    if (chroma) {
+        if (chroma_mode < LT_CCLM) build_refs(c, 1, bx, by, lg);
+        code_component(c, 1, bx, by, lg, chroma_mode, false, true, nullptr, nullptr, 0, nullptr, overflow);
+    }
 }
 
 // leaf search of a DUAL_TREE_CHROMA block (block_splitter.rs:794-885); lg = luma log2 (3)
@@ -1408,7 +1451,6 @@ __device__ __noinline__ LeafResult leaf_chroma(Ctx c, int bx, int by, int lg, in
     lg = uni(lg);
     dm_mode = uni(dm_mode);
     build_refs(c, 1, bx, by, lg);
-    build_refs(c, 2, bx, by, lg);
     const float lt = chroma_aux_cost(c, bx, by, lg, LT_CCLM);
     const float t = chroma_aux_cost(c, bx, by, lg, T_CCLM);
     const float l = chroma_aux_cost(c, bx, by, lg, L_CCLM);
@@ -1437,10 +1479,7 @@ __device__ __noinline__ LeafResult leaf_luma(Ctx c, int tree, int bx, int by, in
     by = uni(by);
     lg = uni(lg);
     build_refs(c, 0, bx, by, lg);
-    if (tree == TREE_SINGLE) {
-        build_refs(c, 1, bx, by, lg);
-        build_refs(c, 2, bx, by, lg);
-    }
+    if (tree == TREE_SINGLE) build_refs(c, 1, bx, by, lg);
     float cost_planar = 0.f, cost_dc = 0.f;
     EvalParts e_planar = {0, 0, 0, 0}, e_dc = {0, 0, 0, 0};
     float min_dir_cost = 3.40282347e+38f;
@@ -1519,7 +1558,7 @@ __device__ __noinline__ LeafResult leaf_luma(Ctx c, int tree, int bx, int by, in
         e_win = e_dir;
     }
     // luma re-run with the winner (:989-1037): puts the winner's luma reconstruction into the tile
-    code_component(c, 0, bx, by, lg, mode, true, true, nullptr, 0, nullptr, overflow);
+    code_component(c, 0, bx, by, lg, mode, true, true, nullptr, nullptr, 0, nullptr, overflow);
     LeafResult r;
     r.luma_mode = mode;
     r.chroma_mode = mode;
@@ -1678,6 +1717,7 @@ __device__ float split_ct_ctu(Ctx& c, int max_depth, int* overflow) {
 // ---------------------------------------------------------------------------
 // Final pass (ctu_encoder.rs:1421-1461) in coding order; writes levels to HBM
 // ---------------------------------------------------------------------------
+// comp 0 = luma block, comp 1 = the Cb+Cr pair of the TU at (tx, ty)
 __device__ __noinline__ void final_component(Ctx c, const PicBufs& pb, int comp, int tx, int ty, int tlg, int mode,
                                              int* overflow) {
     c = uni(c);
@@ -1688,11 +1728,11 @@ __device__ __noinline__ void final_component(Ctx c, const PicBufs& pb, int comp,
     mode = uni(mode);
     const int cs = comp ? 1 : 0;
     const int stride = c.k->W >> cs;
-    const int gx = (c.ctu_x + tx) >> cs, gy = (c.ctu_y + ty) >> cs;
+    const size_t at = (size_t)((c.ctu_y + ty) >> cs) * stride + ((c.ctu_x + tx) >> cs);
     if (mode < LT_CCLM) build_refs(c, comp, tx, ty, tlg);
     int changed = 0;
-    code_component(c, comp, tx, ty, tlg, mode, false, true, pb.lev[comp] + (size_t)gy * stride + gx, stride, &changed,
-                   overflow);
+    code_component(c, comp, tx, ty, tlg, mode, false, true, pb.lev[comp] + at, comp ? pb.lev[2] + at : nullptr, stride,
+                   &changed, overflow);
     if (changed && LANE == 0 && c.write) atomicAdd(c.mismatch, (unsigned long long)changed);
 }
 
@@ -1710,14 +1750,12 @@ __device__ void final_pass_ctu(Ctx c, const PicBufs& pb, int* overflow) {
             if (lg >= 3) {
                 const int mc = SH.chroma_mode[(by >> 3) * 4 + (bx >> 3)];
                 final_component(c, pb, 1, bx, by, lg, mc, overflow);
-                final_component(c, pb, 2, bx, by, lg, mc, overflow);
             }
         }
         if (lg == 2 && (z & 3) == 3) { // after the fourth 4x4 luma CU: the 8x8's chroma CU
             const int pbx = bx & ~7, pby = by & ~7;
             const int mc = SH.chroma_mode[(pby >> 3) * 4 + (pbx >> 3)];
             final_component(c, pb, 1, pbx, pby, 3, mc, overflow);
-            final_component(c, pb, 2, pbx, pby, 3, mc, overflow);
         }
     }
 }

@@ -58,7 +58,7 @@ __global__ __launch_bounds__(64) void test_fwd_dct_kernel(const DevConst* __rest
     const int nn = 1 << (2 * lg);
     for (int i = threadIdx.x; i < nn; i += 64) SH.r1[i] = in[(size_t)blockIdx.x * nn + i];
     WSYNC();
-    fwd_dct_lg(c, lg);
+    fwd_dct_lg(c, lg, 1);
     for (int i = threadIdx.x; i < nn; i += 64) out[(size_t)blockIdx.x * nn + i] = SH.r1[i];
 }
 
@@ -70,7 +70,7 @@ __global__ __launch_bounds__(64) void test_inv_dct_kernel(const DevConst* __rest
     for (int i = threadIdx.x; i < nn; i += 64) // transposed load: dT[x][i] = d[i][x]
         ((int16_t*)SH.r2)[(i & (n - 1)) * n + (i >> lg)] = in[(size_t)blockIdx.x * nn + i];
     WSYNC();
-    inv_dct_lg(c, lg);
+    inv_dct_lg(c, lg, 1);
     for (int i = threadIdx.x; i < nn; i += 64) out[(size_t)blockIdx.x * nn + i] = SH.r1[i];
 }
 
@@ -84,7 +84,7 @@ __global__ __launch_bounds__(64) void test_quantize_kernel(const DevConst* __res
     for (int i = threadIdx.x; i < nn; i += 64) SH.r1[i] = in[(size_t)blockIdx.x * nn + i];
     WSYNC();
     int ovf = 0;
-    const long long lc = quantize(c, lg, false, true, &ovf);
+    const long long lc = quantize(c, lg, 1, false, true, &ovf);
     for (int i = threadIdx.x; i < nn; i += 64) out[(size_t)blockIdx.x * nn + i] = SH.r1[i];
     if (threadIdx.x == 0) {
         cost[blockIdx.x] = lc;
@@ -99,7 +99,7 @@ __global__ __launch_bounds__(64) void test_dequantize_kernel(const DevConst* __r
     const int n = 1 << lg, nn = n * n;
     for (int i = threadIdx.x; i < nn; i += 64) SH.r1[i] = in[(size_t)blockIdx.x * nn + i];
     WSYNC();
-    dequantize_t(c, lg);
+    dequantize_t(c, lg, 1);
     for (int i = threadIdx.x; i < nn; i += 64) // undo the transpose
         out[(size_t)blockIdx.x * nn + i] = ((const int16_t*)SH.r2)[(i & (n - 1)) * n + (i >> lg)];
 }
