@@ -125,7 +125,11 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "kernel": "ctu_search_kernel", "avg_launch_ms": avg_launch_s * 1e3,
-                         "algorithmic_bytes_per_launch": per_launch_bytes},
+                         "algorithmic_bytes_per_launch": per_launch_bytes,
+                         # an encode call runs 4 HIP streams of launches side by side (pictures are
+                         # independent); the whole-GPU rate is the step's bytes over its wall time
+                         "concurrent_streams": 4,
+                         "aggregate_GBs": ALGO_BYTES_PER_PIXEL * pix * total_frames / dt / 1e9},
         }
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(w, h, args.qp, args.depth)   # one full frame, ~15 s

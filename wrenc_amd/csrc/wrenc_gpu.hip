@@ -111,6 +111,11 @@ namespace {
 
 thread_local std::string g_create_error;
 
+// An encode call splits its pictures over this many HIP streams.  Pictures are independent, so the
+// streams' anti-diagonal launches overlap and one lane's tail (partially filled GPU) is filled by
+// the other lanes' work.
+constexpr int kEncodeLanes = 4;
+
 // DCT-2 integer cosines c[j] ~ 64*sqrt(2)*cos(j*pi/128), H.266 8.7.4.5
 // (the reference's 64-point matrix, transformer.rs:934-1191, is row k = c[(2n+1)k])
 const int kCos[65] = {64, 91, 90, 90, 90, 90, 90, 90, 89, 88, 88, 87, 87, 86, 85, 84, 83, 83, 82, 81, 80, 79,
@@ -162,7 +167,10 @@ void diag_scan(int lw, int lh, uint8_t (*out)[2]) { // ctu.rs:54-77
 
 struct wrenc_gpu_ctx {
     wrenc_gpu_config cfg;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;              // uploads, downloads, lane 0 of the encode
+    std::vector<hipStream_t> lanes;            // extra encode lanes (pictures are independent)
+    std::vector<hipEvent_t> lane_done;
+    hipEvent_t ev_fork = nullptr;
     DevConst* d_const = nullptr;
     PicBufs* d_slots = nullptr;
     std::vector<PicBufs> slots;
@@ -337,6 +345,7 @@ void wrenc_gpu_destroy(wrenc_gpu_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->cfg.device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    for (hipStream_t st : ctx->lanes) (void)hipStreamSynchronize(st);
     for (PicBufs& b : ctx->slots) {
         for (int c = 0; c < 3; ++c) {
             if (b.org[c]) (void)hipFree((void*)b.org[c]);
@@ -356,6 +365,9 @@ void wrenc_gpu_destroy(wrenc_gpu_ctx* ctx) {
     if (ctx->ev_begin) (void)hipEventDestroy(ctx->ev_begin);
     if (ctx->ev_end) (void)hipEventDestroy(ctx->ev_end);
     for (hipEvent_t e : ctx->ev_pool) (void)hipEventDestroy(e);
+    for (hipStream_t st : ctx->lanes) (void)hipStreamDestroy(st);
+    for (hipEvent_t e : ctx->lane_done) (void)hipEventDestroy(e);
+    if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -397,6 +409,15 @@ int wrenc_gpu_create(const wrenc_gpu_config* cfg, wrenc_gpu_ctx** out) {
     } while (0)
     CREATE_TRY(hipSetDevice(cfg->device));
     CREATE_TRY(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+    CREATE_TRY(hipEventCreate(&ctx->ev_fork));
+    for (int i = 1; i < kEncodeLanes; ++i) {
+        hipStream_t st = nullptr;
+        CREATE_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+        ctx->lanes.push_back(st);
+        hipEvent_t e = nullptr;
+        CREATE_TRY(hipEventCreate(&e));
+        ctx->lane_done.push_back(e);
+    }
     CREATE_TRY(hipEventCreate(&ctx->ev_begin));
     CREATE_TRY(hipEventCreate(&ctx->ev_end));
     {
@@ -457,17 +478,15 @@ int wrenc_gpu_encode(wrenc_gpu_ctx* ctx, int first_slot, int n_pictures) {
     HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
     const int cols = ctx->ctu_cols, rows = ctx->ctu_rows;
     const int ndiag = cols + 2 * (rows - 1);
-    while ((int)ctx->ev_pool.size() < 2 * ndiag) {
-        hipEvent_t e;
-        HIP_TRY(ctx, hipEventCreate(&e));
-        ctx->ev_pool.push_back(e);
-    }
+    // split the pictures into lanes of whole workgroups (WPB pictures each)
+    const int total_groups = (n_pictures + WPB - 1) / WPB;
+    const int n_lanes = total_groups < kEncodeLanes ? total_groups : kEncodeLanes;
+    const int max_diag = (cols + 1) / 2 < rows ? (cols + 1) / 2 : rows;
     {
-        // widest launch: the longest anti-diagonal times the picture groups
-        const int max_diag = (cols + 1) / 2 < rows ? (cols + 1) / 2 : rows;
-        const size_t need = (size_t)max_diag * ((n_pictures + WPB - 1) / WPB) * WPB * 1024;
+        // 1 KB of prediction scratch per resident wave; lanes run concurrently, so each gets its own
+        const size_t need = (size_t)max_diag * (total_groups + n_lanes) * WPB * 1024;
         if (need > ctx->pred_scratch_bytes) {
-            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+            HIP_TRY(ctx, wrenc_gpu_sync(ctx) == WRENC_GPU_OK ? hipSuccess : hipErrorUnknown);
             if (ctx->d_pred_scratch) (void)hipFree(ctx->d_pred_scratch);
             ctx->d_pred_scratch = nullptr;
             ctx->pred_scratch_bytes = 0;
@@ -475,7 +494,14 @@ int wrenc_gpu_encode(wrenc_gpu_ctx* ctx, int first_slot, int n_pictures) {
             ctx->pred_scratch_bytes = need;
         }
     }
+    while ((int)ctx->ev_pool.size() < 2 * ndiag * n_lanes) {
+        hipEvent_t e;
+        HIP_TRY(ctx, hipEventCreate(&e));
+        ctx->ev_pool.push_back(e);
+    }
     HIP_TRY(ctx, hipEventRecord(ctx->ev_begin, ctx->stream));
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
+    for (int l = 1; l < n_lanes; ++l) HIP_TRY(ctx, hipStreamWaitEvent(ctx->lanes[l - 1], ctx->ev_fork, 0));
     int launches = 0;
     for (int d = 0; d < ndiag; ++d) {
         // rows r with 0 <= d - 2r < cols
@@ -485,14 +511,26 @@ int wrenc_gpu_encode(wrenc_gpu_ctx* ctx, int first_slot, int n_pictures) {
         if (r_max > rows - 1) r_max = rows - 1;
         const int count = r_max - r_min + 1;
         if (count <= 0) continue;
-        HIP_TRY(ctx, hipEventRecord(ctx->ev_pool[2 * launches], ctx->stream));
-        const int groups = (n_pictures + WPB - 1) / WPB;
-        hipLaunchKernelGGL(ctu_search_kernel, dim3(count * groups), dim3(64 * WPB), 0, ctx->stream, ctx->d_const,
-                           ctx->d_slots, first_slot, n_pictures, d, r_min, count, ctx->d_pred_scratch, ctx->d_mismatch,
-                           ctx->d_overflow);
-        HIP_TRY(ctx, hipGetLastError());
-        HIP_TRY(ctx, hipEventRecord(ctx->ev_pool[2 * launches + 1], ctx->stream));
-        ++launches;
+        for (int l = 0; l < n_lanes; ++l) {
+            const int g0 = (int)((long long)total_groups * l / n_lanes), g1 = (int)((long long)total_groups * (l + 1) / n_lanes);
+            const int lane_first = first_slot + g0 * WPB;
+            int lane_pics = (g1 - g0) * WPB;
+            if (g0 * WPB + lane_pics > n_pictures) lane_pics = n_pictures - g0 * WPB;
+            if (lane_pics <= 0) continue;
+            hipStream_t st = l == 0 ? ctx->stream : ctx->lanes[l - 1];
+            uint8_t* scratch = ctx->d_pred_scratch + (size_t)max_diag * (g0 + l) * WPB * 1024;
+            HIP_TRY(ctx, hipEventRecord(ctx->ev_pool[2 * launches], st));
+            hipLaunchKernelGGL(ctu_search_kernel, dim3(count * (g1 - g0)), dim3(64 * WPB), 0, st, ctx->d_const,
+                               ctx->d_slots, lane_first, lane_pics, d, r_min, count, scratch, ctx->d_mismatch,
+                               ctx->d_overflow);
+            HIP_TRY(ctx, hipGetLastError());
+            HIP_TRY(ctx, hipEventRecord(ctx->ev_pool[2 * launches + 1], st));
+            ++launches;
+        }
+    }
+    for (int l = 1; l < n_lanes; ++l) {
+        HIP_TRY(ctx, hipEventRecord(ctx->lane_done[l - 1], ctx->lanes[l - 1]));
+        HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->lane_done[l - 1], 0));
     }
     HIP_TRY(ctx, hipEventRecord(ctx->ev_end, ctx->stream));
     ctx->last_launches = launches;
@@ -505,6 +543,7 @@ int wrenc_gpu_sync(wrenc_gpu_ctx* ctx) {
     if (!ctx) return WRENC_GPU_EINVAL;
     HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    for (hipStream_t st : ctx->lanes) HIP_TRY(ctx, hipStreamSynchronize(st));
     int ovf = 0;
     HIP_TRY(ctx, hipMemcpy(&ovf, ctx->d_overflow, sizeof(int), hipMemcpyDeviceToHost));
     if (ovf) return fail(ctx, WRENC_GPU_ELEVEL, "a quantised level reached 1024 (reference panics: block_splitter.rs:453)");
