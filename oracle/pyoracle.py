@@ -82,6 +82,24 @@ def encode_picture(y, cb, cr, qp, max_split_depth):
     return out
 
 
+def reconstruct_from_record(rec, qp, max_split_depth=3):
+    """Decoder-side reconstruction from (cu_log2_size, luma_mode, chroma_mode, lev_*)."""
+    h4, w4 = rec["cu_log2_size"].shape
+    h, w = h4 * 4, w4 * 4
+    arrs = {k: np.ascontiguousarray(rec[k]) for k in ("lev_y", "lev_cb", "lev_cr", "cu_log2_size", "luma_mode",
+                                                      "chroma_mode")}
+    po = _PicOut(None, None, None, _p(arrs["lev_y"]), _p(arrs["lev_cb"]), _p(arrs["lev_cr"]),
+                 _p(arrs["cu_log2_size"]), _p(arrs["luma_mode"]), _p(arrs["chroma_mode"]), None)
+    y = np.zeros((h, w), np.uint8)
+    cb = np.zeros((h // 2, w // 2), np.uint8)
+    cr = np.zeros((h // 2, w // 2), np.uint8)
+    prm = _Params(w, h, qp, max_split_depth)
+    rc = lib().wro_reconstruct_from_record(C.byref(prm), C.byref(po), _p(y), _p(cb), _p(cr))
+    if rc != 0:
+        raise ValueError("wro_reconstruct_from_record failed: %d" % rc)
+    return y, cb, cr
+
+
 def fwd_dct(res):
     n = res.shape[0]
     res = np.ascontiguousarray(res, np.int16)

@@ -1789,6 +1789,52 @@ struct Splitter {
     }
 };
 
+// Decoder-side reconstruction from an output record (tree + modes + levels): predict ->
+// dequantize -> inverse transform -> clip, CU by CU in coding order.  This is what a VVC decoder
+// does with the bitstream's contents, so "reconstruct(record) == rec planes" is the in-repo form of
+// the reference's only end-to-end check (scripts/intergration_test.sh: decoded == reconstructed).
+struct RecordView {
+    const uint8_t* cu_log2;
+    const uint8_t* luma_mode;
+    const uint8_t* chroma_mode;
+    const int16_t* lev[3];
+};
+
+static void recon_component(Picture& p, Splitter& sp, CU* cu, int c, const RecordView& rv) {
+    const int tw = cu->csize(c), tx = cu->cx(c), ty = cu->cy(c);
+    const int log2n = ilog2(tw);
+    sp.ip.predict(cu, c);
+    for (int y = 0; y < tw; ++y)
+        for (int x = 0; x < tw; ++x)
+            cu->lev[c][(size_t)y * tw + x] = rv.lev[c][(size_t)(ty + y) * p.stride[c] + tx + x];
+    dequantize(cu->lev[c].data(), log2n, p.qp, cu->deq[c].data());
+    inv_dct(cu->deq[c].data(), log2n, cu->itr[c].data());
+    sp.reconstruct(cu, c, false);
+}
+
+static void recon_tree(Picture& p, Splitter& sp, Node* n, const RecordView& rv) {
+    const int w4 = p.W / 4, w8 = p.W / 8;
+    const int sz = rv.cu_log2[(n->y / 4) * w4 + n->x / 4];
+    if (n->tree == SINGLE_TREE && sz < ilog2(n->w)) {
+        sp.split(n);
+        for (Node* c : n->cts) recon_tree(p, sp, c, rv);
+        return;
+    }
+    CU* cu = n->cus[0];
+    if (n->tree != DUAL_TREE_CHROMA) {
+        const int ml = rv.luma_mode[(n->y / 4) * w4 + n->x / 4];
+        const int mc = n->tree == SINGLE_TREE ? rv.chroma_mode[(n->y / 8) * w8 + n->x / 8] : ml;
+        const int m3[3] = {ml, mc, mc};
+        cu->set_intra_pred_mode(m3);
+    } else {
+        const int mc = rv.chroma_mode[(n->y / 8) * w8 + n->x / 8];
+        const int m3[3] = {PLANAR, mc, mc};
+        cu->set_intra_pred_mode(m3);
+    }
+    for (int c = 0; c < 3; ++c)
+        if (cu->active(c)) recon_component(p, sp, cu, c, rv);
+}
+
 static long g_last_final_mismatch = 0;
 
 static void export_tree(const Picture& p, const Node* n, wro_picture_out* out) {
@@ -1873,6 +1919,44 @@ int wro_encode_picture(const wro_params* prm, const uint8_t* y, const uint8_t* c
             out->chroma_mode)
             for (Node* root : p.ctu_root) export_tree(p, root, out);
     }
+    return 0;
+}
+
+int wro_reconstruct_from_record(const wro_params* prm, const wro_picture_out* rec, uint8_t* out_y, uint8_t* out_cb,
+                                uint8_t* out_cr) {
+    init_tables();
+    if (!prm || !rec || (prm->width & 31) || (prm->height & 31) || prm->width <= 0 || prm->height <= 0) return -1;
+    Picture p;
+    p.W = prm->width;
+    p.H = prm->height;
+    p.qp = prm->qp;
+    p.max_depth = prm->max_split_depth;
+    init_rd(p.rd, p.qp);
+    p.stride[0] = p.W;
+    p.stride[1] = p.stride[2] = p.W / 2;
+    for (int c = 0; c < 3; ++c) {
+        const size_t n = (size_t)p.stride[c] * (c == 0 ? p.H : p.H / 2);
+        p.org[c].assign(n, 0);
+        p.pred[c].assign(n, 0);
+        p.rec[c].assign(n, 0);
+    }
+    p.ctu_cols = p.W / 32;
+    p.ctu_rows = p.H / 32;
+    for (int r = 0; r < p.ctu_rows; ++r)
+        for (int c = 0; c < p.ctu_cols; ++c)
+            p.ctu_root.push_back(p.new_node(c * 32, r * 32, 32, 0, SINGLE_TREE, MODE_TYPE_ALL, nullptr));
+    RecordView rv;
+    rv.cu_log2 = rec->cu_log2_size;
+    rv.luma_mode = rec->luma_mode;
+    rv.chroma_mode = rec->chroma_mode;
+    rv.lev[0] = rec->lev_y;
+    rv.lev[1] = rec->lev_cb;
+    rv.lev[2] = rec->lev_cr;
+    Splitter sp(p);
+    for (Node* root : p.ctu_root) recon_tree(p, sp, root, rv);
+    memcpy(out_y, p.rec[0].data(), p.rec[0].size());
+    memcpy(out_cb, p.rec[1].data(), p.rec[1].size());
+    memcpy(out_cr, p.rec[2].data(), p.rec[2].size());
     return 0;
 }
 

@@ -52,6 +52,12 @@ typedef struct wro_picture_out {
 int wro_encode_picture(const wro_params* p, const uint8_t* y, const uint8_t* cb,
                        const uint8_t* cr, wro_picture_out* out);
 
+// Decoder-side reconstruction of a picture from its output record (cu_log2_size, luma_mode,
+// chroma_mode, lev_*): predict -> dequantize -> inverse transform -> clip per CU in coding order.
+// Equality with rec_* is the in-repo form of the reference's integration test (decoded == recon).
+int wro_reconstruct_from_record(const wro_params* p, const wro_picture_out* record, uint8_t* out_y,
+                                uint8_t* out_cb, uint8_t* out_cr);
+
 // Final-pass consistency: number of samples where the final pass recon differs
 // from the recon the search left in the planes (expected 0).
 long wro_last_final_pass_mismatches(void);

@@ -1,0 +1,76 @@
+"""Parity at BASELINE.json's full sizes through size-independent properties:
+decoder-side reconstruction of the GPU's record == the GPU's reconstruction (the in-repo form of
+the reference's integration test), the final pass reproduces the search's reconstruction, the
+top CTU rows equal the oracle's encode of the same rows, identical inputs give identical
+outputs, and out-of-range levels are reported (the reference panics there)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+KEYS = ("cu_log2_size", "luma_mode", "chroma_mode", "lev_y", "lev_cb", "lev_cr", "rec_y", "rec_cb", "rec_cr")
+
+
+def test_1080p_depth2_properties(built):
+    from wrenc_amd import gpu, synth
+    from oracle import pyoracle as po
+    w, h, qp, depth = 1920, 1088, 32, 2
+    y, cb, cr = synth.synth_textured_frame(w, h, 7)
+    y2, cb2, cr2 = synth.synth_frame(w, h, 2)
+    enc = gpu.Encoder(w, h, qp=qp, max_split_depth=depth, n_slots=3)
+    enc.upload(0, y, cb, cr)
+    enc.upload(1, y2, cb2, cr2)
+    enc.upload(2, y, cb, cr)          # same input as slot 0, different wave of the workgroup
+    enc.encode(0, 3)
+    enc.sync()
+    assert enc.final_pass_mismatches() == 0
+    a, b, c = enc.download(0), enc.download(1), enc.download(2)
+    enc.close()
+    for k in KEYS + ("ctu_cost",):
+        assert np.array_equal(a[k], c[k]), k                       # determinism across slots / waves
+    for rec in (a, b):
+        ry, rcb, rcr = po.reconstruct_from_record(rec, qp, depth)  # decoder-side reconstruction
+        assert np.array_equal(ry, rec["rec_y"])
+        assert np.array_equal(rcb, rec["rec_cb"])
+        assert np.array_equal(rcr, rec["rec_cr"])
+    # the first two CTU rows depend on nothing below them: they must equal the oracle on the crop
+    ref = po.encode_picture(y[:64], cb[:32], cr[:32], qp, depth)
+    for k in KEYS:
+        scale = {"cu_log2_size": 4, "luma_mode": 4, "chroma_mode": 8, "rec_cb": 2, "rec_cr": 2, "lev_cb": 2,
+                 "lev_cr": 2}.get(k, 1)
+        assert np.array_equal(a[k][:64 // scale], ref[k]), k
+    assert np.array_equal(a["ctu_cost"][:2 * (w // 32)], ref["ctu_cost"])
+    assert len(np.unique(a["cu_log2_size"])) >= 2 and np.count_nonzero(a["chroma_mode"] >= 81) > 0
+
+
+def test_2160p_depth3_decoder_check(built):
+    from wrenc_amd import gpu, synth
+    from oracle import pyoracle as po
+    w, h, qp, depth = 3840, 2176, 27, 3
+    y, cb, cr = synth.synth_textured_frame(w, h, 11)
+    enc = gpu.Encoder(w, h, qp=qp, max_split_depth=depth)
+    rec = enc.encode_picture(y, cb, cr)
+    assert enc.final_pass_mismatches() == 0
+    enc.close()
+    ry, rcb, rcr = po.reconstruct_from_record(rec, qp, depth)
+    assert np.array_equal(ry, rec["rec_y"]) and np.array_equal(rcb, rec["rec_cb"]) and np.array_equal(rcr, rec["rec_cr"])
+    assert set(np.unique(rec["cu_log2_size"])) >= {2, 3, 4}      # the 8x8 -> 4x4 local dual tree is exercised
+    psnr = 10 * np.log10(255.0 ** 2 / np.mean((rec["rec_y"].astype(np.float64) - y) ** 2))
+    assert psnr > 30.0
+
+
+def test_level_overflow_is_reported(built):
+    """A level that would index the reference's 1024-entry tables out of range is an error
+    (WRENC_GPU_ELEVEL), exactly where the oracle reports the reference's panic."""
+    from wrenc_amd import gpu
+    from oracle import pyoracle as po
+    yy, xx = np.indices((32, 32))
+    y = (((xx + yy) & 1) * 255).astype(np.uint8)
+    c = (((xx[:16, :16] + yy[:16, :16]) & 1) * 255).astype(np.uint8)
+    with pytest.raises(ValueError):
+        po.encode_picture(y, c, c, 0, 2)
+    enc = gpu.Encoder(32, 32, qp=0, max_split_depth=2)
+    with pytest.raises(gpu.WrencGpuError) as ei:
+        enc.encode_picture(y, c, c)
+    assert ei.value.code == -6
+    enc.close()

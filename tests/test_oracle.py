@@ -121,6 +121,9 @@ def test_golden_fixture(path):
     for k in ("rec_y", "rec_cb", "rec_cr", "lev_y", "lev_cb", "lev_cr", "cu_log2_size", "luma_mode",
               "chroma_mode", "ctu_cost"):
         assert np.array_equal(out[k], g[k]), k
+    # decoder-side reconstruction of the record equals the encoder's reconstruction
+    ry, rcb, rcr = po.reconstruct_from_record(out, int(g["qp"]), int(g["depth"]))
+    assert np.array_equal(ry, out["rec_y"]) and np.array_equal(rcb, out["rec_cb"]) and np.array_equal(rcr, out["rec_cr"])
 
 
 def test_edge_cases_single_ctu_and_flat():
