@@ -45,6 +45,11 @@ struct DevConst {
     int8_t fc[32][4];         // common.rs:153
 };
 
+// Pointers that are loaded from memory (PicBufs) lose their address space; these casts tell the
+// compiler they are global memory, so that it emits global_* instead of flat_* accesses.
+#define GLOBAL_AS __attribute__((address_space(1)))
+#define AS_GLOBAL(T, p) ((GLOBAL_AS T*)(p))
+
 // One picture's device buffers.
 struct PicBufs {
     const uint8_t* org[3];
@@ -57,6 +62,106 @@ struct PicBufs {
 };
 
 // LDS working set of one wave / one CTU.
+#define LANE ((int)(threadIdx.x & 63))
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+// SSD and level cost of the luma block and of the chroma pair of one evaluated candidate
+struct EvalParts {
+    uint32_t ssd_y, ssd_c; // <= 1024 * 255^2: fits 32 bits
+    long long lvl_y, lvl_c;
+};
+
+
+// A wave-uniform field of the coroutine state, resident in LDS: reads come back through
+// readfirstlane (scalar registers, scalar branches).
+template <class T>
+struct UF {
+    T v;
+    __device__ __forceinline__ T get() const {
+        if constexpr (sizeof(T) == 8) {
+            const unsigned long long x = (unsigned long long)v;
+            return (T)(((unsigned long long)(unsigned)uni((int)(x >> 32)) << 32) | (unsigned)uni((int)x));
+        } else if constexpr (sizeof(T) == 4 && !(T(0.5f) == T(0))) {
+            return __int_as_float(uni(__float_as_int((float)v)));
+        } else {
+            return (T)uni((int)v);
+        }
+    }
+    // every lane stores the same value to the same address (one LDS pass; keeps the control flow
+    // free of lane predicates so that all of it stays scalar)
+    __device__ __forceinline__ void set(T x) { v = x; }
+    __device__ __forceinline__ operator T() const { return get(); }
+    __device__ __forceinline__ UF& operator=(T x) {
+        set(x);
+        return *this;
+    }
+    __device__ __forceinline__ UF& operator=(const UF& o) {
+        set(o.get());
+        return *this;
+    }
+    __device__ __forceinline__ UF& operator+=(int x) {
+        set((T)(get() + x));
+        return *this;
+    }
+    __device__ __forceinline__ UF& operator-=(int x) {
+        set((T)(get() - x));
+        return *this;
+    }
+    __device__ __forceinline__ UF& operator>>=(int x) {
+        set((T)(get() >> x));
+        return *this;
+    }
+    __device__ __forceinline__ UF& operator++() {
+        set((T)(get() + 1));
+        return *this;
+    }
+};
+
+// EvalParts as kept in the coroutine state
+struct EvalPartsU {
+    UF<uint32_t> ssd_y, ssd_c;
+    UF<long long> lvl_y, lvl_c;
+    __device__ __forceinline__ EvalParts get() const {
+        EvalParts e;
+        e.ssd_y = ssd_y;
+        e.ssd_c = ssd_c;
+        e.lvl_y = lvl_y;
+        e.lvl_c = lvl_c;
+        return e;
+    }
+};
+
+// Leaf search state (block_splitter.rs:794-1078 as a state machine, see leaf_step).
+struct LeafSt {
+    UF<uint8_t> cont;                   // where to continue with the result of the pending request
+    UF<uint8_t> op_ml, op_mc, op_act;   // modes / activity of the pending full evaluation
+    UF<uint8_t> tree, bx, by, lg;
+    UF<uint8_t> need_refs0, need_refs1; // reference samples of the block not built yet (luma / chroma pair)
+    UF<uint8_t> step;
+    UF<uint8_t> cur_mode, best_mode, mode, cclm_mode, dm_mode, dm_wins;
+    UF<uint8_t> luma_mode, chroma_mode; // result
+    UF<uint8_t> best_cls, dir_cls;      // header-bit class (mpm_class) of the best / best directional luma mode
+    UF<float> best_cost;                // best of {planar, DC} so far / of {planar, DC, dir}
+    UF<float> cur_cost, c0;
+    UF<float> cost;                     // result
+    EvalPartsU e_best, e_dir;
+};
+
+// CTU search + final pass state (see ctu_step)
+struct CtuSt {
+    UF<uint8_t> cont, in_leaf;
+    UF<uint8_t> level, bx, by, lg, max_depth;
+    UF<uint8_t> i8, z, rl, rc;       // 4x4 child index, final-pass z-order index, regen modes
+    UF<uint8_t> rbx, rby, rlg;       // regen block
+    UF<uint8_t> ns_luma_cur, ns_chroma_cur;
+    UF<float> ret, ns_cost_cur, split8, ctu_cost;
+    LeafSt leaf;
+};
+
+// element offsets into Lds::refs: left (index 0 = corner) / above references of luma unfiltered,
+// luma filtered, Cb, Cr
+constexpr int R_L0 = 0, R_A0 = 66, R_LF = 130, R_AF = 196, R_LC0 = 260, R_LC1 = 294, R_AC0 = 328, R_AC1 = 360;
+
 struct __attribute__((aligned(16))) Lds {
     // Transform working set, time-multiplexed (see code_component):
     //   r1: residual -> coefficients -> Viterbi chunk costs / levels -> reconstructed residual
@@ -65,8 +170,9 @@ struct __attribute__((aligned(16))) Lds {
     int32_t r2[33 * 32];
     // reference samples of the current block, built once per (block, component) and reused by
     // every candidate mode: luma unfiltered + [1 2 1]-filtered, chroma unfiltered
-    int16_t refL0[66], refA0[64], refLf0[66], refAf0[64];
-    int16_t refLc[2][34], refAc[2][32];
+    // one array addressed by element offsets (R_*), so that choosing among the sets is integer
+    // arithmetic on a DS address, never a pointer select
+    int16_t refs[392];
     uint8_t recYtop[72];       // y = -1, x = -4..67 (index x+4)
     uint8_t recY[32 * 36];     // x = -4..31 (index x+4), stride 36
     uint8_t recCtop[2][40];    // y = -1, x = -4..35
@@ -81,6 +187,7 @@ struct __attribute__((aligned(16))) Lds {
     float ns_cost[4];          // per tree level: no-split cost, running split cost
     float split_cost[4];
     uint8_t ns_luma[4], ns_chroma[4], child[4];
+    CtuSt st;                  // search coroutine state
 };
 
 // Per-wave uniform context.
@@ -88,7 +195,8 @@ struct __attribute__((aligned(16))) Lds {
 // stage functions never reload it from memory.
 struct Ctx {
     const DevConst* __restrict__ k;
-    const uint8_t* org[3];              // original planes of this wave's picture (read-only, L2-resident)
+    const GLOBAL_AS uint8_t* org;       // original planes of this wave's picture: Y, Cb, Cr back to back (read-only)
+    int W, WH;                          // luma width, luma plane size
     uint8_t* pred_scratch;              // 1 KB per wave in HBM: prediction bytes between predict and recon
     unsigned long long* mismatch;
     int ctu_x, ctu_y; // luma, picture coordinates
@@ -112,23 +220,20 @@ struct LdsTab {
 };
 __shared__ Lds SHW[WPB];
 __shared__ LdsTab SHT;
-#define LANE ((int)(threadIdx.x & 63))
 #define WAVE (__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)))
 #define SH (SHW[WAVE])
 
 // Everything in Ctx and every block-geometry argument is wave-uniform.  Out-of-line
 // functions receive arguments in VGPRs; re-deriving them through readfirstlane lets the
 // compiler keep them in SGPRs (scalar ALU, scalar branches, s_load from the constant block).
-__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 __device__ __forceinline__ Ctx uni(Ctx c) {
-    static_assert(sizeof(Ctx) % 4 == 0, "Ctx must be a whole number of dwords");
-    int w[sizeof(Ctx) / 4];
-    __builtin_memcpy(w, &c, sizeof(Ctx));
-#pragma unroll
-    for (unsigned i = 0; i < sizeof(Ctx) / 4; ++i) w[i] = __builtin_amdgcn_readfirstlane(w[i]);
-    Ctx r;
-    __builtin_memcpy(&r, w, sizeof(Ctx));
-    return r;
+    // the pointers come from kernel arguments / scalar loads and keep their (global) address
+    // space only if they are not laundered through integers: make just the integers scalar
+    c.ctu_x = uni(c.ctu_x);
+    c.ctu_y = uni(c.ctu_y);
+    c.cu32_mode = uni(c.cu32_mode);
+    c.write = uni(c.write);
+    return c;
 }
 
 // One wave per block: LDS operations of a wave are issued and serviced in program order,
@@ -142,7 +247,7 @@ __device__ __forceinline__ Ctx uni(Ctx c) {
 // Diagnostic build only (-DWRENC_PROFILE): per-phase cycle counters, summed per wave and
 // added to a global table at CTU end.  Never compiled into the product library.
 #ifdef WRENC_PROFILE
-enum { PH_PREDICT, PH_FDCT, PH_QPRE, PH_QBACK, PH_QTRACE, PH_DEQ, PH_IDCT, PH_RECON, PH_TOTAL, PH_COUNT };
+enum { PH_PREDICT, PH_FDCT, PH_QPRE, PH_QBACK, PH_QTRACE, PH_DEQ, PH_IDCT, PH_RECON, PH_TOTAL, PH_CTRL, PH_REFS, PH_SKIP, PH_NSTEP, PH_NFULL, PH_COUNT };
 __device__ unsigned long long g_prof[PH_COUNT];
 __shared__ unsigned long long s_prof[PH_COUNT];
 #define PROF_T0() const unsigned long long prof_t0_ = __builtin_readcyclecounter()
@@ -159,27 +264,56 @@ __shared__ unsigned long long s_prof[PH_COUNT];
 // ---------------------------------------------------------------------------
 // wave helpers
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ int wave_sum_i32(int v) {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+// Cross-lane reductions with DPP inside the 16-lane rows and v_readlane across the four rows:
+// no LDS-crossbar round trips (ds_bpermute), and the result is a scalar.  All lanes must be active.
+template <int CTRL>
+__device__ __forceinline__ int dpp_mov(int v) {
+    return __builtin_amdgcn_mov_dpp(v, CTRL, 0xF, 0xF, true);
+}
+constexpr int kDppSwap1 = 0xB1;          // quad_perm [1,0,3,2]
+constexpr int kDppSwap2 = 0x4E;          // quad_perm [2,3,0,1]
+constexpr int kDppRowHalfMirror = 0x141; // lane i <-> 7 - i inside each 8 lanes
+constexpr int kDppRowMirror = 0x140;     // lane i <-> 15 - i inside each row
+__device__ __forceinline__ int row_sum_i32(int v) { // every lane: sum over its row of 16
+    v += dpp_mov<kDppSwap1>(v);
+    v += dpp_mov<kDppSwap2>(v);
+    v += dpp_mov<kDppRowHalfMirror>(v);
+    v += dpp_mov<kDppRowMirror>(v);
     return v;
+}
+__device__ __forceinline__ int row_min_i32(int v) {
+    v = min(v, dpp_mov<kDppSwap1>(v));
+    v = min(v, dpp_mov<kDppSwap2>(v));
+    v = min(v, dpp_mov<kDppRowHalfMirror>(v));
+    v = min(v, dpp_mov<kDppRowMirror>(v));
+    return v;
+}
+__device__ __forceinline__ int wave_sum_i32(int v) {
+    v = row_sum_i32(v);
+    return __builtin_amdgcn_readlane(v, 0) + __builtin_amdgcn_readlane(v, 16) + __builtin_amdgcn_readlane(v, 32) +
+           __builtin_amdgcn_readlane(v, 48);
 }
 __device__ __forceinline__ int wave_min_i32(int v) {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) v = min(v, __shfl_xor(v, m, 64));
-    return v;
+    v = row_min_i32(v);
+    return min(min(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)),
+               min(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
 }
-__device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v) {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
-    return v;
+// signed 64-bit sum in three limbs: v = lo + 2^24 * (mid + 2^24 * top), lo and mid 24 bits unsigned,
+// top the signed rest (each limb's 64-lane sum fits 32 bits for |v| < 2^57)
+__device__ __forceinline__ long long wave_sum_i64(long long v) {
+    const long long hi = v >> 24;
+    const long long a = (long long)(unsigned)wave_sum_i32((int)(v & 0xFFFFFF));
+    const long long b = (long long)(unsigned)wave_sum_i32((int)(hi & 0xFFFFFF));
+    const long long c = (long long)wave_sum_i32((int)(hi >> 24));
+    return a + ((b + (c << 24)) << 24);
 }
 // minimum over aligned groups of `width` lanes (width = 64 or 32)
 __device__ __forceinline__ int group_min_i32(int v, int width) {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1)
-        if (m < width) v = min(v, __shfl_xor(v, m, 64));
-    return v;
+    v = row_min_i32(v);
+    const int lo = min(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16));
+    const int hi = min(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48));
+    if (width == 64) return min(lo, hi);
+    return LANE < 32 ? lo : hi;
 }
 __device__ __forceinline__ int ilog2i(int v) { return 31 - __clz(v); }
 
@@ -198,11 +332,15 @@ __device__ __forceinline__ void rec_put(int c, int x, int y, int v) {
 }
 // original sample at CTU-local component coordinates (global load; the planes are read-only
 // for the whole launch, so the loads are cacheable and need no ordering)
+// element offset of plane pc inside a picture's Y | Cb | Cr slab (integer arithmetic only: the
+// three planes are one allocation, so no pointer is ever selected per lane)
+__device__ __forceinline__ unsigned plane_off(const Ctx& c, int pc) {
+    return pc == 0 ? 0u : (pc == 1 ? (unsigned)c.WH : (unsigned)(c.WH + (c.WH >> 2)));
+}
 __device__ __forceinline__ int org_get(const Ctx& c, int pc, int x, int y) {
     const int cs = pc ? 1 : 0;
-    const int stride = c.k->W >> cs;
-    const uint8_t* base = pc == 0 ? c.org[0] : (pc == 1 ? c.org[1] : c.org[2]); // pc may differ per lane
-    return base[(size_t)((c.ctu_y >> cs) + y) * stride + (c.ctu_x >> cs) + x];
+    const int stride = c.W >> cs;
+    return c.org[plane_off(c, pc) + (unsigned)(((c.ctu_y >> cs) + y) * stride + (c.ctu_x >> cs) + x)];
 }
 
 // ---------------------------------------------------------------------------
@@ -212,8 +350,8 @@ __device__ __forceinline__ int org_get(const Ctx& c, int pc, int x, int y) {
 __device__ inline bool above_right_avail(Ctx c, int bx, int by, int lg) {
     for (;;) {
         const int n = 1 << lg;
-        if (c.ctu_x + bx + n >= c.k->W) return false;
-        if (lg == 5) return c.ctu_y > 0 && c.ctu_x + 32 < c.k->W;
+        if (c.ctu_x + bx + n >= c.W) return false;
+        if (lg == 5) return c.ctu_y > 0 && c.ctu_x + 32 < c.W;
         const int px = bx & ~(2 * n - 1), py = by & ~(2 * n - 1);
         if (bx == px && by == py) return c.ctu_y + by > 0;
         if (by == py) { // top-right child: parent's
@@ -241,7 +379,7 @@ __device__ inline bool below_left_avail(Ctx c, int bx, int by, int lg) {
 }
 __device__ __forceinline__ bool nb_avail(Ctx c, int gx, int gy, int tn, int xn, int yn,
                                          bool ar, bool bl) {
-    return xn >= 0 && yn >= 0 && xn < c.k->W && yn < c.k->H &&
+    return xn >= 0 && yn >= 0 && xn < c.W && yn < c.k->H &&
            ((xn >> 5) <= (gx >> 5) || (yn >> 5) < (gy >> 5)) && (yn >> 5) < (gy >> 5) + 1 &&
            (xn < gx + tn || ar) && (yn < gy + tn || bl);
 }
@@ -262,7 +400,7 @@ __device__ __forceinline__ int pdpc_w(int n_scale, int i) {
 // [1 2 1]-filtered version for luma blocks of more than 32 samples (intra_predictor.rs:146-353).
 // The neighbourhood of a block does not change while its candidate modes are evaluated
 // (evaluations only write inside the block), so this runs once per block instead of once per mode.
-__device__ __noinline__ void build_refs(Ctx c, int comp, int tx, int ty, int tlg) {
+__device__ __forceinline__ void build_refs(Ctx c, int comp, int tx, int ty, int tlg) {
     c = uni(c);
     comp = uni(comp);
     tx = uni(tx);
@@ -290,8 +428,8 @@ __device__ __noinline__ void build_refs(Ctx c, int comp, int tx, int ty, int tlg
         const int blk = tt >= total ? 1 : 0;
         const int t = tt - blk * total;
         const int pc = comp + blk;
-        int16_t* refL = pc == 0 ? SH.refL0 : SH.refLc[pc - 1];
-        int16_t* refA = pc == 0 ? SH.refA0 : SH.refAc[pc - 1];
+        int16_t* refL = SH.refs + (pc == 0 ? R_L0 : (pc == 1 ? R_LC0 : R_LC1));
+        int16_t* refA = SH.refs + (pc == 0 ? R_A0 : (pc == 1 ? R_AC0 : R_AC1));
         // unified item: t <= 2n -> left index li = t (li 0 = corner, li k -> y = k-1); else above
         int seg;
         const bool is_left = t <= 2 * n;
@@ -334,8 +472,8 @@ __device__ __noinline__ void build_refs(Ctx c, int comp, int tx, int ty, int tlg
     WSYNC();
     // [1 2 1] filter, intra_predictor.rs:304-352 (used by modes 0, 2, 34, 66 only)
     if (comp == 0 && n * n > 32) {
-        const int16_t* refL = SH.refL0;
-        const int16_t* refA = SH.refA0;
+        const int16_t* refL = SH.refs + R_L0;
+        const int16_t* refA = SH.refs + R_A0;
         for (int t = LANE; t < total; t += 64) {
             if (t <= 2 * n) {
                 const int li = t;
@@ -346,7 +484,7 @@ __device__ __noinline__ void build_refs(Ctx c, int comp, int tx, int ty, int tlg
                     v = (refL[1] + 2 * refL[0] + refA[0] + 2) >> 2;
                 else
                     v = (refL[li + 1] + 2 * refL[li] + refL[li - 1] + 2) >> 2;
-                SH.refLf0[li] = (int16_t)v;
+                SH.refs[R_LF + li] = (int16_t)v;
             } else {
                 const int ai = t - (2 * n + 1);
                 int v;
@@ -356,7 +494,7 @@ __device__ __noinline__ void build_refs(Ctx c, int comp, int tx, int ty, int tlg
                     v = (refL[0] + 2 * refA[0] + refA[1] + 2) >> 2;
                 else
                     v = (refA[ai - 1] + 2 * refA[ai] + refA[ai + 1] + 2) >> 2;
-                SH.refAf0[ai] = (int16_t)v;
+                SH.refs[R_AF + ai] = (int16_t)v;
             }
         }
         WSYNC();
@@ -431,12 +569,20 @@ __device__ __forceinline__ CclmParams cclm_params(Ctx c, int comp, int tx, int t
     const int num_is_4 = !(avail_t && avail_l && mode == LT_CCLM) ? 1 : 0;
     int cnt_t = 0, cnt_l = 0;
     int y0 = 0, y1 = 0, y2 = 0, y3 = 0, c0 = 0, c1 = 0, c2 = 0, c3 = 0; // p_sel_ds_y / p_sel_c
-    auto put = [&](int i, int yy, int cc_) {
-        if (i == 0) { y0 = yy; c0 = cc_; }
-        else if (i == 1) { y1 = yy; c1 = cc_; }
-        else if (i == 2) { y2 = yy; c2 = cc_; }
-        else { y3 = yy; c3 = cc_; }
-    };
+    // selects, not an indexed array: the four slots stay in registers
+#define CCLM_PUT(I, YY, CC)            \
+    do {                               \
+        const int i_ = (I);            \
+        const int yv_ = (YY), cv_ = (CC); \
+        y0 = i_ == 0 ? yv_ : y0;       \
+        c0 = i_ == 0 ? cv_ : c0;       \
+        y1 = i_ == 1 ? yv_ : y1;       \
+        c1 = i_ == 1 ? cv_ : c1;       \
+        y2 = i_ == 2 ? yv_ : y2;       \
+        c2 = i_ == 2 ? cv_ : c2;       \
+        y3 = i_ == 3 ? yv_ : y3;       \
+        c3 = i_ == 3 ? cv_ : c3;       \
+    } while (0)
     if (avail_t && (mode == LT_CCLM || mode == T_CCLM)) {
         const int start = num_samp_t >> (2 + num_is_4);
         const int step = max(num_samp_t >> (1 + num_is_4), 1);
@@ -453,7 +599,7 @@ __device__ __forceinline__ CclmParams cclm_params(Ctx c, int comp, int tx, int t
             else
                 sy = (cclm_w(c, tx, ty, -1, sx - 1, avail_l) + cclm_w(c, tx, ty, -1, sx, avail_l) * 2 +
                       cclm_w(c, tx, ty, -1, sx + 1, avail_l) + 2) >> 2;
-            put(i, sy, sc);
+            CCLM_PUT(i, sy, sc);
         }
     }
     if (avail_l && (mode == LT_CCLM || mode == L_CCLM)) {
@@ -462,9 +608,10 @@ __device__ __forceinline__ CclmParams cclm_params(Ctx c, int comp, int tx, int t
         cnt_l = min((1 + num_is_4) << 1, num_samp_l);
         for (int i = 0; i < cnt_l; ++i) {
             const int pos = start + i * step;
-            put(cnt_t + i, cclm_ds6(c, tx, ty, 2 * pos, -2, avail_l), rec_get(comp, cx - 1, cy + pos));
+            CCLM_PUT(cnt_t + i, cclm_ds6(c, tx, ty, 2 * pos, -2, avail_l), rec_get(comp, cx - 1, cy + pos));
         }
     }
+#undef CCLM_PUT
     // min group {0,2}, max group {1,3} and the four compare-exchanges of :1973-1986,
     // carried out on (luma, chroma) value pairs instead of indices
     int mnAy = y0, mnAc = c0, mnBy = y2, mnBc = c2, mxAy = y1, mxAc = c1, mxBy = y3, mxBc = c3, t;
@@ -507,11 +654,11 @@ __device__ __forceinline__ CclmParams cclm_params(Ctx c, int comp, int tx, int t
     return r;
 }
 
-// one predicted sample of plane pc: accumulate |org - pred|; FULL also stores residual and prediction
-template <bool FULL>
+// one predicted sample of plane pc: accumulate |org - pred|; `full` also stores residual and prediction
+template <bool full>
 __device__ __forceinline__ int emit_sample(const Ctx& c, int pc, int x, int y, int i, int v) {
     const int d = org_get(c, pc, x, y) - v;
-    if (FULL) {
+    if (full) {
         SH.r1[i] = (int16_t)d;
         c.pred_scratch[i] = (uint8_t)v;
     }
@@ -521,10 +668,10 @@ __device__ __forceinline__ int emit_sample(const Ctx& c, int pc, int x, int y, i
 // Prediction of one luma block (comp 0) or of the Cb+Cr pair (comp 1) from the cached reference
 // samples (build_refs must have run for this block; CCLM reads the reconstructed luma instead).
 // Sample index i runs over nb*n*n: block blk = i / (n*n), then row-major inside the block.
-// FULL: the residual org - pred goes to r1[i] and the prediction byte to this wave's scratch
+// full: the residual org - pred goes to r1[i] and the prediction byte to this wave's scratch
 //       (each lane later re-reads exactly the bytes it wrote).
 // Returns the lane's partial sum of |org - pred| (the SAD of block_splitter.rs:96-104).
-template <bool FULL>
+template <bool full>
 __device__ __forceinline__ int predict(Ctx c, int comp, int tx, int ty, int tlg, int mode) {
     c = uni(c);
     comp = uni(comp);
@@ -559,22 +706,24 @@ __device__ __forceinline__ int predict(Ctx c, int comp, int tx, int ty, int tlg,
                 v = ((ds * (blk ? a1 : a0)) >> (blk ? k1 : k0)) + (blk ? b1 : b0);
                 v = min(max(v, 0), 255);
             }
-            sad += emit_sample<FULL>(c, comp + blk, cx + x, cy + y, i, v);
+            sad += emit_sample<full>(c, comp + blk, cx + x, cy + y, i, v);
         }
         WSYNC();
         return sad;
     }
     // luma blocks of more than 32 samples use the filtered references for modes 0, 2, 34, 66
     const bool filt = comp == 0 && nn > 32 && (mode == 0 || mode == 2 || mode == 34 || mode == 66);
-    const int16_t* L0 = comp == 0 ? (filt ? SH.refLf0 : SH.refL0) : SH.refLc[0]; // index 0 = corner
-    const int16_t* A0 = comp == 0 ? (filt ? SH.refAf0 : SH.refA0) : SH.refAc[0];
+    const int oL0 = comp == 0 ? (filt ? R_LF : R_L0) : R_LC0; // index 0 = corner
+    const int oA0 = comp == 0 ? (filt ? R_AF : R_A0) : R_AC0;
+    const int16_t* L0 = SH.refs + oL0;
+    const int16_t* A0 = SH.refs + oA0;
     if (mode == PLANAR || mode == DC) {
         int dcv0 = 0, dcv1 = 0;
         if (mode == DC) {
             int part0 = 0, part1 = 0;
             for (int t = LANE; t < 2 * n; t += 64) {
                 part0 += t < n ? A0[t] : L0[t - n + 1];
-                if (nb == 2) part1 += t < n ? SH.refAc[1][t] : SH.refLc[1][t - n + 1];
+                if (nb == 2) part1 += t < n ? SH.refs[R_AC1 + t] : SH.refs[R_LC1 + t - n + 1];
             }
             dcv0 = ((wave_sum_i32(part0) + n) >> (lg + 1)) & 0xFF; // `as u8`
             if (nb == 2) dcv1 = ((wave_sum_i32(part1) + n) >> (lg + 1)) & 0xFF;
@@ -584,8 +733,8 @@ __device__ __forceinline__ int predict(Ctx c, int comp, int tx, int ty, int tlg,
             const int blk = i >> (2 * lg);
             const int ii = i & (nn - 1);
             const int x = ii & (n - 1), y = ii >> lg;
-            const int16_t* L = blk ? SH.refLc[1] : L0;
-            const int16_t* A = blk ? SH.refAc[1] : A0;
+            const int16_t* L = SH.refs + (blk ? R_LC1 : oL0);
+            const int16_t* A = SH.refs + (blk ? R_AC1 : oA0);
             int v;
             if (mode == PLANAR) {
                 const int pv = (n - 1 - y) * A[x] + (y + 1) * L[n + 1];
@@ -597,7 +746,7 @@ __device__ __forceinline__ int predict(Ctx c, int comp, int tx, int ty, int tlg,
             const int wl = pdpc_w(n_scale, x), wt = pdpc_w(n_scale, y);
             v = (int16_t)(L[y + 1] * wl + A[x] * wt + (64 - wt - wl) * v + 32) >> 6;
             v = min(max(v, 0), 255);
-            sad += emit_sample<FULL>(c, comp + blk, cx + x, cy + y, i, v);
+            sad += emit_sample<full>(c, comp + blk, cx + x, cy + y, i, v);
         }
         WSYNC();
         return sad;
@@ -625,8 +774,8 @@ __device__ __forceinline__ int predict(Ctx c, int comp, int tx, int ty, int tlg,
         const int blk = i >> (2 * lg);
         const int ii = i & (nn - 1);
         const int x = ii & (n - 1), y = ii >> lg;
-        const int16_t* L = blk ? SH.refLc[1] : L0;
-        const int16_t* A = blk ? SH.refAc[1] : A0;
+        const int16_t* L = SH.refs + (blk ? R_LC1 : oL0);
+        const int16_t* A = SH.refs + (blk ? R_AC1 : oA0);
         const int alrs = L[0];
         int v;
         if (mode >= 34) {
@@ -699,7 +848,7 @@ __device__ __forceinline__ int predict(Ctx c, int comp, int tx, int ty, int tlg,
             v = (int16_t)(rl * wl + rt * wt + (64 - wt - wl) * v + 32) >> 6;
             v = min(max(v, 0), 255);
         }
-        sad += emit_sample<FULL>(c, comp + blk, cx + x, cy + y, i, v);
+        sad += emit_sample<full>(c, comp + blk, cx + x, cy + y, i, v);
     }
     WSYNC();
     return sad;
@@ -1104,7 +1253,7 @@ __device__ __forceinline__ long long quantize(Ctx c, int lg, int nb, bool shared
             if (((zmask >> j) & 1) && p0 + j > pf) ++nz_after;
         sum_nz += (long long)nz_after * lv_at(c, 0);
     }
-    const long long sum = (long long)wave_sum_u64((unsigned long long)sum_nz);
+    const long long sum = wave_sum_i64(sum_nz);
     if (__ballot(ovf != 0) != 0ULL) *overflow = 1;
     WSYNC();
     PROF_MARK(q3_);
@@ -1137,54 +1286,82 @@ __device__ __forceinline__ void dequantize_t(Ctx c, int lg, int nb) {
 // ---------------------------------------------------------------------------
 // RD search building blocks (block_splitter.rs)
 // ---------------------------------------------------------------------------
-struct CompCost {
-    unsigned long long ssd;
-    long long level;
+// ---------------------------------------------------------------------------
+// The evaluator: every block evaluation of the search, of the regeneration and of the final pass
+// goes through ONE inlined copy of this code (no function calls in the hot path: the search logic
+// below is written as coroutines that hand out evaluation requests).
+// ---------------------------------------------------------------------------
+enum { K_SADLIST = 0, K_FULL = 1 };
+constexpr int kNoMode = 255; // K_SADLIST entry that is not evaluated (cost f32::MAX)
+
+struct Req {
+    int kind;       // K_SADLIST: predict + SAD of a list of modes (block_splitter.rs:64-108, 476-522);
+                    // K_FULL: predict .. reconstruct (:146-185)
+    int comps;      // bit 0: luma block, bit 1: Cb+Cr pair
+    int tx, ty, tlg;
+    int ml, mc;     // K_FULL: luma / chroma mode
+    bool shared;    // quantiser: pooled Viterbi of the workgroup (search) or solo (regen, final pass)
+    bool active;    // false: walk the schedule only (keeps the workgroup's barriers aligned)
+    bool refs0, refs1; // (re)build the luma / chroma reference samples of the block first
+    bool final;     // final pass: store the levels, count reconstruction changes
+    int n;          // K_SADLIST: number of entries
+    unsigned long long modes_lo, modes_hi; // K_SADLIST: one byte per entry (8 + 8), the same mode for luma and chroma
 };
 
-// predict -> T -> Q -> DQ -> IT -> recon (+SSD) of the luma block (comp 0) or of the Cb+Cr pair
-// (comp 1) of a TU (block_splitter.rs:146-185); returns SSD and level cost summed over the blocks.
-// The TU's reference samples must be current (build_refs).  lev0 != nullptr: the final pass --
-// the levels go to plane position lev0 (and lev1 for Cr), row stride lev_stride, and samples whose
-// reconstruction differs from what the search left in the tile are counted in *changed.
-__device__ __noinline__ CompCost code_component(Ctx c, int comp, int tx, int ty, int tlg, int mode, bool shared,
-                                                bool active, int16_t* lev0, int16_t* lev1, int lev_stride,
-                                                int* changed, int* overflow) {
-    c = uni(c);
-    comp = uni(comp);
-    tx = uni(tx);
-    ty = uni(ty);
-    tlg = uni(tlg);
-    mode = uni(mode);
+struct Res {
+    // K_FULL: SSD and level cost of the luma block and of the chroma pair
+    uint32_t ssd_y, ssd_c;
+    long long lvl_y, lvl_c;
+    // K_SADLIST: costs of the first three entries, first minimum (strict <) and its index
+    float v0, v1, v2, vmin;
+    int imin;
+};
+
+__device__ __forceinline__ float uni_f(float v) { return __int_as_float(uni(__float_as_int(v))); }
+
+// predict .. reconstruct of one component (comp 0: luma block, 1: chroma pair) with `mode`
+__device__ __forceinline__ void evaluate_full(const Ctx& c, const PicBufs& pb, const Req& q, int comp, int mode,
+                                              int* overflow, uint32_t* ssd_out, long long* lvl_out) {
     const int cs = comp ? 1 : 0;
     const int nb = comp ? 2 : 1;
-    const int lg = tlg - cs;
+    const int lg = q.tlg - cs;
+    *ssd_out = 0;
+    *lvl_out = 0;
+    if (!q.active) { // keep the shared-Viterbi barriers company (all waves run the same schedule)
+        PROF_MARK(ts0_);
+        quantize(c, lg, nb, q.shared, false, overflow);
+        PROF_MARK(ts1_);
+        PROF_ADD2(PH_SKIP, ts0_, ts1_);
+        return;
+    }
+    PROF_MARK(tr0_);
+    if ((comp ? q.refs1 : q.refs0) && mode < LT_CCLM) build_refs(c, comp, q.tx, q.ty, q.tlg);
+    PROF_MARK(t0_);
+    PROF_ADD2(PH_REFS, tr0_, t0_);
+    predict<true>(c, comp, q.tx, q.ty, q.tlg, mode);
+    PROF_MARK(t1_);
+    PROF_ADD2(PH_PREDICT, t0_, t1_);
     const int n = 1 << lg;
     const int nn = n * n;
-    const int cx = tx >> cs, cy = ty >> cs;
-    CompCost r;
-    if (!active) { // keep the shared-Viterbi barriers company (all waves run the same schedule)
-        r.level = quantize(c, lg, nb, shared, false, overflow);
-        r.ssd = 0;
-        return r;
-    }
-    PROF_MARK(t0_);
-    predict<true>(c, comp, tx, ty, tlg, mode);
-    PROF_MARK(t1_);
+    const int cx = q.tx >> cs, cy = q.ty >> cs;
     fwd_dct_lg(c, lg, nb);
     PROF_MARK(t2_);
-    r.level = quantize(c, lg, nb, shared, true, overflow);
+    *lvl_out = quantize(c, lg, nb, q.shared, true, overflow);
     PROF_MARK(t3_);
-    if (lev0 != nullptr && c.write)
+    if (q.final && c.write) {
+        const int stride = c.W >> cs;
+        const size_t at = (size_t)((c.ctu_y + q.ty) >> cs) * stride + ((c.ctu_x + q.tx) >> cs);
+        GLOBAL_AS int16_t* lev0 = AS_GLOBAL(int16_t, pb.lev[0]) + plane_off(c, comp) + at;
+        GLOBAL_AS int16_t* lev1 = AS_GLOBAL(int16_t, pb.lev[0]) + plane_off(c, 2) + at;
         for (int i = LANE; i < nb * nn; i += 64) {
             const int blk = i >> (2 * lg), ii = i & (nn - 1);
-            (blk ? lev1 : lev0)[(size_t)(ii >> lg) * lev_stride + (ii & (n - 1))] = SH.r1[i];
+            (blk ? lev1 : lev0)[(size_t)(ii >> lg) * stride + (ii & (n - 1))] = SH.r1[i];
         }
+    }
     dequantize_t(c, lg, nb);
     PROF_MARK(t4_);
     inv_dct_lg(c, lg, nb);
     PROF_MARK(t5_);
-    PROF_ADD2(PH_PREDICT, t0_, t1_);
     PROF_ADD2(PH_FDCT, t1_, t2_);
     PROF_ADD2(PH_DEQ, t3_, t4_);
     PROF_ADD2(PH_IDCT, t4_, t5_);
@@ -1196,32 +1373,79 @@ __device__ __noinline__ CompCost code_component(Ctx c, int comp, int tx, int ty,
         const int pc = comp + blk;
         int v = (int16_t)((int)c.pred_scratch[i] + (int)SH.r1[i]); // pred as i16 + res, clamp (:178)
         v = min(max(v, 0), 255);
-        if (changed != nullptr && v != rec_get(pc, cx + x, cy + y)) ++diff;
+        if (q.final && v != rec_get(pc, cx + x, cy + y)) ++diff;
         rec_put(pc, cx + x, cy + y, v);
         const int d = v - org_get(c, pc, cx + x, cy + y);
         part += (unsigned)(d * d);
     }
-    r.ssd = wave_sum_u64((unsigned long long)part);
-    if (changed != nullptr) *changed += wave_sum_i32(diff);
+    *ssd_out = (uint32_t)wave_sum_i32((int)part); // <= 1024 * 255^2: fits 32 bits
+    if (q.final) {
+        const int changed = wave_sum_i32(diff);
+        if (changed && LANE == 0 && c.write) atomicAdd(c.mismatch, (unsigned long long)changed);
+    }
     WSYNC();
     PROF_MARK(t6_);
     PROF_ADD2(PH_RECON, t5_, t6_);
-    return r;
 }
 
-// predict + SAD of the luma block or the Cb+Cr pair (block_splitter.rs:64-108); nothing is stored
-__device__ __noinline__ unsigned int sad_component(Ctx c, int comp, int tx, int ty, int tlg, int mode) {
-    c = uni(c);
-    comp = uni(comp);
-    tx = uni(tx);
-    ty = uni(ty);
-    tlg = uni(tlg);
-    mode = uni(mode);
+// The evaluator: every block evaluation of the search, of the regeneration and of the final pass
+// goes through this one inlined copy (the search logic below is a state machine that hands out
+// evaluation requests; no function calls in the hot path).
+__device__ __forceinline__ Res evaluate(const Ctx& c, const PicBufs& pb, const Req& q, int* overflow) {
+    Res r;
+    r.ssd_y = 0;
+    r.ssd_c = 0;
+    r.lvl_y = 0;
+    r.lvl_c = 0;
+    r.v0 = r.v1 = r.v2 = r.vmin = 3.40282347e+38f;
+    r.imin = 0;
+    if (q.kind == K_FULL) {
+#pragma unroll 1
+        for (int comp = 0; comp < 2; ++comp) {
+            if (!((q.comps >> comp) & 1)) continue;
+            uint32_t ssd;
+            long long lvl;
+            evaluate_full(c, pb, q, comp, comp ? q.mc : q.ml, overflow, &ssd, &lvl);
+            if (comp) {
+                r.ssd_c = ssd;
+                r.lvl_c = lvl;
+            } else {
+                r.ssd_y = ssd;
+                r.lvl_y = lvl;
+            }
+        }
+        return r;
+    }
+    // K_SADLIST: get_intra_pred_aux_cost / get_chroma_intra_pred_aux_cost of each listed mode
+    PROF_MARK(tr0_);
+    if (q.refs0 && (q.comps & 1)) build_refs(c, 0, q.tx, q.ty, q.tlg);
+    if (q.refs1 && (q.comps & 2)) build_refs(c, 1, q.tx, q.ty, q.tlg);
     PROF_MARK(t0_);
-    const int part = predict<false>(c, comp, tx, ty, tlg, mode);
+    PROF_ADD2(PH_REFS, tr0_, t0_);
+#pragma unroll 1
+    for (int i = 0; i < q.n; ++i) {
+        const int m = (int)(((i < 8 ? q.modes_lo : q.modes_hi) >> (8 * (i & 7))) & 255u);
+        float cost = 3.40282347e+38f;
+        if (m != kNoMode) {
+            unsigned long long sad = 0;
+#pragma unroll 1
+            for (int comp = 0; comp < 2; ++comp) {
+                if (!((q.comps >> comp) & 1)) continue;
+                sad += (unsigned long long)(unsigned)wave_sum_i32(predict<false>(c, comp, q.tx, q.ty, q.tlg, m));
+            }
+            cost = uni_f((float)sad);
+        }
+        if (i == 0) r.v0 = cost;
+        if (i == 1) r.v1 = cost;
+        if (i == 2) r.v2 = cost;
+        if (cost < r.vmin) { // first minimum
+            r.vmin = cost;
+            r.imin = i;
+        }
+    }
     PROF_MARK(t1_);
     PROF_ADD2(PH_PREDICT, t0_, t1_);
-    return (unsigned)wave_sum_i32(part);
+    return r;
 }
 
 // luma mode of the CU covering picture position (CTU-local x, y), as the search sees it
@@ -1233,7 +1457,7 @@ __device__ __forceinline__ int nb_luma_mode(Ctx c, int x, int y, bool* exists) {
     }
     if (y >= 0 && x < 0 && c.ctu_x > 0) {
         *exists = true;
-        return SH.left_mode[y >> 2];
+        return uni((int)SH.left_mode[y >> 2]);
     }
     *exists = false;
     return PLANAR;
@@ -1241,12 +1465,7 @@ __device__ __forceinline__ int nb_luma_mode(Ctx c, int x, int y, bool* exists) {
 
 // mode class index for the header-bit table: 0 planar, 1..5 mpm_idx, 6..66 remainder
 // (ctu.rs:1498-1635)
-__device__ __noinline__ int mpm_class(Ctx c, int bx, int by, int lg, int mode) {
-    c = uni(c);
-    bx = uni(bx);
-    by = uni(by);
-    lg = uni(lg);
-    mode = uni(mode);
+__device__ __forceinline__ int mpm_class(const Ctx& c, int bx, int by, int lg, int mode) {
     if (mode == PLANAR) return 0;
     const int n = 1 << lg;
     bool le, ae;
@@ -1325,26 +1544,15 @@ __device__ __forceinline__ float rd_cost(unsigned long long ssd, long long level
     return (float)ssd + prod;
 }
 
-struct LeafResult {
-    float cost;
-    int luma_mode;
-    int chroma_mode; // TU-array chroma prediction mode
-};
-
 // SSD and level cost of the luma and of the chroma pair of one evaluated candidate.  Evaluations
 // are deterministic functions of (block, mode, neighbourhood[, luma recon for CCLM]), so where the
 // reference re-runs an evaluation it has already done (block_splitter.rs:1040,1068-1075) the
 // parts are re-used and only the cost is re-assembled.
-struct EvalParts {
-    unsigned long long ssd_y, ssd_c;
-    long long lvl_y, lvl_c;
-};
-
 // get_intra_pred_cost (block_splitter.rs:110-474) from already evaluated parts, modes [ml, mc, mc]
 __device__ __forceinline__ float assemble_cost(const Ctx& c, int tree, int cls, int mc, const EvalParts& e) {
     const bool single = tree == TREE_SINGLE;
     const int cc = (single && mc >= LT_CCLM) ? 1 + (mc - LT_CCLM) : 0;
-    const unsigned long long ssd = e.ssd_y + (single ? e.ssd_c : 0ULL);
+    const unsigned long long ssd = (unsigned long long)e.ssd_y + (single ? (unsigned long long)e.ssd_c : 0ULL);
     const long long level = e.lvl_y + (single ? e.lvl_c : 0LL) + c.k->hb_luma[single ? 0 : 1][cc][cls];
     return rd_cost(ssd, level, c.k->lambda_rd);
 }
@@ -1352,65 +1560,7 @@ __device__ __forceinline__ float assemble_cost(const Ctx& c, int tree, int cls, 
 // get_chroma_intra_pred_cost (block_splitter.rs:524-780) from already evaluated parts
 __device__ __forceinline__ float assemble_chroma_cost(const Ctx& c, int mc, const EvalParts& e) {
     const long long level = e.lvl_c + c.k->hb_chroma[mc >= LT_CCLM ? 1 + (mc - LT_CCLM) : 0];
-    return rd_cost(e.ssd_c, level, c.k->lambda_rd_chroma);
-}
-
-// evaluate the chroma pair with mode mc into e.ssd_c / e.lvl_c
-__device__ __forceinline__ CompCost eval_chroma(Ctx c, int bx, int by, int lg, int mc, bool active, int* overflow) {
-    return code_component(c, 1, bx, by, lg, mc, true, active, nullptr, nullptr, 0, nullptr, overflow);
-}
-
-struct FullRes {
-    float cost;
-    EvalParts e;
-};
-
-// get_intra_pred_cost (block_splitter.rs:110-474) for modes [ml, mc, mc], with its parts
-__device__ __noinline__ FullRes full_cost(Ctx c, int tree, int bx, int by, int lg, int ml, int mc, bool active,
-                                         int* overflow) {
-    c = uni(c);
-    tree = uni(tree);
-    bx = uni(bx);
-    by = uni(by);
-    lg = uni(lg);
-    ml = uni(ml);
-    mc = uni(mc);
-    EvalParts p = {0, 0, 0, 0};
-    {
-        const CompCost r = code_component(c, 0, bx, by, lg, ml, true, active, nullptr, nullptr, 0, nullptr, overflow);
-        p.ssd_y = r.ssd;
-        p.lvl_y = r.level;
-    }
-    if (tree == TREE_SINGLE) {
-        const CompCost cc = eval_chroma(c, bx, by, lg, mc, active, overflow);
-        p.ssd_c = cc.ssd;
-        p.lvl_c = cc.level;
-    }
-    FullRes out;
-    out.e = p;
-    // a skipped evaluation is f32::MAX in the reference
-    out.cost = active ? assemble_cost(c, tree, mpm_class(c, bx, by, lg, ml), mc, p) : 3.40282347e+38f;
-    return out;
-}
-
-// get_intra_pred_aux_cost (block_splitter.rs:64-108) for modes [m; 3]
-__device__ __forceinline__ float aux_cost(Ctx c, int tree, int bx, int by, int lg, int m) {
-    unsigned long long sad = sad_component(c, 0, bx, by, lg, m);
-    if (tree == TREE_SINGLE) sad += sad_component(c, 1, bx, by, lg, m);
-    return (float)sad;
-}
-
-// get_chroma_intra_pred_cost (block_splitter.rs:524-780)
-__device__ __forceinline__ float chroma_full_cost(Ctx c, int bx, int by, int lg, int mc, EvalParts& e, int* overflow) {
-    const CompCost cc = eval_chroma(c, bx, by, lg, mc, true, overflow);
-    e.ssd_c = cc.ssd;
-    e.lvl_c = cc.level;
-    return assemble_chroma_cost(c, mc, e);
-}
-
-// get_chroma_intra_pred_aux_cost (block_splitter.rs:476-522)
-__device__ __forceinline__ float chroma_aux_cost(Ctx c, int bx, int by, int lg, int mc) {
-    return (float)(unsigned long long)sad_component(c, 1, bx, by, lg, mc);
+    return rd_cost((unsigned long long)e.ssd_c, level, c.k->lambda_rd_chroma);
 }
 
 __device__ __forceinline__ int pick_cclm(float lt, float t, float l) {
@@ -1420,184 +1570,8 @@ __device__ __forceinline__ int pick_cclm(float lt, float t, float l) {
     return L_CCLM;
 }
 
-// Re-create the reconstruction of a decided block by running its evaluation again with the
-// solo Viterbi (no workgroup barriers: which blocks need this differs from wave to wave).  The
-// neighbourhood is unchanged, so the result equals what the evaluation produced the first time;
-// this replaces the reference's cache_reconsts / restore_reconsts copies (block_splitter.rs:
-// 807-840, 1085-1145) without keeping saved planes in LDS.
-__device__ __noinline__ void regen_block(Ctx c, int bx, int by, int lg, int luma_mode, int chroma_mode, bool luma,
-                                         bool chroma, int* overflow) {
-    c = uni(c);
-    bx = uni(bx);
-    by = uni(by);
-    lg = uni(lg);
-    luma_mode = uni(luma_mode);
-    chroma_mode = uni(chroma_mode);
-    if (luma) {
-        build_refs(c, 0, bx, by, lg);
-        code_component(c, 0, bx, by, lg, luma_mode, false, true, nullptr, nullptr, 0, nullptr, overflow);
-    }
-    if (chroma) {
-        if (chroma_mode < LT_CCLM) build_refs(c, 1, bx, by, lg);
-        code_component(c, 1, bx, by, lg, chroma_mode, false, true, nullptr, nullptr, 0, nullptr, overflow);
-    }
-}
-
-// leaf search of a DUAL_TREE_CHROMA block (block_splitter.rs:794-885); lg = luma log2 (3)
-__device__ __noinline__ LeafResult leaf_chroma(Ctx c, int bx, int by, int lg, int dm_mode, int* overflow) {
-    c = uni(c);
-    bx = uni(bx);
-    by = uni(by);
-    lg = uni(lg);
-    dm_mode = uni(dm_mode);
-    build_refs(c, 1, bx, by, lg);
-    const float lt = chroma_aux_cost(c, bx, by, lg, LT_CCLM);
-    const float t = chroma_aux_cost(c, bx, by, lg, T_CCLM);
-    const float l = chroma_aux_cost(c, bx, by, lg, L_CCLM);
-    const int cclm_mode = pick_cclm(lt, t, l);
-    EvalParts e_cclm = {0, 0, 0, 0}, e_dm = {0, 0, 0, 0};
-    const float cclm_cost = chroma_full_cost(c, bx, by, lg, cclm_mode, e_cclm, overflow);
-    const float cur = chroma_full_cost(c, bx, by, lg, dm_mode, e_dm, overflow);
-    LeafResult r;
-    r.luma_mode = 0;
-    const float mn = fminf(cclm_cost, fminf(cur, 3.40282347e+38f));
-    r.cost = mn;
-    if (cur == mn) {
-        r.chroma_mode = dm_mode;
-    } else {
-        r.chroma_mode = cclm_mode;
-        regen_block(c, bx, by, lg, 0, cclm_mode, false, true, overflow); // :869-873 restore_reconsts
-    }
-    return r;
-}
-
-// leaf search of a SINGLE_TREE / DUAL_TREE_LUMA block (block_splitter.rs:886-1078)
-__device__ __noinline__ LeafResult leaf_luma(Ctx c, int tree, int bx, int by, int lg, int* overflow) {
-    c = uni(c);
-    tree = uni(tree);
-    bx = uni(bx);
-    by = uni(by);
-    lg = uni(lg);
-    build_refs(c, 0, bx, by, lg);
-    if (tree == TREE_SINGLE) build_refs(c, 1, bx, by, lg);
-    float cost_planar = 0.f, cost_dc = 0.f;
-    EvalParts e_planar = {0, 0, 0, 0}, e_dc = {0, 0, 0, 0};
-    float min_dir_cost = 3.40282347e+38f;
-    int min_dir_mode = 2;
-    for (int i = 0; i < 15; ++i) {
-        // {0,1,2,7,13,18,23,29,34,39,45,50,55,60,66} (:887), 7 bits each
-        const int m = i < 8 ? (int)((0x3A5C90D0E08080ULL >> (7 * i)) & 127) : (int)((0x109E3764B53A2ULL >> (7 * (i - 8))) & 127);
-        if (m <= 1) {
-            const FullRes fr = full_cost(c, tree, bx, by, lg, m, m, true, overflow);
-            if (m == 0) {
-                cost_planar = fr.cost;
-                e_planar = fr.e;
-            } else {
-                cost_dc = fr.cost;
-                e_dc = fr.e;
-            }
-        } else {
-            const float v = aux_cost(c, tree, bx, by, lg, m);
-            if (v < min_dir_cost) { // first minimum (:899-904)
-                min_dir_cost = v;
-                min_dir_mode = m;
-            }
-        }
-    }
-    // step_search(mode, 2, cost, aux=true) (:905-973)
-    int cur_mode = min_dir_mode;
-    float cur_cost = min_dir_cost;
-    for (int step = 2; step > 0; step >>= 1) {
-        const float c0 = cur_mode < 2 + step ? 3.40282347e+38f : aux_cost(c, tree, bx, by, lg, cur_mode - step);
-        const float c1 = cur_mode + step > 66 ? 3.40282347e+38f : aux_cost(c, tree, bx, by, lg, cur_mode + step);
-        const float mn = fminf(fminf(cur_cost, c0), c1);
-        if (cur_cost == mn) {
-        } else if (c0 == mn) {
-            cur_mode -= step;
-            cur_cost = c0;
-        } else {
-            cur_mode += step;
-            cur_cost = c1;
-        }
-    }
-    // step_search(mode, 1, _, aux=false) (:974)
-    EvalParts e_dir = {0, 0, 0, 0};
-    {
-        // out-of-range neighbours are "evaluated" inactive: the wave still walks the schedule so
-        // that the workgroup's shared Viterbi barriers stay aligned; the result is f32::MAX
-        const FullRes f = full_cost(c, tree, bx, by, lg, cur_mode, cur_mode, true, overflow);
-        const FullRes f0 = full_cost(c, tree, bx, by, lg, cur_mode - 1, cur_mode - 1, !(cur_mode < 3), overflow);
-        const FullRes f1 = full_cost(c, tree, bx, by, lg, cur_mode + 1, cur_mode + 1, !(cur_mode + 1 > 66), overflow);
-        cur_cost = f.cost;
-        e_dir = f.e;
-        const float c0 = f0.cost, c1 = f1.cost;
-        const float mn = fminf(fminf(cur_cost, c0), c1);
-        if (cur_cost == mn) {
-        } else if (c0 == mn) {
-            cur_mode -= 1;
-            cur_cost = c0;
-            e_dir = f0.e;
-        } else {
-            cur_mode += 1;
-            cur_cost = c1;
-            e_dir = f1.e;
-        }
-    }
-    // min of {planar, DC, dir}, first index wins (:975-978)
-    float min_cost = fminf(cur_cost, fminf(cost_dc, fminf(cost_planar, 3.40282347e+38f)));
-    int mode;
-    EvalParts e_win;
-    if (cost_planar == min_cost) {
-        mode = 0;
-        e_win = e_planar;
-    } else if (cost_dc == min_cost) {
-        mode = 1;
-        e_win = e_dc;
-    } else {
-        mode = cur_mode;
-        e_win = e_dir;
-    }
-    // luma re-run with the winner (:989-1037): puts the winner's luma reconstruction into the tile
-    code_component(c, 0, bx, by, lg, mode, true, true, nullptr, nullptr, 0, nullptr, overflow);
-    LeafResult r;
-    r.luma_mode = mode;
-    r.chroma_mode = mode;
-    if (tree != TREE_DUAL_LUMA) {
-        // :1040 get_chroma_intra_pred_cost(mode) repeats the winner's chroma evaluation: re-use it
-        const float cur = assemble_chroma_cost(c, mode, e_win);
-        const float lt = chroma_aux_cost(c, bx, by, lg, LT_CCLM);
-        const float t = chroma_aux_cost(c, bx, by, lg, T_CCLM);
-        const float l = chroma_aux_cost(c, bx, by, lg, L_CCLM);
-        const int cclm_mode = pick_cclm(lt, t, l);
-        EvalParts e_cclm = e_win;
-        const float cclm_cost = chroma_full_cost(c, bx, by, lg, cclm_mode, e_cclm, overflow);
-        const float mn = fminf(cclm_cost, fminf(cur, 3.40282347e+38f));
-        const bool dm_wins = cur == mn;
-        // :1062-1072 final get_intra_pred_cost: luma = the re-run above; the chroma pair is the DM
-        // evaluation (re-done only to put its reconstruction back when DM wins; an inactive walk of
-        // the schedule otherwise) or the CCLM evaluation just made
-        eval_chroma(c, bx, by, lg, mode, dm_wins, overflow);
-        const int cls = mpm_class(c, bx, by, lg, mode);
-        if (dm_wins) {
-            min_cost = assemble_cost(c, tree, cls, mode, e_win);
-        } else {
-            r.chroma_mode = cclm_mode;
-            min_cost = assemble_cost(c, tree, cls, cclm_mode, e_cclm);
-        }
-    } else if (mode <= 1) {
-        // :1073-1076 repeats the luma evaluation just re-run: same parts, same cost
-        min_cost = assemble_cost(c, tree, mpm_class(c, bx, by, lg, mode), mode, e_win);
-    }
-    r.cost = min_cost;
-    return r;
-}
-
-// ---------------------------------------------------------------------------
-// Decision maps and recon save/restore
-// ---------------------------------------------------------------------------
-__device__ __noinline__ void fill_maps(Ctx c, int bx, int by, int lg, int luma_mode, int chroma_mode,
-                          bool luma, bool chroma) {
-    c = uni(c);
+__device__ __noinline__ void fill_maps(int bx, int by, int lg, int luma_mode, int chroma_mode, bool luma,
+                                       bool chroma) {
     bx = uni(bx);
     by = uni(by);
     lg = uni(lg);
@@ -1618,75 +1592,440 @@ __device__ __noinline__ void fill_maps(Ctx c, int bx, int by, int lg, int luma_m
     WSYNC();
 }
 
+
 // ---------------------------------------------------------------------------
-// split_ct (block_splitter.rs:782-1154): exhaustive quad-tree search of one CTU as an
-// explicit depth-first walk (level 0 = 32x32 ... level 2 = 8x8; an 8x8 node's split is
-// four DUAL_TREE_LUMA 4x4 leaves + one DUAL_TREE_CHROMA 4x4 leaf, ctu.rs:1990-2063).
-// Per-level state lives in LDS (wave-uniform).
+// Search control as state machines: a step function runs until it needs a block evaluated, stores
+// the request and where to continue, and returns true; the driver evaluates the block and calls
+// it again with the result.  All state lives in LDS (CtuSt / LeafSt, wave-uniform); the control
+// flow is a plain loop around a switch (reducible, all scalar branches).
 // ---------------------------------------------------------------------------
-__device__ __noinline__ float split_node8(Ctx c, int bx, int by, int* overflow) {
-    c = uni(c);
-    bx = uni(bx);
-    by = uni(by);
-    float split_cost = 0.0f;
-    for (int i = 0; i < 4; ++i) {
-        const int cxx = bx + (i & 1) * 4, cyy = by + (i >> 1) * 4;
-        const LeafResult r = leaf_luma(c, TREE_DUAL_LUMA, cxx, cyy, 2, overflow);
-        fill_maps(c, cxx, cyy, 2, r.luma_mode, 0, true, false);
-        split_cost = split_cost + r.cost;
-    }
-    // DM = luma mode of the CU covering the parent's centre (block_splitter.rs:795-805)
-    const int dm = SH.luma_mode[((by + 4) >> 2) * 8 + ((bx + 4) >> 2)];
-    const LeafResult r = leaf_chroma(c, bx, by, 3, dm, overflow);
-    fill_maps(c, bx, by, 3, 0, r.chroma_mode, false, true);
-    return split_cost + r.cost;
+__device__ __forceinline__ void req_full(Req& q, int comps, int tx, int ty, int tlg, int ml, int mc, bool shared,
+                                         bool active, bool refs0, bool refs1, bool final) {
+    q.kind = K_FULL;
+    q.comps = comps;
+    q.tx = tx;
+    q.ty = ty;
+    q.tlg = tlg;
+    q.ml = ml;
+    q.mc = mc;
+    q.shared = shared;
+    q.active = active;
+    q.refs0 = refs0;
+    q.refs1 = refs1;
+    q.final = final;
 }
 
-__device__ float split_ct_ctu(Ctx& c, int max_depth, int* overflow) {
-    int level = 0;
-    int bx = 0, by = 0;
-    float ret = 0.0f;
-    for (;;) {
-        // ---- enter node (bx, by) at `level` ----
-        const int lg = 5 - level;
-        const LeafResult ns = leaf_luma(c, TREE_SINGLE, bx, by, lg, overflow);
-        fill_maps(c, bx, by, lg, ns.luma_mode, ns.chroma_mode, true, true);
-        if (level == 0) c.cu32_mode = ns.luma_mode;
-        bool done;
-        if (max_depth - level == 0) {
-            ret = ns.cost;
-            done = true;
+enum {
+    C_START = 0, C_PLANAR, C_DCM, C_LIST, C_PAIR_EMIT, C_PAIR, C_F0, C_F1, C_F2, C_WIN, C_CX, C_CCLM, C_DM,
+    C_DC_START, C_DC2, C_DC3, C_DC4, C_DC5
+};
+
+__device__ __forceinline__ void leaf_init(LeafSt& s, int tree, int bx, int by, int lg, int dm_mode) {
+    s.cont = (uint8_t)(tree == TREE_DUAL_CHROMA ? C_DC_START : C_START);
+    s.tree = (uint8_t)tree;
+    s.bx = (uint8_t)bx;
+    s.by = (uint8_t)by;
+    s.lg = (uint8_t)lg;
+    s.dm_mode = (uint8_t)dm_mode;
+    s.need_refs0 = 1;
+    s.need_refs1 = 1;
+}
+
+// full evaluation (get_intra_pred_cost, block_splitter.rs:110-474) of comps with modes [ml, mc, mc];
+// the first request of a leaf for a component also (re)builds its reference samples
+__device__ __forceinline__ void leaf_full(LeafSt& s, Req& q, int comps, int ml, int mc, bool act, int cont,
+                                          bool solo = false) {
+    const bool r0 = (comps & 1) && s.need_refs0 != 0;
+    const bool r1 = (comps & 2) && mc < LT_CCLM && s.need_refs1 != 0;
+    req_full(q, comps, s.bx, s.by, s.lg, ml, mc, !solo, act, r0, r1, false);
+    if (act) {
+        if (r0) s.need_refs0 = 0;
+        if (r1) s.need_refs1 = 0;
+    }
+    s.op_ml = (uint8_t)ml;
+    s.op_mc = (uint8_t)mc;
+    s.op_act = act ? 1 : 0;
+    s.cont = (uint8_t)cont;
+}
+
+// SAD list (get_intra_pred_aux_cost / get_chroma_intra_pred_aux_cost) of n modes, one byte each
+__device__ __forceinline__ void leaf_sadlist(LeafSt& s, Req& q, int comps, int n, uint32_t m0, uint32_t m1, uint32_t m2,
+                                             uint32_t m3, bool chroma_refs, int cont) {
+    q.kind = K_SADLIST;
+    q.comps = comps;
+    q.tx = s.bx;
+    q.ty = s.by;
+    q.tlg = s.lg;
+    q.n = n;
+    q.modes_lo = (unsigned long long)m0 | ((unsigned long long)m1 << 32);
+    q.modes_hi = (unsigned long long)m2 | ((unsigned long long)m3 << 32);
+    q.refs0 = (comps & 1) && s.need_refs0 != 0;
+    q.refs1 = (comps & 2) && chroma_refs && s.need_refs1 != 0;
+    if (q.refs0) s.need_refs0 = 0;
+    if (q.refs1) s.need_refs1 = 0;
+    s.cont = (uint8_t)cont;
+}
+
+__device__ __forceinline__ EvalParts res_parts(const Res& r) {
+    EvalParts e;
+    e.ssd_y = r.ssd_y;
+    e.ssd_c = r.ssd_c;
+    e.lvl_y = r.lvl_y;
+    e.lvl_c = r.lvl_c;
+    return e;
+}
+__device__ __forceinline__ void put_parts(EvalPartsU& d, const EvalParts& e) {
+    d.ssd_y = e.ssd_y;
+    d.ssd_c = e.ssd_c;
+    d.lvl_y = e.lvl_y;
+    d.lvl_c = e.lvl_c;
+}
+
+// One step of a leaf search: SINGLE_TREE / DUAL_TREE_LUMA blocks (block_splitter.rs:886-1078) and
+// DUAL_TREE_CHROMA blocks (:794-885; lg = luma log2 = 3).  r is the result of the request the
+// previous step made (unused at the first step).  Returns false when the leaf is decided
+// (s.cost, s.luma_mode, s.chroma_mode).  The reference's "first minimum wins" selections are kept
+// as strict-less running updates in the reference's candidate order; a candidate = one request
+// (luma block and chroma pair together, SAD candidates as one list).
+__device__ __forceinline__ bool leaf_step(const Ctx& c, LeafSt& s, const Res& r, Req& q) {
+    const int tree = s.tree;
+    const int both = tree == TREE_SINGLE ? 3 : 1;
+    int cont = s.cont;
+    // RD cost of the full evaluation that just came back (candidates of C_PLANAR .. C_F2)
+    float val = 0.0f;
+    int cls = 0;
+    const EvalParts rp = res_parts(r);
+    if (cont == C_PLANAR || cont == C_DCM || cont == C_F0 || cont == C_F1 || cont == C_F2) {
+        if (s.op_act) {
+            cls = mpm_class(c, s.bx, s.by, s.lg, s.op_ml);
+            val = uni_f(assemble_cost(c, tree, cls, s.op_mc, rp));
         } else {
+            val = 3.40282347e+38f; // a skipped evaluation is f32::MAX in the reference
+        }
+    }
+    for (;;) {
+        switch (cont) {
+        case C_START: // candidates {0,1,2,7,13,18,23,29,34,39,45,50,55,60,66} (:887)
+            leaf_full(s, q, both, PLANAR, PLANAR, true, C_PLANAR);
+            return true;
+        case C_PLANAR:
+            s.best_cost = val;
+            put_parts(s.e_best, rp);
+            s.mode = PLANAR;
+            s.best_cls = (uint8_t)cls;
+            leaf_full(s, q, both, DC, DC, true, C_DCM);
+            return true;
+        case C_DCM:
+            if (val < s.best_cost) { // {planar, DC}: first minimum
+                s.best_cost = val;
+                put_parts(s.e_best, rp);
+                s.mode = DC;
+                s.best_cls = (uint8_t)cls;
+            }
+            // the 13 directional candidates: SAD, first minimum (:899-904)
+            leaf_sadlist(s, q, both, 13, 2u | (7u << 8) | (13u << 16) | (18u << 24),
+                         23u | (29u << 8) | (34u << 16) | (39u << 24), 45u | (50u << 8) | (55u << 16) | (60u << 24), 66u,
+                         true, C_LIST);
+            return true;
+        case C_LIST: {
+            // entry i of the list = candidate i + 2 of {0,1,2,7,13,18,23,29,34,39,45,50,55,60,66}, 7 bits each
+            const int j = r.imin + 2;
+            const int m = j < 8 ? (int)((0x3A5C90D0E08080ULL >> (7 * j)) & 127)
+                                : (int)((0x109E3764B53A2ULL >> (7 * (j - 8))) & 127);
+            // step_search(mode, 2, cost, aux=true) (:905-973)
+            s.cur_mode = (uint8_t)m;
+            s.cur_cost = r.vmin;
+            s.step = 2;
+            cont = C_PAIR_EMIT;
+            break;
+        }
+        case C_PAIR_EMIT: {
+            const int cm = s.cur_mode, st = s.step;
+            const int lo = !(cm < 2 + st) ? cm - st : kNoMode;
+            const int hi = !(cm + st > 66) ? cm + st : kNoMode;
+            leaf_sadlist(s, q, both, 2, (uint32_t)lo | ((uint32_t)hi << 8), 0, 0, 0, true, C_PAIR);
+            return true;
+        }
+        case C_PAIR: {
+            const float cur = s.cur_cost, c0 = r.v0, c1 = r.v1;
+            const int st = s.step;
+            const float mn = fminf(fminf(cur, c0), c1);
+            if (cur == mn) {
+            } else if (c0 == mn) {
+                s.cur_mode -= st;
+                s.cur_cost = c0;
+            } else {
+                s.cur_mode += st;
+                s.cur_cost = c1;
+            }
+            if ((st >> 1) > 0) {
+                s.step = (uint8_t)(st >> 1);
+                cont = C_PAIR_EMIT;
+                break;
+            }
+            // step_search(mode, 1, _, aux=false) (:974).  Out-of-range neighbours are "evaluated"
+            // inactive: the wave still walks the schedule so that the workgroup's shared Viterbi
+            // barriers stay aligned
+            const int cm = s.cur_mode;
+            leaf_full(s, q, both, cm, cm, true, C_F0);
+            return true;
+        }
+        case C_F0: {
+            s.cur_cost = val;
+            put_parts(s.e_dir, rp);
+            s.dir_cls = (uint8_t)cls;
+            const int cm = s.cur_mode;
+            s.best_mode = (uint8_t)cm;
+            leaf_full(s, q, both, cm - 1, cm - 1, !(cm < 3), C_F1);
+            return true;
+        }
+        case C_F1: {
+            const int cm = s.cur_mode;
+            if (val < s.cur_cost) {
+                s.cur_cost = val;
+                put_parts(s.e_dir, rp);
+                s.dir_cls = (uint8_t)cls;
+                s.best_mode = (uint8_t)(cm - 1);
+            }
+            leaf_full(s, q, both, cm + 1, cm + 1, !(cm + 1 > 66), C_F2);
+            return true;
+        }
+        case C_F2: {
+            if (val < s.cur_cost) {
+                s.cur_cost = val;
+                put_parts(s.e_dir, rp);
+                s.dir_cls = (uint8_t)cls;
+                s.best_mode = (uint8_t)(s.cur_mode + 1);
+            }
+            // min of {planar, DC, dir}, first index wins (:975-978)
+            if (s.cur_cost < s.best_cost) {
+                s.best_cost = s.cur_cost;
+                s.e_best = s.e_dir;
+                s.mode = s.best_mode;
+                s.best_cls = s.dir_cls;
+            }
+            s.cost = s.best_cost;
+            // luma re-run with the winner (:989-1037): puts the winner's luma reconstruction into the tile
+            const int m = s.mode;
+            leaf_full(s, q, 1, m, m, true, C_WIN);
+            return true;
+        }
+        case C_WIN: {
+            const int m = s.mode;
+            s.luma_mode = (uint8_t)m;
+            s.chroma_mode = (uint8_t)m;
+            if (tree == TREE_DUAL_LUMA) {
+                // :1073-1076 repeats the luma evaluation just re-run for planar / DC: same parts, same
+                // header bits, so the cost it assigns is the candidate's cost already in s.cost
+                return false;
+            }
+            // :1040 get_chroma_intra_pred_cost(mode) repeats the winner's chroma evaluation: re-use it
+            s.cur_cost = uni_f(assemble_chroma_cost(c, m, s.e_best.get()));
+            leaf_sadlist(s, q, 2, 3, (uint32_t)LT_CCLM | ((uint32_t)T_CCLM << 8) | ((uint32_t)L_CCLM << 16), 0, 0, 0, false,
+                         C_CX);
+            return true;
+        }
+        case C_CX: {
+            const int cm = pick_cclm(r.v0, r.v1, r.v2);
+            s.cclm_mode = (uint8_t)cm;
+            leaf_full(s, q, 2, 0, cm, true, C_CCLM);
+            return true;
+        }
+        case C_CCLM: {
+            // the CCLM candidate = the winner's luma parts + the chroma parts just evaluated
+            EvalParts e = s.e_best.get();
+            e.ssd_c = rp.ssd_c;
+            e.lvl_c = rp.lvl_c;
+            put_parts(s.e_dir, e);
+            const float cclm_cost = uni_f(assemble_chroma_cost(c, s.cclm_mode, e));
+            const float cur = s.cur_cost;
+            const bool dm_wins = cur == fminf(cclm_cost, fminf(cur, 3.40282347e+38f));
+            s.dm_wins = dm_wins ? 1 : 0;
+            // :1062-1072 final get_intra_pred_cost: luma = the re-run above; the chroma pair is the DM
+            // evaluation (re-done only to put its reconstruction back when DM wins; an inactive walk
+            // of the schedule otherwise) or the CCLM evaluation just made
+            leaf_full(s, q, 2, 0, s.mode, dm_wins, C_DM);
+            return true;
+        }
+        case C_DM: {
+            const int m = s.mode;
+            const int bcls = s.best_cls; // mpm_class of the winner, from its candidate evaluation
+            if (s.dm_wins) {
+                s.cost = uni_f(assemble_cost(c, tree, bcls, m, s.e_best.get()));
+            } else {
+                s.chroma_mode = s.cclm_mode;
+                s.cost = uni_f(assemble_cost(c, tree, bcls, s.cclm_mode, s.e_dir.get()));
+            }
+            return false;
+        }
+        // ---- DUAL_TREE_CHROMA leaf (:794-885) ----
+        case C_DC_START:
+            leaf_sadlist(s, q, 2, 3, (uint32_t)LT_CCLM | ((uint32_t)T_CCLM << 8) | ((uint32_t)L_CCLM << 16), 0, 0, 0, false,
+                         C_DC2);
+            return true;
+        case C_DC2: {
+            const int cm = pick_cclm(r.v0, r.v1, r.v2);
+            s.cclm_mode = (uint8_t)cm;
+            leaf_full(s, q, 2, 0, cm, true, C_DC3);
+            return true;
+        }
+        case C_DC3:
+            s.c0 = uni_f(assemble_chroma_cost(c, s.cclm_mode, rp));
+            leaf_full(s, q, 2, 0, s.dm_mode, true, C_DC4);
+            return true;
+        case C_DC4: {
+            const float dm_cost = uni_f(assemble_chroma_cost(c, s.dm_mode, rp));
+            const float cost = fminf(s.c0, fminf(dm_cost, 3.40282347e+38f));
+            s.luma_mode = 0;
+            s.cost = cost;
+            if (dm_cost == cost) {
+                s.chroma_mode = s.dm_mode;
+                return false;
+            }
+            s.chroma_mode = s.cclm_mode;
+            // :869-873 restore_reconsts: re-create the CCLM reconstruction (solo: data-dependent)
+            leaf_full(s, q, 2, 0, s.cclm_mode, true, C_DC5, true);
+            return true;
+        }
+        default: // C_DC5
+            return false;
+        }
+    }
+}
+
+// split_ct (block_splitter.rs:782-1154) for one CTU + the final pass (ctu_encoder.rs:1421-1461):
+// exhaustive quad-tree search as an explicit depth-first walk (level 0 = 32x32 ... level 2 = 8x8;
+// an 8x8 node's split is four DUAL_TREE_LUMA 4x4 leaves + one DUAL_TREE_CHROMA 4x4 leaf,
+// ctu.rs:1990-2063), per-level state in LDS.
+//
+// Decided blocks whose reconstruction was overwritten by later candidates are re-created by
+// evaluating them again with the solo Viterbi (which blocks need this differs from wave to wave,
+// so no workgroup barriers).  The neighbourhood is unchanged, so the result equals what the
+// evaluation produced the first time; this replaces the reference's cache_reconsts /
+// restore_reconsts copies (block_splitter.rs:807-840, 1085-1145) without saved planes in LDS.
+enum { T_START = 0, T_ENTER, T_NODE_LEAF, T_LEAF4_EMIT, T_LEAF4, T_LEAFC, T_REGEN_DONE, T_RETURN, T_FINAL_Z, T_FZ_TAIL, T_FZ_NEXT };
+
+__device__ __forceinline__ bool ctu_step(Ctx& c, const Res& r, Req& q) {
+    CtuSt& t = SH.st;
+    bool in_leaf = t.in_leaf != 0;
+    int cont = t.cont;
+    for (;;) {
+        if (in_leaf) {
+            if (leaf_step(c, t.leaf, r, q)) {
+                t.cont = (uint8_t)cont;
+                t.in_leaf = 1;
+                return true;
+            }
+            t.in_leaf = 0;
+            in_leaf = false;
+        }
+        switch (cont) {
+        case T_START:
+            t.level = 0;
+            t.bx = 0;
+            t.by = 0;
+            cont = T_ENTER;
+            break;
+        case T_ENTER: { // enter node (bx, by) at `level`: the unsplit candidate
+            const int lg = 5 - t.level;
+            t.lg = (uint8_t)lg;
+            leaf_init(t.leaf, TREE_SINGLE, t.bx, t.by, lg, 0);
+            in_leaf = true;
+            cont = T_NODE_LEAF;
+            break;
+        }
+        case T_NODE_LEAF: {
+            const float ns = t.leaf.cost;
+            const int ml = t.leaf.luma_mode, mc = t.leaf.chroma_mode;
+            const int level = t.level, lg = t.lg;
+            t.ns_cost_cur = ns;
+            t.ns_luma_cur = (uint8_t)ml;
+            t.ns_chroma_cur = (uint8_t)mc;
+            fill_maps(t.bx, t.by, lg, ml, mc, true, true);
+            if (level == 0) c.cu32_mode = ml;
+            if (t.max_depth - level == 0) {
+                t.ret = ns;
+                cont = T_RETURN;
+                break;
+            }
             if (LANE == 0) {
-                SH.ns_cost[level] = ns.cost;
-                SH.ns_luma[level] = (uint8_t)ns.luma_mode;
-                SH.ns_chroma[level] = (uint8_t)ns.chroma_mode;
+                SH.ns_cost[level] = ns;
+                SH.ns_luma[level] = (uint8_t)ml;
+                SH.ns_chroma[level] = (uint8_t)mc;
                 SH.split_cost[level] = 0.0f;
                 SH.child[level] = 0;
             }
             WSYNC();
             if (lg > 3) {
-                level += 1; // descend into child 0 (same top-left corner)
-                continue;
+                t.level = (uint8_t)(level + 1); // descend into child 0 (same top-left corner)
+                cont = T_ENTER;
+                break;
             }
-            const float sc = split_node8(c, bx, by, overflow);
-            if (sc > ns.cost) { // :1125-1145
-                regen_block(c, bx, by, lg, ns.luma_mode, ns.chroma_mode, true, true, overflow);
-                fill_maps(c, bx, by, lg, ns.luma_mode, ns.chroma_mode, true, true);
-                ret = ns.cost;
-            } else {
-                ret = sc;
-            }
-            done = true;
+            // 8x8: four DUAL_TREE_LUMA 4x4 leaves, then the DUAL_TREE_CHROMA leaf
+            t.split8 = 0.0f;
+            t.i8 = 0;
+            cont = T_LEAF4_EMIT;
+            break;
         }
-        // ---- return `ret` from a finished node to its ancestors ----
-        while (done) {
-            if (level == 0) return ret;
+        case T_LEAF4_EMIT: {
+            const int i8 = t.i8;
+            leaf_init(t.leaf, TREE_DUAL_LUMA, t.bx + (i8 & 1) * 4, t.by + (i8 >> 1) * 4, 2, 0);
+            in_leaf = true;
+            cont = T_LEAF4;
+            break;
+        }
+        case T_LEAF4: {
+            fill_maps(t.leaf.bx, t.leaf.by, 2, t.leaf.luma_mode, 0, true, false);
+            t.split8 = t.split8 + t.leaf.cost;
+            const int i8 = t.i8 + 1;
+            t.i8 = (uint8_t)i8;
+            if (i8 < 4) {
+                cont = T_LEAF4_EMIT;
+                break;
+            }
+            // DM = luma mode of the CU covering the parent's centre (block_splitter.rs:795-805)
+            const int bx = t.bx, by = t.by;
+            leaf_init(t.leaf, TREE_DUAL_CHROMA, bx, by, 3, uni((int)SH.luma_mode[((by + 4) >> 2) * 8 + ((bx + 4) >> 2)]));
+            in_leaf = true;
+            cont = T_LEAFC;
+            break;
+        }
+        case T_LEAFC: {
+            fill_maps(t.bx, t.by, 3, 0, t.leaf.chroma_mode, false, true);
+            const float split8 = t.split8 + t.leaf.cost;
+            if (split8 > t.ns_cost_cur) { // :1125-1145: the unsplit 8x8 wins, put it back
+                t.rbx = t.bx;
+                t.rby = t.by;
+                t.rlg = t.lg;
+                t.rl = t.ns_luma_cur;
+                t.rc = t.ns_chroma_cur;
+                req_full(q, 3, t.rbx, t.rby, t.rlg, t.rl, t.rc, false, true, true, true, false);
+                t.cont = T_REGEN_DONE;
+                return true;
+            }
+            t.ret = split8;
+            cont = T_RETURN;
+            break;
+        }
+        case T_REGEN_DONE:
+            fill_maps(t.rbx, t.rby, t.rlg, t.rl, t.rc, true, true);
+            t.ret = uni_f(SH.ns_cost[t.level]);
+            cont = T_RETURN;
+            break;
+        case T_RETURN: { // return `ret` from the finished node at `level` to its parent
+            const int level = t.level;
+            if (level == 0) {
+                t.ctu_cost = t.ret;
+                t.z = 0;
+                cont = T_FINAL_Z;
+                break;
+            }
             const int pl = level - 1;
             const int psz = 1 << (5 - pl);
-            const int pbx = bx & ~(psz - 1), pby = by & ~(psz - 1);
-            const float acc = SH.split_cost[pl] + ret; // children in z-order, f32 (:1116-1123)
-            const int ch = SH.child[pl] + 1;
+            const int pbx = t.bx & ~(psz - 1), pby = t.by & ~(psz - 1);
+            // children in z-order, f32 (:1116-1123)
+            const float acc = uni_f(uni_f(SH.split_cost[pl]) + t.ret);
+            const int ch = uni((int)SH.child[pl]) + 1;
             WSYNC();
             if (LANE == 0) {
                 SH.split_cost[pl] = acc;
@@ -1694,68 +2033,67 @@ __device__ float split_ct_ctu(Ctx& c, int max_depth, int* overflow) {
             }
             WSYNC();
             if (ch < 4) { // next sibling
-                bx = pbx + (ch & 1) * (psz >> 1);
-                by = pby + (ch >> 1) * (psz >> 1);
-                done = false;
-            } else { // parent complete
-                const float nsc = SH.ns_cost[pl];
-                bx = pbx;
-                by = pby;
-                level = pl;
-                if (acc > nsc) {
-                    regen_block(c, bx, by, 5 - pl, SH.ns_luma[pl], SH.ns_chroma[pl], true, true, overflow);
-                    fill_maps(c, bx, by, 5 - pl, SH.ns_luma[pl], SH.ns_chroma[pl], true, true);
-                    ret = nsc;
-                } else {
-                    ret = acc;
-                }
+                t.bx = (uint8_t)(pbx + (ch & 1) * (psz >> 1));
+                t.by = (uint8_t)(pby + (ch >> 1) * (psz >> 1));
+                cont = T_ENTER;
+                break;
             }
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------
-// Final pass (ctu_encoder.rs:1421-1461) in coding order; writes levels to HBM
-// ---------------------------------------------------------------------------
-// comp 0 = luma block, comp 1 = the Cb+Cr pair of the TU at (tx, ty)
-__device__ __noinline__ void final_component(Ctx c, const PicBufs& pb, int comp, int tx, int ty, int tlg, int mode,
-                                             int* overflow) {
-    c = uni(c);
-    comp = uni(comp);
-    tx = uni(tx);
-    ty = uni(ty);
-    tlg = uni(tlg);
-    mode = uni(mode);
-    const int cs = comp ? 1 : 0;
-    const int stride = c.k->W >> cs;
-    const size_t at = (size_t)((c.ctu_y + ty) >> cs) * stride + ((c.ctu_x + tx) >> cs);
-    if (mode < LT_CCLM) build_refs(c, comp, tx, ty, tlg);
-    int changed = 0;
-    code_component(c, comp, tx, ty, tlg, mode, false, true, pb.lev[comp] + at, comp ? pb.lev[2] + at : nullptr, stride,
-                   &changed, overflow);
-    if (changed && LANE == 0 && c.write) atomicAdd(c.mismatch, (unsigned long long)changed);
-}
-
-// coding order = z-order over the 4x4 units; a CU is emitted at its top-left unit
-__device__ void final_pass_ctu(Ctx c, const PicBufs& pb, int* overflow) {
-    for (int z = 0; z < 64; ++z) {
-        const int x4 = (z & 1) | ((z >> 1) & 2) | ((z >> 2) & 4);
-        const int y4 = ((z >> 1) & 1) | ((z >> 2) & 2) | ((z >> 3) & 4);
-        const int lg = SH.cu_log2[y4 * 8 + x4];
-        const int bx = x4 * 4, by = y4 * 4;
-        const int sz = 1 << lg;
-        if ((bx & (sz - 1)) == 0 && (by & (sz - 1)) == 0) {
-            const int ml = SH.luma_mode[y4 * 8 + x4];
-            final_component(c, pb, 0, bx, by, lg, ml, overflow);
-            if (lg >= 3) {
-                const int mc = SH.chroma_mode[(by >> 3) * 4 + (bx >> 3)];
-                final_component(c, pb, 1, bx, by, lg, mc, overflow);
+            // parent complete: split vs unsplit (:1125-1145)
+            t.bx = (uint8_t)pbx;
+            t.by = (uint8_t)pby;
+            t.level = (uint8_t)pl;
+            if (acc > uni_f(SH.ns_cost[pl])) {
+                t.rbx = (uint8_t)pbx;
+                t.rby = (uint8_t)pby;
+                t.rlg = (uint8_t)(5 - pl);
+                t.rl = (uint8_t)uni((int)SH.ns_luma[pl]);
+                t.rc = (uint8_t)uni((int)SH.ns_chroma[pl]);
+                req_full(q, 3, t.rbx, t.rby, t.rlg, t.rl, t.rc, false, true, true, true, false);
+                t.cont = T_REGEN_DONE;
+                return true;
             }
+            t.ret = acc;
+            break; // cont stays T_RETURN
         }
-        if (lg == 2 && (z & 3) == 3) { // after the fourth 4x4 luma CU: the 8x8's chroma CU
-            const int pbx = bx & ~7, pby = by & ~7;
-            const int mc = SH.chroma_mode[(pby >> 3) * 4 + (pbx >> 3)];
-            final_component(c, pb, 1, pbx, pby, 3, mc, overflow);
+        // ---- final pass (ctu_encoder.rs:1421-1461): coding order = z-order over the 4x4 units; a
+        // CU is emitted at its top-left unit (luma TB, then the chroma TBs) ----
+        case T_FINAL_Z: {
+            const int z = t.z;
+            if (z == 64) {
+                t.cont = T_START;
+                return false;
+            }
+            const int bx = 4 * ((z & 1) | ((z >> 1) & 2) | ((z >> 2) & 4));
+            const int by = 4 * (((z >> 1) & 1) | ((z >> 2) & 2) | ((z >> 3) & 4));
+            const int lg = uni((int)SH.cu_log2[(by >> 2) * 8 + (bx >> 2)]);
+            t.bx = (uint8_t)bx;
+            t.by = (uint8_t)by;
+            t.lg = (uint8_t)lg;
+            if ((bx & ((1 << lg) - 1)) == 0 && (by & ((1 << lg) - 1)) == 0) {
+                const int ml = uni((int)SH.luma_mode[(by >> 2) * 8 + (bx >> 2)]);
+                const int mc = uni((int)SH.chroma_mode[(by >> 3) * 4 + (bx >> 3)]);
+                req_full(q, lg >= 3 ? 3 : 1, bx, by, lg, ml, mc, false, true, true, true, true);
+                t.cont = T_FZ_TAIL;
+                return true;
+            }
+            cont = T_FZ_NEXT;
+            break;
+        }
+        case T_FZ_TAIL: {
+            const int bx = t.bx, by = t.by;
+            if (t.lg == 2 && (t.z & 3) == 3) { // after the fourth 4x4 luma CU: the 8x8's chroma CU
+                req_full(q, 2, bx & ~7, by & ~7, 3, 0, uni((int)SH.chroma_mode[(by >> 3) * 4 + (bx >> 3)]), false, true,
+                         true, true, true);
+                t.cont = T_FZ_NEXT;
+                return true;
+            }
+            cont = T_FZ_NEXT;
+            break;
+        }
+        default: // T_FZ_NEXT
+            t.z = (uint8_t)(t.z + 1);
+            cont = T_FINAL_Z;
+            break;
         }
     }
 }
@@ -1763,7 +2101,7 @@ __device__ void final_pass_ctu(Ctx c, const PicBufs& pb, int* overflow) {
 // ---------------------------------------------------------------------------
 // CTU entry: load, search, final pass, store
 // ---------------------------------------------------------------------------
-__device__ void load_tables(Ctx c) {
+__device__ __forceinline__ void load_tables(Ctx c) {
     for (int i = threadIdx.x; i < 256; i += blockDim.x) {
         SHT.ldq[i] = (int32_t)c.k->ldq[i];
         SHT.lv[i] = (int32_t)c.k->lv[i];
@@ -1772,9 +2110,10 @@ __device__ void load_tables(Ctx c) {
     __syncthreads();
 }
 
-__device__ void encode_ctu(Ctx& c, const PicBufs& pb, int ctu_col, int ctu_row, int* overflow) {
+
+__device__ __forceinline__ void encode_ctu(Ctx& c, const PicBufs& pb, int ctu_col, int ctu_row, int* overflow) {
     const DevConst* k = c.k;
-    const int W = k->W, H = k->H;
+    const int W = k->W;
     const int Wc = W >> 1;
     c.ctu_x = ctu_col * 32;
     c.ctu_y = ctu_row * 32;
@@ -1785,25 +2124,26 @@ __device__ void encode_ctu(Ctx& c, const PicBufs& pb, int ctu_col, int ctu_row, 
 #endif
     PROF_MARK(tt0_);
     load_tables(c);
+    GLOBAL_AS uint8_t* const rec = AS_GLOBAL(uint8_t, pb.rec[0]);
     // neighbour border of the reconstruction: row -1 (x = -4..67) and columns -4..-1
     for (int i = LANE; i < 72; i += 64) {
         const int gx = c.ctu_x - 4 + i, gy = c.ctu_y - 1;
-        SH.recYtop[i] = (gx >= 0 && gx < W && gy >= 0) ? pb.rec[0][(size_t)gy * W + gx] : 0;
+        SH.recYtop[i] = (gx >= 0 && gx < W && gy >= 0) ? rec[(size_t)gy * W + gx] : 0;
     }
     for (int i = LANE; i < 32 * 4; i += 64) {
         const int y = i >> 2, x = (i & 3) - 4;
         const int gx = c.ctu_x + x, gy = c.ctu_y + y;
-        SH.recY[y * 36 + x + 4] = gx >= 0 ? pb.rec[0][(size_t)gy * W + gx] : 0;
+        SH.recY[y * 36 + x + 4] = gx >= 0 ? rec[(size_t)gy * W + gx] : 0;
     }
     for (int comp = 1; comp < 3; ++comp) {
         for (int i = LANE; i < 40; i += 64) {
             const int gx = (c.ctu_x >> 1) - 4 + i, gy = (c.ctu_y >> 1) - 1;
-            SH.recCtop[comp - 1][i] = (gx >= 0 && gx < Wc && gy >= 0) ? pb.rec[comp][(size_t)gy * Wc + gx] : 0;
+            SH.recCtop[comp - 1][i] = (gx >= 0 && gx < Wc && gy >= 0) ? rec[plane_off(c, comp) + (size_t)gy * Wc + gx] : 0;
         }
         for (int i = LANE; i < 16 * 4; i += 64) {
             const int y = i >> 2, x = (i & 3) - 4;
             const int gx = (c.ctu_x >> 1) + x, gy = (c.ctu_y >> 1) + y;
-            SH.recC[comp - 1][y * 20 + x + 4] = gx >= 0 ? pb.rec[comp][(size_t)gy * Wc + gx] : 0;
+            SH.recC[comp - 1][y * 20 + x + 4] = gx >= 0 ? rec[plane_off(c, comp) + (size_t)gy * Wc + gx] : 0;
         }
     }
     // tile.rs:49-58: planes start at zero
@@ -1812,34 +2152,47 @@ __device__ void encode_ctu(Ctx& c, const PicBufs& pb, int ctu_col, int ctu_row, 
         for (int i = LANE; i < 256; i += 64) SH.recC[comp - 1][(i >> 4) * 20 + (i & 15) + 4] = 0;
     if (LANE < 8)
         SH.left_mode[LANE] =
-            c.ctu_x > 0 ? pb.luma_mode[(size_t)((c.ctu_y >> 2) + LANE) * (W >> 2) + (c.ctu_x >> 2) - 1] : 0;
+            c.ctu_x > 0 ? AS_GLOBAL(uint8_t, pb.luma_mode)[(size_t)((c.ctu_y >> 2) + LANE) * (W >> 2) + (c.ctu_x >> 2) - 1] : 0;
     WSYNC();
-    (void)H;
-    const float cost = split_ct_ctu(c, k->max_depth, overflow);
-    final_pass_ctu(c, pb, overflow);
+    // ---- the search + final pass: one evaluator, driven by the coroutines ----
+    static_assert(sizeof(Lds) * WPB + sizeof(LdsTab) <= 81920, "two workgroups per CU need <= 80 KB each");
+    SH.st.cont = T_START;
+    SH.st.in_leaf = 0;
+    SH.st.max_depth = (uint8_t)k->max_depth;
+    Res r = {};
+    Req q = {};
+    for (;;) {
+        PROF_MARK(tc0_);
+        const bool more = ctu_step(c, r, q);
+        PROF_MARK(tc1_);
+        PROF_ADD2(PH_CTRL, tc0_, tc1_);
+        PROF_ADD2(PH_NSTEP, 0, 1);
+        PROF_ADD2(PH_NFULL, 0, (q.kind == K_FULL ? 1 : 0));
+        if (!more) break;
+        r = evaluate(c, pb, q, overflow);
+    }
+    const float cost = SH.st.ctu_cost;
     // store recon + decisions
     if (c.write) {
-    for (int i = LANE; i < 1024 / 4; i += 64) {
-        const int y = i >> 3, x4 = (i & 7) * 4;
-        *(uint32_t*)&pb.rec[0][(size_t)(c.ctu_y + y) * W + c.ctu_x + x4] = *(const uint32_t*)&SH.recY[y * 36 + x4 + 4];
-    }
-    for (int comp = 1; comp < 3; ++comp)
-        for (int i = LANE; i < 256 / 4; i += 64) {
-            const int y = i >> 2, x4 = (i & 3) * 4;
-            *(uint32_t*)&pb.rec[comp][(size_t)((c.ctu_y >> 1) + y) * Wc + (c.ctu_x >> 1) + x4] =
-                *(const uint32_t*)&SH.recC[comp - 1][y * 20 + x4 + 4];
+        for (int i = LANE; i < 1024 / 4; i += 64) {
+            const int y = i >> 3, x4 = (i & 7) * 4;
+            *(GLOBAL_AS uint32_t*)&rec[(size_t)(c.ctu_y + y) * W + c.ctu_x + x4] = *(const uint32_t*)&SH.recY[y * 36 + x4 + 4];
         }
-    {
+        for (int comp = 1; comp < 3; ++comp)
+            for (int i = LANE; i < 256 / 4; i += 64) {
+                const int y = i >> 2, x4 = (i & 3) * 4;
+                *(GLOBAL_AS uint32_t*)&rec[plane_off(c, comp) + (size_t)((c.ctu_y >> 1) + y) * Wc + (c.ctu_x >> 1) + x4] =
+                    *(const uint32_t*)&SH.recC[comp - 1][y * 20 + x4 + 4];
+            }
         const int i = LANE; // 64 4x4 units
         const size_t o = (size_t)((c.ctu_y >> 2) + (i >> 3)) * (W >> 2) + (c.ctu_x >> 2) + (i & 7);
-        pb.cu_log2[o] = SH.cu_log2[i];
-        pb.luma_mode[o] = SH.luma_mode[i];
+        AS_GLOBAL(uint8_t, pb.cu_log2)[o] = SH.cu_log2[i];
+        AS_GLOBAL(uint8_t, pb.luma_mode)[o] = SH.luma_mode[i];
         if (i < 16) {
             const size_t oc = (size_t)((c.ctu_y >> 3) + (i >> 2)) * (W >> 3) + (c.ctu_x >> 3) + (i & 3);
-            pb.chroma_mode[oc] = SH.chroma_mode[i];
+            AS_GLOBAL(uint8_t, pb.chroma_mode)[oc] = SH.chroma_mode[i];
         }
-        if (i == 0) pb.ctu_cost[ctu_row * k->ctu_cols + ctu_col] = cost;
-    }
+        if (i == 0) AS_GLOBAL(float, pb.ctu_cost)[ctu_row * k->ctu_cols + ctu_col] = cost;
     }
 #ifdef WRENC_PROFILE
     PROF_MARK(tt1_);

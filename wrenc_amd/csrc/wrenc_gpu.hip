@@ -41,9 +41,9 @@ __global__ __launch_bounds__(64 * WPB, 4) void ctu_search_kernel(const DevConst*
     c.write = pic < n_pictures ? 1 : 0;
     if (pic >= n_pictures) pic = n_pictures - 1; // padding wave: same work, no stores
     const PicBufs pb = slots[first_slot + pic];
-    c.org[0] = pb.org[0];
-    c.org[1] = pb.org[1];
-    c.org[2] = pb.org[2];
+    c.org = (const GLOBAL_AS uint8_t*)pb.org[0]; // Y | Cb | Cr are one slab (see wrenc_gpu_create)
+    c.W = k->W;
+    c.WH = k->W * k->H;
     c.pred_scratch = pred_scratch + ((size_t)blockIdx.x * WPB + WAVE) * 1024;
     int ovf = 0;
     encode_ctu(c, pb, col, row, &ovf);
@@ -347,11 +347,10 @@ void wrenc_gpu_destroy(wrenc_gpu_ctx* ctx) {
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     for (hipStream_t st : ctx->lanes) (void)hipStreamSynchronize(st);
     for (PicBufs& b : ctx->slots) {
-        for (int c = 0; c < 3; ++c) {
-            if (b.org[c]) (void)hipFree((void*)b.org[c]);
-            if (b.rec[c]) (void)hipFree(b.rec[c]);
-            if (b.lev[c]) (void)hipFree(b.lev[c]);
-        }
+        // planes 1 and 2 point into plane 0's slab
+        if (b.org[0]) (void)hipFree((void*)b.org[0]);
+        if (b.rec[0]) (void)hipFree(b.rec[0]);
+        if (b.lev[0]) (void)hipFree(b.lev[0]);
         if (b.cu_log2) (void)hipFree(b.cu_log2);
         if (b.luma_mode) (void)hipFree(b.luma_mode);
         if (b.chroma_mode) (void)hipFree(b.chroma_mode);
@@ -437,11 +436,20 @@ int wrenc_gpu_create(const wrenc_gpu_config* cfg, wrenc_gpu_ctx** out) {
     ctx->state.assign(cfg->n_slots, 0);
     for (int s = 0; s < cfg->n_slots; ++s) {
         PicBufs& b = ctx->slots[s];
-        for (int c = 0; c < 3; ++c) {
-            CREATE_TRY(hipMalloc((void**)&b.org[c], plane_bytes(*cfg, c, 1)));
-            CREATE_TRY(hipMalloc((void**)&b.rec[c], plane_bytes(*cfg, c, 1)));
-            CREATE_TRY(hipMalloc((void**)&b.lev[c], plane_bytes(*cfg, c, 2)));
-        }
+        // Y | Cb | Cr of a picture are one slab each for originals, reconstruction and levels: the
+        // kernel addresses a plane by an element offset, never by selecting a pointer per lane
+        const size_t wh = (size_t)cfg->width * cfg->height;
+        uint8_t* org_slab = nullptr;
+        CREATE_TRY(hipMalloc((void**)&org_slab, wh + wh / 2));
+        b.org[0] = org_slab;
+        b.org[1] = org_slab + wh;
+        b.org[2] = org_slab + wh + wh / 4;
+        CREATE_TRY(hipMalloc((void**)&b.rec[0], wh + wh / 2));
+        b.rec[1] = b.rec[0] + wh;
+        b.rec[2] = b.rec[0] + wh + wh / 4;
+        CREATE_TRY(hipMalloc((void**)&b.lev[0], (wh + wh / 2) * sizeof(int16_t)));
+        b.lev[1] = b.lev[0] + wh;
+        b.lev[2] = b.lev[0] + wh + wh / 4;
         CREATE_TRY(hipMalloc((void**)&b.cu_log2, (size_t)(cfg->width / 4) * (cfg->height / 4)));
         CREATE_TRY(hipMalloc((void**)&b.luma_mode, (size_t)(cfg->width / 4) * (cfg->height / 4)));
         CREATE_TRY(hipMalloc((void**)&b.chroma_mode, (size_t)(cfg->width / 8) * (cfg->height / 8)));
