@@ -50,6 +50,13 @@ struct DevConst {
 #define GLOBAL_AS __attribute__((address_space(1)))
 #define AS_GLOBAL(T, p) ((GLOBAL_AS T*)(p))
 
+// Per-wave global scratch: 1 KB of prediction bytes, then kReconSlots saved reconstructions
+// (slot 0: best candidate of the running leaf; 1 + level: unsplit candidate of the open node at
+// that tree level), each 1024 B luma + 2 x 256 B chroma.
+constexpr int kReconSlots = 4;
+constexpr int kSlotBytes = 1536;
+constexpr int kWaveScratch = 1024 + kReconSlots * kSlotBytes;
+
 // One picture's device buffers.
 struct PicBufs {
     const uint8_t* org[3];
@@ -140,11 +147,12 @@ struct LeafSt {
     UF<uint8_t> step;
     UF<uint8_t> cur_mode, best_mode, mode, cclm_mode, dm_mode, dm_wins;
     UF<uint8_t> luma_mode, chroma_mode; // result
-    UF<uint8_t> best_cls, dir_cls;      // header-bit class (mpm_class) of the best / best directional luma mode
+    UF<uint8_t> best_cls;               // header-bit class (mpm_class) of the best luma mode
+    UF<uint8_t> need_save, tile_best;   // best candidate's reconstruction: not saved yet / still in the tile
     UF<float> best_cost;                // best of {planar, DC} so far / of {planar, DC, dir}
     UF<float> cur_cost, c0;
     UF<float> cost;                     // result
-    EvalPartsU e_best, e_dir;
+    EvalPartsU e_best;
 };
 
 // CTU search + final pass state (see ctu_step)
@@ -154,6 +162,7 @@ struct CtuSt {
     UF<uint8_t> i8, z, rl, rc;       // 4x4 child index, final-pass z-order index, regen modes
     UF<uint8_t> rbx, rby, rlg;       // regen block
     UF<uint8_t> ns_luma_cur, ns_chroma_cur;
+    UF<uint8_t> pend, pbx, pby, plg, pslot; // reconstruction save to attach to the next request
     UF<float> ret, ns_cost_cur, split8, ctu_cost;
     LeafSt leaf;
 };
@@ -198,6 +207,7 @@ struct Ctx {
     const GLOBAL_AS uint8_t* org;       // original planes of this wave's picture: Y, Cb, Cr back to back (read-only)
     int W, WH;                          // luma width, luma plane size
     uint8_t* pred_scratch;              // 1 KB per wave in HBM: prediction bytes between predict and recon
+    GLOBAL_AS uint8_t* slots;           // kReconSlots saved reconstructions of this wave (see copy_block)
     unsigned long long* mismatch;
     int ctu_x, ctu_y; // luma, picture coordinates
     int cu32_mode;    // in-CTU neighbour lookups during search resolve to the root CU
@@ -1286,12 +1296,10 @@ __device__ __forceinline__ void dequantize_t(Ctx c, int lg, int nb) {
 // ---------------------------------------------------------------------------
 // RD search building blocks (block_splitter.rs)
 // ---------------------------------------------------------------------------
+// Evaluation requests and the evaluator
 // ---------------------------------------------------------------------------
-// The evaluator: every block evaluation of the search, of the regeneration and of the final pass
-// goes through ONE inlined copy of this code (no function calls in the hot path: the search logic
-// below is written as coroutines that hand out evaluation requests).
-// ---------------------------------------------------------------------------
-enum { K_SADLIST = 0, K_FULL = 1 };
+enum { K_SADLIST = 0, K_FULL = 1, K_NOP = 2 };
+enum { COPY_NONE = 0, COPY_SAVE = 1, COPY_RESTORE = 2 };
 constexpr int kNoMode = 255; // K_SADLIST entry that is not evaluated (cost f32::MAX)
 
 struct Req {
@@ -1305,6 +1313,9 @@ struct Req {
     bool refs0, refs1; // (re)build the luma / chroma reference samples of the block first
     bool final;     // final pass: store the levels, count reconstruction changes
     int n;          // K_SADLIST: number of entries
+    // before the evaluation: save the block's reconstruction to a slot / restore it from there
+    // (the reference's cache_reconsts / restore_reconsts, block_splitter.rs:807-840, 1085-1145)
+    int pre_copy, copy_comps, copy_slot, copy_tx, copy_ty, copy_tlg;
     unsigned long long modes_lo, modes_hi; // K_SADLIST: one byte per entry (8 + 8), the same mode for luma and chroma
 };
 
@@ -1388,6 +1399,39 @@ __device__ __forceinline__ void evaluate_full(const Ctx& c, const PicBufs& pb, c
     PROF_ADD2(PH_RECON, t5_, t6_);
 }
 
+// Save the reconstruction of a block (comps bit 0: luma n x n, bit 1: Cb and Cr (n/2) x (n/2)) from
+// the LDS tile to a slot in global scratch, or restore it from there.  Dwords: block corners are
+// multiples of 4 samples in every plane that takes part.
+__device__ __forceinline__ void copy_block(const Ctx& c, int mode, int comps, int slot, int tx, int ty, int tlg) {
+    GLOBAL_AS uint32_t* g = (GLOBAL_AS uint32_t*)(c.slots + slot * kSlotBytes);
+    if (comps & 1) {
+        const int words = 1 << (2 * tlg - 2);
+        for (int w = LANE; w < words; w += 64) {
+            const int row = (4 * w) >> tlg, col = (4 * w) & ((1 << tlg) - 1);
+            uint32_t* l = (uint32_t*)&SH.recY[(ty + row) * 36 + tx + col + 4];
+            if (mode == COPY_SAVE)
+                g[w] = *l;
+            else
+                *l = g[w];
+        }
+    }
+    if (comps & 2) {
+        const int lg = tlg - 1;
+        const int words = 1 << (2 * lg - 2); // per plane
+        for (int w = LANE; w < 2 * words; w += 64) {
+            const int pl = w >= words ? 1 : 0;
+            const int ww = w - pl * words;
+            const int row = (4 * ww) >> lg, col = (4 * ww) & ((1 << lg) - 1);
+            uint32_t* l = (uint32_t*)&SH.recC[pl][((ty >> 1) + row) * 20 + (tx >> 1) + col + 4];
+            if (mode == COPY_SAVE)
+                g[256 + pl * 64 + ww] = *l;
+            else
+                *l = g[256 + pl * 64 + ww];
+        }
+    }
+    WSYNC();
+}
+
 // The evaluator: every block evaluation of the search, of the regeneration and of the final pass
 // goes through this one inlined copy (the search logic below is a state machine that hands out
 // evaluation requests; no function calls in the hot path).
@@ -1399,6 +1443,8 @@ __device__ __forceinline__ Res evaluate(const Ctx& c, const PicBufs& pb, const R
     r.lvl_c = 0;
     r.v0 = r.v1 = r.v2 = r.vmin = 3.40282347e+38f;
     r.imin = 0;
+    if (q.pre_copy != COPY_NONE) copy_block(c, q.pre_copy, q.copy_comps, q.copy_slot, q.copy_tx, q.copy_ty, q.copy_tlg);
+    if (q.kind == K_NOP) return r;
     if (q.kind == K_FULL) {
 #pragma unroll 1
         for (int comp = 0; comp < 2; ++comp) {
@@ -1613,6 +1659,16 @@ __device__ __forceinline__ void req_full(Req& q, int comps, int tx, int ty, int 
     q.refs0 = refs0;
     q.refs1 = refs1;
     q.final = final;
+    q.pre_copy = COPY_NONE;
+}
+
+__device__ __forceinline__ void req_copy(Req& q, int mode, int comps, int slot, int tx, int ty, int tlg) {
+    q.pre_copy = mode;
+    q.copy_comps = comps;
+    q.copy_slot = slot;
+    q.copy_tx = tx;
+    q.copy_ty = ty;
+    q.copy_tlg = tlg;
 }
 
 enum {
@@ -1629,6 +1685,24 @@ __device__ __forceinline__ void leaf_init(LeafSt& s, int tree, int bx, int by, i
     s.dm_mode = (uint8_t)dm_mode;
     s.need_refs0 = 1;
     s.need_refs1 = 1;
+    s.need_save = 0;
+    s.tile_best = 0;
+}
+
+// a new best candidate's reconstruction is saved to slot 0 by the request that follows it (before
+// anything overwrites the tile)
+__device__ __forceinline__ void leaf_attach_save(LeafSt& s, Req& q) {
+    q.pre_copy = COPY_NONE;
+    if (s.need_save) {
+        req_copy(q, COPY_SAVE, s.tree == TREE_SINGLE ? 3 : 1, 0, s.bx, s.by, s.lg);
+        s.need_save = 0;
+    }
+}
+// a request that only saves / restores a reconstruction
+__device__ __forceinline__ void leaf_copy_only(LeafSt& s, Req& q, int mode, int comps, int cont) {
+    q.kind = K_NOP;
+    req_copy(q, mode, comps, 0, s.bx, s.by, s.lg);
+    s.cont = (uint8_t)cont;
 }
 
 // full evaluation (get_intra_pred_cost, block_splitter.rs:110-474) of comps with modes [ml, mc, mc];
@@ -1638,6 +1712,7 @@ __device__ __forceinline__ void leaf_full(LeafSt& s, Req& q, int comps, int ml, 
     const bool r0 = (comps & 1) && s.need_refs0 != 0;
     const bool r1 = (comps & 2) && mc < LT_CCLM && s.need_refs1 != 0;
     req_full(q, comps, s.bx, s.by, s.lg, ml, mc, !solo, act, r0, r1, false);
+    leaf_attach_save(s, q);
     if (act) {
         if (r0) s.need_refs0 = 0;
         if (r1) s.need_refs1 = 0;
@@ -1663,6 +1738,7 @@ __device__ __forceinline__ void leaf_sadlist(LeafSt& s, Req& q, int comps, int n
     q.refs1 = (comps & 2) && chroma_refs && s.need_refs1 != 0;
     if (q.refs0) s.need_refs0 = 0;
     if (q.refs1) s.need_refs1 = 0;
+    leaf_attach_save(s, q);
     s.cont = (uint8_t)cont;
 }
 
@@ -1680,6 +1756,23 @@ __device__ __forceinline__ void put_parts(EvalPartsU& d, const EvalParts& e) {
     d.lvl_y = e.lvl_y;
     d.lvl_c = e.lvl_c;
 }
+
+// result of a full candidate with luma mode M: running first minimum over the candidates in the
+// reference's order; a new best is saved by the next request, any other active candidate has
+// overwritten the tile
+#define LEAF_CANDIDATE(M)                 \
+    do {                                  \
+        if (val < s.best_cost) {          \
+            s.best_cost = val;            \
+            put_parts(s.e_best, rp);      \
+            s.mode = (uint8_t)(M);        \
+            s.best_cls = (uint8_t)cls;    \
+            s.need_save = 1;              \
+            s.tile_best = 1;              \
+        } else if (s.op_act) {            \
+            s.tile_best = 0;              \
+        }                                 \
+    } while (0)
 
 // One step of a leaf search: SINGLE_TREE / DUAL_TREE_LUMA blocks (block_splitter.rs:886-1078) and
 // DUAL_TREE_CHROMA blocks (:794-885; lg = luma log2 = 3).  r is the result of the request the
@@ -1713,15 +1806,12 @@ __device__ __forceinline__ bool leaf_step(const Ctx& c, LeafSt& s, const Res& r,
             put_parts(s.e_best, rp);
             s.mode = PLANAR;
             s.best_cls = (uint8_t)cls;
+            s.need_save = 1;
+            s.tile_best = 1;
             leaf_full(s, q, both, DC, DC, true, C_DCM);
             return true;
         case C_DCM:
-            if (val < s.best_cost) { // {planar, DC}: first minimum
-                s.best_cost = val;
-                put_parts(s.e_best, rp);
-                s.mode = DC;
-                s.best_cls = (uint8_t)cls;
-            }
+            LEAF_CANDIDATE(DC);
             // the 13 directional candidates: SAD, first minimum (:899-904)
             leaf_sadlist(s, q, both, 13, 2u | (7u << 8) | (13u << 16) | (18u << 24),
                          23u | (29u << 8) | (34u << 16) | (39u << 24), 45u | (50u << 8) | (55u << 16) | (60u << 24), 66u,
@@ -1763,68 +1853,51 @@ __device__ __forceinline__ bool leaf_step(const Ctx& c, LeafSt& s, const Res& r,
                 cont = C_PAIR_EMIT;
                 break;
             }
-            // step_search(mode, 1, _, aux=false) (:974).  Out-of-range neighbours are "evaluated"
-            // inactive: the wave still walks the schedule so that the workgroup's shared Viterbi
-            // barriers stay aligned
+            // step_search(mode, 1, _, aux=false) (:974) on {cur, cur - 1, cur + 1}, then the minimum of
+            // {planar, DC, dir} (:975-978): first minimum of [planar, DC, cur, cur - 1, cur + 1], kept as
+            // one running best.  Out-of-range neighbours are "evaluated" inactive: the wave still
+            // walks the schedule so that the workgroup's shared Viterbi barriers stay aligned
             const int cm = s.cur_mode;
             leaf_full(s, q, both, cm, cm, true, C_F0);
             return true;
         }
         case C_F0: {
-            s.cur_cost = val;
-            put_parts(s.e_dir, rp);
-            s.dir_cls = (uint8_t)cls;
             const int cm = s.cur_mode;
-            s.best_mode = (uint8_t)cm;
+            LEAF_CANDIDATE(cm);
             leaf_full(s, q, both, cm - 1, cm - 1, !(cm < 3), C_F1);
             return true;
         }
         case C_F1: {
             const int cm = s.cur_mode;
-            if (val < s.cur_cost) {
-                s.cur_cost = val;
-                put_parts(s.e_dir, rp);
-                s.dir_cls = (uint8_t)cls;
-                s.best_mode = (uint8_t)(cm - 1);
-            }
+            LEAF_CANDIDATE(cm - 1);
             leaf_full(s, q, both, cm + 1, cm + 1, !(cm + 1 > 66), C_F2);
             return true;
         }
         case C_F2: {
-            if (val < s.cur_cost) {
-                s.cur_cost = val;
-                put_parts(s.e_dir, rp);
-                s.dir_cls = (uint8_t)cls;
-                s.best_mode = (uint8_t)(s.cur_mode + 1);
-            }
-            // min of {planar, DC, dir}, first index wins (:975-978)
-            if (s.cur_cost < s.best_cost) {
-                s.best_cost = s.cur_cost;
-                s.e_best = s.e_dir;
-                s.mode = s.best_mode;
-                s.best_cls = s.dir_cls;
-            }
+            LEAF_CANDIDATE(s.cur_mode + 1);
             s.cost = s.best_cost;
-            // luma re-run with the winner (:989-1037): puts the winner's luma reconstruction into the tile
-            const int m = s.mode;
-            leaf_full(s, q, 1, m, m, true, C_WIN);
-            return true;
-        }
-        case C_WIN: {
             const int m = s.mode;
             s.luma_mode = (uint8_t)m;
             s.chroma_mode = (uint8_t)m;
+            // :989-1037 re-runs the winner's luma to have its reconstruction in the tile; here the
+            // winner's reconstruction comes back from slot 0 unless it is still in the tile
+            const bool in_tile = s.tile_best != 0;
             if (tree == TREE_DUAL_LUMA) {
-                // :1073-1076 repeats the luma evaluation just re-run for planar / DC: same parts, same
-                // header bits, so the cost it assigns is the candidate's cost already in s.cost
-                return false;
+                // :1073-1076 repeats the luma evaluation for planar / DC: same parts, same header bits,
+                // so the cost it assigns is the candidate's cost already in s.cost
+                if (in_tile) return false;
+                leaf_copy_only(s, q, COPY_RESTORE, 1, C_WIN);
+                return true;
             }
             // :1040 get_chroma_intra_pred_cost(mode) repeats the winner's chroma evaluation: re-use it
             s.cur_cost = uni_f(assemble_chroma_cost(c, m, s.e_best.get()));
             leaf_sadlist(s, q, 2, 3, (uint32_t)LT_CCLM | ((uint32_t)T_CCLM << 8) | ((uint32_t)L_CCLM << 16), 0, 0, 0, false,
                          C_CX);
+            if (!in_tile) req_copy(q, COPY_RESTORE, 1, 0, s.bx, s.by, s.lg); // (its save went out earlier)
             return true;
         }
+        case C_WIN:
+            return false;
         case C_CX: {
             const int cm = pick_cclm(r.v0, r.v1, r.v2);
             s.cclm_mode = (uint8_t)cm;
@@ -1836,28 +1909,24 @@ __device__ __forceinline__ bool leaf_step(const Ctx& c, LeafSt& s, const Res& r,
             EvalParts e = s.e_best.get();
             e.ssd_c = rp.ssd_c;
             e.lvl_c = rp.lvl_c;
-            put_parts(s.e_dir, e);
             const float cclm_cost = uni_f(assemble_chroma_cost(c, s.cclm_mode, e));
             const float cur = s.cur_cost;
             const bool dm_wins = cur == fminf(cclm_cost, fminf(cur, 3.40282347e+38f));
-            s.dm_wins = dm_wins ? 1 : 0;
-            // :1062-1072 final get_intra_pred_cost: luma = the re-run above; the chroma pair is the DM
-            // evaluation (re-done only to put its reconstruction back when DM wins; an inactive walk
-            // of the schedule otherwise) or the CCLM evaluation just made
-            leaf_full(s, q, 2, 0, s.mode, dm_wins, C_DM);
-            return true;
-        }
-        case C_DM: {
+            // :1062-1072 final get_intra_pred_cost: luma = the winner; the chroma pair is the DM
+            // evaluation (its reconstruction comes back from slot 0) or the CCLM evaluation just made
             const int m = s.mode;
             const int bcls = s.best_cls; // mpm_class of the winner, from its candidate evaluation
-            if (s.dm_wins) {
+            if (dm_wins) {
                 s.cost = uni_f(assemble_cost(c, tree, bcls, m, s.e_best.get()));
-            } else {
-                s.chroma_mode = s.cclm_mode;
-                s.cost = uni_f(assemble_cost(c, tree, bcls, s.cclm_mode, s.e_dir.get()));
+                leaf_copy_only(s, q, COPY_RESTORE, 2, C_DM);
+                return true;
             }
+            s.chroma_mode = s.cclm_mode;
+            s.cost = uni_f(assemble_cost(c, tree, bcls, s.cclm_mode, e));
             return false;
         }
+        case C_DM:
+            return false;
         // ---- DUAL_TREE_CHROMA leaf (:794-885) ----
         case C_DC_START:
             leaf_sadlist(s, q, 2, 3, (uint32_t)LT_CCLM | ((uint32_t)T_CCLM << 8) | ((uint32_t)L_CCLM << 16), 0, 0, 0, false,
@@ -1872,6 +1941,7 @@ __device__ __forceinline__ bool leaf_step(const Ctx& c, LeafSt& s, const Res& r,
         case C_DC3:
             s.c0 = uni_f(assemble_chroma_cost(c, s.cclm_mode, rp));
             leaf_full(s, q, 2, 0, s.dm_mode, true, C_DC4);
+            req_copy(q, COPY_SAVE, 2, 0, s.bx, s.by, s.lg); // keep the CCLM reconstruction (:807-840)
             return true;
         case C_DC4: {
             const float dm_cost = uni_f(assemble_chroma_cost(c, s.dm_mode, rp));
@@ -1883,8 +1953,7 @@ __device__ __forceinline__ bool leaf_step(const Ctx& c, LeafSt& s, const Res& r,
                 return false;
             }
             s.chroma_mode = s.cclm_mode;
-            // :869-873 restore_reconsts: re-create the CCLM reconstruction (solo: data-dependent)
-            leaf_full(s, q, 2, 0, s.cclm_mode, true, C_DC5, true);
+            leaf_copy_only(s, q, COPY_RESTORE, 2, C_DC5); // :869-873 restore_reconsts
             return true;
         }
         default: // C_DC5
@@ -1898,11 +1967,10 @@ __device__ __forceinline__ bool leaf_step(const Ctx& c, LeafSt& s, const Res& r,
 // an 8x8 node's split is four DUAL_TREE_LUMA 4x4 leaves + one DUAL_TREE_CHROMA 4x4 leaf,
 // ctu.rs:1990-2063), per-level state in LDS.
 //
-// Decided blocks whose reconstruction was overwritten by later candidates are re-created by
-// evaluating them again with the solo Viterbi (which blocks need this differs from wave to wave,
-// so no workgroup barriers).  The neighbourhood is unchanged, so the result equals what the
-// evaluation produced the first time; this replaces the reference's cache_reconsts /
-// restore_reconsts copies (block_splitter.rs:807-840, 1085-1145) without saved planes in LDS.
+// Decided blocks whose reconstruction was overwritten by later candidates come back from the
+// slots in global scratch they were saved to (copy_block): the reference's cache_reconsts /
+// restore_reconsts (block_splitter.rs:807-840, 1085-1145), with the saved planes kept in L2/HBM
+// instead of LDS.
 enum { T_START = 0, T_ENTER, T_NODE_LEAF, T_LEAF4_EMIT, T_LEAF4, T_LEAFC, T_REGEN_DONE, T_RETURN, T_FINAL_Z, T_FZ_TAIL, T_FZ_NEXT };
 
 __device__ __forceinline__ bool ctu_step(Ctx& c, const Res& r, Req& q) {
@@ -1912,6 +1980,10 @@ __device__ __forceinline__ bool ctu_step(Ctx& c, const Res& r, Req& q) {
     for (;;) {
         if (in_leaf) {
             if (leaf_step(c, t.leaf, r, q)) {
+                if (t.pend) { // the first request of a node's first child saves the unsplit candidate
+                    req_copy(q, COPY_SAVE, 3, t.pslot, t.pbx, t.pby, t.plg);
+                    t.pend = 0;
+                }
                 t.cont = (uint8_t)cont;
                 t.in_leaf = 1;
                 return true;
@@ -1948,6 +2020,12 @@ __device__ __forceinline__ bool ctu_step(Ctx& c, const Res& r, Req& q) {
                 cont = T_RETURN;
                 break;
             }
+            // the unsplit candidate's reconstruction goes to slot 1 + level (cache_reconsts, :1085-1100)
+            t.pend = 1;
+            t.pbx = t.bx;
+            t.pby = t.by;
+            t.plg = (uint8_t)lg;
+            t.pslot = (uint8_t)(1 + level);
             if (LANE == 0) {
                 SH.ns_cost[level] = ns;
                 SH.ns_luma[level] = (uint8_t)ml;
@@ -1999,7 +2077,8 @@ __device__ __forceinline__ bool ctu_step(Ctx& c, const Res& r, Req& q) {
                 t.rlg = t.lg;
                 t.rl = t.ns_luma_cur;
                 t.rc = t.ns_chroma_cur;
-                req_full(q, 3, t.rbx, t.rby, t.rlg, t.rl, t.rc, false, true, true, true, false);
+                q.kind = K_NOP;
+                req_copy(q, COPY_RESTORE, 3, 1 + t.level, t.rbx, t.rby, t.rlg);
                 t.cont = T_REGEN_DONE;
                 return true;
             }
@@ -2048,7 +2127,8 @@ __device__ __forceinline__ bool ctu_step(Ctx& c, const Res& r, Req& q) {
                 t.rlg = (uint8_t)(5 - pl);
                 t.rl = (uint8_t)uni((int)SH.ns_luma[pl]);
                 t.rc = (uint8_t)uni((int)SH.ns_chroma[pl]);
-                req_full(q, 3, t.rbx, t.rby, t.rlg, t.rl, t.rc, false, true, true, true, false);
+                q.kind = K_NOP;
+                req_copy(q, COPY_RESTORE, 3, 1 + pl, t.rbx, t.rby, t.rlg);
                 t.cont = T_REGEN_DONE;
                 return true;
             }
@@ -2158,6 +2238,7 @@ __device__ __forceinline__ void encode_ctu(Ctx& c, const PicBufs& pb, int ctu_co
     static_assert(sizeof(Lds) * WPB + sizeof(LdsTab) <= 81920, "two workgroups per CU need <= 80 KB each");
     SH.st.cont = T_START;
     SH.st.in_leaf = 0;
+    SH.st.pend = 0;
     SH.st.max_depth = (uint8_t)k->max_depth;
     Res r = {};
     Req q = {};

@@ -44,7 +44,8 @@ __global__ __launch_bounds__(64 * WPB, 4) void ctu_search_kernel(const DevConst*
     c.org = (const GLOBAL_AS uint8_t*)pb.org[0]; // Y | Cb | Cr are one slab (see wrenc_gpu_create)
     c.W = k->W;
     c.WH = k->W * k->H;
-    c.pred_scratch = pred_scratch + ((size_t)blockIdx.x * WPB + WAVE) * 1024;
+    c.pred_scratch = pred_scratch + ((size_t)blockIdx.x * WPB + WAVE) * kWaveScratch;
+    c.slots = (GLOBAL_AS uint8_t*)(c.pred_scratch + 1024);
     int ovf = 0;
     encode_ctu(c, pb, col, row, &ovf);
     if (ovf && LANE == 0) atomicOr(overflow, 1);
@@ -177,7 +178,7 @@ struct wrenc_gpu_ctx {
     std::vector<int> state; // 0 empty, 1 uploaded, 2 encoded
     unsigned long long* d_mismatch = nullptr;
     int* d_overflow = nullptr;
-    uint8_t* d_pred_scratch = nullptr; // 1 KB per resident wave: prediction bytes between predict and recon
+    uint8_t* d_pred_scratch = nullptr; // kWaveScratch bytes per resident wave: prediction bytes + saved reconstructions
     size_t pred_scratch_bytes = 0;
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;
     std::vector<hipEvent_t> ev_pool;
@@ -492,7 +493,7 @@ int wrenc_gpu_encode(wrenc_gpu_ctx* ctx, int first_slot, int n_pictures) {
     const int max_diag = (cols + 1) / 2 < rows ? (cols + 1) / 2 : rows;
     {
         // 1 KB of prediction scratch per resident wave; lanes run concurrently, so each gets its own
-        const size_t need = (size_t)max_diag * (total_groups + n_lanes) * WPB * 1024;
+        const size_t need = (size_t)max_diag * (total_groups + n_lanes) * WPB * kWaveScratch;
         if (need > ctx->pred_scratch_bytes) {
             HIP_TRY(ctx, wrenc_gpu_sync(ctx) == WRENC_GPU_OK ? hipSuccess : hipErrorUnknown);
             if (ctx->d_pred_scratch) (void)hipFree(ctx->d_pred_scratch);
@@ -526,7 +527,7 @@ int wrenc_gpu_encode(wrenc_gpu_ctx* ctx, int first_slot, int n_pictures) {
             if (g0 * WPB + lane_pics > n_pictures) lane_pics = n_pictures - g0 * WPB;
             if (lane_pics <= 0) continue;
             hipStream_t st = l == 0 ? ctx->stream : ctx->lanes[l - 1];
-            uint8_t* scratch = ctx->d_pred_scratch + (size_t)max_diag * (g0 + l) * WPB * 1024;
+            uint8_t* scratch = ctx->d_pred_scratch + (size_t)max_diag * (g0 + l) * WPB * kWaveScratch;
             HIP_TRY(ctx, hipEventRecord(ctx->ev_pool[2 * launches], st));
             hipLaunchKernelGGL(ctu_search_kernel, dim3(count * (g1 - g0)), dim3(64 * WPB), 0, st, ctx->d_const,
                                ctx->d_slots, lane_first, lane_pics, d, r_min, count, scratch, ctx->d_mismatch,
