@@ -42,12 +42,15 @@ struct DevConst {
     uint8_t diag_sb[4][64][2]; // sub-block scan for 1, 4, 16, 64 sub-blocks
     uint16_t scan_idx[4][1024]; // raster index y*n+x of reverse-scan position p (p = 0: last in scan)
     int16_t intra_angle[95];  // common.rs:145
+    int32_t ang_tab[67];      // per mode: intraPredAngle (low half) | invAngle (high half), read with one scalar load
     int8_t fc[32][4];         // common.rs:153
 };
 
 // Pointers that are loaded from memory (PicBufs) lose their address space; these casts tell the
 // compiler they are global memory, so that it emits global_* instead of flat_* accesses.
 #define GLOBAL_AS __attribute__((address_space(1)))
+// The constant block is written by the host before the launch and never during it.
+#define CONST_AS __attribute__((address_space(4)))
 #define AS_GLOBAL(T, p) ((GLOBAL_AS T*)(p))
 
 // Per-wave global scratch: 1 KB of prediction bytes, then kReconSlots saved reconstructions
@@ -203,7 +206,7 @@ struct __attribute__((aligned(16))) Lds {
 // Per-wave uniform context, passed BY VALUE (a few registers) so that the out-of-line
 // stage functions never reload it from memory.
 struct Ctx {
-    const DevConst* __restrict__ k;
+    const CONST_AS DevConst* k;         // constant address space: uniform reads become scalar loads
     const GLOBAL_AS uint8_t* org;       // original planes of this wave's picture: Y, Cb, Cr back to back (read-only)
     int W, WH;                          // luma width, luma plane size
     uint8_t* pred_scratch;              // 1 KB per wave in HBM: prediction bytes between predict and recon
@@ -664,10 +667,42 @@ __device__ __forceinline__ CclmParams cclm_params(Ctx c, int comp, int tx, int t
     return r;
 }
 
-// one predicted sample of plane pc: accumulate |org - pred|; `full` also stores residual and prediction
+// Original sample for prediction index i (plane pc, component coordinates x, y).  A full
+// evaluation reads the picture; SAD lists read the copy of the block's originals that
+// stage_org() put into r2 (free while no transform runs), index obase + i.
 template <bool full>
-__device__ __forceinline__ int emit_sample(const Ctx& c, int pc, int x, int y, int i, int v) {
-    const int d = org_get(c, pc, x, y) - v;
+__device__ __forceinline__ int pred_org(const Ctx& c, int pc, int x, int y, int obase, int i) {
+    if (full) return org_get(c, pc, x, y);
+    return ((const uint8_t*)SH.r2)[obase + i];
+}
+__device__ __forceinline__ void stage_org(const Ctx& c, int comps, int tx, int ty, int tlg) {
+    uint32_t* dst = (uint32_t*)SH.r2;
+    if (comps & 1) {
+        const int words = 1 << (2 * tlg - 2);
+        for (int w = LANE; w < words; w += 64) {
+            const int row = (4 * w) >> tlg, col = (4 * w) & ((1 << tlg) - 1);
+            dst[w] = *(const GLOBAL_AS uint32_t*)&c.org[(unsigned)((c.ctu_y + ty + row) * c.W + c.ctu_x + tx + col)];
+        }
+    }
+    if (comps & 2) {
+        const int lg = tlg - 1;
+        const int words = 1 << (2 * lg - 2); // per plane
+        for (int w = LANE; w < 2 * words; w += 64) {
+            const int pl = w >= words ? 1 : 0;
+            const int ww = w - pl * words;
+            const int row = (4 * ww) >> lg, col = (4 * ww) & ((1 << lg) - 1);
+            dst[256 + w] = *(const GLOBAL_AS uint32_t*)&c.org[plane_off(c, 1 + pl) +
+                                                             (unsigned)((((c.ctu_y + ty) >> 1) + row) * (c.W >> 1) +
+                                                                        ((c.ctu_x + tx) >> 1) + col)];
+        }
+    }
+    WSYNC();
+}
+
+// one predicted sample: accumulate |org - pred|; `full` also stores residual and prediction
+template <bool full>
+__device__ __forceinline__ int emit_sample(const Ctx& c, int o, int i, int v) {
+    const int d = o - v;
     if (full) {
         SH.r1[i] = (int16_t)d;
         c.pred_scratch[i] = (uint8_t)v;
@@ -695,6 +730,7 @@ __device__ __forceinline__ int predict(Ctx c, int comp, int tx, int ty, int tlg,
     const int n = 1 << lg;
     const int cx = tx >> cs, cy = ty >> cs;
     const int nn = n * n;
+    const int obase = comp ? 1024 : 0;
     int sad = 0;
     if (mode >= LT_CCLM) {
         // model parameters of both planes in one pass: odd lanes derive Cr, even lanes Cb
@@ -708,6 +744,7 @@ __device__ __forceinline__ int predict(Ctx c, int comp, int tx, int ty, int tlg,
             const int blk = i >> (2 * lg);
             const int ii = i & (nn - 1);
             const int x = ii & (n - 1), y = ii >> lg;
+            const int o = pred_org<full>(c, comp + blk, cx + x, cy + y, obase, i); // issued early
             int v;
             if (flat128) {
                 v = 128;
@@ -716,7 +753,7 @@ __device__ __forceinline__ int predict(Ctx c, int comp, int tx, int ty, int tlg,
                 v = ((ds * (blk ? a1 : a0)) >> (blk ? k1 : k0)) + (blk ? b1 : b0);
                 v = min(max(v, 0), 255);
             }
-            sad += emit_sample<full>(c, comp + blk, cx + x, cy + y, i, v);
+            sad += emit_sample<full>(c, o, i, v);
         }
         WSYNC();
         return sad;
@@ -743,6 +780,7 @@ __device__ __forceinline__ int predict(Ctx c, int comp, int tx, int ty, int tlg,
             const int blk = i >> (2 * lg);
             const int ii = i & (nn - 1);
             const int x = ii & (n - 1), y = ii >> lg;
+            const int o = pred_org<full>(c, comp + blk, cx + x, cy + y, obase, i); // issued early
             const int16_t* L = SH.refs + (blk ? R_LC1 : oL0);
             const int16_t* A = SH.refs + (blk ? R_AC1 : oA0);
             int v;
@@ -756,18 +794,15 @@ __device__ __forceinline__ int predict(Ctx c, int comp, int tx, int ty, int tlg,
             const int wl = pdpc_w(n_scale, x), wt = pdpc_w(n_scale, y);
             v = (int16_t)(L[y + 1] * wl + A[x] * wt + (64 - wt - wl) * v + 32) >> 6;
             v = min(max(v, 0), 255);
-            sad += emit_sample<full>(c, comp + blk, cx + x, cy + y, i, v);
+            sad += emit_sample<full>(c, o, i, v);
         }
         WSYNC();
         return sad;
     }
     // angular 2..66 (intra_predictor.rs:1287-1602), square blocks
-    const int angle = c.k->intra_angle[14 + mode];
-    int inv_angle = 0;
-    if (angle > 0)
-        inv_angle = (512 * 32 + angle / 2) / angle;
-    else if (angle < 0)
-        inv_angle = -((512 * 32 + (-angle) / 2) / -angle);
+    const int at = c.k->ang_tab[mode];
+    const int angle = (int)(int16_t)(at & 0xFFFF);
+    const int inv_angle = at >> 16;
     bool filter_flag = false;
     if (!(mode == 2 || mode == 34 || mode == 66)) {
         const int md = min(abs(mode - 50), abs(mode - 18));
@@ -784,6 +819,7 @@ __device__ __forceinline__ int predict(Ctx c, int comp, int tx, int ty, int tlg,
         const int blk = i >> (2 * lg);
         const int ii = i & (nn - 1);
         const int x = ii & (n - 1), y = ii >> lg;
+        const int o = pred_org<full>(c, comp + blk, cx + x, cy + y, obase, i); // issued early
         const int16_t* L = SH.refs + (blk ? R_LC1 : oL0);
         const int16_t* A = SH.refs + (blk ? R_AC1 : oA0);
         const int alrs = L[0];
@@ -858,7 +894,7 @@ __device__ __forceinline__ int predict(Ctx c, int comp, int tx, int ty, int tlg,
             v = (int16_t)(rl * wl + rt * wt + (64 - wt - wl) * v + 32) >> 6;
             v = min(max(v, 0), 255);
         }
-        sad += emit_sample<full>(c, comp + blk, cx + x, cy + y, i, v);
+        sad += emit_sample<full>(c, o, i, v);
     }
     WSYNC();
     return sad;
@@ -894,7 +930,7 @@ __device__ void fwd_dct(Ctx c, int nb) {
     const int g = LANE >> LG;
     uint32_t t[N / 2];
     {
-        const uint32_t* src = (const uint32_t*)&c.k->dct[LG - 2][u][0];
+        const CONST_AS uint32_t* src = (const CONST_AS uint32_t*)&c.k->dct[LG - 2][u][0];
 #pragma unroll
         for (int k = 0; k < N / 2; ++k) t[k] = src[k];
     }
@@ -938,7 +974,7 @@ __device__ void inv_dct(Ctx c, int nb) {
     int16_t* vbuf = (int16_t*)SH.r2 + 1024;
     uint32_t t[N / 2]; // Tt[u][i] = T_N[i][u]
     {
-        const uint32_t* src = (const uint32_t*)&c.k->dct_t[LG - 2][u][0];
+        const CONST_AS uint32_t* src = (const CONST_AS uint32_t*)&c.k->dct_t[LG - 2][u][0];
 #pragma unroll
         for (int k = 0; k < N / 2; ++k) t[k] = src[k];
     }
@@ -1047,14 +1083,14 @@ __device__ __forceinline__ long long quantize(Ctx c, int lg, int nb, bool shared
     c = uni(c);
     lg = uni(lg);
     nb = uni(nb);
-    const DevConst* k = c.k;
+    const CONST_AS DevConst* k = c.k;
     const int n = 1 << lg;
     const int P = n * n;
     const int lgP = 2 * lg;
     const int sh = 8 + lg - 5 + 1; // quantizer.rs:558-569
     const int off = (1 << sh) >> 1;
     const int lsc = k->lsc;
-    const uint16_t* scan = k->scan_idx[lg - 2];
+    const CONST_AS uint16_t* scan = k->scan_idx[lg - 2];
     int16_t* tcs = (int16_t*)SH.r2;          // [blk][p]: coefficient in reverse-scan order
     int16_t* qds = (int16_t*)SH.r2 + 1024;   // [blk][p]: |(tc << sh) - off| / lsc
     int32_t* cc = (int32_t*)SH.r1;           // chunk: [blk][CH][6] ints (coefficients are dead after the gather)
@@ -1466,6 +1502,7 @@ __device__ __forceinline__ Res evaluate(const Ctx& c, const PicBufs& pb, const R
     PROF_MARK(tr0_);
     if (q.refs0 && (q.comps & 1)) build_refs(c, 0, q.tx, q.ty, q.tlg);
     if (q.refs1 && (q.comps & 2)) build_refs(c, 1, q.tx, q.ty, q.tlg);
+    stage_org(c, q.comps, q.tx, q.ty, q.tlg);
     PROF_MARK(t0_);
     PROF_ADD2(PH_REFS, tr0_, t0_);
 #pragma unroll 1
@@ -2186,13 +2223,13 @@ __device__ __forceinline__ void load_tables(Ctx c) {
         SHT.ldq[i] = (int32_t)c.k->ldq[i];
         SHT.lv[i] = (int32_t)c.k->lv[i];
     }
-    for (int i = threadIdx.x; i < 128; i += blockDim.x) ((int8_t*)SHT.fc)[i] = ((const int8_t*)c.k->fc)[i];
+    for (int i = threadIdx.x; i < 128; i += blockDim.x) ((int8_t*)SHT.fc)[i] = ((const CONST_AS int8_t*)c.k->fc)[i];
     __syncthreads();
 }
 
 
 __device__ __forceinline__ void encode_ctu(Ctx& c, const PicBufs& pb, int ctu_col, int ctu_row, int* overflow) {
-    const DevConst* k = c.k;
+    const CONST_AS DevConst* k = c.k;
     const int W = k->W;
     const int Wc = W >> 1;
     c.ctu_x = ctu_col * 32;

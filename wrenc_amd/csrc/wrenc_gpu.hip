@@ -36,7 +36,7 @@ __global__ __launch_bounds__(64 * WPB, 4) void ctu_search_kernel(const DevConst*
     const int col = diag - 2 * row;
     int pic = group * WPB + WAVE;
     Ctx c = {};
-    c.k = k;
+    c.k = (const CONST_AS DevConst*)k;
     c.mismatch = mismatch;
     c.write = pic < n_pictures ? 1 : 0;
     if (pic >= n_pictures) pic = n_pictures - 1; // padding wave: same work, no stores
@@ -55,7 +55,7 @@ __global__ __launch_bounds__(64 * WPB, 4) void ctu_search_kernel(const DevConst*
 __global__ __launch_bounds__(64) void test_fwd_dct_kernel(const DevConst* __restrict__ k,
                                                           const int16_t* in, int lg, int16_t* out) {
     Ctx c = {};
-    c.k = k;
+    c.k = (const CONST_AS DevConst*)k;
     const int nn = 1 << (2 * lg);
     for (int i = threadIdx.x; i < nn; i += 64) SH.r1[i] = in[(size_t)blockIdx.x * nn + i];
     WSYNC();
@@ -66,7 +66,7 @@ __global__ __launch_bounds__(64) void test_fwd_dct_kernel(const DevConst* __rest
 __global__ __launch_bounds__(64) void test_inv_dct_kernel(const DevConst* __restrict__ k,
                                                           const int16_t* in, int lg, int16_t* out) {
     Ctx c = {};
-    c.k = k;
+    c.k = (const CONST_AS DevConst*)k;
     const int n = 1 << lg, nn = n * n;
     for (int i = threadIdx.x; i < nn; i += 64) // transposed load: dT[x][i] = d[i][x]
         ((int16_t*)SH.r2)[(i & (n - 1)) * n + (i >> lg)] = in[(size_t)blockIdx.x * nn + i];
@@ -79,7 +79,7 @@ __global__ __launch_bounds__(64) void test_quantize_kernel(const DevConst* __res
                                                            const int16_t* in, int lg, int16_t* out,
                                                            long long* cost, int* overflow) {
     Ctx c = {};
-    c.k = k;
+    c.k = (const CONST_AS DevConst*)k;
     load_tables(c);
     const int nn = 1 << (2 * lg);
     for (int i = threadIdx.x; i < nn; i += 64) SH.r1[i] = in[(size_t)blockIdx.x * nn + i];
@@ -96,7 +96,7 @@ __global__ __launch_bounds__(64) void test_quantize_kernel(const DevConst* __res
 __global__ __launch_bounds__(64) void test_dequantize_kernel(const DevConst* __restrict__ k,
                                                              const int16_t* in, int lg, int16_t* out) {
     Ctx c = {};
-    c.k = k;
+    c.k = (const CONST_AS DevConst*)k;
     const int n = 1 << lg, nn = n * n;
     for (int i = threadIdx.x; i < nn; i += 64) SH.r1[i] = in[(size_t)blockIdx.x * nn + i];
     WSYNC();
@@ -250,6 +250,16 @@ void fill_dev_const(const wrenc_gpu_config& cfg, DevConst& k) {
         }
     }
     memcpy(k.intra_angle, kIntraAngle, sizeof(kIntraAngle));
+    for (int mode = 0; mode < 67; ++mode) {
+        // intraPredAngle and invAngle (intra_predictor.rs:1287-1310) of mode 2..66, one dword per mode
+        const int angle = mode >= 2 ? kIntraAngle[14 + mode] : 0;
+        int inv = 0;
+        if (angle > 0)
+            inv = (512 * 32 + angle / 2) / angle;
+        else if (angle < 0)
+            inv = -((512 * 32 + (-angle) / 2) / -angle);
+        k.ang_tab[mode] = (int32_t)(((uint32_t)(uint16_t)(int16_t)angle) | ((uint32_t)(uint16_t)(int16_t)inv << 16));
+    }
     memcpy(k.fc, kFC, sizeof(kFC));
 }
 
