@@ -192,6 +192,7 @@ struct __attribute__((aligned(16))) Lds {
     uint32_t decw[128];        // trellis decisions: 4 bits per position, 8 positions per word
     int32_t q_istar[2];        // shared-Viterbi hand-off, per block: first position with a non-zero state-0 level
     int32_t q_active;          // this wave's TB takes part in the shared Viterbi
+    uint16_t q_pm[2][4][4];    // per block and sub-block of the chunk: parity masks (delta 0, 1), state-0 flag
     uint8_t cu_log2[64];       // per 4x4 luma unit
     uint8_t luma_mode[64];
     uint8_t chroma_mode[16];   // per 8x8 luma unit
@@ -1054,14 +1055,21 @@ __device__ __forceinline__ int compose_map(int g2, int g1) {
     return r;
 }
 
-// Path costs are kept in 32 bits.  Only cost DIFFERENCES between the four states decide the
-// path, and they are bounded: any state reaches any other state's continuation within two
-// steps (q_state_trans_table is 2-step complete), and one step costs at most
-// 128*65535 + lambda_q*dq_table[1023] < 2^25 (QP 63), so |C_s - C_s'| < 2^26.2.  Subtracting the
-// quad minimum every 16 positions therefore keeps every value below 2^26.2 + 16*2^25 < 2^30.
-// A zero coefficient has no second branch; it is given the cost 2^29, which can never win
-// against branch 0 (K0 <= n0 + 2^25 <= n1 + 2^26.2 + 2^25 < n1 + 2^29) and cannot overflow.
-constexpr int kNoBranch = 1 << 29;
+// Path costs are kept in 32 bits, DOUBLED, with the tie-break of quantizer.rs:505 in the low bit.
+// Only cost DIFFERENCES between the four states decide the path, and they are bounded: any
+// state reaches any other state's continuation within two steps (q_state_trans_table is 2-step
+// complete), and one step costs at most 128*65535 + lambda_q*dq_table[1023] < 2^25 (QP 63), so
+// |C_s - C_s'| < 2^26.2.  Subtracting the quad minimum every 16 positions therefore keeps every
+// cost below 2^26.2 + 16*2^25 < 2^29.1, its double below 2^30.1.
+// A zero coefficient has no second branch; it is given the cost 2^27, which can never win
+// against branch 0 (K0 <= n0 + 2^25 <= n1 + 2^26.2 + 2^25 < n1 + 2^27) and cannot overflow.
+//
+// Walk step of state s: the two candidates are K0 = c0 + C[trans[s][par]] ("keep a0") and
+// K1 = c1 + C[trans[s][par ^ 1]] ("take a0 + 1"), par = parity of a0; K1 wins only if K1 < K0.
+// The chunk precompute stores, per position and state class, u = cost that goes with
+// C[trans[s][0]] and w = cost that goes with C[trans[s][1]], as 2*cost + tie bit such that the
+// single comparison KB < KA (KA = u + CA, KB = w + CB) is exact: choseB == pick1 ^ par.
+constexpr int kNoBranch = 1 << 27;
 
 // Dependent quantisation of nb transform blocks of side n (nb = 1 luma, 2 = Cb+Cr pair):
 // coefficients r1 ([blk][y][x]) -> levels in place; returns the summed level cost
@@ -1139,79 +1147,100 @@ __device__ __forceinline__ long long quantize(Ctx c, int lg, int nb, bool shared
     int ovf = 0;
     for (int base = P - CH; base >= 0; base -= CH) {
         WSYNC();
-        if (active && LANE < nb * CH) {
-            // per position: [c0 d0, c1 d0, c0 d1, c1 d1, c0 d0 inside the trailing run, flags]
+        if (active) {
+            // per position and state class (0: state 0, 1: state 1, 2: states 2 and 3): (u, w) doubled,
+            // see above; per sub-block: parity masks of the two delta classes and, for state 0, whether
+            // its first position in coding order (kk == 15) keeps a zero inside the trailing run
+            const bool mine = LANE < nb * CH;
             const int blk = LANE >= CH ? 1 : 0;
-            const int p = base + LANE - blk * CH;
-            const int tc = tcs[blk * P + p];
-            const int qd = qds[blk * P + p];
-            const bool dcn = p == P - 1;
-            int flags = 0;
-            int c0tz = 0;
+            const int i = LANE - blk * CH;
+            const int p = base + i;
+            int par0 = 0, par1 = 0, adj = 0;
+            if (mine) {
+                const int tc = tcs[blk * P + p];
+                const int qd = qds[blk * P + p];
+                const bool dcn = p == P - 1;
+                const bool tzp = p <= (blk ? istar1 : istar0); // inside the trailing run (matters to state 0)
+                int c0d[2], c1d[2], c0tz = 0;
 #pragma unroll
-            for (int d = 0; d < 2; ++d) {
-                int c0, c1;
-                if (tc != 0) {
-                    const int a0 = dcn ? (qd >> 1) : ((qd + d) >> 1); // quantizer.rs:378 / :441
-                    int q0 = dcn ? (int)(int16_t)(2 * a0 - d) : (a0 > 0 ? 2 * a0 - d : 0);
-                    const int a1 = a0 + 1;
-                    int q1 = dcn ? (int)(int16_t)(2 * a1 - d) : 2 * a1 - d;
-                    if (tc < 0) {
-                        q0 = dcn ? (int)(int16_t)(-q0) : -q0;
-                        q1 = dcn ? (int)(int16_t)(-q1) : -q1;
+                for (int d = 0; d < 2; ++d) {
+                    int c0, c1;
+                    if (tc != 0) {
+                        const int a0 = dcn ? (qd >> 1) : ((qd + d) >> 1); // quantizer.rs:378 / :441
+                        int q0 = dcn ? (int)(int16_t)(2 * a0 - d) : (a0 > 0 ? 2 * a0 - d : 0);
+                        const int a1 = a0 + 1;
+                        int q1 = dcn ? (int)(int16_t)(2 * a1 - d) : 2 * a1 - d;
+                        if (tc < 0) {
+                            q0 = dcn ? (int)(int16_t)(-q0) : -q0;
+                            q1 = dcn ? (int)(int16_t)(-q1) : -q1;
+                        }
+                        const int d0 = abs(tc - ((q0 * lsc + off) >> sh));
+                        const int d1 = abs(tc - ((q1 * lsc + off) >> sh));
+                        if (a1 + 1 >= 1024) ovf = 1;
+                        c0 = (int)(128LL * d0 + ldq_at(c, min(a0 + 1, 1023)));
+                        c1 = (int)(128LL * d1 + ldq_at(c, min(a1 + 1, 1023)));
+                        if (d == 0) {
+                            par0 = a0 & 1; // parity of a0 -> which successor state
+                            adj = (tzp && a0 == 0) ? 1 : 0;
+                            c0tz = a0 == 0 ? c0 - ldq1 : c0; // bits 0 instead of 1 in the trailing run (:449-453)
+                        } else {
+                            par1 = a0 & 1;
+                        }
+                    } else {
+                        c0 = ldq1; // zero coefficient outside the trailing run: dq_table[1] (:433)
+                        c1 = kNoBranch;
+                        if (d == 0) {
+                            adj = tzp ? 1 : 0;
+                            c0tz = 0;
+                        }
                     }
-                    const int d0 = abs(tc - ((q0 * lsc + off) >> sh));
-                    const int d1 = abs(tc - ((q1 * lsc + off) >> sh));
-                    if (a1 + 1 >= 1024) ovf = 1;
-                    c0 = (int)(128LL * d0 + ldq_at(c, min(a0 + 1, 1023)));
-                    c1 = (int)(128LL * d1 + ldq_at(c, min(a1 + 1, 1023)));
-                    flags |= (a0 & 1) << d;              // bit d: parity of a0 -> which successor state
-                    if (d == 0) {
-                        flags |= (a0 == 0 ? 1 : 0) << 2; // bit 2: a0 == 0 in state class delta 0
-                        c0tz = a0 == 0 ? c0 - ldq1 : c0; // bits 0 instead of 1 in the trailing run (:449-453)
-                    }
-                } else {
-                    c0 = ldq1; // zero coefficient outside the trailing run: dq_table[1] (:433)
-                    c1 = kNoBranch;
-                    if (d == 0) {
-                        flags |= 1 << 2;
-                        c0tz = 0;
-                    }
+                    c0d[d] = c0;
+                    c1d[d] = c1;
                 }
-                cc[LANE * 6 + 2 * d] = c0;
-                cc[LANE * 6 + 2 * d + 1] = c1;
+                const int c0s0 = tzp ? c0tz : c0d[0];
+                // u goes with C[trans[s][0]]: c0 if par == 0, else c1; tie bit: the side of K1 gets +1
+                int* e = cc + LANE * 6;
+                e[0] = 2 * (par0 ? c1d[0] : c0s0) + par0;
+                e[1] = 2 * (par0 ? c0s0 : c1d[0]) + 1 - par0;
+                e[2] = 2 * (par0 ? c1d[0] : c0d[0]) + par0;
+                e[3] = 2 * (par0 ? c0d[0] : c1d[0]) + 1 - par0;
+                e[4] = 2 * (par1 ? c1d[1] : c0d[1]) + par1;
+                e[5] = 2 * (par1 ? c0d[1] : c1d[1]) + 1 - par1;
             }
-            cc[LANE * 6 + 4] = c0tz;
-            cc[LANE * 6 + 5] = flags;
+            const unsigned long long b0 = __ballot(mine && par0), b1 = __ballot(mine && par1), ba = __ballot(mine && adj);
+            if (mine && (LANE & 15) == 0) {
+                uint16_t* pm = SH.q_pm[blk][i >> 4];
+                pm[0] = (uint16_t)(b0 >> LANE);
+                pm[1] = (uint16_t)(b1 >> LANE);
+                pm[2] = (uint16_t)((ba >> (LANE + 15)) & 1);
+            }
         }
         if (shared)
             __syncthreads();
         else
             WSYNC();
         if (walker && (!shared || tb->q_active)) {
-            const int wistar = shared ? tb->q_istar[wblk] : (wblk ? istar1 : istar0);
+            const int cls = st == 0 ? 0 : (st == 1 ? 1 : 2);
             uint16_t* wdec = (uint16_t*)const_cast<uint32_t*>(tb->decw) + wblk * (P >> 2);
             for (int g16 = CH - 16; g16 >= 0; g16 -= 16) { // one 4x4 sub-block per iteration
+                const uint16_t* pm = tb->q_pm[wblk][g16 >> 4];
+                const unsigned parmask = pm[st > 1 ? 1 : 0];
+                const bool adj = st == 0 && pm[2] != 0;
                 unsigned bits = 0;
 #pragma unroll
                 for (int kk = 15; kk >= 0; --kk) {
-                    const int i = g16 + kk;
-                    const int p = base + i;
-                    const int2 cv = *(const int2*)&wcc[i * 6 + 2 * delta];
-                    const int2 ex = *(const int2*)&wcc[i * 6 + 4]; // (c0 in trailing run, flags)
-                    const bool tz = st == 0 && p <= wistar;
-                    const bool par = (ex.y >> delta) & 1;
-                    const int CA = dpp_quad<0xD8>(C); // C[trans[s][0]]: quad_perm [0,2,1,3]
-                    const int CB = dpp_quad<0x72>(C); // C[trans[s][1]]: quad_perm [2,0,3,1]
-                    const int K0 = (tz ? ex.x : cv.x) + (par ? CB : CA); // keep a0
-                    const int K1 = cv.y + (par ? CA : CB);               // take a0 + 1
-                    const bool pick1 = K1 < K0;                            // tie -> a0 (:505)
-                    C = pick1 ? K1 : K0;
+                    const int2 e = *(const int2*)&wcc[(g16 + kk) * 6 + 2 * cls];
+                    const int KA = e.x + dpp_quad<0xD8>(C); // C[trans[s][0]]: quad_perm [0,2,1,3]
+                    const int KB = e.y + dpp_quad<0x72>(C); // C[trans[s][1]]: quad_perm [2,0,3,1]
+                    const bool choseB = KB < KA;
+                    C = (choseB ? KB : KA) & ~1;
+                    bits = (bits << 1) | (choseB ? 1u : 0u);
                     if (kk == 15) { // first position of a sub-block in coding order (:512-514)
-                        if (!pick1 && tz && ((ex.y >> 2) & 1)) C -= ldq1;
+                        const bool pick1 = choseB != (((parmask >> 15) & 1) != 0);
+                        if (!pick1 && adj) C -= 2 * ldq1;
                     }
-                    bits |= (pick1 ? 1u : 0u) << kk;
                 }
+                bits ^= parmask; // choseB -> pick1
                 // renormalise: subtract the quad minimum (decisions depend on differences only)
                 int m = min(C, dpp_quad<0xB1>(C));  // quad_perm [1,0,3,2]
                 m = min(m, dpp_quad<0x4E>(m));      // quad_perm [2,3,0,1]
