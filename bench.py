@@ -28,6 +28,22 @@ if ROOT not in sys.path:
 WIDTH, HEIGHT, QP, DEPTH = 1920, 1088, 32, 2
 ALGO_BYTES_PER_PIXEL = 6.0      # 1.5 B read + 1.5 B recon + 3.0 B levels
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: 8 TB/s spec
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "traffic.json")
+
+
+def measured_traffic(batch, width, height, qp, depth):
+    """HBM bytes per launch of the search kernel from the committed rocprofv3 PMC passes
+    (FETCH_SIZE and WRITE_SIZE in separate runs of this same command, see profiles/).  Per the
+    guide FETCH_SIZE counts half of the bytes read on gfx950, so it is doubled; both are in KiB.
+    None when the passes were made for another workload."""
+    try:
+        t = json.load(open(TRAFFIC_FILE))
+    except (OSError, ValueError):
+        return None
+    if [t.get("batch"), t.get("width"), t.get("height"), t.get("qp"), t.get("depth")] != [batch, width, height, qp, depth]:
+        return None
+    return (2.0 * t["fetch_size_kb_per_launch"] + t["write_size_kb_per_launch"]) * 1024.0
+
 
 
 def cpu_baseline(width, height, qp, depth, rows=None):
@@ -123,7 +139,8 @@ def main():
                        "pictures_per_step_per_gpu": B, "parallelism": "picture-sharded x%d, no collective" % world,
                        "final_pass_mismatches": mism},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": measured_traffic(B, w, h, args.qp, args.depth),
                          "kernel": "ctu_search_kernel", "avg_launch_ms": avg_launch_s * 1e3,
                          "algorithmic_bytes_per_launch": per_launch_bytes,
                          # an encode call runs 4 HIP streams of launches side by side (pictures are
