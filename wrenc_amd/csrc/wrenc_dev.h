@@ -261,7 +261,7 @@ __device__ __forceinline__ Ctx uni(Ctx c) {
 // Diagnostic build only (-DWRENC_PROFILE): per-phase cycle counters, summed per wave and
 // added to a global table at CTU end.  Never compiled into the product library.
 #ifdef WRENC_PROFILE
-enum { PH_PREDICT, PH_FDCT, PH_QPRE, PH_QBACK, PH_QTRACE, PH_DEQ, PH_IDCT, PH_RECON, PH_TOTAL, PH_CTRL, PH_REFS, PH_SKIP, PH_NSTEP, PH_NFULL, PH_COUNT };
+enum { PH_PREDICT, PH_FDCT, PH_QPRE, PH_QBACK, PH_QTRACE, PH_DEQ, PH_IDCT, PH_RECON, PH_TOTAL, PH_CTRL, PH_REFS, PH_SKIP, PH_NSTEP, PH_NFULL, PH_PSZ, PH_PSZ_END = PH_PSZ + 8, PH_PCNT, PH_PCNT_END = PH_PCNT + 8, PH_QB_PRE, PH_QB_WAIT1, PH_QB_WALK, PH_QB_WAIT2, PH_COUNT };
 __device__ unsigned long long g_prof[PH_COUNT];
 __shared__ unsigned long long s_prof[PH_COUNT];
 #define PROF_T0() const unsigned long long prof_t0_ = __builtin_readcyclecounter()
@@ -816,6 +816,28 @@ __device__ __forceinline__ int predict(Ctx c, int comp, int tx, int ty, int tlg,
         n_scale = min(lg - ilog2i(3 * inv_angle - 2) + 8, 2);
     else
         n_scale = (2 * lg - 2) >> 2;
+    // The main reference of the mode, projected once (intra_predictor.rs:1311-1420): entry idx in
+    // [-n, 2n + 3] = ref[idx] of the reference's refx / refy arrays: idx >= 0 reads the main side
+    // (0 = corner, k = sample k - 1, clamped to 2n), idx < 0 the side array at the inverse-angle
+    // projection.  It lives in the upper half of r2 (no transform runs during a prediction), so
+    // a sample's taps are consecutive LDS reads with no selects.
+    const bool vertical = mode >= 34;
+    constexpr int RM0 = 1024, RMS = 104; // int16 index of the table in r2, stride per block
+    int16_t* rm = (int16_t*)SH.r2 + RM0;
+    {
+        const int ne = 3 * n + 4;
+        for (int e = LANE; e < nb * ne; e += 64) {
+            const int blk = e >= ne ? 1 : 0;
+            const int ee = e - blk * ne;
+            const int idx = ee - n;
+            const int oL = blk ? R_LC1 : oL0, oA = blk ? R_AC1 : oA0;
+            const int k = idx >= 0 ? min(idx, 2 * n) : max(min((idx * inv_angle + 256) >> 9, n), 0);
+            const bool from_above = (idx >= 0) == vertical;
+            // k == 0 is the corner (L[0]); above sample k - 1 = A[k - 1], left sample k - 1 = L[k]
+            rm[blk * RMS + ee] = SH.refs[k == 0 ? oL : (from_above ? oA + k - 1 : oL + k)];
+        }
+        WSYNC();
+    }
     for (int i = LANE; i < nb * nn; i += 64) {
         const int blk = i >> (2 * lg);
         const int ii = i & (nn - 1);
@@ -825,54 +847,31 @@ __device__ __forceinline__ int predict(Ctx c, int comp, int tx, int ty, int tlg,
         const int16_t* A = SH.refs + (blk ? R_AC1 : oA0);
         const int alrs = L[0];
         int v;
-        if (mode >= 34) {
-            const int i_idx = ((y + 1) * angle) >> 5;
-            const int i_fact = ((y + 1) * angle) & 31;
-            // refx[idx]: 0 corner, 1.. above; negative idx -> projected left samples
-            auto ref = [&](int idx) -> int {
-                if (idx < 0) return L[min((idx * inv_angle + 256) >> 9, n)];
-                if (idx == 0) return alrs;
-                return A[min(idx - 1, 2 * n - 1)];
-            };
+        {
+            const int along = vertical ? y : x, across = vertical ? x : y;
+            const int i_idx = ((along + 1) * angle) >> 5;
+            const int i_fact = ((along + 1) * angle) & 31;
+            const int16_t* tap = rm + blk * RMS + n + across + i_idx; // tap[t] = ref[across + i_idx + t]
             if (comp == 0) {
-                int acc = 0;
-                for (int t = 0; t < 4; ++t) {
-                    const int f = filter_flag ? (t == 0 ? 16 - (i_fact >> 1)
-                                                        : t == 1 ? 32 - (i_fact >> 1)
-                                                                 : t == 2 ? 16 + (i_fact >> 1) : (i_fact >> 1))
-                                              : (int)SHT.fc[i_fact][t];
-                    acc += f * ref(x + i_idx + t);
+                int f0, f1, f2, f3;
+                if (filter_flag) {
+                    f0 = 16 - (i_fact >> 1);
+                    f1 = 32 - (i_fact >> 1);
+                    f2 = 16 + (i_fact >> 1);
+                    f3 = i_fact >> 1;
+                } else {
+                    const int w = *(const int*)&SHT.fc[i_fact][0];
+                    f0 = (int)(int8_t)w;
+                    f1 = (int)(int8_t)(w >> 8);
+                    f2 = (int)(int8_t)(w >> 16);
+                    f3 = w >> 24;
                 }
+                const int acc = f0 * tap[0] + f1 * tap[1] + f2 * tap[2] + f3 * tap[3];
                 v = min(max((acc + 32) >> 6, 0), 255);
             } else if (i_fact != 0) {
-                v = (((32 - i_fact) * ref(x + i_idx + 1) + i_fact * ref(x + i_idx + 2) + 16) >> 5) & 0xFF;
+                v = (((32 - i_fact) * tap[1] + i_fact * tap[2] + 16) >> 5) & 0xFF;
             } else {
-                v = ref(x + i_idx + 1) & 0xFF;
-            }
-        } else {
-            const int i_idx = ((x + 1) * angle) >> 5;
-            const int i_fact = ((x + 1) * angle) & 31;
-            auto ref = [&](int idx) -> int {
-                if (idx < 0) {
-                    const int t = min((idx * inv_angle + 256) >> 9, n);
-                    return t == 0 ? alrs : A[t - 1];
-                }
-                return L[min(idx, 2 * n)];
-            };
-            if (comp == 0) {
-                int acc = 0;
-                for (int t = 0; t < 4; ++t) {
-                    const int f = filter_flag ? (t == 0 ? 16 - (i_fact >> 1)
-                                                        : t == 1 ? 32 - (i_fact >> 1)
-                                                                 : t == 2 ? 16 + (i_fact >> 1) : (i_fact >> 1))
-                                              : (int)SHT.fc[i_fact][t];
-                    acc += f * ref(y + i_idx + t);
-                }
-                v = min(max((acc + 32) >> 6, 0), 255);
-            } else if (i_fact != 0) {
-                v = (((32 - i_fact) * ref(y + i_idx + 1) + i_fact * ref(y + i_idx + 2) + 16) >> 5) & 0xFF;
-            } else {
-                v = ref(y + i_idx + 1) & 0xFF;
+                v = tap[1] & 0xFF;
             }
         }
         if (do_pdpc) {
@@ -1146,6 +1145,7 @@ __device__ __forceinline__ long long quantize(Ctx c, int lg, int nb, bool shared
     int C = 0;
     int ovf = 0;
     for (int base = P - CH; base >= 0; base -= CH) {
+        PROF_MARK(qb0_);
         WSYNC();
         if (active) {
             // per position and state class (0: state 0, 1: state 1, 2: states 2 and 3): (u, w) doubled,
@@ -1215,10 +1215,12 @@ __device__ __forceinline__ long long quantize(Ctx c, int lg, int nb, bool shared
                 pm[2] = (uint16_t)((ba >> (LANE + 15)) & 1);
             }
         }
+        PROF_MARK(qb1_);
         if (shared)
             __syncthreads();
         else
             WSYNC();
+        PROF_MARK(qb2_);
         if (walker && (!shared || tb->q_active)) {
             const int cls = st == 0 ? 0 : (st == 1 ? 1 : 2);
             uint16_t* wdec = (uint16_t*)const_cast<uint32_t*>(tb->decw) + wblk * (P >> 2);
@@ -1226,10 +1228,15 @@ __device__ __forceinline__ long long quantize(Ctx c, int lg, int nb, bool shared
                 const uint16_t* pm = tb->q_pm[wblk][g16 >> 4];
                 const unsigned parmask = pm[st > 1 ? 1 : 0];
                 const bool adj = st == 0 && pm[2] != 0;
+                // all 16 entries of the sub-block are fetched before its walk (a serial dependency
+                // chain that should not wait for LDS position by position)
+                int2 cur[16];
+#pragma unroll
+                for (int kk = 0; kk < 16; ++kk) cur[kk] = *(const int2*)&wcc[(g16 + kk) * 6 + 2 * cls];
                 unsigned bits = 0;
 #pragma unroll
                 for (int kk = 15; kk >= 0; --kk) {
-                    const int2 e = *(const int2*)&wcc[(g16 + kk) * 6 + 2 * cls];
+                    const int2 e = cur[kk];
                     const int KA = e.x + dpp_quad<0xD8>(C); // C[trans[s][0]]: quad_perm [0,2,1,3]
                     const int KB = e.y + dpp_quad<0x72>(C); // C[trans[s][1]]: quad_perm [2,0,3,1]
                     const bool choseB = KB < KA;
@@ -1248,7 +1255,13 @@ __device__ __forceinline__ long long quantize(Ctx c, int lg, int nb, bool shared
                 wdec[((base + g16) >> 4) * 4 + st] = (uint16_t)bits;
             }
         }
+        PROF_MARK(qb3_);
         if (shared) __syncthreads();
+        PROF_MARK(qb4_);
+        PROF_ADD2(PH_QB_PRE, qb0_, qb1_);
+        PROF_ADD2(PH_QB_WAIT1, qb1_, qb2_);
+        PROF_ADD2(PH_QB_WALK, qb2_, qb3_);
+        PROF_ADD2(PH_QB_WAIT2, qb3_, qb4_);
     }
     WSYNC();
     PROF_MARK(q2_);
@@ -1281,14 +1294,19 @@ __device__ __forceinline__ long long quantize(Ctx c, int lg, int nb, bool shared
             fmap = compose_map(g, fmap);
         }
     }
-    // inclusive prefix composition across the lanes of a block
+    // inclusive prefix composition across the lanes of a block: Hillis-Steele inside the 16-lane rows
+    // with row_shr DPP moves (lanes without a source get the identity map), then the row totals
+    // travel with row_bcast:15 / row_bcast:31 (the two blocks of a chroma pair are lanes 0..31 and
+    // 32..63, so they simply skip the last step).  No LDS-crossbar shuffles.
     int pre = fmap;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const int other = __shfl_up(pre, d, 64);
-        if (lane_in >= d) pre = compose_map(pre, other);
-    }
-    int entry = __shfl_up(pre, 1, 64) & 3; // state after all previous lanes of the block, starting from 0
+    pre = compose_map(pre, __builtin_amdgcn_update_dpp(0xE4, pre, 0x111, 0xF, 0xF, false)); // row_shr:1
+    pre = compose_map(pre, __builtin_amdgcn_update_dpp(0xE4, pre, 0x112, 0xF, 0xF, false)); // row_shr:2
+    pre = compose_map(pre, __builtin_amdgcn_update_dpp(0xE4, pre, 0x114, 0xF, 0xF, false)); // row_shr:4
+    pre = compose_map(pre, __builtin_amdgcn_update_dpp(0xE4, pre, 0x118, 0xF, 0xF, false)); // row_shr:8
+    pre = compose_map(pre, __builtin_amdgcn_update_dpp(0xE4, pre, 0x142, 0xA, 0xF, false)); // row_bcast:15 -> rows 1, 3
+    if (nb == 1) pre = compose_map(pre, __builtin_amdgcn_update_dpp(0xE4, pre, 0x143, 0xC, 0xF, false)); // row_bcast:31 -> rows 2, 3
+    // state after all previous lanes of the block, starting from 0
+    int entry = __builtin_amdgcn_update_dpp(0, pre, 0x138, 0xF, 0xF, false) & 3; // wave_shr:1
     if (lane_in == 0) entry = 0;
     long long sum_nz = 0;
     unsigned zmask = 0;
@@ -1543,7 +1561,11 @@ __device__ __forceinline__ Res evaluate(const Ctx& c, const PicBufs& pb, const R
 #pragma unroll 1
             for (int comp = 0; comp < 2; ++comp) {
                 if (!((q.comps >> comp) & 1)) continue;
+                PROF_MARK(tp0_);
                 sad += (unsigned long long)(unsigned)wave_sum_i32(predict<false>(c, comp, q.tx, q.ty, q.tlg, m));
+                PROF_MARK(tp1_);
+                PROF_ADD2(PH_PSZ + ((q.tlg - 2) * 2 + comp), tp0_, tp1_);
+                PROF_ADD2(PH_PCNT + ((q.tlg - 2) * 2 + comp), 0, 1);
             }
             cost = uni_f((float)sad);
         }
