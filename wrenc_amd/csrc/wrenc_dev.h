@@ -192,7 +192,7 @@ struct __attribute__((aligned(16))) Lds {
     uint32_t decw[128];        // trellis decisions: 4 bits per position, 8 positions per word
     int32_t q_istar[2];        // shared-Viterbi hand-off, per block: first position with a non-zero state-0 level
     int32_t q_active;          // this wave's TB takes part in the shared Viterbi
-    uint16_t q_pm[2][4][4];    // per block and sub-block of the chunk: parity masks (delta 0, 1), state-0 flag
+    uint16_t q_pm[3][4][4];    // per block and sub-block of the chunk: parity masks (delta 0, 1), state-0 flag
     uint8_t cu_log2[64];       // per 4x4 luma unit
     uint8_t luma_mode[64];
     uint8_t chroma_mode[16];   // per 8x8 luma unit
@@ -704,7 +704,7 @@ __device__ __forceinline__ void stage_org(const Ctx& c, int comps, int tx, int t
 template <bool full>
 __device__ __forceinline__ int emit_sample(const Ctx& c, int o, int i, int v) {
     const int d = o - v;
-    if (full) {
+    if (full) { // i already includes the block's base in r1 / the prediction scratch
         SH.r1[i] = (int16_t)d;
         c.pred_scratch[i] = (uint8_t)v;
     }
@@ -718,8 +718,9 @@ __device__ __forceinline__ int emit_sample(const Ctx& c, int o, int i, int v) {
 //       (each lane later re-reads exactly the bytes it wrote).
 // Returns the lane's partial sum of |org - pred| (the SAD of block_splitter.rs:96-104).
 template <bool full>
-__device__ __forceinline__ int predict(Ctx c, int comp, int tx, int ty, int tlg, int mode) {
+__device__ __forceinline__ int predict(Ctx c, int comp, int tx, int ty, int tlg, int mode, int rbase = 0) {
     c = uni(c);
+    rbase = uni(rbase);
     comp = uni(comp);
     tx = uni(tx);
     ty = uni(ty);
@@ -754,7 +755,7 @@ __device__ __forceinline__ int predict(Ctx c, int comp, int tx, int ty, int tlg,
                 v = ((ds * (blk ? a1 : a0)) >> (blk ? k1 : k0)) + (blk ? b1 : b0);
                 v = min(max(v, 0), 255);
             }
-            sad += emit_sample<full>(c, o, i, v);
+            sad += emit_sample<full>(c, o, rbase + i, v);
         }
         WSYNC();
         return sad;
@@ -795,7 +796,7 @@ __device__ __forceinline__ int predict(Ctx c, int comp, int tx, int ty, int tlg,
             const int wl = pdpc_w(n_scale, x), wt = pdpc_w(n_scale, y);
             v = (int16_t)(L[y + 1] * wl + A[x] * wt + (64 - wt - wl) * v + 32) >> 6;
             v = min(max(v, 0), 255);
-            sad += emit_sample<full>(c, o, i, v);
+            sad += emit_sample<full>(c, o, rbase + i, v);
         }
         WSYNC();
         return sad;
@@ -894,7 +895,7 @@ __device__ __forceinline__ int predict(Ctx c, int comp, int tx, int ty, int tlg,
             v = (int16_t)(rl * wl + rt * wt + (64 - wt - wl) * v + 32) >> 6;
             v = min(max(v, 0), 255);
         }
-        sad += emit_sample<full>(c, o, i, v);
+        sad += emit_sample<full>(c, o, rbase + i, v);
     }
     WSYNC();
     return sad;
@@ -922,7 +923,7 @@ __device__ __forceinline__ int dot2(uint32_t a, uint32_t b, int acc) {
 // forward: nb residual blocks in r1 ([blk][y][x] i16) -> coefficients in place, via r2;
 // transformer.rs:2040-2378
 template <int LG>
-__device__ void fwd_dct(Ctx c, int nb) {
+__device__ void fwd_dct(Ctx c, int nb, int o1) {
     constexpr int N = 1 << LG;
     constexpr int G = 64 / N;
     constexpr int HS = N + 1; // r2 row stride
@@ -937,7 +938,7 @@ __device__ void fwd_dct(Ctx c, int nb) {
     // stage 1: H[u][y] = (sum_x T[u][x] r[y][x] + d) >> (LG-1)   (:2139-2209); rows of all blocks
 #pragma unroll 1
     for (int yy = g; yy < nb * N; yy += G) {
-        const uint32_t* row = (const uint32_t*)&SH.r1[yy * N];
+        const uint32_t* row = (const uint32_t*)&SH.r1[o1 + yy * N];
         int acc = 0;
 #pragma unroll
         for (int k = 0; k < N / 2; ++k) acc = dot2(row[k], t[k], acc);
@@ -957,7 +958,7 @@ __device__ void fwd_dct(Ctx c, int nb) {
             acc += __mul24((int)(short)(t[k] & 0xFFFF), col[2 * k]);
             acc += __mul24((int)t[k] >> 16, col[2 * k + 1]);
         }
-        SH.r1[blk * (N * N) + u * N + x] = (int16_t)((acc + (1 << (LG + 5))) >> (LG + 6));
+        SH.r1[o1 + blk * (N * N) + u * N + x] = (int16_t)((acc + (1 << (LG + 5))) >> (LG + 6));
     }
     WSYNC();
 }
@@ -965,7 +966,7 @@ __device__ void fwd_dct(Ctx c, int nb) {
 // inverse: nb transposed dequantised blocks in the lower half of r2 ([blk][x][i], i16) ->
 // residuals r1 ([blk][y][x]); the intermediate lives in the upper half of r2.  transformer.rs:2380-2737
 template <int LG>
-__device__ void inv_dct(Ctx c, int nb) {
+__device__ void inv_dct(Ctx c, int nb, int o1) {
     constexpr int N = 1 << LG;
     constexpr int G = 64 / N;
     const int u = LANE & (N - 1);
@@ -998,31 +999,34 @@ __device__ void inv_dct(Ctx c, int nb) {
         int acc = 0;
 #pragma unroll
         for (int k = 0; k < N / 2; ++k) acc = dot2(row[k], t[k], acc);
-        SH.r1[yy * N + u] = (int16_t)((acc + 2048) >> 12);
+        SH.r1[o1 + yy * N + u] = (int16_t)((acc + 2048) >> 12);
     }
     WSYNC();
 }
 
-__device__ __forceinline__ void fwd_dct_lg(Ctx c, int lg, int nb) {
+// o1: where the blocks start in r1 (i16 units, a multiple of 2)
+__device__ __forceinline__ void fwd_dct_lg(Ctx c, int lg, int nb, int o1 = 0) {
     c = uni(c);
     lg = uni(lg);
     nb = uni(nb);
+    o1 = uni(o1);
     switch (lg) {
-    case 2: fwd_dct<2>(c, nb); break;
-    case 3: fwd_dct<3>(c, nb); break;
-    case 4: fwd_dct<4>(c, nb); break;
-    default: fwd_dct<5>(c, nb); break;
+    case 2: fwd_dct<2>(c, nb, o1); break;
+    case 3: fwd_dct<3>(c, nb, o1); break;
+    case 4: fwd_dct<4>(c, nb, o1); break;
+    default: fwd_dct<5>(c, nb, o1); break;
     }
 }
-__device__ __forceinline__ void inv_dct_lg(Ctx c, int lg, int nb) {
+__device__ __forceinline__ void inv_dct_lg(Ctx c, int lg, int nb, int o1 = 0) {
     c = uni(c);
     lg = uni(lg);
     nb = uni(nb);
+    o1 = uni(o1);
     switch (lg) {
-    case 2: inv_dct<2>(c, nb); break;
-    case 3: inv_dct<3>(c, nb); break;
-    case 4: inv_dct<4>(c, nb); break;
-    default: inv_dct<5>(c, nb); break;
+    case 2: inv_dct<2>(c, nb, o1); break;
+    case 3: inv_dct<3>(c, nb, o1); break;
+    case 4: inv_dct<4>(c, nb, o1); break;
+    default: inv_dct<5>(c, nb, o1); break;
     }
 }
 
@@ -1354,12 +1358,301 @@ __device__ __forceinline__ long long quantize(Ctx c, int lg, int nb, bool shared
     return sum;
 }
 
+// Dependent quantisation of the three transform blocks of one candidate in ONE pooled pass: luma
+// n0 x n0 at r1[0, P0), Cb and Cr (n0/2)^2 at r1[P0, P0 + Pc) and r1[P0 + Pc, P0 + 2 Pc), n0 = 8 or
+// 16 (search only: every wave of the workgroup is in this call with the same block size).  Same
+// algorithm as quantize(); the chroma chains are a quarter as long as the luma chain, so a chunk is
+// 64 luma + 16 + 16 chroma positions and the chroma blocks ride along for free: wave 0 walks the
+// 8 luma blocks (lanes 0..31) and the 8 Cb blocks (lanes 32..63), wave 1 the 8 Cr blocks.
+// Scratch: r2 = [scan-order coefficients | quotients | chunk entries], decw.
+__device__ __forceinline__ void quantize3(Ctx c, int lg0, bool active, int* overflow, long long* lvl_y,
+                                          long long* lvl_c) {
+    static_assert(WPB == 8, "the merged pass maps 8 waves x 3 blocks onto two walker waves");
+    c = uni(c);
+    lg0 = uni(lg0);
+    const CONST_AS DevConst* k = c.k;
+    const int lgc = lg0 - 1;
+    const int P0 = 1 << (2 * lg0), Pc = P0 >> 2, T = P0 + 2 * Pc;
+    const int sh0 = lg0 + 4, shc = lgc + 4; // 8 + lg - 5 + 1 (quantizer.rs:558-569)
+    const int lsc = k->lsc;
+    const CONST_AS uint16_t* scan0 = k->scan_idx[lg0 - 2];
+    const CONST_AS uint16_t* scanc = k->scan_idx[lgc - 2];
+    int16_t* tcs = (int16_t*)SH.r2;               // [T]: coefficient in reverse-scan order, block after block
+    int16_t* qds = (int16_t*)SH.r2 + T;           // [T]: |(tc << sh) - off| / lsc
+    constexpr int kCcByte = 1536;                 // 2 * 2 * T <= 1536 for T <= 384
+    int32_t* cc = (int32_t*)((char*)SH.r2 + kCcByte); // chunk: [96][6] ints
+    *lvl_y = 0;
+    *lvl_c = 0;
+    PROF_MARK(q0_);
+    int istar0 = P0, istar1 = Pc, istar2 = Pc;
+    if (active) {
+        int first0 = P0, first1 = Pc, first2 = Pc;
+        for (int idx = LANE; idx < T; idx += 64) {
+            const int b = idx < P0 ? 0 : (idx < P0 + Pc ? 1 : 2);
+            const int boff = b == 0 ? 0 : (b == 1 ? P0 : P0 + Pc);
+            const int p = idx - boff;
+            const int sh = b == 0 ? sh0 : shc;
+            const int off = (1 << sh) >> 1;
+            const int tc = SH.r1[boff + (b == 0 ? scan0[p] : scanc[p])];
+            int S = (int)((unsigned)tc << sh) - off;
+            if (tc < 0) S = -S;
+            const int qd = tc == 0 ? 0 : (int)(((unsigned long long)(unsigned)S * k->div_magic) >> 47);
+            tcs[idx] = (int16_t)tc;
+            qds[idx] = (int16_t)qd;
+            if (tc != 0 && (qd >> 1) > 0) {
+                if (b == 0)
+                    first0 = min(first0, p);
+                else if (b == 1)
+                    first1 = min(first1, p);
+                else
+                    first2 = min(first2, p);
+            }
+        }
+        istar0 = wave_min_i32(first0);
+        istar1 = wave_min_i32(first1);
+        istar2 = wave_min_i32(first2);
+    }
+    if (LANE == 0) SH.q_active = active ? 1 : 0;
+    PROF_MARK(q1_);
+    PROF_ADD2(PH_QPRE, q0_, q1_);
+    const int ldq1 = (int)ldq_at(c, 1);
+    const int st = LANE & 3;
+    const int cls = st == 0 ? 0 : (st == 1 ? 1 : 2);
+    // walker lanes: wave 0 lanes 0..31 luma of wave LANE/4, lanes 32..63 Cb; wave 1 lanes 0..31 Cr
+    const int wv = WAVE;
+    const int wb = wv == 0 ? (LANE < 32 ? 0 : 1) : 2;
+    const bool walker = wv == 0 || (wv == 1 && LANE < 32);
+    const Lds* tb = &SHW[(LANE & 31) >> 2];
+    const int32_t* wcc = (const int32_t*)((const char*)tb->r2 + kCcByte) + (wb == 0 ? 0 : (wb == 1 ? 64 : 80)) * 6;
+    uint16_t* wdec = (uint16_t*)const_cast<uint32_t*>(tb->decw) + (wb == 0 ? 0 : (wb == 1 ? (P0 >> 2) : (P0 >> 2) + (Pc >> 2)));
+    const int wnsb = wb == 0 ? 4 : 1; // sub-blocks of the walker's block per chunk
+    int C = 0;
+    int ovf = 0;
+    const int nch = P0 >> 6;
+    for (int ch = 0; ch < nch; ++ch) {
+        const int base0 = P0 - 64 * (ch + 1), basec = Pc - 16 * (ch + 1);
+        PROF_MARK(qb0_);
+        WSYNC();
+        if (active) {
+#pragma unroll 1
+            for (int pass = 0; pass < 2; ++pass) {
+                const int e = LANE + 64 * pass;
+                const bool mine = e < 96;
+                const int b = e < 64 ? 0 : (e < 80 ? 1 : 2);
+                const int i = b == 0 ? e : ((e - 64) & 15);
+                const int p = (b == 0 ? base0 : basec) + i;
+                const int Pb = b == 0 ? P0 : Pc;
+                const int gidx = (b == 0 ? 0 : (b == 1 ? P0 : P0 + Pc)) + p;
+                int par0 = 0, par1 = 0, adj = 0;
+                if (mine) {
+                    const int sh = b == 0 ? sh0 : shc;
+                    const int off = (1 << sh) >> 1;
+                    const int tc = tcs[gidx];
+                    const int qd = qds[gidx];
+                    const bool dcn = p == Pb - 1;
+                    const bool tzp = p <= (b == 0 ? istar0 : (b == 1 ? istar1 : istar2));
+                    int c0d[2], c1d[2], c0tz = 0;
+#pragma unroll
+                    for (int d = 0; d < 2; ++d) {
+                        int c0, c1;
+                        if (tc != 0) {
+                            const int a0 = dcn ? (qd >> 1) : ((qd + d) >> 1); // quantizer.rs:378 / :441
+                            int q0 = dcn ? (int)(int16_t)(2 * a0 - d) : (a0 > 0 ? 2 * a0 - d : 0);
+                            const int a1 = a0 + 1;
+                            int q1 = dcn ? (int)(int16_t)(2 * a1 - d) : 2 * a1 - d;
+                            if (tc < 0) {
+                                q0 = dcn ? (int)(int16_t)(-q0) : -q0;
+                                q1 = dcn ? (int)(int16_t)(-q1) : -q1;
+                            }
+                            const int d0 = abs(tc - ((q0 * lsc + off) >> sh));
+                            const int d1 = abs(tc - ((q1 * lsc + off) >> sh));
+                            if (a1 + 1 >= 1024) ovf = 1;
+                            c0 = (int)(128LL * d0 + ldq_at(c, min(a0 + 1, 1023)));
+                            c1 = (int)(128LL * d1 + ldq_at(c, min(a1 + 1, 1023)));
+                            if (d == 0) {
+                                par0 = a0 & 1;
+                                adj = (tzp && a0 == 0) ? 1 : 0;
+                                c0tz = a0 == 0 ? c0 - ldq1 : c0; // :449-453
+                            } else {
+                                par1 = a0 & 1;
+                            }
+                        } else {
+                            c0 = ldq1; // :433
+                            c1 = kNoBranch;
+                            if (d == 0) {
+                                adj = tzp ? 1 : 0;
+                                c0tz = 0;
+                            }
+                        }
+                        c0d[d] = c0;
+                        c1d[d] = c1;
+                    }
+                    const int c0s0 = tzp ? c0tz : c0d[0];
+                    int* en = cc + e * 6;
+                    en[0] = 2 * (par0 ? c1d[0] : c0s0) + par0;
+                    en[1] = 2 * (par0 ? c0s0 : c1d[0]) + 1 - par0;
+                    en[2] = 2 * (par0 ? c1d[0] : c0d[0]) + par0;
+                    en[3] = 2 * (par0 ? c0d[0] : c1d[0]) + 1 - par0;
+                    en[4] = 2 * (par1 ? c1d[1] : c0d[1]) + par1;
+                    en[5] = 2 * (par1 ? c0d[1] : c1d[1]) + 1 - par1;
+                }
+                const unsigned long long b0 = __ballot(mine && par0), b1 = __ballot(mine && par1),
+                                         ba = __ballot(mine && adj);
+                if (mine && (LANE & 15) == 0) {
+                    // pass 0: luma sub-block LANE / 16; pass 1: lanes 0..15 Cb, 16..31 Cr (one sub-block each)
+                    uint16_t* pm = SH.q_pm[b][b == 0 ? (LANE >> 4) : 0];
+                    pm[0] = (uint16_t)(b0 >> LANE);
+                    pm[1] = (uint16_t)(b1 >> LANE);
+                    pm[2] = (uint16_t)((ba >> (LANE + 15)) & 1);
+                }
+            }
+        }
+        PROF_MARK(qb1_);
+        __syncthreads();
+        PROF_MARK(qb2_);
+        if (walker && tb->q_active) {
+            for (int sbi = wnsb - 1; sbi >= 0; --sbi) { // one 4x4 sub-block per iteration
+                const int g16 = sbi * 16;
+                const uint16_t* pm = tb->q_pm[wb][sbi];
+                const unsigned parmask = pm[st > 1 ? 1 : 0];
+                const bool adj = st == 0 && pm[2] != 0;
+                int2 cur[16];
+#pragma unroll
+                for (int kk = 0; kk < 16; ++kk) cur[kk] = *(const int2*)&wcc[(g16 + kk) * 6 + 2 * cls];
+                unsigned bits = 0;
+#pragma unroll
+                for (int kk = 15; kk >= 0; --kk) {
+                    const int2 en = cur[kk];
+                    const int KA = en.x + dpp_quad<0xD8>(C); // C[trans[s][0]]: quad_perm [0,2,1,3]
+                    const int KB = en.y + dpp_quad<0x72>(C); // C[trans[s][1]]: quad_perm [2,0,3,1]
+                    const bool choseB = KB < KA;
+                    C = (choseB ? KB : KA) & ~1;
+                    bits = (bits << 1) | (choseB ? 1u : 0u);
+                    if (kk == 15) { // first position of a sub-block in coding order (:512-514)
+                        const bool pick1 = choseB != (((parmask >> 15) & 1) != 0);
+                        if (!pick1 && adj) C -= 2 * ldq1;
+                    }
+                }
+                bits ^= parmask; // choseB -> pick1
+                int m = min(C, dpp_quad<0xB1>(C));
+                m = min(m, dpp_quad<0x4E>(m));
+                C -= m;
+                wdec[(((wb == 0 ? base0 : basec) + g16) >> 4) * 4 + st] = (uint16_t)bits;
+            }
+        }
+        PROF_MARK(qb3_);
+        __syncthreads();
+        PROF_MARK(qb4_);
+        PROF_ADD2(PH_QB_PRE, qb0_, qb1_);
+        PROF_ADD2(PH_QB_WAIT1, qb1_, qb2_);
+        PROF_ADD2(PH_QB_WALK, qb2_, qb3_);
+        PROF_ADD2(PH_QB_WAIT2, qb3_, qb4_);
+    }
+    WSYNC();
+    PROF_MARK(q2_);
+    PROF_ADD2(PH_QBACK, q1_, q2_);
+    if (!active) return;
+    // ---- forward trace + level cost: lanes 0..31 luma, 32..47 Cb, 48..63 Cr ----
+    const int b = LANE < 32 ? 0 : (LANE < 48 ? 1 : 2);
+    const int lane_in = b == 0 ? LANE : (LANE & 15);
+    const int Pb = b == 0 ? P0 : Pc;
+    const int per = b == 0 ? (P0 >> 5) : (Pc >> 4); // P0 / 32 = Pc / 16 * 2
+    const int boff = b == 0 ? 0 : (b == 1 ? P0 : P0 + Pc);
+    const int p0 = lane_in * per;
+    const int16_t* btcs = tcs + boff;
+    const int16_t* bqds = qds + boff;
+    const uint16_t* bdec = (const uint16_t*)SH.decw + (b == 0 ? 0 : (b == 1 ? (P0 >> 2) : (P0 >> 2) + (Pc >> 2)));
+    int fmap = 0xE4; // identity map
+    for (int j = 0; j < per; ++j) {
+        const int p = p0 + j;
+        const int tc = btcs[p], qd = bqds[p], nib = dec_nib(bdec, p);
+        int g = 0;
+#pragma unroll
+        for (int sidx = 0; sidx < 4; ++sidx) {
+            const int dl = sidx > 1 ? 1 : 0;
+            int a = 0;
+            if (tc != 0) a = ((p == Pb - 1) ? (qd >> 1) : ((qd + dl) >> 1)) + ((nib >> sidx) & 1);
+            g |= ((0x7D28 >> (2 * (2 * sidx + (a & 1)))) & 3) << (2 * sidx);
+        }
+        fmap = compose_map(g, fmap);
+    }
+    int pre = fmap;
+    pre = compose_map(pre, __builtin_amdgcn_update_dpp(0xE4, pre, 0x111, 0xF, 0xF, false)); // row_shr:1
+    pre = compose_map(pre, __builtin_amdgcn_update_dpp(0xE4, pre, 0x112, 0xF, 0xF, false)); // row_shr:2
+    pre = compose_map(pre, __builtin_amdgcn_update_dpp(0xE4, pre, 0x114, 0xF, 0xF, false)); // row_shr:4
+    pre = compose_map(pre, __builtin_amdgcn_update_dpp(0xE4, pre, 0x118, 0xF, 0xF, false)); // row_shr:8
+    pre = compose_map(pre, __builtin_amdgcn_update_dpp(0xE4, pre, 0x142, 0x2, 0xF, false)); // row_bcast:15 -> row 1 (luma)
+    int entry = __builtin_amdgcn_update_dpp(0, pre, 0x138, 0xF, 0xF, false) & 3; // wave_shr:1
+    if (lane_in == 0) entry = 0;
+    long long sum_nz = 0;
+    unsigned zmask = 0;
+    int fnz = Pb;
+    {
+        int state = entry;
+        for (int j = 0; j < per; ++j) {
+            const int p = p0 + j;
+            const int tc = btcs[p], qd = bqds[p], nib = dec_nib(bdec, p);
+            const int dl = state > 1 ? 1 : 0;
+            int q = 0, a = 0;
+            if (tc != 0) {
+                a = ((p == Pb - 1) ? (qd >> 1) : ((qd + dl) >> 1)) + ((nib >> state) & 1);
+                if (p == Pb - 1)
+                    q = (int)(int16_t)(2 * a - dl); // usize wrap + `as i16` (quantizer.rs:379,391)
+                else
+                    q = a > 0 ? 2 * a - dl : 0;
+                if (tc < 0) q = -q;
+            }
+            SH.r1[boff + (b == 0 ? scan0[p] : scanc[p])] = (int16_t)q;
+            const int qc = abs(q);
+            if (qc == 0) {
+                zmask |= 1u << j;
+            } else {
+                const int aw = (qc + dl) >> 1;
+                if (aw >= 1024) ovf = 1;
+                sum_nz += lv_at(c, min(aw, 1023));
+                fnz = min(fnz, p);
+            }
+            state = (0x7D28 >> (2 * (2 * state + (a & 1)))) & 3;
+        }
+    }
+    // zeros before a block's first non-zero level cost nothing: minimum per block (rows 0-1 | 2 | 3)
+    {
+        const int rm = row_min_i32(fnz);
+        const int m0 = min(__builtin_amdgcn_readlane(rm, 0), __builtin_amdgcn_readlane(rm, 16));
+        const int m1 = __builtin_amdgcn_readlane(rm, 32), m2 = __builtin_amdgcn_readlane(rm, 48);
+        const int pf = b == 0 ? m0 : (b == 1 ? m1 : m2);
+        int nz_after = 0;
+        for (int j = 0; j < per; ++j)
+            if (((zmask >> j) & 1) && p0 + j > pf) ++nz_after;
+        sum_nz += (long long)nz_after * lv_at(c, 0);
+    }
+    // level cost of the luma block (rows 0-1) and of the chroma pair (rows 2-3), three limbs each
+    {
+        const long long hi = sum_nz >> 24;
+        const int ra = row_sum_i32((int)(sum_nz & 0xFFFFFF)), rb = row_sum_i32((int)(hi & 0xFFFFFF)),
+                  rc = row_sum_i32((int)(hi >> 24));
+        const long long ya = (long long)(unsigned)(__builtin_amdgcn_readlane(ra, 0) + __builtin_amdgcn_readlane(ra, 16));
+        const long long yb = (long long)(unsigned)(__builtin_amdgcn_readlane(rb, 0) + __builtin_amdgcn_readlane(rb, 16));
+        const long long yc = (long long)(__builtin_amdgcn_readlane(rc, 0) + __builtin_amdgcn_readlane(rc, 16));
+        const long long ca = (long long)(unsigned)(__builtin_amdgcn_readlane(ra, 32) + __builtin_amdgcn_readlane(ra, 48));
+        const long long cb = (long long)(unsigned)(__builtin_amdgcn_readlane(rb, 32) + __builtin_amdgcn_readlane(rb, 48));
+        const long long cc2 = (long long)(__builtin_amdgcn_readlane(rc, 32) + __builtin_amdgcn_readlane(rc, 48));
+        *lvl_y = ya + ((yb + (yc << 24)) << 24);
+        *lvl_c = ca + ((cb + (cc2 << 24)) << 24);
+    }
+    if (__ballot(ovf != 0) != 0ULL) *overflow = 1;
+    WSYNC();
+    PROF_MARK(q3_);
+    PROF_ADD2(PH_QTRACE, q2_, q3_);
+}
+
 // levels r1 (row-major) -> transposed dequantised coefficients in r2 (dT[x][i] = d[i][x]);
 // quantizer.rs:761-1079
-__device__ __forceinline__ void dequantize_t(Ctx c, int lg, int nb) {
+__device__ __forceinline__ void dequantize_t(Ctx c, int lg, int nb, int o1 = 0) {
     c = uni(c);
     lg = uni(lg);
     nb = uni(nb);
+    o1 = uni(o1);
     const int n = 1 << lg;
     const int nn = n * n;
     const int sh = 8 + lg - 5 + 1;
@@ -1369,7 +1662,7 @@ __device__ __forceinline__ void dequantize_t(Ctx c, int lg, int nb) {
     for (int i = LANE; i < nb * nn; i += 64) {
         const int blk = i >> (2 * lg), ii = i & (nn - 1);
         const int x = ii & (n - 1), y = ii >> lg;
-        int v = ((int)SH.r1[i] * lsc + off) >> sh;
+        int v = ((int)SH.r1[o1 + i] * lsc + off) >> sh;
         v = min(max(v, -32768), 32767);
         out[blk * nn + x * n + y] = (int16_t)v;
     }
@@ -1413,34 +1706,34 @@ struct Res {
 
 __device__ __forceinline__ float uni_f(float v) { return __int_as_float(uni(__float_as_int(v))); }
 
-// predict .. reconstruct of one component (comp 0: luma block, 1: chroma pair) with `mode`
-__device__ __forceinline__ void evaluate_full(const Ctx& c, const PicBufs& pb, const Req& q, int comp, int mode,
-                                              int* overflow, uint32_t* ssd_out, long long* lvl_out) {
+// First half of a full evaluation of one component (comp 0: luma block, 1: chroma pair): reference
+// samples, prediction, forward transform.  Residual / coefficients at r1[rbase ..], prediction bytes
+// at pred_scratch[rbase ..].
+__device__ __forceinline__ void full_front(const Ctx& c, const Req& q, int comp, int mode, int rbase) {
     const int cs = comp ? 1 : 0;
     const int nb = comp ? 2 : 1;
     const int lg = q.tlg - cs;
-    *ssd_out = 0;
-    *lvl_out = 0;
-    if (!q.active) { // keep the shared-Viterbi barriers company (all waves run the same schedule)
-        PROF_MARK(ts0_);
-        quantize(c, lg, nb, q.shared, false, overflow);
-        PROF_MARK(ts1_);
-        PROF_ADD2(PH_SKIP, ts0_, ts1_);
-        return;
-    }
     PROF_MARK(tr0_);
     if ((comp ? q.refs1 : q.refs0) && mode < LT_CCLM) build_refs(c, comp, q.tx, q.ty, q.tlg);
     PROF_MARK(t0_);
     PROF_ADD2(PH_REFS, tr0_, t0_);
-    predict<true>(c, comp, q.tx, q.ty, q.tlg, mode);
+    predict<true>(c, comp, q.tx, q.ty, q.tlg, mode, rbase);
     PROF_MARK(t1_);
     PROF_ADD2(PH_PREDICT, t0_, t1_);
+    fwd_dct_lg(c, lg, nb, rbase);
+    PROF_MARK(t2_);
+    PROF_ADD2(PH_FDCT, t1_, t2_);
+}
+
+// Second half: levels at r1[rbase ..] -> (final pass: store them) -> dequantise, inverse transform,
+// reconstruct into the tile; returns the SSD against the originals (block_splitter.rs:146-185)
+__device__ __forceinline__ uint32_t full_back(const Ctx& c, const PicBufs& pb, const Req& q, int comp, int rbase) {
+    const int cs = comp ? 1 : 0;
+    const int nb = comp ? 2 : 1;
+    const int lg = q.tlg - cs;
     const int n = 1 << lg;
     const int nn = n * n;
     const int cx = q.tx >> cs, cy = q.ty >> cs;
-    fwd_dct_lg(c, lg, nb);
-    PROF_MARK(t2_);
-    *lvl_out = quantize(c, lg, nb, q.shared, true, overflow);
     PROF_MARK(t3_);
     if (q.final && c.write) {
         const int stride = c.W >> cs;
@@ -1449,14 +1742,13 @@ __device__ __forceinline__ void evaluate_full(const Ctx& c, const PicBufs& pb, c
         GLOBAL_AS int16_t* lev1 = AS_GLOBAL(int16_t, pb.lev[0]) + plane_off(c, 2) + at;
         for (int i = LANE; i < nb * nn; i += 64) {
             const int blk = i >> (2 * lg), ii = i & (nn - 1);
-            (blk ? lev1 : lev0)[(size_t)(ii >> lg) * stride + (ii & (n - 1))] = SH.r1[i];
+            (blk ? lev1 : lev0)[(size_t)(ii >> lg) * stride + (ii & (n - 1))] = SH.r1[rbase + i];
         }
     }
-    dequantize_t(c, lg, nb);
+    dequantize_t(c, lg, nb, rbase);
     PROF_MARK(t4_);
-    inv_dct_lg(c, lg, nb);
+    inv_dct_lg(c, lg, nb, rbase);
     PROF_MARK(t5_);
-    PROF_ADD2(PH_FDCT, t1_, t2_);
     PROF_ADD2(PH_DEQ, t3_, t4_);
     PROF_ADD2(PH_IDCT, t4_, t5_);
     unsigned int part = 0;
@@ -1465,14 +1757,14 @@ __device__ __forceinline__ void evaluate_full(const Ctx& c, const PicBufs& pb, c
         const int blk = i >> (2 * lg), ii = i & (nn - 1);
         const int x = ii & (n - 1), y = ii >> lg;
         const int pc = comp + blk;
-        int v = (int16_t)((int)c.pred_scratch[i] + (int)SH.r1[i]); // pred as i16 + res, clamp (:178)
+        int v = (int16_t)((int)c.pred_scratch[rbase + i] + (int)SH.r1[rbase + i]); // pred as i16 + res, clamp (:178)
         v = min(max(v, 0), 255);
         if (q.final && v != rec_get(pc, cx + x, cy + y)) ++diff;
         rec_put(pc, cx + x, cy + y, v);
         const int d = v - org_get(c, pc, cx + x, cy + y);
         part += (unsigned)(d * d);
     }
-    *ssd_out = (uint32_t)wave_sum_i32((int)part); // <= 1024 * 255^2: fits 32 bits
+    const uint32_t ssd = (uint32_t)wave_sum_i32((int)part); // <= 1024 * 255^2: fits 32 bits
     if (q.final) {
         const int changed = wave_sum_i32(diff);
         if (changed && LANE == 0 && c.write) atomicAdd(c.mismatch, (unsigned long long)changed);
@@ -1480,6 +1772,7 @@ __device__ __forceinline__ void evaluate_full(const Ctx& c, const PicBufs& pb, c
     WSYNC();
     PROF_MARK(t6_);
     PROF_ADD2(PH_RECON, t5_, t6_);
+    return ssd;
 }
 
 // Save the reconstruction of a block (comps bit 0: luma n x n, bit 1: Cb and Cr (n/2) x (n/2)) from
@@ -1529,18 +1822,45 @@ __device__ __forceinline__ Res evaluate(const Ctx& c, const PicBufs& pb, const R
     if (q.pre_copy != COPY_NONE) copy_block(c, q.pre_copy, q.copy_comps, q.copy_slot, q.copy_tx, q.copy_ty, q.copy_tlg);
     if (q.kind == K_NOP) return r;
     if (q.kind == K_FULL) {
+        // A candidate of the search with an 8x8 or 16x16 luma block quantises its three transform
+        // blocks in one pooled pass (quantize3): both components go through the first half, then
+        // the pass, then both through the second half.  Everything else runs component by component
+        // (the two share r1 / r2).  One copy of each stage either way.
+        const bool merged = WPB == 8 && q.shared && q.comps == 3 && q.tlg <= 4;
+        const int p0 = 1 << (2 * q.tlg);
+        const int rounds = merged ? 1 : 2;
 #pragma unroll 1
-        for (int comp = 0; comp < 2; ++comp) {
-            if (!((q.comps >> comp) & 1)) continue;
-            uint32_t ssd;
-            long long lvl;
-            evaluate_full(c, pb, q, comp, comp ? q.mc : q.ml, overflow, &ssd, &lvl);
-            if (comp) {
-                r.ssd_c = ssd;
-                r.lvl_c = lvl;
+        for (int round = 0; round < rounds; ++round) {
+            const int cset = merged ? 3 : (q.comps & (1 << round));
+            if (!cset) continue;
+            if (q.active) {
+#pragma unroll 1
+                for (int comp = 0; comp < 2; ++comp)
+                    if ((cset >> comp) & 1) full_front(c, q, comp, comp ? q.mc : q.ml, (merged && comp) ? p0 : 0);
+            }
+            PROF_MARK(ts0_);
+            if (merged) {
+                quantize3(c, q.tlg, q.active, overflow, &r.lvl_y, &r.lvl_c);
             } else {
-                r.ssd_y = ssd;
-                r.lvl_y = lvl;
+                const long long lvl = quantize(c, q.tlg - round, round ? 2 : 1, q.shared, q.active, overflow);
+                if (round)
+                    r.lvl_c = lvl;
+                else
+                    r.lvl_y = lvl;
+            }
+            PROF_MARK(ts1_);
+            if (!q.active) { // only kept the shared-Viterbi barriers company
+                PROF_ADD2(PH_SKIP, ts0_, ts1_);
+                continue;
+            }
+#pragma unroll 1
+            for (int comp = 0; comp < 2; ++comp) {
+                if (!((cset >> comp) & 1)) continue;
+                const uint32_t ssd = full_back(c, pb, q, comp, (merged && comp) ? p0 : 0);
+                if (comp)
+                    r.ssd_c = ssd;
+                else
+                    r.ssd_y = ssd;
             }
         }
         return r;
