@@ -1044,18 +1044,42 @@ __device__ __forceinline__ int dpp_quad(int v) {
     return __builtin_amdgcn_mov_dpp(v, CTRL, 0xF, 0xF, true);
 }
 
-__device__ __forceinline__ int dec_nib(const uint16_t* dec16, int p) {
-    const uint16_t* g = dec16 + (p >> 4) * 4;
+// Decisions of the 16 positions of one sub-block: one 16-bit mask per state (bit k = position k
+// takes a0 + 1 when it is reached in that state), two dwords.
+struct DecMasks {
+    uint32_t m01, m23;
+};
+__device__ __forceinline__ DecMasks dec_masks(const uint16_t* dec16, int p) {
+    const uint2 v = *(const uint2*)(dec16 + (p >> 4) * 4);
+    DecMasks m;
+    m.m01 = v.x;
+    m.m23 = v.y;
+    return m;
+}
+__device__ __forceinline__ int dec_nib(DecMasks m, int p) { // bit s = decision of position p in state s
     const int k = p & 15;
-    return ((g[0] >> k) & 1) | (((g[1] >> k) & 1) << 1) | (((g[2] >> k) & 1) << 2) | (((g[3] >> k) & 1) << 3);
+    const uint32_t t01 = m.m01 >> k, t23 = m.m23 >> k;
+    return (int)((t01 & 1u) | ((t01 >> 15) & 2u) | ((t23 & 1u) << 2) | ((t23 >> 13) & 8u));
 }
 
+// State maps {0..3} -> {0..3} are kept as one byte per state, so that composing two maps is one
+// byte permute (v_perm_b32): (g2 o g1)(s) = g2[g1[s]].
+constexpr int kMapId = 0x03020100;
 __device__ __forceinline__ int compose_map(int g2, int g1) {
-    // (g2 o g1)(s) = g2[g1[s]]; maps {0..3}->{0..3} packed 2 bits per entry
-    int r = 0;
-#pragma unroll
-    for (int s = 0; s < 4; ++s) r |= ((g2 >> (2 * ((g1 >> (2 * s)) & 3))) & 3) << (2 * s);
-    return r;
+    return (int)__builtin_amdgcn_perm(0u, (uint32_t)g2, (uint32_t)g1);
+}
+// map of one position: state s goes to q_state_trans_table[s][parity of a_s] (encoder_context.rs:339),
+// a_s = a0 of the state's delta class + the position's decision in state s; the table entry is
+// (s >> 1) + 2 * (parity ^ (s & 1))
+__device__ __forceinline__ int position_map(int tc, int qd, bool dcn, int nib) {
+    int pv = 0; // bit s = parity of a_s
+    if (tc != 0) {
+        const int b0 = (qd >> 1) & 1;
+        const int b1 = dcn ? b0 : (((qd + 1) >> 1) & 1);
+        pv = nib ^ (b0 ? 3 : 0) ^ (b1 ? 12 : 0);
+    }
+    const unsigned x = (unsigned)(pv ^ 10);
+    return (int)(0x01010000u + (((x * 0x00204081u) & 0x01010101u) << 1));
 }
 
 // Path costs are kept in 32 bits, DOUBLED, with the tie-break of quantizer.rs:505 in the low bit.
@@ -1282,20 +1306,12 @@ __device__ __forceinline__ long long quantize(Ctx c, int lg, int nb, bool shared
     const int16_t* btcs = tcs + blk * P;
     const int16_t* bqds = qds + blk * P;
     const uint16_t* bdec = dec16 + blk * (P >> 2);
-    int fmap = 0xE4; // identity map
+    int fmap = kMapId;
+    const DecMasks dm = dec_masks(bdec, act ? p0 : 0); // a lane's positions lie in one sub-block (per divides 16)
     if (act) {
         for (int j = 0; j < per; ++j) {
             const int p = p0 + j;
-            const int tc = btcs[p], qd = bqds[p], nib = dec_nib(bdec, p);
-            int g = 0;
-#pragma unroll
-            for (int sidx = 0; sidx < 4; ++sidx) {
-                const int dl = sidx > 1 ? 1 : 0;
-                int a = 0;
-                if (tc != 0) a = ((p == P - 1) ? (qd >> 1) : ((qd + dl) >> 1)) + ((nib >> sidx) & 1);
-                g |= ((0x7D28 >> (2 * (2 * sidx + (a & 1)))) & 3) << (2 * sidx);
-            }
-            fmap = compose_map(g, fmap);
+            fmap = compose_map(position_map(btcs[p], bqds[p], p == P - 1, dec_nib(dm, p)), fmap);
         }
     }
     // inclusive prefix composition across the lanes of a block: Hillis-Steele inside the 16-lane rows
@@ -1303,12 +1319,12 @@ __device__ __forceinline__ long long quantize(Ctx c, int lg, int nb, bool shared
     // travel with row_bcast:15 / row_bcast:31 (the two blocks of a chroma pair are lanes 0..31 and
     // 32..63, so they simply skip the last step).  No LDS-crossbar shuffles.
     int pre = fmap;
-    pre = compose_map(pre, __builtin_amdgcn_update_dpp(0xE4, pre, 0x111, 0xF, 0xF, false)); // row_shr:1
-    pre = compose_map(pre, __builtin_amdgcn_update_dpp(0xE4, pre, 0x112, 0xF, 0xF, false)); // row_shr:2
-    pre = compose_map(pre, __builtin_amdgcn_update_dpp(0xE4, pre, 0x114, 0xF, 0xF, false)); // row_shr:4
-    pre = compose_map(pre, __builtin_amdgcn_update_dpp(0xE4, pre, 0x118, 0xF, 0xF, false)); // row_shr:8
-    pre = compose_map(pre, __builtin_amdgcn_update_dpp(0xE4, pre, 0x142, 0xA, 0xF, false)); // row_bcast:15 -> rows 1, 3
-    if (nb == 1) pre = compose_map(pre, __builtin_amdgcn_update_dpp(0xE4, pre, 0x143, 0xC, 0xF, false)); // row_bcast:31 -> rows 2, 3
+    pre = compose_map(pre, __builtin_amdgcn_update_dpp(kMapId, pre, 0x111, 0xF, 0xF, false)); // row_shr:1
+    pre = compose_map(pre, __builtin_amdgcn_update_dpp(kMapId, pre, 0x112, 0xF, 0xF, false)); // row_shr:2
+    pre = compose_map(pre, __builtin_amdgcn_update_dpp(kMapId, pre, 0x114, 0xF, 0xF, false)); // row_shr:4
+    pre = compose_map(pre, __builtin_amdgcn_update_dpp(kMapId, pre, 0x118, 0xF, 0xF, false)); // row_shr:8
+    pre = compose_map(pre, __builtin_amdgcn_update_dpp(kMapId, pre, 0x142, 0xA, 0xF, false)); // row_bcast:15 -> rows 1, 3
+    if (nb == 1) pre = compose_map(pre, __builtin_amdgcn_update_dpp(kMapId, pre, 0x143, 0xC, 0xF, false)); // row_bcast:31 -> rows 2, 3
     // state after all previous lanes of the block, starting from 0
     int entry = __builtin_amdgcn_update_dpp(0, pre, 0x138, 0xF, 0xF, false) & 3; // wave_shr:1
     if (lane_in == 0) entry = 0;
@@ -1319,7 +1335,7 @@ __device__ __forceinline__ long long quantize(Ctx c, int lg, int nb, bool shared
         int state = entry;
         for (int j = 0; j < per; ++j) {
             const int p = p0 + j;
-            const int tc = btcs[p], qd = bqds[p], nib = dec_nib(bdec, p);
+            const int tc = btcs[p], qd = bqds[p], nib = dec_nib(dm, p);
             const int dl = state > 1 ? 1 : 0;
             int q = 0, a = 0;
             if (tc != 0) {
@@ -1562,26 +1578,18 @@ __device__ __forceinline__ void quantize3(Ctx c, int lg0, bool active, int* over
     const int16_t* btcs = tcs + boff;
     const int16_t* bqds = qds + boff;
     const uint16_t* bdec = (const uint16_t*)SH.decw + (b == 0 ? 0 : (b == 1 ? (P0 >> 2) : (P0 >> 2) + (Pc >> 2)));
-    int fmap = 0xE4; // identity map
+    int fmap = kMapId;
+    const DecMasks dm = dec_masks(bdec, p0); // a lane's positions lie in one sub-block (per divides 16)
     for (int j = 0; j < per; ++j) {
         const int p = p0 + j;
-        const int tc = btcs[p], qd = bqds[p], nib = dec_nib(bdec, p);
-        int g = 0;
-#pragma unroll
-        for (int sidx = 0; sidx < 4; ++sidx) {
-            const int dl = sidx > 1 ? 1 : 0;
-            int a = 0;
-            if (tc != 0) a = ((p == Pb - 1) ? (qd >> 1) : ((qd + dl) >> 1)) + ((nib >> sidx) & 1);
-            g |= ((0x7D28 >> (2 * (2 * sidx + (a & 1)))) & 3) << (2 * sidx);
-        }
-        fmap = compose_map(g, fmap);
+        fmap = compose_map(position_map(btcs[p], bqds[p], p == Pb - 1, dec_nib(dm, p)), fmap);
     }
     int pre = fmap;
-    pre = compose_map(pre, __builtin_amdgcn_update_dpp(0xE4, pre, 0x111, 0xF, 0xF, false)); // row_shr:1
-    pre = compose_map(pre, __builtin_amdgcn_update_dpp(0xE4, pre, 0x112, 0xF, 0xF, false)); // row_shr:2
-    pre = compose_map(pre, __builtin_amdgcn_update_dpp(0xE4, pre, 0x114, 0xF, 0xF, false)); // row_shr:4
-    pre = compose_map(pre, __builtin_amdgcn_update_dpp(0xE4, pre, 0x118, 0xF, 0xF, false)); // row_shr:8
-    pre = compose_map(pre, __builtin_amdgcn_update_dpp(0xE4, pre, 0x142, 0x2, 0xF, false)); // row_bcast:15 -> row 1 (luma)
+    pre = compose_map(pre, __builtin_amdgcn_update_dpp(kMapId, pre, 0x111, 0xF, 0xF, false)); // row_shr:1
+    pre = compose_map(pre, __builtin_amdgcn_update_dpp(kMapId, pre, 0x112, 0xF, 0xF, false)); // row_shr:2
+    pre = compose_map(pre, __builtin_amdgcn_update_dpp(kMapId, pre, 0x114, 0xF, 0xF, false)); // row_shr:4
+    pre = compose_map(pre, __builtin_amdgcn_update_dpp(kMapId, pre, 0x118, 0xF, 0xF, false)); // row_shr:8
+    pre = compose_map(pre, __builtin_amdgcn_update_dpp(kMapId, pre, 0x142, 0x2, 0xF, false)); // row_bcast:15 -> row 1 (luma)
     int entry = __builtin_amdgcn_update_dpp(0, pre, 0x138, 0xF, 0xF, false) & 3; // wave_shr:1
     if (lane_in == 0) entry = 0;
     long long sum_nz = 0;
@@ -1591,7 +1599,7 @@ __device__ __forceinline__ void quantize3(Ctx c, int lg0, bool active, int* over
         int state = entry;
         for (int j = 0; j < per; ++j) {
             const int p = p0 + j;
-            const int tc = btcs[p], qd = bqds[p], nib = dec_nib(bdec, p);
+            const int tc = btcs[p], qd = bqds[p], nib = dec_nib(dm, p);
             const int dl = state > 1 ? 1 : 0;
             int q = 0, a = 0;
             if (tc != 0) {
