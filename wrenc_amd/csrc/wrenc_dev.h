@@ -1098,6 +1098,62 @@ __device__ __forceinline__ int position_map(int tc, int qd, bool dcn, int nib) {
 // single comparison KB < KA (KA = u + CA, KB = w + CB) is exact: choseB == pick1 ^ par.
 constexpr int kNoBranch = 1 << 27;
 
+// lambda_q * dq_table[idx] (quantizer.rs:29-31): the first 256 entries are in LDS; larger levels are
+// rare, and a wave without any takes no branch
+__device__ __forceinline__ int ldq_fast(const Ctx& c, int idx) {
+    int v = SHT.ldq[min(idx, 255)];
+    if (__ballot(idx > 255) != 0ULL) {
+        if (idx > 255) v = (int)c.k->ldq[idx];
+    }
+    return v;
+}
+
+// Chunk entry of one position (see the comment above kNoBranch): writes (u, w) of the three state
+// classes, returns the parities of a0 in the two delta classes and the state-0 "kept zero inside the
+// trailing run" flag.  Branch-free apart from the rare large-level table reads.
+//   tc, qd: coefficient and quotient of the position; dcn: the DC position (p == P - 1), whose
+//   levels wrap through i16 (quantizer.rs:378-391); tzp: p <= istar; sh / off / lsc: quantiser scale
+__device__ __forceinline__ void chunk_entry(const Ctx& c, int* en, int tc, int qd, bool dcn, bool tzp, int sh, int off,
+                                            int lsc, int ldq1, int* par0_out, int* par1_out, int* adj_out,
+                                            int* ovf) {
+    const bool nz = tc != 0;
+    int c0d[2], c1d[2], par[2];
+#pragma unroll
+    for (int d = 0; d < 2; ++d) {
+        const int a0 = (qd + (dcn ? 0 : d)) >> 1; // quantizer.rs:378 / :441
+        const int a1 = a0 + 1;
+        // 2*a - d fits i16, so the reference's `as i16` only matters for a0 = 0, d = 1 at the DC position (-1)
+        int q0 = (a0 > 0 || dcn) ? 2 * a0 - d : 0;
+        int q1 = 2 * a1 - d;
+        if (tc < 0) {
+            q0 = -q0;
+            q1 = -q1;
+        }
+        const int d0 = abs(tc - ((q0 * lsc + off) >> sh));
+        const int d1 = abs(tc - ((q1 * lsc + off) >> sh));
+        if (nz && a1 + 1 >= 1024) *ovf = 1;
+        const int l0 = ldq_fast(c, min(a0 + 1, 1023)), l1 = ldq_fast(c, min(a1 + 1, 1023));
+        c0d[d] = nz ? 128 * d0 + l0 : ldq1;       // zero coefficient outside the trailing run: dq_table[1] (:433)
+        c1d[d] = nz ? 128 * d1 + l1 : kNoBranch;
+        par[d] = nz ? (a0 & 1) : 0;               // parity of a0 -> which successor state
+    }
+    const int a00 = qd >> 1;                      // a0 of delta class 0
+    const bool zero0 = !nz || a00 == 0;
+    // bits 0 instead of 1 for a zero kept inside the trailing run (:449-453)
+    const int c0tz = nz ? (a00 == 0 ? c0d[0] - ldq1 : c0d[0]) : 0;
+    const int c0s0 = tzp ? c0tz : c0d[0];
+    const int p0 = par[0], p1 = par[1];
+    en[0] = 2 * (p0 ? c1d[0] : c0s0) + p0;
+    en[1] = 2 * (p0 ? c0s0 : c1d[0]) + 1 - p0;
+    en[2] = 2 * (p0 ? c1d[0] : c0d[0]) + p0;
+    en[3] = 2 * (p0 ? c0d[0] : c1d[0]) + 1 - p0;
+    en[4] = 2 * (p1 ? c1d[1] : c0d[1]) + p1;
+    en[5] = 2 * (p1 ? c0d[1] : c1d[1]) + 1 - p1;
+    *par0_out = p0;
+    *par1_out = p1;
+    *adj_out = (tzp && zero0) ? 1 : 0;
+}
+
 // Dependent quantisation of nb transform blocks of side n (nb = 1 luma, 2 = Cb+Cr pair):
 // coefficients r1 ([blk][y][x]) -> levels in place; returns the summed level cost
 // (block_splitter.rs:436-458).  Scratch: r2, decw.  `*overflow` is set when a level needs a table
@@ -1184,57 +1240,9 @@ __device__ __forceinline__ long long quantize(Ctx c, int lg, int nb, bool shared
             const int i = LANE - blk * CH;
             const int p = base + i;
             int par0 = 0, par1 = 0, adj = 0;
-            if (mine) {
-                const int tc = tcs[blk * P + p];
-                const int qd = qds[blk * P + p];
-                const bool dcn = p == P - 1;
-                const bool tzp = p <= (blk ? istar1 : istar0); // inside the trailing run (matters to state 0)
-                int c0d[2], c1d[2], c0tz = 0;
-#pragma unroll
-                for (int d = 0; d < 2; ++d) {
-                    int c0, c1;
-                    if (tc != 0) {
-                        const int a0 = dcn ? (qd >> 1) : ((qd + d) >> 1); // quantizer.rs:378 / :441
-                        int q0 = dcn ? (int)(int16_t)(2 * a0 - d) : (a0 > 0 ? 2 * a0 - d : 0);
-                        const int a1 = a0 + 1;
-                        int q1 = dcn ? (int)(int16_t)(2 * a1 - d) : 2 * a1 - d;
-                        if (tc < 0) {
-                            q0 = dcn ? (int)(int16_t)(-q0) : -q0;
-                            q1 = dcn ? (int)(int16_t)(-q1) : -q1;
-                        }
-                        const int d0 = abs(tc - ((q0 * lsc + off) >> sh));
-                        const int d1 = abs(tc - ((q1 * lsc + off) >> sh));
-                        if (a1 + 1 >= 1024) ovf = 1;
-                        c0 = (int)(128LL * d0 + ldq_at(c, min(a0 + 1, 1023)));
-                        c1 = (int)(128LL * d1 + ldq_at(c, min(a1 + 1, 1023)));
-                        if (d == 0) {
-                            par0 = a0 & 1; // parity of a0 -> which successor state
-                            adj = (tzp && a0 == 0) ? 1 : 0;
-                            c0tz = a0 == 0 ? c0 - ldq1 : c0; // bits 0 instead of 1 in the trailing run (:449-453)
-                        } else {
-                            par1 = a0 & 1;
-                        }
-                    } else {
-                        c0 = ldq1; // zero coefficient outside the trailing run: dq_table[1] (:433)
-                        c1 = kNoBranch;
-                        if (d == 0) {
-                            adj = tzp ? 1 : 0;
-                            c0tz = 0;
-                        }
-                    }
-                    c0d[d] = c0;
-                    c1d[d] = c1;
-                }
-                const int c0s0 = tzp ? c0tz : c0d[0];
-                // u goes with C[trans[s][0]]: c0 if par == 0, else c1; tie bit: the side of K1 gets +1
-                int* e = cc + LANE * 6;
-                e[0] = 2 * (par0 ? c1d[0] : c0s0) + par0;
-                e[1] = 2 * (par0 ? c0s0 : c1d[0]) + 1 - par0;
-                e[2] = 2 * (par0 ? c1d[0] : c0d[0]) + par0;
-                e[3] = 2 * (par0 ? c0d[0] : c1d[0]) + 1 - par0;
-                e[4] = 2 * (par1 ? c1d[1] : c0d[1]) + par1;
-                e[5] = 2 * (par1 ? c0d[1] : c1d[1]) + 1 - par1;
-            }
+            if (mine)
+                chunk_entry(c, cc + LANE * 6, tcs[blk * P + p], qds[blk * P + p], p == P - 1, p <= (blk ? istar1 : istar0),
+                            sh, off, lsc, ldq1, &par0, &par1, &adj, &ovf);
             const unsigned long long b0 = __ballot(mine && par0), b1 = __ballot(mine && par1), ba = __ballot(mine && adj);
             if (mine && (LANE & 15) == 0) {
                 uint16_t* pm = SH.q_pm[blk][i >> 4];
@@ -1462,55 +1470,9 @@ __device__ __forceinline__ void quantize3(Ctx c, int lg0, bool active, int* over
                 int par0 = 0, par1 = 0, adj = 0;
                 if (mine) {
                     const int sh = b == 0 ? sh0 : shc;
-                    const int off = (1 << sh) >> 1;
-                    const int tc = tcs[gidx];
-                    const int qd = qds[gidx];
-                    const bool dcn = p == Pb - 1;
-                    const bool tzp = p <= (b == 0 ? istar0 : (b == 1 ? istar1 : istar2));
-                    int c0d[2], c1d[2], c0tz = 0;
-#pragma unroll
-                    for (int d = 0; d < 2; ++d) {
-                        int c0, c1;
-                        if (tc != 0) {
-                            const int a0 = dcn ? (qd >> 1) : ((qd + d) >> 1); // quantizer.rs:378 / :441
-                            int q0 = dcn ? (int)(int16_t)(2 * a0 - d) : (a0 > 0 ? 2 * a0 - d : 0);
-                            const int a1 = a0 + 1;
-                            int q1 = dcn ? (int)(int16_t)(2 * a1 - d) : 2 * a1 - d;
-                            if (tc < 0) {
-                                q0 = dcn ? (int)(int16_t)(-q0) : -q0;
-                                q1 = dcn ? (int)(int16_t)(-q1) : -q1;
-                            }
-                            const int d0 = abs(tc - ((q0 * lsc + off) >> sh));
-                            const int d1 = abs(tc - ((q1 * lsc + off) >> sh));
-                            if (a1 + 1 >= 1024) ovf = 1;
-                            c0 = (int)(128LL * d0 + ldq_at(c, min(a0 + 1, 1023)));
-                            c1 = (int)(128LL * d1 + ldq_at(c, min(a1 + 1, 1023)));
-                            if (d == 0) {
-                                par0 = a0 & 1;
-                                adj = (tzp && a0 == 0) ? 1 : 0;
-                                c0tz = a0 == 0 ? c0 - ldq1 : c0; // :449-453
-                            } else {
-                                par1 = a0 & 1;
-                            }
-                        } else {
-                            c0 = ldq1; // :433
-                            c1 = kNoBranch;
-                            if (d == 0) {
-                                adj = tzp ? 1 : 0;
-                                c0tz = 0;
-                            }
-                        }
-                        c0d[d] = c0;
-                        c1d[d] = c1;
-                    }
-                    const int c0s0 = tzp ? c0tz : c0d[0];
-                    int* en = cc + e * 6;
-                    en[0] = 2 * (par0 ? c1d[0] : c0s0) + par0;
-                    en[1] = 2 * (par0 ? c0s0 : c1d[0]) + 1 - par0;
-                    en[2] = 2 * (par0 ? c1d[0] : c0d[0]) + par0;
-                    en[3] = 2 * (par0 ? c0d[0] : c1d[0]) + 1 - par0;
-                    en[4] = 2 * (par1 ? c1d[1] : c0d[1]) + par1;
-                    en[5] = 2 * (par1 ? c0d[1] : c1d[1]) + 1 - par1;
+                    chunk_entry(c, cc + e * 6, tcs[gidx], qds[gidx], p == Pb - 1,
+                                p <= (b == 0 ? istar0 : (b == 1 ? istar1 : istar2)), sh, (1 << sh) >> 1, lsc, ldq1, &par0,
+                                &par1, &adj, &ovf);
                 }
                 const unsigned long long b0 = __ballot(mine && par0), b1 = __ballot(mine && par1),
                                          ba = __ballot(mine && adj);
