@@ -1154,6 +1154,39 @@ __device__ __forceinline__ void chunk_entry(const Ctx& c, int* en, int tc, int q
     *adj_out = (tzp && zero0) ? 1 : 0;
 }
 
+// level-cost table (block_splitter.rs:436-458), same access pattern as ldq_fast
+__device__ __forceinline__ int lv_fast(const Ctx& c, int a) {
+    int v = SHT.lv[min(a, 255)];
+    if (__ballot(a > 255) != 0ULL) {
+        if (a > 255) v = (int)c.k->lv[a];
+    }
+    return v;
+}
+
+// One position of the forward trace (quantizer.rs:686-721) in `state`: returns the level, advances the
+// state, and accumulates the level-cost terms of the position (block_splitter.rs:436-458): the
+// table cost of a non-zero level, a bit in zmask for a zero, the first non-zero position.
+__device__ __forceinline__ int emit_level(const Ctx& c, int tc, int qd, bool dcn, int nib, int p, int j, int& state,
+                                          unsigned& zmask, long long& sum_nz, int& fnz, int& ovf) {
+    const int dl = state > 1 ? 1 : 0;
+    const bool nz = tc != 0;
+    const int a = nz ? ((qd + (dcn ? 0 : dl)) >> 1) + ((nib >> state) & 1) : 0;
+    // 2*a - dl fits i16: the reference's usize wrap + `as i16` (quantizer.rs:379,391) only shows for
+    // a = 0, dl = 1 at the DC position (-1)
+    int q = (nz && (a > 0 || dcn)) ? 2 * a - dl : 0;
+    if (tc < 0) q = -q;
+    const int qc = abs(q);
+    const bool zero = qc == 0;
+    zmask |= (zero ? 1u : 0u) << j;
+    const int aw = (qc + dl) >> 1;
+    if (!zero && aw >= 1024) ovf = 1;
+    const int lv = lv_fast(c, min(aw, 1023));
+    sum_nz += zero ? 0 : lv;
+    fnz = zero ? fnz : min(fnz, p);
+    state = (0x7D28 >> (2 * (2 * state + (a & 1)))) & 3;
+    return q;
+}
+
 // Dependent quantisation of nb transform blocks of side n (nb = 1 luma, 2 = Cb+Cr pair):
 // coefficients r1 ([blk][y][x]) -> levels in place; returns the summed level cost
 // (block_splitter.rs:436-458).  Scratch: r2, decw.  `*overflow` is set when a level needs a table
@@ -1343,37 +1376,13 @@ __device__ __forceinline__ long long quantize(Ctx c, int lg, int nb, bool shared
         int state = entry;
         for (int j = 0; j < per; ++j) {
             const int p = p0 + j;
-            const int tc = btcs[p], qd = bqds[p], nib = dec_nib(dm, p);
-            const int dl = state > 1 ? 1 : 0;
-            int q = 0, a = 0;
-            if (tc != 0) {
-                a = ((p == P - 1) ? (qd >> 1) : ((qd + dl) >> 1)) + ((nib >> state) & 1);
-                if (p == P - 1)
-                    q = (int)(int16_t)(2 * a - dl); // usize wrap + `as i16` (quantizer.rs:379,391)
-                else
-                    q = a > 0 ? 2 * a - dl : 0;
-                if (tc < 0) q = -q;
-            }
-            SH.r1[blk * P + scan[p]] = (int16_t)q;
-            const int qc = abs(q);
-            if (qc == 0) {
-                zmask |= 1u << j;
-            } else {
-                const int aw = (qc + dl) >> 1;
-                if (aw >= 1024) ovf = 1;
-                sum_nz += lv_at(c, min(aw, 1023));
-                fnz = min(fnz, p);
-            }
-            state = (0x7D28 >> (2 * (2 * state + (a & 1)))) & 3;
+            SH.r1[blk * P + scan[p]] =
+                (int16_t)emit_level(c, btcs[p], bqds[p], p == P - 1, dec_nib(dm, p), p, j, state, zmask, sum_nz, fnz, ovf);
         }
     }
     const int pf = group_min_i32(fnz, half); // zeros before a block's first non-zero level cost nothing
-    if (act) {
-        int nz_after = 0;
-        for (int j = 0; j < per; ++j)
-            if (((zmask >> j) & 1) && p0 + j > pf) ++nz_after;
-        sum_nz += (long long)nz_after * lv_at(c, 0);
-    }
+    if (act) // zeros after the first non-zero position: positions j > pf - p0 of this lane
+        sum_nz += (long long)__popc(zmask >> min(max(pf - p0 + 1, 0), 16)) * SHT.lv[0];
     const long long sum = wave_sum_i64(sum_nz);
     if (__ballot(ovf != 0) != 0ULL) *overflow = 1;
     WSYNC();
@@ -1561,28 +1570,8 @@ __device__ __forceinline__ void quantize3(Ctx c, int lg0, bool active, int* over
         int state = entry;
         for (int j = 0; j < per; ++j) {
             const int p = p0 + j;
-            const int tc = btcs[p], qd = bqds[p], nib = dec_nib(dm, p);
-            const int dl = state > 1 ? 1 : 0;
-            int q = 0, a = 0;
-            if (tc != 0) {
-                a = ((p == Pb - 1) ? (qd >> 1) : ((qd + dl) >> 1)) + ((nib >> state) & 1);
-                if (p == Pb - 1)
-                    q = (int)(int16_t)(2 * a - dl); // usize wrap + `as i16` (quantizer.rs:379,391)
-                else
-                    q = a > 0 ? 2 * a - dl : 0;
-                if (tc < 0) q = -q;
-            }
-            SH.r1[boff + (b == 0 ? scan0[p] : scanc[p])] = (int16_t)q;
-            const int qc = abs(q);
-            if (qc == 0) {
-                zmask |= 1u << j;
-            } else {
-                const int aw = (qc + dl) >> 1;
-                if (aw >= 1024) ovf = 1;
-                sum_nz += lv_at(c, min(aw, 1023));
-                fnz = min(fnz, p);
-            }
-            state = (0x7D28 >> (2 * (2 * state + (a & 1)))) & 3;
+            SH.r1[boff + (b == 0 ? scan0[p] : scanc[p])] =
+                (int16_t)emit_level(c, btcs[p], bqds[p], p == Pb - 1, dec_nib(dm, p), p, j, state, zmask, sum_nz, fnz, ovf);
         }
     }
     // zeros before a block's first non-zero level cost nothing: minimum per block (rows 0-1 | 2 | 3)
@@ -1591,10 +1580,7 @@ __device__ __forceinline__ void quantize3(Ctx c, int lg0, bool active, int* over
         const int m0 = min(__builtin_amdgcn_readlane(rm, 0), __builtin_amdgcn_readlane(rm, 16));
         const int m1 = __builtin_amdgcn_readlane(rm, 32), m2 = __builtin_amdgcn_readlane(rm, 48);
         const int pf = b == 0 ? m0 : (b == 1 ? m1 : m2);
-        int nz_after = 0;
-        for (int j = 0; j < per; ++j)
-            if (((zmask >> j) & 1) && p0 + j > pf) ++nz_after;
-        sum_nz += (long long)nz_after * lv_at(c, 0);
+        sum_nz += (long long)__popc(zmask >> min(max(pf - p0 + 1, 0), 16)) * SHT.lv[0];
     }
     // level cost of the luma block (rows 0-1) and of the chroma pair (rows 2-3), three limbs each
     {
