@@ -846,7 +846,6 @@ __device__ __forceinline__ int predict(Ctx c, int comp, int tx, int ty, int tlg,
         const int o = pred_org<full>(c, comp + blk, cx + x, cy + y, obase, i); // issued early
         const int16_t* L = SH.refs + (blk ? R_LC1 : oL0);
         const int16_t* A = SH.refs + (blk ? R_AC1 : oA0);
-        const int alrs = L[0];
         int v;
         {
             const int along = vertical ? y : x, across = vertical ? x : y;
@@ -869,16 +868,16 @@ __device__ __forceinline__ int predict(Ctx c, int comp, int tx, int ty, int tlg,
                 }
                 const int acc = f0 * tap[0] + f1 * tap[1] + f2 * tap[2] + f3 * tap[3];
                 v = min(max((acc + 32) >> 6, 0), 255);
-            } else if (i_fact != 0) {
-                v = (((32 - i_fact) * tap[1] + i_fact * tap[2] + 16) >> 5) & 0xFF;
             } else {
-                v = tap[1] & 0xFF;
+                // i_fact == 0 gives tap[1] itself; a convex combination of 8-bit samples needs no `& 0xFF`
+                v = ((32 - i_fact) * tap[1] + i_fact * tap[2] + 16) >> 5;
             }
         }
         if (do_pdpc) {
             // intra_predictor.rs:355-757; left[] = L+1, above[] = A
             int rl = 0, rt = 0, wl = 0, wt = 0;
             if (mode == 18 || mode == 50) {
+                const int alrs = L[0];
                 rl = (int16_t)(L[y + 1] - alrs + v);
                 rt = (int16_t)(A[x] - alrs + v);
                 wl = mode == 50 ? pdpc_w(n_scale, x) : 0;
@@ -1828,31 +1827,38 @@ __device__ __forceinline__ Res evaluate(const Ctx& c, const PicBufs& pb, const R
     stage_org(c, q.comps, q.tx, q.ty, q.tlg);
     PROF_MARK(t0_);
     PROF_ADD2(PH_REFS, tr0_, t0_);
+    // SADs stay integers (< 2^20, so the f32 the reference compares is exact and ordered the same
+    // way); they become floats once, at the end.  An entry that is not evaluated costs f32::MAX.
+    constexpr unsigned kNoSad = 0xFFFFFFFFu;
+    unsigned s0 = kNoSad, s1 = kNoSad, s2 = kNoSad, smin = kNoSad;
 #pragma unroll 1
     for (int i = 0; i < q.n; ++i) {
         const int m = (int)(((i < 8 ? q.modes_lo : q.modes_hi) >> (8 * (i & 7))) & 255u);
-        float cost = 3.40282347e+38f;
+        unsigned sad = kNoSad;
         if (m != kNoMode) {
-            unsigned long long sad = 0;
+            sad = 0;
 #pragma unroll 1
             for (int comp = 0; comp < 2; ++comp) {
                 if (!((q.comps >> comp) & 1)) continue;
                 PROF_MARK(tp0_);
-                sad += (unsigned long long)(unsigned)wave_sum_i32(predict<false>(c, comp, q.tx, q.ty, q.tlg, m));
+                sad += (unsigned)wave_sum_i32(predict<false>(c, comp, q.tx, q.ty, q.tlg, m));
                 PROF_MARK(tp1_);
                 PROF_ADD2(PH_PSZ + ((q.tlg - 2) * 2 + comp), tp0_, tp1_);
                 PROF_ADD2(PH_PCNT + ((q.tlg - 2) * 2 + comp), 0, 1);
             }
-            cost = uni_f((float)sad);
         }
-        if (i == 0) r.v0 = cost;
-        if (i == 1) r.v1 = cost;
-        if (i == 2) r.v2 = cost;
-        if (cost < r.vmin) { // first minimum
-            r.vmin = cost;
+        if (i == 0) s0 = sad;
+        if (i == 1) s1 = sad;
+        if (i == 2) s2 = sad;
+        if (sad < smin) { // first minimum
+            smin = sad;
             r.imin = i;
         }
     }
+    r.v0 = s0 == kNoSad ? 3.40282347e+38f : uni_f((float)s0);
+    r.v1 = s1 == kNoSad ? 3.40282347e+38f : uni_f((float)s1);
+    r.v2 = s2 == kNoSad ? 3.40282347e+38f : uni_f((float)s2);
+    r.vmin = smin == kNoSad ? 3.40282347e+38f : uni_f((float)smin);
     PROF_MARK(t1_);
     PROF_ADD2(PH_PREDICT, t0_, t1_);
     return r;
