@@ -671,13 +671,16 @@ __device__ __forceinline__ CclmParams cclm_params(Ctx c, int comp, int tx, int t
 // Original sample for prediction index i (plane pc, component coordinates x, y).  A full
 // evaluation reads the picture; SAD lists read the copy of the block's originals that
 // stage_org() put into r2 (free while no transform runs), index obase + i.
+// byte offset in r2 of the staged originals (luma at +0, Cb | Cr at +1024): the last 1.5 KB, so that
+// r1 and the first 2688 bytes of r2 are one free region during SAD lists
+constexpr int kOrgStage = 2688;
 template <bool full>
 __device__ __forceinline__ int pred_org(const Ctx& c, int pc, int x, int y, int obase, int i) {
     if (full) return org_get(c, pc, x, y);
-    return ((const uint8_t*)SH.r2)[obase + i];
+    return ((const uint8_t*)SH.r2)[kOrgStage + obase + i];
 }
 __device__ __forceinline__ void stage_org(const Ctx& c, int comps, int tx, int ty, int tlg) {
-    uint32_t* dst = (uint32_t*)SH.r2;
+    uint32_t* dst = (uint32_t*)((char*)SH.r2 + kOrgStage);
     if (comps & 1) {
         const int words = 1 << (2 * tlg - 2);
         for (int w = LANE; w < words; w += 64) {
@@ -898,6 +901,168 @@ __device__ __forceinline__ int predict(Ctx c, int comp, int tx, int ty, int tlg,
     }
     WSYNC();
     return sad;
+}
+
+constexpr int kNoMode = 255; // list entry that is not evaluated (cost f32::MAX)
+
+// SADs of a LIST of angular modes (2..66) of one block: get_intra_pred_aux_cost of each entry
+// (block_splitter.rs:64-108), luma block and/or chroma pair.  Same arithmetic as predict<false>,
+// organised so that the per-mode fixed work is done once per list:
+//   * lane mi derives the parameters of entry mi (angle, inverse angle, filter / PDPC variant);
+//     the uniform loop over the entries fetches them with v_readlane;
+//   * the projected main references of ALL entries are built in one pass into r1 .. r2 (free
+//     during SAD lists), stride 4n per block;
+//   * a lane adds the SAD of entry mi into its accumulator when LANE == mi.
+// acc (lane mi): summed SAD of entry mi over the components; entries with mode kNoMode stay 0.
+__device__ __forceinline__ unsigned sad_list_angular(const Ctx& c, int comps, int tx, int ty, int tlg, int nmodes,
+                                                     unsigned long long modes_lo, unsigned long long modes_hi) {
+    unsigned acc = 0;
+    const int my_mode = LANE < nmodes ? (int)(((LANE < 8 ? modes_lo : modes_hi) >> (8 * (LANE & 7))) & 255u) : kNoMode;
+    int16_t* tab = SH.r1;                   // [entry][blk][4n] projected references
+    uint32_t* ptab = (uint32_t*)SH.decw + 32; // [entry]: inv_angle (low half) | vertical << 16 | valid << 17
+#pragma unroll 1
+    for (int comp = 0; comp < 2; ++comp) {
+        if (!((comps >> comp) & 1)) continue;
+        const int cs = comp ? 1 : 0;
+        const int nb = comp ? 2 : 1;
+        const int lg = tlg - cs;
+        const int n = 1 << lg;
+        const int nn = n * n;
+        const int cx = tx >> cs, cy = ty >> cs;
+        const int obase = comp ? 1024 : 0;
+        const int lgs = lg + 2; // table stride 4n >= 3n + 4 per block
+        // ---- parameters of my entry (intra_predictor.rs:1287-1310, 355-372) ----
+        const bool valid = my_mode != kNoMode;
+        const int mm = valid ? my_mode : 2;
+        const int at = c.k->ang_tab[mm];
+        const int my_angle = (int)(int16_t)(at & 0xFFFF);
+        const int my_inv = at >> 16;
+        int my_flags; // bit 0 filter_flag, bits 1-2 PDPC variant (0 none, 1 mode 18/50, 2 mode < 18, 3 mode > 50), bits 4.. n_scale
+        {
+            bool filter_flag = false;
+            if (!(mm == 2 || mm == 34 || mm == 66)) {
+                const int md = min(abs(mm - 50), abs(mm - 18));
+                const int thr = lg == 2 ? 24 : (lg == 3 ? 14 : (lg == 4 ? 2 : 0));
+                filter_flag = md > thr;
+            }
+            int n_scale;
+            if (mm > 50 || (mm > 1 && mm < 18))
+                n_scale = min(lg - ilog2i(3 * my_inv - 2) + 8, 2);
+            else
+                n_scale = (2 * lg - 2) >> 2;
+            int kind = 0;
+            if (mm == 18 || mm == 50)
+                kind = 1;
+            else if (mm < 18 && n_scale >= 0)
+                kind = 2;
+            else if (mm > 50 && n_scale >= 0)
+                kind = 3;
+            my_flags = (filter_flag ? 1 : 0) | (kind << 1) | (max(n_scale, 0) << 4);
+        }
+        if (LANE < nmodes) ptab[LANE] = ((uint32_t)my_inv & 0xFFFFu) | (mm >= 34 ? 0x10000u : 0u) | (valid ? 0x20000u : 0u);
+        WSYNC();
+        // ---- projected main references of every entry (intra_predictor.rs:1311-1420) ----
+        {
+            const int oL0 = comp == 0 ? R_L0 : R_LC0, oA0 = comp == 0 ? R_A0 : R_AC0; // (filtered refs: modes 2, 34, 66 below)
+            const int total = nmodes << (lgs + cs);
+            for (int e = LANE; e < total; e += 64) {
+                const int mi = e >> (lgs + cs);
+                const int blk = cs ? ((e >> lgs) & 1) : 0;
+                const int ee = e & ((1 << lgs) - 1);
+                const uint32_t pw = ptab[mi];
+                const int inv_angle = (int)(int16_t)(pw & 0xFFFF);
+                const bool vertical = (pw >> 16) & 1;
+                const int idx = ee - n;
+                int oL = blk ? R_LC1 : oL0, oA = blk ? R_AC1 : oA0;
+                if (comp == 0 && nn > 32) { // luma blocks of more than 32 samples: modes 2, 34, 66 use the filtered references
+                    const int m = (int)(((mi < 8 ? modes_lo : modes_hi) >> (8 * (mi & 7))) & 255u);
+                    if (m == 2 || m == 34 || m == 66) {
+                        oL = R_LF;
+                        oA = R_AF;
+                    }
+                }
+                const int k = idx >= 0 ? min(idx, 2 * n) : max(min((idx * inv_angle + 256) >> 9, n), 0);
+                const bool from_above = (idx >= 0) == vertical;
+                tab[e] = SH.refs[k == 0 ? oL : (from_above ? oA + k - 1 : oL + k)];
+            }
+        }
+        WSYNC();
+        // ---- entry by entry: one predicted sample per lane and iteration, |org - pred| summed ----
+#pragma unroll 1
+        for (int mi = 0; mi < nmodes; ++mi) {
+            const int mode = __builtin_amdgcn_readlane(my_mode, mi);
+            if (mode == kNoMode) continue;
+            const int angle = __builtin_amdgcn_readlane(my_angle, mi);
+            const int inv_angle = __builtin_amdgcn_readlane(my_inv, mi);
+            const int flags = __builtin_amdgcn_readlane(my_flags, mi);
+            const bool filter_flag = flags & 1;
+            const int kind = (flags >> 1) & 3;
+            const int n_scale = flags >> 4;
+            const bool vertical = mode >= 34;
+            const bool filt = comp == 0 && nn > 32 && (mode == 2 || mode == 34 || mode == 66);
+            const int oL0 = comp == 0 ? (filt ? R_LF : R_L0) : R_LC0;
+            const int oA0 = comp == 0 ? (filt ? R_AF : R_A0) : R_AC0;
+            int sad = 0;
+            for (int i = LANE; i < nb * nn; i += 64) {
+                const int blk = i >> (2 * lg);
+                const int ii = i & (nn - 1);
+                const int x = ii & (n - 1), y = ii >> lg;
+                const int o = ((const uint8_t*)SH.r2)[kOrgStage + obase + i];
+                const int16_t* L = SH.refs + (blk ? R_LC1 : oL0);
+                const int16_t* A = SH.refs + (blk ? R_AC1 : oA0);
+                const int along = vertical ? y : x, across = vertical ? x : y;
+                const int i_idx = ((along + 1) * angle) >> 5;
+                const int i_fact = ((along + 1) * angle) & 31;
+                const int16_t* tap = tab + (((mi << cs) + blk) << lgs) + n + across + i_idx; // tap[t] = ref[across + i_idx + t]
+                int v;
+                if (comp == 0) {
+                    int f0, f1, f2, f3;
+                    if (filter_flag) {
+                        f0 = 16 - (i_fact >> 1);
+                        f1 = 32 - (i_fact >> 1);
+                        f2 = 16 + (i_fact >> 1);
+                        f3 = i_fact >> 1;
+                    } else {
+                        const int w = *(const int*)&SHT.fc[i_fact][0];
+                        f0 = (int)(int8_t)w;
+                        f1 = (int)(int8_t)(w >> 8);
+                        f2 = (int)(int8_t)(w >> 16);
+                        f3 = w >> 24;
+                    }
+                    const int a4 = f0 * tap[0] + f1 * tap[1] + f2 * tap[2] + f3 * tap[3];
+                    v = min(max((a4 + 32) >> 6, 0), 255);
+                } else {
+                    v = ((32 - i_fact) * tap[1] + i_fact * tap[2] + 16) >> 5;
+                }
+                if (kind != 0) { // PDPC, intra_predictor.rs:355-757; left[] = L+1, above[] = A
+                    int rl = 0, rt = 0, wl = 0, wt = 0;
+                    if (kind == 1) {
+                        const int alrs = L[0];
+                        rl = (int16_t)(L[y + 1] - alrs + v);
+                        rt = (int16_t)(A[x] - alrs + v);
+                        wl = mode == 50 ? pdpc_w(n_scale, x) : 0;
+                        wt = mode == 18 ? pdpc_w(n_scale, y) : 0;
+                    } else if (kind == 2) {
+                        const int dx_int = ((y + 1) * inv_angle + 256) >> 9;
+                        rt = y < (3 << n_scale) ? A[x + dx_int] : 0;
+                        wt = pdpc_w(n_scale, y);
+                    } else {
+                        const int dy_int = ((x + 1) * inv_angle + 256) >> 9;
+                        rl = x < (3 << n_scale) ? L[1 + y + dy_int] : 0;
+                        wl = pdpc_w(n_scale, x);
+                    }
+                    v = (int16_t)(rl * wl + rt * wt + (64 - wt - wl) * v + 32) >> 6;
+                    v = min(max(v, 0), 255);
+                }
+                const int d = o - v;
+                sad += d < 0 ? -d : d;
+            }
+            const int total = wave_sum_i32(sad);
+            acc += LANE == mi ? (unsigned)total : 0u;
+        }
+        WSYNC(); // the next component overwrites the tables
+    }
+    return acc;
 }
 
 // ---------------------------------------------------------------------------
@@ -1631,7 +1796,6 @@ __device__ __forceinline__ void dequantize_t(Ctx c, int lg, int nb, int o1 = 0) 
 // ---------------------------------------------------------------------------
 enum { K_SADLIST = 0, K_FULL = 1, K_NOP = 2 };
 enum { COPY_NONE = 0, COPY_SAVE = 1, COPY_RESTORE = 2 };
-constexpr int kNoMode = 255; // K_SADLIST entry that is not evaluated (cost f32::MAX)
 
 struct Req {
     int kind;       // K_SADLIST: predict + SAD of a list of modes (block_splitter.rs:64-108, 476-522);
@@ -1831,28 +1995,48 @@ __device__ __forceinline__ Res evaluate(const Ctx& c, const PicBufs& pb, const R
     // way); they become floats once, at the end.  An entry that is not evaluated costs f32::MAX.
     constexpr unsigned kNoSad = 0xFFFFFFFFu;
     unsigned s0 = kNoSad, s1 = kNoSad, s2 = kNoSad, smin = kNoSad;
-#pragma unroll 1
-    for (int i = 0; i < q.n; ++i) {
-        const int m = (int)(((i < 8 ? q.modes_lo : q.modes_hi) >> (8 * (i & 7))) & 255u);
-        unsigned sad = kNoSad;
-        if (m != kNoMode) {
-            sad = 0;
-#pragma unroll 1
-            for (int comp = 0; comp < 2; ++comp) {
-                if (!((q.comps >> comp) & 1)) continue;
-                PROF_MARK(tp0_);
-                sad += (unsigned)wave_sum_i32(predict<false>(c, comp, q.tx, q.ty, q.tlg, m));
-                PROF_MARK(tp1_);
-                PROF_ADD2(PH_PSZ + ((q.tlg - 2) * 2 + comp), tp0_, tp1_);
-                PROF_ADD2(PH_PCNT + ((q.tlg - 2) * 2 + comp), 0, 1);
-            }
+    const int m_first = (int)(q.modes_lo & 255u);
+    const int m_second = (int)((q.modes_lo >> 8) & 255u);
+    if ((m_first >= 2 && m_first <= 66) || (m_first == kNoMode && m_second <= 66)) {
+        // a list of angular modes (the 13 directional candidates, a step-search pair)
+        const unsigned acc = sad_list_angular(c, q.comps, q.tx, q.ty, q.tlg, q.n, q.modes_lo, q.modes_hi);
+        const int my_mode = LANE < q.n ? (int)(((LANE < 8 ? q.modes_lo : q.modes_hi) >> (8 * (LANE & 7))) & 255u) : kNoMode;
+        // first minimum = smallest (sad, index) pair
+        const int key = my_mode != kNoMode ? (int)((acc << 4) | (unsigned)LANE) : 0x7FFFFFFF;
+        const int kmin = wave_min_i32(key);
+        if (kmin != 0x7FFFFFFF) {
+            smin = (unsigned)kmin >> 4;
+            r.imin = kmin & 15;
         }
-        if (i == 0) s0 = sad;
-        if (i == 1) s1 = sad;
-        if (i == 2) s2 = sad;
-        if (sad < smin) { // first minimum
-            smin = sad;
-            r.imin = i;
+        const unsigned a0 = (unsigned)__builtin_amdgcn_readlane((int)acc, 0), a1 = (unsigned)__builtin_amdgcn_readlane((int)acc, 1),
+                       a2 = (unsigned)__builtin_amdgcn_readlane((int)acc, 2);
+        if (m_first != kNoMode) s0 = a0;
+        if (q.n > 1 && m_second != kNoMode) s1 = a1;
+        if (q.n > 2 && (int)((q.modes_lo >> 16) & 255u) != kNoMode) s2 = a2;
+    } else {
+#pragma unroll 1
+        for (int i = 0; i < q.n; ++i) {
+            const int m = (int)(((i < 8 ? q.modes_lo : q.modes_hi) >> (8 * (i & 7))) & 255u);
+            unsigned sad = kNoSad;
+            if (m != kNoMode) {
+                sad = 0;
+#pragma unroll 1
+                for (int comp = 0; comp < 2; ++comp) {
+                    if (!((q.comps >> comp) & 1)) continue;
+                    PROF_MARK(tp0_);
+                    sad += (unsigned)wave_sum_i32(predict<false>(c, comp, q.tx, q.ty, q.tlg, m));
+                    PROF_MARK(tp1_);
+                    PROF_ADD2(PH_PSZ + ((q.tlg - 2) * 2 + comp), tp0_, tp1_);
+                    PROF_ADD2(PH_PCNT + ((q.tlg - 2) * 2 + comp), 0, 1);
+                }
+            }
+            if (i == 0) s0 = sad;
+            if (i == 1) s1 = sad;
+            if (i == 2) s2 = sad;
+            if (sad < smin) { // first minimum
+                smin = sad;
+                r.imin = i;
+            }
         }
     }
     r.v0 = s0 == kNoSad ? 3.40282347e+38f : uni_f((float)s0);
