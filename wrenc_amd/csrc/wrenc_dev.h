@@ -330,6 +330,10 @@ __device__ __forceinline__ int group_min_i32(int v, int width) {
     return LANE < 32 ? lo : hi;
 }
 __device__ __forceinline__ int ilog2i(int v) { return 31 - __clz(v); }
+// Full-rate multiply (v_mul_i32_i24): both factors fit 24 bits everywhere it is used (sample values,
+// filter taps, weights, block coordinates, angles, levels, quantiser scales); a plain `*` on ints
+// compiles to the quarter-rate v_mul_lo_u32.
+#define M24(a, b) __mul24((int)(a), (int)(b))
 
 // ---------------------------------------------------------------------------
 // recon tile access (CTU-local component coordinates)
@@ -755,7 +759,7 @@ __device__ __forceinline__ int predict(Ctx c, int comp, int tx, int ty, int tlg,
                 v = 128;
             } else {
                 const int ds = cclm_ds6(c, tx, ty, 2 * y, 2 * x, avail_l);
-                v = ((ds * (blk ? a1 : a0)) >> (blk ? k1 : k0)) + (blk ? b1 : b0);
+                v = (M24(ds, blk ? a1 : a0) >> (blk ? k1 : k0)) + (blk ? b1 : b0);
                 v = min(max(v, 0), 255);
             }
             sad += emit_sample<full>(c, o, rbase + i, v);
@@ -790,14 +794,14 @@ __device__ __forceinline__ int predict(Ctx c, int comp, int tx, int ty, int tlg,
             const int16_t* A = SH.refs + (blk ? R_AC1 : oA0);
             int v;
             if (mode == PLANAR) {
-                const int pv = (n - 1 - y) * A[x] + (y + 1) * L[n + 1];
-                const int ph = (n - 1 - x) * L[y + 1] + (x + 1) * A[n];
+                const int pv = M24(n - 1 - y, A[x]) + M24(y + 1, L[n + 1]);
+                const int ph = M24(n - 1 - x, L[y + 1]) + M24(x + 1, A[n]);
                 v = ((pv + ph + n) >> (lg + 1)) & 0xFF;
             } else {
                 v = blk ? dcv1 : dcv0;
             }
             const int wl = pdpc_w(n_scale, x), wt = pdpc_w(n_scale, y);
-            v = (int16_t)(L[y + 1] * wl + A[x] * wt + (64 - wt - wl) * v + 32) >> 6;
+            v = (int16_t)(M24(L[y + 1], wl) + M24(A[x], wt) + M24(64 - wt - wl, v) + 32) >> 6;
             v = min(max(v, 0), 255);
             sad += emit_sample<full>(c, o, rbase + i, v);
         }
@@ -835,7 +839,7 @@ __device__ __forceinline__ int predict(Ctx c, int comp, int tx, int ty, int tlg,
             const int ee = e - blk * ne;
             const int idx = ee - n;
             const int oL = blk ? R_LC1 : oL0, oA = blk ? R_AC1 : oA0;
-            const int k = idx >= 0 ? min(idx, 2 * n) : max(min((idx * inv_angle + 256) >> 9, n), 0);
+            const int k = idx >= 0 ? min(idx, 2 * n) : max(min((M24(idx, inv_angle) + 256) >> 9, n), 0);
             const bool from_above = (idx >= 0) == vertical;
             // k == 0 is the corner (L[0]); above sample k - 1 = A[k - 1], left sample k - 1 = L[k]
             rm[blk * RMS + ee] = SH.refs[k == 0 ? oL : (from_above ? oA + k - 1 : oL + k)];
@@ -852,8 +856,8 @@ __device__ __forceinline__ int predict(Ctx c, int comp, int tx, int ty, int tlg,
         int v;
         {
             const int along = vertical ? y : x, across = vertical ? x : y;
-            const int i_idx = ((along + 1) * angle) >> 5;
-            const int i_fact = ((along + 1) * angle) & 31;
+            const int i_idx = M24(along + 1, angle) >> 5;
+            const int i_fact = M24(along + 1, angle) & 31;
             const int16_t* tap = rm + blk * RMS + n + across + i_idx; // tap[t] = ref[across + i_idx + t]
             if (comp == 0) {
                 int f0, f1, f2, f3;
@@ -869,11 +873,11 @@ __device__ __forceinline__ int predict(Ctx c, int comp, int tx, int ty, int tlg,
                     f2 = (int)(int8_t)(w >> 16);
                     f3 = w >> 24;
                 }
-                const int acc = f0 * tap[0] + f1 * tap[1] + f2 * tap[2] + f3 * tap[3];
+                const int acc = M24(f0, tap[0]) + M24(f1, tap[1]) + M24(f2, tap[2]) + M24(f3, tap[3]);
                 v = min(max((acc + 32) >> 6, 0), 255);
             } else {
                 // i_fact == 0 gives tap[1] itself; a convex combination of 8-bit samples needs no `& 0xFF`
-                v = ((32 - i_fact) * tap[1] + i_fact * tap[2] + 16) >> 5;
+                v = (M24(32 - i_fact, tap[1]) + M24(i_fact, tap[2]) + 16) >> 5;
             }
         }
         if (do_pdpc) {
@@ -886,15 +890,15 @@ __device__ __forceinline__ int predict(Ctx c, int comp, int tx, int ty, int tlg,
                 wl = mode == 50 ? pdpc_w(n_scale, x) : 0;
                 wt = mode == 18 ? pdpc_w(n_scale, y) : 0;
             } else if (mode < 18 && n_scale >= 0) {
-                const int dx_int = ((y + 1) * inv_angle + 256) >> 9;
+                const int dx_int = (M24(y + 1, inv_angle) + 256) >> 9;
                 rt = y < (3 << n_scale) ? A[x + dx_int] : 0;
                 wt = pdpc_w(n_scale, y);
             } else if (mode > 50 && n_scale >= 0) {
-                const int dy_int = ((x + 1) * inv_angle + 256) >> 9;
+                const int dy_int = (M24(x + 1, inv_angle) + 256) >> 9;
                 rl = x < (3 << n_scale) ? L[1 + y + dy_int] : 0;
                 wl = pdpc_w(n_scale, x);
             }
-            v = (int16_t)(rl * wl + rt * wt + (64 - wt - wl) * v + 32) >> 6;
+            v = (int16_t)(M24(rl, wl) + M24(rt, wt) + M24(64 - wt - wl, v) + 32) >> 6;
             v = min(max(v, 0), 255);
         }
         sad += emit_sample<full>(c, o, rbase + i, v);
@@ -981,7 +985,7 @@ __device__ __forceinline__ unsigned sad_list_angular(const Ctx& c, int comps, in
                         oA = R_AF;
                     }
                 }
-                const int k = idx >= 0 ? min(idx, 2 * n) : max(min((idx * inv_angle + 256) >> 9, n), 0);
+                const int k = idx >= 0 ? min(idx, 2 * n) : max(min((M24(idx, inv_angle) + 256) >> 9, n), 0);
                 const bool from_above = (idx >= 0) == vertical;
                 tab[e] = SH.refs[k == 0 ? oL : (from_above ? oA + k - 1 : oL + k)];
             }
@@ -1011,8 +1015,8 @@ __device__ __forceinline__ unsigned sad_list_angular(const Ctx& c, int comps, in
                 const int16_t* L = SH.refs + (blk ? R_LC1 : oL0);
                 const int16_t* A = SH.refs + (blk ? R_AC1 : oA0);
                 const int along = vertical ? y : x, across = vertical ? x : y;
-                const int i_idx = ((along + 1) * angle) >> 5;
-                const int i_fact = ((along + 1) * angle) & 31;
+                const int i_idx = M24(along + 1, angle) >> 5;
+                const int i_fact = M24(along + 1, angle) & 31;
                 const int16_t* tap = tab + (((mi << cs) + blk) << lgs) + n + across + i_idx; // tap[t] = ref[across + i_idx + t]
                 int v;
                 if (comp == 0) {
@@ -1029,10 +1033,10 @@ __device__ __forceinline__ unsigned sad_list_angular(const Ctx& c, int comps, in
                         f2 = (int)(int8_t)(w >> 16);
                         f3 = w >> 24;
                     }
-                    const int a4 = f0 * tap[0] + f1 * tap[1] + f2 * tap[2] + f3 * tap[3];
+                    const int a4 = M24(f0, tap[0]) + M24(f1, tap[1]) + M24(f2, tap[2]) + M24(f3, tap[3]);
                     v = min(max((a4 + 32) >> 6, 0), 255);
                 } else {
-                    v = ((32 - i_fact) * tap[1] + i_fact * tap[2] + 16) >> 5;
+                    v = (M24(32 - i_fact, tap[1]) + M24(i_fact, tap[2]) + 16) >> 5;
                 }
                 if (kind != 0) { // PDPC, intra_predictor.rs:355-757; left[] = L+1, above[] = A
                     int rl = 0, rt = 0, wl = 0, wt = 0;
@@ -1043,15 +1047,15 @@ __device__ __forceinline__ unsigned sad_list_angular(const Ctx& c, int comps, in
                         wl = mode == 50 ? pdpc_w(n_scale, x) : 0;
                         wt = mode == 18 ? pdpc_w(n_scale, y) : 0;
                     } else if (kind == 2) {
-                        const int dx_int = ((y + 1) * inv_angle + 256) >> 9;
+                        const int dx_int = (M24(y + 1, inv_angle) + 256) >> 9;
                         rt = y < (3 << n_scale) ? A[x + dx_int] : 0;
                         wt = pdpc_w(n_scale, y);
                     } else {
-                        const int dy_int = ((x + 1) * inv_angle + 256) >> 9;
+                        const int dy_int = (M24(x + 1, inv_angle) + 256) >> 9;
                         rl = x < (3 << n_scale) ? L[1 + y + dy_int] : 0;
                         wl = pdpc_w(n_scale, x);
                     }
-                    v = (int16_t)(rl * wl + rt * wt + (64 - wt - wl) * v + 32) >> 6;
+                    v = (int16_t)(M24(rl, wl) + M24(rt, wt) + M24(64 - wt - wl, v) + 32) >> 6;
                     v = min(max(v, 0), 255);
                 }
                 const int d = o - v;
@@ -1293,8 +1297,8 @@ __device__ __forceinline__ void chunk_entry(const Ctx& c, int* en, int tc, int q
             q0 = -q0;
             q1 = -q1;
         }
-        const int d0 = abs(tc - ((q0 * lsc + off) >> sh));
-        const int d1 = abs(tc - ((q1 * lsc + off) >> sh));
+        const int d0 = abs(tc - ((M24(q0, lsc) + off) >> sh)); // |q| <= 2047, lsc < 2^21
+        const int d1 = abs(tc - ((M24(q1, lsc) + off) >> sh));
         if (nz && a1 + 1 >= 1024) *ovf = 1;
         const int l0 = ldq_fast(c, min(a0 + 1, 1023)), l1 = ldq_fast(c, min(a1 + 1, 1023));
         c0d[d] = nz ? 128 * d0 + l0 : ldq1;       // zero coefficient outside the trailing run: dq_table[1] (:433)
@@ -1782,7 +1786,7 @@ __device__ __forceinline__ void dequantize_t(Ctx c, int lg, int nb, int o1 = 0) 
     for (int i = LANE; i < nb * nn; i += 64) {
         const int blk = i >> (2 * lg), ii = i & (nn - 1);
         const int x = ii & (n - 1), y = ii >> lg;
-        int v = ((int)SH.r1[o1 + i] * lsc + off) >> sh;
+        int v = (M24(SH.r1[o1 + i], lsc) + off) >> sh;
         v = min(max(v, -32768), 32767);
         out[blk * nn + x * n + y] = (int16_t)v;
     }
@@ -1881,7 +1885,7 @@ __device__ __forceinline__ uint32_t full_back(const Ctx& c, const PicBufs& pb, c
         if (q.final && v != rec_get(pc, cx + x, cy + y)) ++diff;
         rec_put(pc, cx + x, cy + y, v);
         const int d = v - org_get(c, pc, cx + x, cy + y);
-        part += (unsigned)(d * d);
+        part += (unsigned)M24(d, d);
     }
     const uint32_t ssd = (uint32_t)wave_sum_i32((int)part); // <= 1024 * 255^2: fits 32 bits
     if (q.final) {
