@@ -924,6 +924,7 @@ __device__ __forceinline__ unsigned sad_list_angular(const Ctx& c, int comps, in
     const int my_mode = LANE < nmodes ? (int)(((LANE < 8 ? modes_lo : modes_hi) >> (8 * (LANE & 7))) & 255u) : kNoMode;
     int16_t* tab = SH.r1;                   // [entry][blk][4n] projected references
     uint32_t* ptab = (uint32_t*)SH.decw + 32; // [entry]: inv_angle (low half) | vertical << 16 | valid << 17
+    uint32_t* ptab2 = (uint32_t*)SH.decw + 48; // [entry]: angle (low half) | flags << 16 | mode << 24
 #pragma unroll 1
     for (int comp = 0; comp < 2; ++comp) {
         if (!((comps >> comp) & 1)) continue;
@@ -963,7 +964,10 @@ __device__ __forceinline__ unsigned sad_list_angular(const Ctx& c, int comps, in
                 kind = 3;
             my_flags = (filter_flag ? 1 : 0) | (kind << 1) | (max(n_scale, 0) << 4);
         }
-        if (LANE < nmodes) ptab[LANE] = ((uint32_t)my_inv & 0xFFFFu) | (mm >= 34 ? 0x10000u : 0u) | (valid ? 0x20000u : 0u);
+        if (LANE < nmodes) {
+            ptab[LANE] = ((uint32_t)my_inv & 0xFFFFu) | (mm >= 34 ? 0x10000u : 0u) | (valid ? 0x20000u : 0u);
+            ptab2[LANE] = ((uint32_t)my_angle & 0xFFFFu) | ((uint32_t)my_flags << 16) | ((uint32_t)mm << 24);
+        }
         WSYNC();
         // ---- projected main references of every entry (intra_predictor.rs:1311-1420) ----
         {
@@ -991,6 +995,82 @@ __device__ __forceinline__ unsigned sad_list_angular(const Ctx& c, int comps, in
             }
         }
         WSYNC();
+        if (nb * nn <= 32) {
+            // ---- small blocks (4x4 luma: 16 samples, 4x4 chroma pair: 32): 4 or 2 entries share an
+            // iteration, the entry's parameters are per-lane values ----
+            const int lgS = nb * nn == 32 ? 5 : 4;
+            const int slot = LANE >> lgS;
+            const int i = LANE & ((1 << lgS) - 1);
+            const int blk = i >> (2 * lg);
+            const int ii = i & (nn - 1);
+            const int x = ii & (n - 1), y = ii >> lg;
+            const int o = ((const uint8_t*)SH.r2)[kOrgStage + obase + i];
+            const int16_t* L = SH.refs + (blk ? R_LC1 : (comp == 0 ? R_L0 : R_LC0));
+            const int16_t* A = SH.refs + (blk ? R_AC1 : (comp == 0 ? R_A0 : R_AC0));
+#pragma unroll 1
+            for (int base = 0; base < nmodes; base += 64 >> lgS) {
+                const int mi = base + slot;
+                const uint32_t pw = ptab[min(mi, 15)], pw2 = ptab2[min(mi, 15)];
+                const bool on = mi < nmodes && ((pw >> 17) & 1);
+                const int inv_angle = (int)(int16_t)(pw & 0xFFFF);
+                const bool vertical = (pw >> 16) & 1;
+                const int angle = (int)(int16_t)(pw2 & 0xFFFF);
+                const int flags = (int)((pw2 >> 16) & 0xFF);
+                const int mode = (int)(pw2 >> 24);
+                const bool filter_flag = flags & 1;
+                const int kind = (flags >> 1) & 3;
+                const int n_scale = flags >> 4;
+                const int along = vertical ? y : x, across = vertical ? x : y;
+                const int i_idx = M24(along + 1, angle) >> 5;
+                const int i_fact = M24(along + 1, angle) & 31;
+                const int16_t* tap = tab + (((min(mi, 15) << cs) + blk) << lgs) + n + across + i_idx;
+                int v;
+                if (comp == 0) {
+                    const int w = *(const int*)&SHT.fc[i_fact][0];
+                    const int h = i_fact >> 1;
+                    const int f0 = filter_flag ? 16 - h : (int)(int8_t)w;
+                    const int f1 = filter_flag ? 32 - h : (int)(int8_t)(w >> 8);
+                    const int f2 = filter_flag ? 16 + h : (int)(int8_t)(w >> 16);
+                    const int f3 = filter_flag ? h : (w >> 24);
+                    const int a4 = M24(f0, tap[0]) + M24(f1, tap[1]) + M24(f2, tap[2]) + M24(f3, tap[3]);
+                    v = min(max((a4 + 32) >> 6, 0), 255);
+                } else {
+                    v = (M24(32 - i_fact, tap[1]) + M24(i_fact, tap[2]) + 16) >> 5;
+                }
+                if (kind != 0) { // PDPC, intra_predictor.rs:355-757; left[] = L+1, above[] = A
+                    int rl = 0, rt = 0, wl = 0, wt = 0;
+                    if (kind == 1) {
+                        const int alrs = L[0];
+                        rl = (int16_t)(L[y + 1] - alrs + v);
+                        rt = (int16_t)(A[x] - alrs + v);
+                        wl = mode == 50 ? pdpc_w(n_scale, x) : 0;
+                        wt = mode == 18 ? pdpc_w(n_scale, y) : 0;
+                    } else if (kind == 2) {
+                        const int dx_int = (M24(y + 1, inv_angle) + 256) >> 9;
+                        rt = y < (3 << n_scale) ? A[x + dx_int] : 0;
+                        wt = pdpc_w(n_scale, y);
+                    } else {
+                        const int dy_int = (M24(x + 1, inv_angle) + 256) >> 9;
+                        rl = x < (3 << n_scale) ? L[1 + y + dy_int] : 0;
+                        wl = pdpc_w(n_scale, x);
+                    }
+                    v = (int16_t)(M24(rl, wl) + M24(rt, wt) + M24(64 - wt - wl, v) + 32) >> 6;
+                    v = min(max(v, 0), 255);
+                }
+                const int d = o - v;
+                const int rs = row_sum_i32(on ? (d < 0 ? -d : d) : 0); // every lane: total of its row of 16
+                // slot totals: 16-sample slots are the rows, 32-sample slots two rows each
+                const int t0 = __builtin_amdgcn_readlane(rs, 0), t1 = __builtin_amdgcn_readlane(rs, 16),
+                          t2 = __builtin_amdgcn_readlane(rs, 32), t3 = __builtin_amdgcn_readlane(rs, 48);
+                if (lgS == 4) {
+                    acc += LANE == base ? (unsigned)t0 : (LANE == base + 1 ? (unsigned)t1 : (LANE == base + 2 ? (unsigned)t2 : (LANE == base + 3 ? (unsigned)t3 : 0u)));
+                } else {
+                    acc += LANE == base ? (unsigned)(t0 + t1) : (LANE == base + 1 ? (unsigned)(t2 + t3) : 0u);
+                }
+            }
+            WSYNC();
+            continue;
+        }
         // ---- entry by entry: one predicted sample per lane and iteration, |org - pred| summed ----
 #pragma unroll 1
         for (int mi = 0; mi < nmodes; ++mi) {
