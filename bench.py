@@ -69,7 +69,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=int(os.environ.get("WRENC_BENCH_BATCH", "512")),
+    ap.add_argument("--batch", type=int, default=int(os.environ.get("WRENC_BENCH_BATCH", "1024")),
                     help="pictures resident per GPU and encoded per step")
     ap.add_argument("--width", type=int, default=WIDTH)
     ap.add_argument("--height", type=int, default=HEIGHT)

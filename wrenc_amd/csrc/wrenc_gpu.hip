@@ -24,11 +24,37 @@ using namespace wrenc;
 // ---------------------------------------------------------------------------
 // kernels
 // ---------------------------------------------------------------------------
+// scratch regions for resident workgroups (>= 2 per CU x 256 CUs; 32 bitmap words of 64)
+constexpr int kScratchSlots = 2048;
+
 __global__ __launch_bounds__(64 * WPB, 4) void ctu_search_kernel(const DevConst* __restrict__ k,
                                                               const PicBufs* __restrict__ slots, int first_slot,
                                                               int n_pictures, int diag, int r_min, int count,
-                                                              uint8_t* pred_scratch, unsigned long long* mismatch,
-                                                              int* overflow) {
+                                                              uint8_t* pred_scratch, unsigned long long* slot_map,
+                                                              unsigned long long* mismatch, int* overflow) {
+    // Per-workgroup global scratch comes from a pool of kScratchSlots regions handed out through a
+    // bitmap: the pool covers the workgroups that can be resident at once (2 per CU), not the ones
+    // of a launch, so the scratch that is live stays small enough to live in L2 / Infinity Cache
+    // whatever the batch size.  A slot is only ever used by one workgroup at a time and nothing is
+    // read that the same workgroup did not write, so its contents need no hand-over.
+    __shared__ int s_scratch_slot;
+    if (threadIdx.x == 0) {
+        unsigned w = (blockIdx.x * 2654435761u) >> (32 - 5); // start word, 0 .. kScratchSlots / 64 - 1
+        int slot = -1;
+        while (slot < 0) {
+            const unsigned long long cur = __hip_atomic_load(&slot_map[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (~cur) {
+                const int b = __ffsll((unsigned long long)~cur) - 1;
+                const unsigned long long bit = 1ULL << b;
+                if (!(atomicOr(&slot_map[w], bit) & bit)) slot = (int)(w * 64 + b);
+            } else {
+                w = (w + 1) & (kScratchSlots / 64 - 1);
+            }
+        }
+        s_scratch_slot = slot;
+    }
+    __syncthreads();
+    const int scratch_slot = s_scratch_slot;
     // one workgroup = the same CTU of WPB consecutive pictures, one wave each
     const int group = blockIdx.x / count;
     const int j = blockIdx.x - group * count;
@@ -44,11 +70,15 @@ __global__ __launch_bounds__(64 * WPB, 4) void ctu_search_kernel(const DevConst*
     c.org = (const GLOBAL_AS uint8_t*)pb.org[0]; // Y | Cb | Cr are one slab (see wrenc_gpu_create)
     c.W = k->W;
     c.WH = k->W * k->H;
-    c.pred_scratch = pred_scratch + ((size_t)blockIdx.x * WPB + WAVE) * kWaveScratch;
+    c.pred_scratch = pred_scratch + ((size_t)scratch_slot * WPB + WAVE) * kWaveScratch;
     c.slots = (GLOBAL_AS uint8_t*)(c.pred_scratch + 1024);
     int ovf = 0;
     encode_ctu(c, pb, col, row, &ovf);
     if (ovf && LANE == 0) atomicOr(overflow, 1);
+    // give the scratch slot back once every wave's stores to it are out
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAnd(&slot_map[scratch_slot >> 6], ~(1ULL << (scratch_slot & 63)));
 }
 
 // building-block kernels: one wave per block of side 1 << lg
@@ -178,8 +208,8 @@ struct wrenc_gpu_ctx {
     std::vector<int> state; // 0 empty, 1 uploaded, 2 encoded
     unsigned long long* d_mismatch = nullptr;
     int* d_overflow = nullptr;
-    uint8_t* d_pred_scratch = nullptr; // kWaveScratch bytes per resident wave: prediction bytes + saved reconstructions
-    size_t pred_scratch_bytes = 0;
+    uint8_t* d_pred_scratch = nullptr; // kScratchSlots x WPB x kWaveScratch: prediction bytes + saved reconstructions
+    unsigned long long* d_slot_map = nullptr; // kScratchSlots bits: scratch regions in use
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;
     std::vector<hipEvent_t> ev_pool;
     int last_launches = 0;
@@ -372,6 +402,7 @@ void wrenc_gpu_destroy(wrenc_gpu_ctx* ctx) {
     if (ctx->d_mismatch) (void)hipFree(ctx->d_mismatch);
     if (ctx->d_overflow) (void)hipFree(ctx->d_overflow);
     if (ctx->d_pred_scratch) (void)hipFree(ctx->d_pred_scratch);
+    if (ctx->d_slot_map) (void)hipFree(ctx->d_slot_map);
     if (ctx->ev_begin) (void)hipEventDestroy(ctx->ev_begin);
     if (ctx->ev_end) (void)hipEventDestroy(ctx->ev_end);
     for (hipEvent_t e : ctx->ev_pool) (void)hipEventDestroy(e);
@@ -500,18 +531,10 @@ int wrenc_gpu_encode(wrenc_gpu_ctx* ctx, int first_slot, int n_pictures) {
     // split the pictures into lanes of whole workgroups (WPB pictures each)
     const int total_groups = (n_pictures + WPB - 1) / WPB;
     const int n_lanes = total_groups < kEncodeLanes ? total_groups : kEncodeLanes;
-    const int max_diag = (cols + 1) / 2 < rows ? (cols + 1) / 2 : rows;
-    {
-        // 1 KB of prediction scratch per resident wave; lanes run concurrently, so each gets its own
-        const size_t need = (size_t)max_diag * (total_groups + n_lanes) * WPB * kWaveScratch;
-        if (need > ctx->pred_scratch_bytes) {
-            HIP_TRY(ctx, wrenc_gpu_sync(ctx) == WRENC_GPU_OK ? hipSuccess : hipErrorUnknown);
-            if (ctx->d_pred_scratch) (void)hipFree(ctx->d_pred_scratch);
-            ctx->d_pred_scratch = nullptr;
-            ctx->pred_scratch_bytes = 0;
-            HIP_TRY(ctx, hipMalloc((void**)&ctx->d_pred_scratch, need));
-            ctx->pred_scratch_bytes = need;
-        }
+    if (!ctx->d_pred_scratch) {
+        HIP_TRY(ctx, hipMalloc((void**)&ctx->d_pred_scratch, (size_t)kScratchSlots * WPB * kWaveScratch));
+        HIP_TRY(ctx, hipMalloc((void**)&ctx->d_slot_map, kScratchSlots / 8));
+        HIP_TRY(ctx, hipMemset(ctx->d_slot_map, 0, kScratchSlots / 8));
     }
     while ((int)ctx->ev_pool.size() < 2 * ndiag * n_lanes) {
         hipEvent_t e;
@@ -537,10 +560,10 @@ int wrenc_gpu_encode(wrenc_gpu_ctx* ctx, int first_slot, int n_pictures) {
             if (g0 * WPB + lane_pics > n_pictures) lane_pics = n_pictures - g0 * WPB;
             if (lane_pics <= 0) continue;
             hipStream_t st = l == 0 ? ctx->stream : ctx->lanes[l - 1];
-            uint8_t* scratch = ctx->d_pred_scratch + (size_t)max_diag * (g0 + l) * WPB * kWaveScratch;
             HIP_TRY(ctx, hipEventRecord(ctx->ev_pool[2 * launches], st));
             hipLaunchKernelGGL(ctu_search_kernel, dim3(count * (g1 - g0)), dim3(64 * WPB), 0, st, ctx->d_const,
-                               ctx->d_slots, lane_first, lane_pics, d, r_min, count, scratch, ctx->d_mismatch,
+                               ctx->d_slots, lane_first, lane_pics, d, r_min, count, ctx->d_pred_scratch, ctx->d_slot_map,
+                               ctx->d_mismatch,
                                ctx->d_overflow);
             HIP_TRY(ctx, hipGetLastError());
             HIP_TRY(ctx, hipEventRecord(ctx->ev_pool[2 * launches + 1], st));
