@@ -708,12 +708,19 @@ __device__ __forceinline__ void stage_org(const Ctx& c, int comps, int tx, int t
 }
 
 // one predicted sample: accumulate |org - pred|; `full` also stores residual and prediction
+// The prediction itself is parked in the block's own area of the reconstruction tile until the
+// residual is added to it (nothing reads that area in between: the reference samples are cached, and
+// CCLM reads the luma plane while it writes chroma).  Only the final pass, which compares its
+// reconstruction with the search's, keeps the tile and parks the prediction in global scratch.
 template <bool full>
-__device__ __forceinline__ int emit_sample(const Ctx& c, int o, int i, int v) {
+__device__ __forceinline__ int emit_sample(const Ctx& c, int o, int i, int v, int pc, int x, int y, bool to_tile) {
     const int d = o - v;
     if (full) { // i already includes the block's base in r1 / the prediction scratch
         SH.r1[i] = (int16_t)d;
-        c.pred_scratch[i] = (uint8_t)v;
+        if (to_tile)
+            rec_put(pc, x, y, v);
+        else
+            c.pred_scratch[i] = (uint8_t)v;
     }
     return d < 0 ? -d : d;
 }
@@ -725,7 +732,8 @@ __device__ __forceinline__ int emit_sample(const Ctx& c, int o, int i, int v) {
 //       (each lane later re-reads exactly the bytes it wrote).
 // Returns the lane's partial sum of |org - pred| (the SAD of block_splitter.rs:96-104).
 template <bool full>
-__device__ __forceinline__ int predict(Ctx c, int comp, int tx, int ty, int tlg, int mode, int rbase = 0) {
+__device__ __forceinline__ int predict(Ctx c, int comp, int tx, int ty, int tlg, int mode, int rbase = 0,
+                                       bool to_tile = true) {
     c = uni(c);
     rbase = uni(rbase);
     comp = uni(comp);
@@ -762,7 +770,7 @@ __device__ __forceinline__ int predict(Ctx c, int comp, int tx, int ty, int tlg,
                 v = (M24(ds, blk ? a1 : a0) >> (blk ? k1 : k0)) + (blk ? b1 : b0);
                 v = min(max(v, 0), 255);
             }
-            sad += emit_sample<full>(c, o, rbase + i, v);
+            sad += emit_sample<full>(c, o, rbase + i, v, comp + blk, cx + x, cy + y, to_tile);
         }
         WSYNC();
         return sad;
@@ -803,7 +811,7 @@ __device__ __forceinline__ int predict(Ctx c, int comp, int tx, int ty, int tlg,
             const int wl = pdpc_w(n_scale, x), wt = pdpc_w(n_scale, y);
             v = (int16_t)(M24(L[y + 1], wl) + M24(A[x], wt) + M24(64 - wt - wl, v) + 32) >> 6;
             v = min(max(v, 0), 255);
-            sad += emit_sample<full>(c, o, rbase + i, v);
+            sad += emit_sample<full>(c, o, rbase + i, v, comp + blk, cx + x, cy + y, to_tile);
         }
         WSYNC();
         return sad;
@@ -901,7 +909,7 @@ __device__ __forceinline__ int predict(Ctx c, int comp, int tx, int ty, int tlg,
             v = (int16_t)(M24(rl, wl) + M24(rt, wt) + M24(64 - wt - wl, v) + 32) >> 6;
             v = min(max(v, 0), 255);
         }
-        sad += emit_sample<full>(c, o, rbase + i, v);
+        sad += emit_sample<full>(c, o, rbase + i, v, comp + blk, cx + x, cy + y, to_tile);
     }
     WSYNC();
     return sad;
@@ -1911,7 +1919,7 @@ __device__ __forceinline__ float uni_f(float v) { return __int_as_float(uni(__fl
 
 // First half of a full evaluation of one component (comp 0: luma block, 1: chroma pair): reference
 // samples, prediction, forward transform.  Residual / coefficients at r1[rbase ..], prediction bytes
-// at pred_scratch[rbase ..].
+// in the tile (final pass: at pred_scratch[rbase ..]).
 __device__ __forceinline__ void full_front(const Ctx& c, const Req& q, int comp, int mode, int rbase) {
     const int cs = comp ? 1 : 0;
     const int nb = comp ? 2 : 1;
@@ -1920,7 +1928,7 @@ __device__ __forceinline__ void full_front(const Ctx& c, const Req& q, int comp,
     if ((comp ? q.refs1 : q.refs0) && mode < LT_CCLM) build_refs(c, comp, q.tx, q.ty, q.tlg);
     PROF_MARK(t0_);
     PROF_ADD2(PH_REFS, tr0_, t0_);
-    predict<true>(c, comp, q.tx, q.ty, q.tlg, mode, rbase);
+    predict<true>(c, comp, q.tx, q.ty, q.tlg, mode, rbase, !q.final);
     PROF_MARK(t1_);
     PROF_ADD2(PH_PREDICT, t0_, t1_);
     fwd_dct_lg(c, lg, nb, rbase);
@@ -1960,7 +1968,8 @@ __device__ __forceinline__ uint32_t full_back(const Ctx& c, const PicBufs& pb, c
         const int blk = i >> (2 * lg), ii = i & (nn - 1);
         const int x = ii & (n - 1), y = ii >> lg;
         const int pc = comp + blk;
-        int v = (int16_t)((int)c.pred_scratch[rbase + i] + (int)SH.r1[rbase + i]); // pred as i16 + res, clamp (:178)
+        const int pred = q.final ? (int)c.pred_scratch[rbase + i] : rec_get(pc, cx + x, cy + y);
+        int v = (int16_t)(pred + (int)SH.r1[rbase + i]); // pred as i16 + res, clamp (:178)
         v = min(max(v, 0), 255);
         if (q.final && v != rec_get(pc, cx + x, cy + y)) ++diff;
         rec_put(pc, cx + x, cy + y, v);
