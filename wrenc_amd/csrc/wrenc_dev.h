@@ -556,19 +556,15 @@ __device__ __forceinline__ CclmParams cclm_params(Ctx c, int comp, int tx, int t
     int num_top_right = 0, num_below_left = 0;
     if (mode == T_CCLM) {
         const bool ar = above_right_avail(c, tx, ty, tlg), bl = below_left_avail(c, tx, ty, tlg);
-        bool a = true;
-        for (int x = tw; x < 2 * tw && a; ++x) {
-            a = nb_avail(c, gx, gy, tn, gx + x * 2, gy - 1, ar, bl);
-            if (a) ++num_top_right;
-        }
+        // run of available above-right samples (:1881-1893): one position per lane, then the length
+        // of the leading run of set bits
+        const bool a = LANE < tw && nb_avail(c, gx, gy, tn, gx + (tw + LANE) * 2, gy - 1, ar, bl);
+        num_top_right = min((int)__ffsll(~__ballot(a)) - 1, tw);
     }
     if (mode == L_CCLM) {
         const bool ar = above_right_avail(c, tx, ty, tlg), bl = below_left_avail(c, tx, ty, tlg);
-        bool a = true;
-        for (int y = th; y < 2 * th && a; ++y) {
-            a = nb_avail(c, gx, gy, tn, gx - 1, gy + y * 2, ar, bl);
-            if (a) ++num_below_left;
-        }
+        const bool a = LANE < th && nb_avail(c, gx, gy, tn, gx - 1, gy + (th + LANE) * 2, ar, bl);
+        num_below_left = min((int)__ffsll(~__ballot(a)) - 1, th);
     }
     int num_samp_t, num_samp_l;
     if (mode == LT_CCLM) {
