@@ -1334,6 +1334,11 @@ __device__ __forceinline__ int position_map(int tc, int qd, bool dcn, int nib) {
     return (int)(0x01010000u + (((x * 0x00204081u) & 0x01010101u) << 1));
 }
 
+// Which wave of the workgroup walks the pooled Viterbi.  Waves w and w + 4 share a SIMD with the same
+// two waves of the CU's other workgroup; if every workgroup walked in wave 0, one SIMD of each CU would
+// carry all the serial walks and its waves would reach every barrier last.  Spread by workgroup index.
+__device__ __forceinline__ int walker_wave() { return (int)((blockIdx.x * 2654435761u) >> 30); }
+
 // Path costs are kept in 32 bits, DOUBLED, with the tie-break of quantizer.rs:505 in the low bit.
 // Only cost DIFFERENCES between the four states decide the path, and they are bounded: any
 // state reaches any other state's continuation within two steps (q_state_trans_table is 2-step
@@ -1508,7 +1513,7 @@ __device__ __forceinline__ long long quantize(Ctx c, int lg, int nb, bool shared
     const int quad = LANE >> 2;
     const int wblk = nb == 2 ? (quad & 1) : 0;
     const int wwave = nb == 2 ? (quad >> 1) : quad;
-    const bool walker = shared ? (WAVE == 0 && wwave < WPB) : (quad < nb);
+    const bool walker = shared ? (WAVE == walker_wave() && wwave < WPB) : (quad < nb);
     const Lds* tb = shared ? &SHW[wwave < WPB ? wwave : 0] : &SH;
     const int32_t* wcc = (const int32_t*)tb->r1 + wblk * CH * 6;
     int C = 0;
@@ -1704,7 +1709,7 @@ __device__ __forceinline__ void quantize3(Ctx c, int lg0, bool active, int* over
     const int st = LANE & 3;
     const int cls = st == 0 ? 0 : (st == 1 ? 1 : 2);
     // walker lanes: wave 0 lanes 0..31 luma of wave LANE/4, lanes 32..63 Cb; wave 1 lanes 0..31 Cr
-    const int wv = WAVE;
+    const int wv = (WAVE - walker_wave()) & (WPB - 1); // 0 and 1: the two walker waves
     const int wb = wv == 0 ? (LANE < 32 ? 0 : 1) : 2;
     const bool walker = wv == 0 || (wv == 1 && LANE < 32);
     const Lds* tb = &SHW[(LANE & 31) >> 2];
