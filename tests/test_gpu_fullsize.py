@@ -74,3 +74,24 @@ def test_level_overflow_is_reported(built):
         enc.encode_picture(y, c, c)
     assert ei.value.code == -6
     enc.close()
+
+
+def test_4320p_depth2_decoder_check(built):
+    """The largest configuration of SURVEY.md 8d (7680x4320, 32400 CTUs): decoder-side reconstruction of
+    the record equals the encoder's, the final pass reproduces the search, and the picture's first CTU
+    row equals the oracle's encode of that row alone (a CTU row depends on nothing below it)."""
+    from wrenc_amd import gpu, synth
+    from oracle import pyoracle as po
+    w, h, qp, depth = 7680, 4320, 32, 2
+    y, cb, cr = synth.synth_frame(w, h, 5)
+    enc = gpu.Encoder(w, h, qp=qp, max_split_depth=depth)
+    rec = enc.encode_picture(y, cb, cr)
+    assert enc.final_pass_mismatches() == 0
+    enc.close()
+    ry, rcb, rcr = po.reconstruct_from_record(rec, qp, depth)
+    assert np.array_equal(ry, rec["rec_y"]) and np.array_equal(rcb, rec["rec_cb"]) and np.array_equal(rcr, rec["rec_cr"])
+    ref = po.encode_picture(y[:32], cb[:16], cr[:16], qp, depth)
+    for k, scale in (("cu_log2_size", 4), ("luma_mode", 4), ("chroma_mode", 8), ("lev_y", 1), ("lev_cb", 2), ("lev_cr", 2),
+                     ("rec_y", 1), ("rec_cb", 2), ("rec_cr", 2)):
+        assert np.array_equal(rec[k][:32 // scale], ref[k]), k
+    assert np.array_equal(rec["ctu_cost"][:w // 32], ref["ctu_cost"])
