@@ -156,6 +156,24 @@ def chroma_header_bits(cclm_flag, cclm_idx):
     return int(lib().wro_chroma_header_bits(cclm_flag, cclm_idx))
 
 
+def encode_picture_traced(y, cb, cr, qp, max_split_depth):
+    """encode_picture plus the trace of every candidate evaluation: dict (x, y, log2n, tree, kind, ml, mc) ->
+    set of f32 bit patterns returned for that key (re-evaluations give the same value)."""
+    lib().wro_trace_enable(1)
+    try:
+        out = encode_picture(y, cb, cr, qp, max_split_depth)
+        lib().wro_trace_read.restype = C.c_long
+        n = lib().wro_trace_read(None, C.c_long(0))
+        buf = np.zeros((n, 8), np.int32)
+        lib().wro_trace_read(_p(buf), C.c_long(n))
+    finally:
+        lib().wro_trace_enable(0)
+    trace = {}
+    for rec in buf.tolist():
+        trace.setdefault(tuple(rec[:7]), set()).add(rec[7] & 0xFFFFFFFF)
+    return out, trace
+
+
 def dct64():
     m = np.zeros((64, 64), np.int16)
     lib().wro_dct64(_p(m))

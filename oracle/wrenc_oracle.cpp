@@ -1415,6 +1415,20 @@ struct Predictor {
     }
 };
 
+// Optional trace of every candidate evaluation of the search (tests compare it with the GPU's):
+// kind 0 get_intra_pred_aux_cost, 1 get_intra_pred_cost, 2 get_chroma_intra_pred_aux_cost,
+// 3 get_chroma_intra_pred_cost; value = the f32 the function returns.
+struct TraceRec {
+    int32_t x, y, log2n, tree, kind, ml, mc;
+    float value;
+};
+static bool g_trace_on = false;
+static std::vector<TraceRec> g_trace;
+static inline float trace_put(int x, int y, int w, int tree, int kind, int ml, int mc, float v) {
+    if (g_trace_on) g_trace.push_back(TraceRec{x, y, ilog2(w), tree, kind, ml, mc, v});
+    return v;
+}
+
 static unsigned long long g_dbg_ssd = 0;
 static long long g_dbg_level = 0;
 
@@ -1475,7 +1489,7 @@ struct Splitter {
                 ip.predict(cu, c);
                 s += sad(cu, c);
             }
-        return (float)s;
+        return trace_put(cu->x, cu->y, cu->w, ct->tree, 0, mode[0], mode[1], (float)s);
     }
 
     // block_splitter.rs:110-474
@@ -1506,7 +1520,7 @@ struct Splitter {
         const float lambda = rd_lambda(p.rd);
         g_dbg_ssd = ssd;
         g_dbg_level = level;
-        return (float)ssd + lambda * ((float)level / 16384.0f);
+        return trace_put(cu->x, cu->y, cu->w, tree_type, 1, mode[0], mode[1], (float)ssd + lambda * ((float)level / 16384.0f));
     }
 
     // block_splitter.rs:476-522
@@ -1520,7 +1534,7 @@ struct Splitter {
                 ip.predict(cu, c);
                 s += sad(cu, c);
             }
-        return (float)s;
+        return trace_put(cu->x, cu->y, cu->w, ct->tree, 2, 0, m, (float)s);
     }
 
     // block_splitter.rs:524-780
@@ -1542,7 +1556,7 @@ struct Splitter {
         for (int c = 1; c < 3; ++c) sum += level_cost(p.rd, cu->lev[c].data(), ilog2(cu->csize(1)));
         const int64_t level = sum + hb;
         const float lambda = rd_lambda(p.rd);
-        return (float)ssd + lambda * ((float)level / 16384.0f);
+        return trace_put(cu->x, cu->y, cu->w, ct->tree, 3, 0, m, (float)ssd + lambda * ((float)level / 16384.0f));
     }
 
     void cache_reconsts(const Node* ct, int c0, int c1, std::vector<uint8_t> out[3]) {
@@ -1961,6 +1975,17 @@ int wro_reconstruct_from_record(const wro_params* prm, const wro_picture_out* re
 }
 
 long wro_last_final_pass_mismatches(void) { return g_last_final_mismatch; }
+
+void wro_trace_enable(int on) {
+    g_trace_on = on != 0;
+    g_trace.clear();
+}
+// copies up to max records of 8 int32 words (x, y, log2n, tree, kind, ml, mc, value bits); returns the count
+long wro_trace_read(int32_t* out, long max) {
+    const long n = (long)g_trace.size() < max ? (long)g_trace.size() : max;
+    if (n > 0) memcpy(out, g_trace.data(), (size_t)n * sizeof(TraceRec));
+    return (long)g_trace.size();
+}
 void wro_debug_last_cost(unsigned long long* ssd, long long* level) {
     *ssd = g_dbg_ssd;
     *level = g_dbg_level;

@@ -91,6 +91,14 @@ int64_t wro_header_bits(int tree, int non_planar, int mpm_flag, int mpm_idx,
 // chroma cost function header bits (block_splitter.rs:695-712)
 int64_t wro_chroma_header_bits(int cclm_flag, int cclm_idx);
 
+// Trace of every candidate evaluation of the search (block_splitter.rs:64-108, 110-474, 476-522,
+// 524-780): enable, run wro_encode_picture, read.  A record is 8 int32 words: x, y (luma, picture
+// coordinates of the CU), log2 size, tree type (0 single, 1 dual luma, 2 dual chroma), kind
+// (0 aux cost, 1 full cost, 2 chroma aux cost, 3 chroma full cost), luma mode (0 for kinds 2, 3),
+// chroma mode, and the bits of the f32 the function returned.  Returns the number of records made.
+void wro_trace_enable(int on);
+long wro_trace_read(int32_t* out, long max);
+
 // 64x64 DCT-2 matrix rows (transformer.rs:934-1191 after symmetric extension)
 void wro_dct64(int16_t* m64x64);
 

@@ -275,6 +275,32 @@ __shared__ unsigned long long s_prof[PH_COUNT];
 #define PROF_ADD2(ph, a, b)
 #endif
 
+// Diagnostic build (-DWRENC_TRACE, never the product library): every candidate evaluation of the
+// search is appended to a device buffer, 8 ints per record, in the layout of the oracle's trace
+// (oracle/wrenc_oracle.h: x, y, log2 size, tree, kind, luma mode, chroma mode, f32 bits).
+#ifdef WRENC_TRACE
+constexpr unsigned kTraceMax = 1u << 19;
+__device__ unsigned int g_trace_n;
+__device__ int g_trace[kTraceMax * 8];
+__device__ __forceinline__ void trace_rec(int x, int y, int lg, int tree, int kind, int ml, int mc, int bits) {
+    const unsigned idx = atomicAdd(&g_trace_n, 1u);
+    if (idx < kTraceMax) {
+        int* r = g_trace + (size_t)idx * 8;
+        r[0] = x;
+        r[1] = y;
+        r[2] = lg;
+        r[3] = tree;
+        r[4] = kind;
+        r[5] = ml;
+        r[6] = mc;
+        r[7] = bits;
+    }
+}
+#define TRACE_REC(...) trace_rec(__VA_ARGS__)
+#else
+#define TRACE_REC(...) do { } while (0)
+#endif
+
 // ---------------------------------------------------------------------------
 // wave helpers
 // ---------------------------------------------------------------------------
@@ -1901,6 +1927,7 @@ struct Req {
     bool refs0, refs1; // (re)build the luma / chroma reference samples of the block first
     bool final;     // final pass: store the levels, count reconstruction changes
     int n;          // K_SADLIST: number of entries
+    int tree;       // tree type of the leaf that asks (diagnostic trace only)
     // before the evaluation: save the block's reconstruction to a slot / restore it from there
     // (the reference's cache_reconsts / restore_reconsts, block_splitter.rs:807-840, 1085-1145)
     int pre_copy, copy_comps, copy_slot, copy_tx, copy_ty, copy_tlg;
@@ -2095,6 +2122,9 @@ __device__ __forceinline__ Res evaluate(const Ctx& c, const PicBufs& pb, const R
         // a list of angular modes (the 13 directional candidates, a step-search pair)
         const unsigned acc = sad_list_angular(c, q.comps, q.tx, q.ty, q.tlg, q.n, q.modes_lo, q.modes_hi);
         const int my_mode = LANE < q.n ? (int)(((LANE < 8 ? q.modes_lo : q.modes_hi) >> (8 * (LANE & 7))) & 255u) : kNoMode;
+        if (c.write && my_mode != kNoMode)
+            TRACE_REC(c.ctu_x + q.tx, c.ctu_y + q.ty, q.tlg, q.tree, (q.comps & 1) ? 0 : 2, (q.comps & 1) ? my_mode : 0, my_mode,
+                      __float_as_int((float)acc));
         // first minimum = smallest (sad, index) pair
         const int key = my_mode != kNoMode ? (int)((acc << 4) | (unsigned)LANE) : 0x7FFFFFFF;
         const int kmin = wave_min_i32(key);
@@ -2124,6 +2154,9 @@ __device__ __forceinline__ Res evaluate(const Ctx& c, const PicBufs& pb, const R
                     PROF_ADD2(PH_PCNT + ((q.tlg - 2) * 2 + comp), 0, 1);
                 }
             }
+            if (c.write && LANE == 0 && m != kNoMode)
+                TRACE_REC(c.ctu_x + q.tx, c.ctu_y + q.ty, q.tlg, q.tree, (q.comps & 1) ? 0 : 2, (q.comps & 1) ? m : 0, m,
+                          __float_as_int((float)sad));
             if (i == 0) s0 = sad;
             if (i == 1) s1 = sad;
             if (i == 2) s2 = sad;
@@ -2360,6 +2393,7 @@ __device__ __forceinline__ void leaf_full(LeafSt& s, Req& q, int comps, int ml, 
     const bool r0 = (comps & 1) && s.need_refs0 != 0;
     const bool r1 = (comps & 2) && mc < LT_CCLM && s.need_refs1 != 0;
     req_full(q, comps, s.bx, s.by, s.lg, ml, mc, !solo, act, r0, r1, false);
+    q.tree = s.tree;
     leaf_attach_save(s, q);
     if (act) {
         if (r0) s.need_refs0 = 0;
@@ -2375,6 +2409,7 @@ __device__ __forceinline__ void leaf_full(LeafSt& s, Req& q, int comps, int ml, 
 __device__ __forceinline__ void leaf_sadlist(LeafSt& s, Req& q, int comps, int n, uint32_t m0, uint32_t m1, uint32_t m2,
                                              uint32_t m3, bool chroma_refs, int cont) {
     q.kind = K_SADLIST;
+    q.tree = s.tree;
     q.comps = comps;
     q.tx = s.bx;
     q.ty = s.by;
@@ -2440,6 +2475,8 @@ __device__ __forceinline__ bool leaf_step(const Ctx& c, LeafSt& s, const Res& r,
         if (s.op_act) {
             cls = mpm_class(c, s.bx, s.by, s.lg, s.op_ml);
             val = uni_f(assemble_cost(c, tree, cls, s.op_mc, rp));
+            if (c.write && LANE == 0)
+                TRACE_REC(c.ctu_x + s.bx, c.ctu_y + s.by, s.lg, tree, 1, s.op_ml, s.op_mc, __float_as_int(val));
         } else {
             val = 3.40282347e+38f; // a skipped evaluation is f32::MAX in the reference
         }
@@ -2539,6 +2576,8 @@ __device__ __forceinline__ bool leaf_step(const Ctx& c, LeafSt& s, const Res& r,
             }
             // :1040 get_chroma_intra_pred_cost(mode) repeats the winner's chroma evaluation: re-use it
             s.cur_cost = uni_f(assemble_chroma_cost(c, m, s.e_best.get()));
+            if (c.write && LANE == 0)
+                TRACE_REC(c.ctu_x + s.bx, c.ctu_y + s.by, s.lg, tree, 3, 0, m, __float_as_int((float)s.cur_cost));
             leaf_sadlist(s, q, 2, 3, (uint32_t)LT_CCLM | ((uint32_t)T_CCLM << 8) | ((uint32_t)L_CCLM << 16), 0, 0, 0, false,
                          C_CX);
             if (!in_tile) req_copy(q, COPY_RESTORE, 1, 0, s.bx, s.by, s.lg); // (its save went out earlier)
@@ -2558,6 +2597,8 @@ __device__ __forceinline__ bool leaf_step(const Ctx& c, LeafSt& s, const Res& r,
             e.ssd_c = rp.ssd_c;
             e.lvl_c = rp.lvl_c;
             const float cclm_cost = uni_f(assemble_chroma_cost(c, s.cclm_mode, e));
+            if (c.write && LANE == 0)
+                TRACE_REC(c.ctu_x + s.bx, c.ctu_y + s.by, s.lg, tree, 3, 0, s.cclm_mode, __float_as_int(cclm_cost));
             const float cur = s.cur_cost;
             const bool dm_wins = cur == fminf(cclm_cost, fminf(cur, 3.40282347e+38f));
             // :1062-1072 final get_intra_pred_cost: luma = the winner; the chroma pair is the DM
@@ -2588,11 +2629,15 @@ __device__ __forceinline__ bool leaf_step(const Ctx& c, LeafSt& s, const Res& r,
         }
         case C_DC3:
             s.c0 = uni_f(assemble_chroma_cost(c, s.cclm_mode, rp));
+            if (c.write && LANE == 0)
+                TRACE_REC(c.ctu_x + s.bx, c.ctu_y + s.by, s.lg, tree, 3, 0, s.cclm_mode, __float_as_int((float)s.c0));
             leaf_full(s, q, 2, 0, s.dm_mode, true, C_DC4);
             req_copy(q, COPY_SAVE, 2, 0, s.bx, s.by, s.lg); // keep the CCLM reconstruction (:807-840)
             return true;
         case C_DC4: {
             const float dm_cost = uni_f(assemble_chroma_cost(c, s.dm_mode, rp));
+            if (c.write && LANE == 0)
+                TRACE_REC(c.ctu_x + s.bx, c.ctu_y + s.by, s.lg, tree, 3, 0, s.dm_mode, __float_as_int(dm_cost));
             const float cost = fminf(s.c0, fminf(dm_cost, 3.40282347e+38f));
             s.luma_mode = 0;
             s.cost = cost;

@@ -654,6 +654,23 @@ int wrenc_gpu_final_pass_mismatches(wrenc_gpu_ctx* ctx, long long* count) {
     return WRENC_GPU_OK;
 }
 
+#ifdef WRENC_TRACE
+// diagnostic build only: copies up to max_records records (8 ints each) of the last encode call's trace,
+// returns the number of records made; resets the trace
+extern "C" long wrenc_gpu_trace_read(wrenc_gpu_ctx* ctx, int* out, long max_records) {
+    if (!ctx) return -1;
+    if (hipSetDevice(ctx->cfg.device) != hipSuccess || hipDeviceSynchronize() != hipSuccess) return -1;
+    unsigned int n = 0;
+    if (hipMemcpyFromSymbol(&n, HIP_SYMBOL(g_trace_n), sizeof(n)) != hipSuccess) return -1;
+    long take = n < kTraceMax ? (long)n : (long)kTraceMax;
+    if (take > max_records) take = max_records;
+    if (take > 0 && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_trace), (size_t)take * 8 * sizeof(int)) != hipSuccess) return -1;
+    const unsigned int zero = 0;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_trace_n), &zero, sizeof(zero)) != hipSuccess) return -1;
+    return (long)n;
+}
+#endif
+
 #ifdef WRENC_PROFILE
 // diagnostic build only: read and clear the per-phase cycle counters
 int wrenc_gpu_prof_read(wrenc_gpu_ctx* ctx, unsigned long long* out, int n) {
