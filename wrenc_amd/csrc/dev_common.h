@@ -1,0 +1,414 @@
+// dev_common.h -- constants, per-launch / per-picture structures, the per-wave LDS working set, search state, wave helpers, tile access, availability
+// Part of the gfx950 device code of the RD-search path; see wrenc_dev.h for the overall model.
+#pragma once
+
+namespace wrenc {
+
+enum { PLANAR = 0, DC = 1, LT_CCLM = 81, L_CCLM = 82, T_CCLM = 83 };
+enum { TREE_SINGLE = 0, TREE_DUAL_LUMA = 1, TREE_DUAL_CHROMA = 2 };
+
+// Constants resolved on the host (see wrenc_gpu_config in include/wrenc_gpu.h).
+struct DevConst {
+    int32_t W, H, qp, max_depth, ctu_cols, ctu_rows;
+    int32_t lsc;              // quantizer.rs:617-622 (16*LEVEL_SCALE[0][(qp+1)%6]) << ((qp+1)/6)
+    uint64_t div_magic;       // floor(2^47 / lsc) + 1: exact n / lsc for n < 2^26
+    int64_t lambda_q;
+    float lambda_rd;
+    float lambda_rd_chroma;
+    int64_t ldq[1024];        // lambda_q * dq_table[bits]  (quantizer.rs:29-31)
+    int64_t lv[1024];
+    int64_t hb_luma[2][4][67];
+    int64_t hb_chroma[4];
+    int16_t dct[4][32][32];   // T_N[u][k] = dct64[u * 64/N][k], N = 4 << idx (transformer.rs:1212-1221)
+    int16_t dct_t[4][32][32]; // transposed: dct_t[idx][y][i] = T_N[i][y]
+    uint8_t diag4[16][2];     // 4x4 up-right diagonal scan (x, y)   (ctu.rs:14-81)
+    uint8_t diag_sb[4][64][2]; // sub-block scan for 1, 4, 16, 64 sub-blocks
+    uint16_t scan_idx[4][1024]; // raster index y*n+x of reverse-scan position p (p = 0: last in scan)
+    int16_t intra_angle[95];  // common.rs:145
+    int32_t ang_tab[67];      // per mode: intraPredAngle (low half) | invAngle (high half), read with one scalar load
+    int8_t fc[32][4];         // common.rs:153
+};
+
+// Pointers that are loaded from memory (PicBufs) lose their address space; these casts tell the
+// compiler they are global memory, so that it emits global_* instead of flat_* accesses.
+#define GLOBAL_AS __attribute__((address_space(1)))
+// The constant block is written by the host before the launch and never during it.
+#define CONST_AS __attribute__((address_space(4)))
+#define AS_GLOBAL(T, p) ((GLOBAL_AS T*)(p))
+
+// Per-wave global scratch: 1 KB of prediction bytes, then kReconSlots saved reconstructions
+// (slot 0: best candidate of the running leaf; 1 + level: unsplit candidate of the open node at
+// that tree level), each 1024 B luma + 2 x 256 B chroma.
+constexpr int kReconSlots = 4;
+constexpr int kSlotBytes = 1536;
+constexpr int kWaveScratch = 1024 + kReconSlots * kSlotBytes;
+
+// One picture's device buffers.
+struct PicBufs {
+    const uint8_t* org[3];
+    uint8_t* rec[3];
+    int16_t* lev[3];
+    uint8_t* cu_log2;
+    uint8_t* luma_mode;
+    uint8_t* chroma_mode;
+    float* ctu_cost;
+};
+
+// LDS working set of one wave / one CTU.
+#define LANE ((int)(threadIdx.x & 63))
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+// SSD and level cost of the luma block and of the chroma pair of one evaluated candidate
+struct EvalParts {
+    uint32_t ssd_y, ssd_c; // <= 1024 * 255^2: fits 32 bits
+    long long lvl_y, lvl_c;
+};
+
+
+// A wave-uniform field of the search state, resident in LDS: reads come back through
+// readfirstlane (scalar registers, scalar branches).
+template <class T>
+struct UF {
+    T v;
+    __device__ __forceinline__ T get() const {
+        if constexpr (sizeof(T) == 8) {
+            const unsigned long long x = (unsigned long long)v;
+            return (T)(((unsigned long long)(unsigned)uni((int)(x >> 32)) << 32) | (unsigned)uni((int)x));
+        } else if constexpr (sizeof(T) == 4 && !(T(0.5f) == T(0))) {
+            return __int_as_float(uni(__float_as_int((float)v)));
+        } else {
+            return (T)uni((int)v);
+        }
+    }
+    // every lane stores the same value to the same address (one LDS pass; keeps the control flow
+    // free of lane predicates so that all of it stays scalar)
+    __device__ __forceinline__ void set(T x) { v = x; }
+    __device__ __forceinline__ operator T() const { return get(); }
+    __device__ __forceinline__ UF& operator=(T x) {
+        set(x);
+        return *this;
+    }
+    __device__ __forceinline__ UF& operator=(const UF& o) {
+        set(o.get());
+        return *this;
+    }
+    __device__ __forceinline__ UF& operator+=(int x) {
+        set((T)(get() + x));
+        return *this;
+    }
+    __device__ __forceinline__ UF& operator-=(int x) {
+        set((T)(get() - x));
+        return *this;
+    }
+    __device__ __forceinline__ UF& operator>>=(int x) {
+        set((T)(get() >> x));
+        return *this;
+    }
+    __device__ __forceinline__ UF& operator++() {
+        set((T)(get() + 1));
+        return *this;
+    }
+};
+
+// EvalParts as kept in the search state
+struct EvalPartsU {
+    UF<uint32_t> ssd_y, ssd_c;
+    UF<long long> lvl_y, lvl_c;
+    __device__ __forceinline__ EvalParts get() const {
+        EvalParts e;
+        e.ssd_y = ssd_y;
+        e.ssd_c = ssd_c;
+        e.lvl_y = lvl_y;
+        e.lvl_c = lvl_c;
+        return e;
+    }
+};
+
+// Leaf search state (block_splitter.rs:794-1078 as a state machine, see leaf_step).
+struct LeafSt {
+    UF<uint8_t> cont;                   // where to continue with the result of the pending request
+    UF<uint8_t> op_ml, op_mc, op_act;   // modes / activity of the pending full evaluation
+    UF<uint8_t> tree, bx, by, lg;
+    UF<uint8_t> need_refs0, need_refs1; // reference samples of the block not built yet (luma / chroma pair)
+    UF<uint8_t> step;
+    UF<uint8_t> cur_mode, best_mode, mode, cclm_mode, dm_mode, dm_wins;
+    UF<uint8_t> luma_mode, chroma_mode; // result
+    UF<uint8_t> best_cls;               // header-bit class (mpm_class) of the best luma mode
+    UF<uint8_t> need_save, tile_best;   // best candidate's reconstruction: not saved yet / still in the tile
+    UF<float> best_cost;                // best of {planar, DC} so far / of {planar, DC, dir}
+    UF<float> cur_cost, c0;
+    UF<float> cost;                     // result
+    EvalPartsU e_best;
+};
+
+// CTU search + final pass state (see ctu_step)
+struct CtuSt {
+    UF<uint8_t> cont, in_leaf;
+    UF<uint8_t> level, bx, by, lg, max_depth;
+    UF<uint8_t> i8, z, rl, rc;       // 4x4 child index, final-pass z-order index, regen modes
+    UF<uint8_t> rbx, rby, rlg;       // regen block
+    UF<uint8_t> ns_luma_cur, ns_chroma_cur;
+    UF<uint8_t> pend, pbx, pby, plg, pslot; // reconstruction save to attach to the next request
+    UF<float> ret, ns_cost_cur, split8, ctu_cost;
+    LeafSt leaf;
+};
+
+// element offsets into Lds::refs: left (index 0 = corner) / above references of luma unfiltered,
+// luma filtered, Cb, Cr
+constexpr int R_L0 = 0, R_A0 = 66, R_LF = 130, R_AF = 196, R_LC0 = 260, R_LC1 = 294, R_AC0 = 328, R_AC1 = 360;
+
+struct __attribute__((aligned(16))) Lds {
+    // Transform working set, time-multiplexed through a full evaluation (dev_search.h):
+    //   r1: residual -> coefficients -> Viterbi chunk costs / levels -> reconstructed residual
+    //   r2: stage-1 DCT output (i32) -> scan-order coefficients + quotients -> dequantised^T + V
+    int16_t r1[1024];
+    int32_t r2[33 * 32];
+    // reference samples of the current block, built once per (block, component) and reused by
+    // every candidate mode: luma unfiltered + [1 2 1]-filtered, chroma unfiltered
+    // one array addressed by element offsets (R_*), so that choosing among the sets is integer
+    // arithmetic on a DS address, never a pointer select
+    int16_t refs[392];
+    uint8_t recYtop[72];       // y = -1, x = -4..67 (index x+4)
+    uint8_t recY[32 * 36];     // x = -4..31 (index x+4), stride 36
+    uint8_t recCtop[2][40];    // y = -1, x = -4..35
+    uint8_t recC[2][16 * 20];  // x = -4..15, stride 20
+    uint32_t decw[128];        // trellis decisions: 4 bits per position, 8 positions per word
+    int32_t q_istar[2];        // shared-Viterbi hand-off, per block: first position with a non-zero state-0 level
+    int32_t q_active;          // this wave's TB takes part in the shared Viterbi
+    uint16_t q_pm[3][4][4];    // per block and sub-block of the chunk: parity masks (delta 0, 1), state-0 flag
+    uint8_t cu_log2[64];       // per 4x4 luma unit
+    uint8_t luma_mode[64];
+    uint8_t chroma_mode[16];   // per 8x8 luma unit
+    uint8_t left_mode[8];      // luma mode of the CU left of the CTU, per 4 rows
+    float ns_cost[4];          // per tree level: no-split cost, running split cost
+    float split_cost[4];
+    uint8_t ns_luma[4], ns_chroma[4], child[4];
+    CtuSt st;                  // state of the search (dev_search.h)
+};
+
+// Per-wave uniform context.
+// Per-wave uniform context, passed BY VALUE (a few registers) so that the (inlined)
+// stage functions never reload it from memory.
+struct Ctx {
+    const CONST_AS DevConst* k;         // constant address space: uniform reads become scalar loads
+    const GLOBAL_AS uint8_t* org;       // original planes of this wave's picture: Y, Cb, Cr back to back (read-only)
+    int W, WH;                          // luma width, luma plane size
+    uint8_t* pred_scratch;              // 1 KB per wave in HBM: prediction bytes between predict and recon
+    GLOBAL_AS uint8_t* slots;           // kReconSlots saved reconstructions of this wave (see copy_block)
+    unsigned long long* mismatch;
+    int ctu_x, ctu_y; // luma, picture coordinates
+    int cu32_mode;    // in-CTU neighbour lookups during search resolve to the root CU
+    int write;        // 0 for a padding wave (batch not a multiple of WPB): compute, never store
+};
+
+// LDS: one working set per wave (= per CTU), WPB waves per workgroup, plus tables shared
+// by the workgroup.  File scope so that every access is a DS instruction (no FLAT ops).
+// The waves of a workgroup process the SAME CTU position of WPB different pictures, so
+// they execute the same schedule; the 4-lane Viterbi of all WPB transform blocks is run by
+// wave 0 in WPB quads at once (see quantize()).
+#ifndef WRENC_WPB
+#define WRENC_WPB 8
+#endif
+constexpr int WPB = WRENC_WPB;
+struct LdsTab {
+    int32_t ldq[256];
+    int32_t lv[256];
+    int8_t fc[32][4]; // common.rs:153 (copied from the constant block)
+};
+__shared__ Lds SHW[WPB];
+__shared__ LdsTab SHT;
+#define WAVE (__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)))
+#define SH (SHW[WAVE])
+
+// Everything in Ctx and every block-geometry argument is wave-uniform.  Out-of-line
+// functions receive arguments in VGPRs; re-deriving them through readfirstlane lets the
+// compiler keep them in SGPRs (scalar ALU, scalar branches, s_load from the constant block).
+__device__ __forceinline__ Ctx uni(Ctx c) {
+    // the pointers come from kernel arguments / scalar loads and keep their (global) address
+    // space only if they are not laundered through integers: make just the integers scalar
+    c.ctu_x = uni(c.ctu_x);
+    c.ctu_y = uni(c.ctu_y);
+    c.cu32_mode = uni(c.cu32_mode);
+    c.write = uni(c.write);
+    return c;
+}
+
+// One wave per block: LDS operations of a wave are issued and serviced in program order,
+// so "synchronising" only has to stop the compiler from reordering LDS accesses.
+#define WSYNC()                                                  \
+    do {                                                         \
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   \
+        __builtin_amdgcn_wave_barrier();                         \
+    } while (0)
+
+// Diagnostic build only (-DWRENC_PROFILE): per-phase cycle counters, summed per wave and
+// added to a global table at CTU end.  Never compiled into the product library.
+#ifdef WRENC_PROFILE
+enum { PH_PREDICT, PH_FDCT, PH_QPRE, PH_QBACK, PH_QTRACE, PH_DEQ, PH_IDCT, PH_RECON, PH_TOTAL, PH_CTRL, PH_REFS, PH_SKIP, PH_NSTEP, PH_NFULL, PH_PSZ, PH_PSZ_END = PH_PSZ + 8, PH_PCNT, PH_PCNT_END = PH_PCNT + 8, PH_QB_PRE, PH_QB_WAIT1, PH_QB_WALK, PH_QB_WAIT2, PH_COUNT };
+__device__ unsigned long long g_prof[PH_COUNT];
+__shared__ unsigned long long s_prof[PH_COUNT];
+#define PROF_T0() const unsigned long long prof_t0_ = __builtin_readcyclecounter()
+#define PROF_ADD(ph) do { if (threadIdx.x == 0) s_prof[ph] += __builtin_readcyclecounter() - prof_t0_; } while (0)
+#define PROF_MARK(var) const unsigned long long var = __builtin_readcyclecounter()
+#define PROF_ADD2(ph, a, b) do { if (threadIdx.x == 0) s_prof[ph] += (b) - (a); } while (0)
+#else
+#define PROF_T0()
+#define PROF_ADD(ph)
+#define PROF_MARK(var)
+#define PROF_ADD2(ph, a, b)
+#endif
+
+// Diagnostic build (-DWRENC_TRACE, never the product library): every candidate evaluation of the
+// search is appended to a device buffer, 8 ints per record, in the layout of the oracle's trace
+// (oracle/wrenc_oracle.h: x, y, log2 size, tree, kind, luma mode, chroma mode, f32 bits).
+#ifdef WRENC_TRACE
+constexpr unsigned kTraceMax = 1u << 19;
+__device__ unsigned int g_trace_n;
+__device__ int g_trace[kTraceMax * 8];
+__device__ __forceinline__ void trace_rec(int x, int y, int lg, int tree, int kind, int ml, int mc, int bits) {
+    const unsigned idx = atomicAdd(&g_trace_n, 1u);
+    if (idx < kTraceMax) {
+        int* r = g_trace + (size_t)idx * 8;
+        r[0] = x;
+        r[1] = y;
+        r[2] = lg;
+        r[3] = tree;
+        r[4] = kind;
+        r[5] = ml;
+        r[6] = mc;
+        r[7] = bits;
+    }
+}
+#define TRACE_REC(...) trace_rec(__VA_ARGS__)
+#else
+#define TRACE_REC(...) do { } while (0)
+#endif
+
+// ---------------------------------------------------------------------------
+// wave helpers
+// ---------------------------------------------------------------------------
+// Cross-lane reductions with DPP inside the 16-lane rows and v_readlane across the four rows:
+// no LDS-crossbar round trips (ds_bpermute), and the result is a scalar.  All lanes must be active.
+template <int CTRL>
+__device__ __forceinline__ int dpp_mov(int v) {
+    return __builtin_amdgcn_mov_dpp(v, CTRL, 0xF, 0xF, true);
+}
+constexpr int kDppSwap1 = 0xB1;          // quad_perm [1,0,3,2]
+constexpr int kDppSwap2 = 0x4E;          // quad_perm [2,3,0,1]
+constexpr int kDppRowHalfMirror = 0x141; // lane i <-> 7 - i inside each 8 lanes
+constexpr int kDppRowMirror = 0x140;     // lane i <-> 15 - i inside each row
+__device__ __forceinline__ int row_sum_i32(int v) { // every lane: sum over its row of 16
+    v += dpp_mov<kDppSwap1>(v);
+    v += dpp_mov<kDppSwap2>(v);
+    v += dpp_mov<kDppRowHalfMirror>(v);
+    v += dpp_mov<kDppRowMirror>(v);
+    return v;
+}
+__device__ __forceinline__ int row_min_i32(int v) {
+    v = min(v, dpp_mov<kDppSwap1>(v));
+    v = min(v, dpp_mov<kDppSwap2>(v));
+    v = min(v, dpp_mov<kDppRowHalfMirror>(v));
+    v = min(v, dpp_mov<kDppRowMirror>(v));
+    return v;
+}
+__device__ __forceinline__ int wave_sum_i32(int v) {
+    v = row_sum_i32(v);
+    return __builtin_amdgcn_readlane(v, 0) + __builtin_amdgcn_readlane(v, 16) + __builtin_amdgcn_readlane(v, 32) +
+           __builtin_amdgcn_readlane(v, 48);
+}
+__device__ __forceinline__ int wave_min_i32(int v) {
+    v = row_min_i32(v);
+    return min(min(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)),
+               min(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
+}
+// signed 64-bit sum in three limbs: v = lo + 2^24 * (mid + 2^24 * top), lo and mid 24 bits unsigned,
+// top the signed rest (each limb's 64-lane sum fits 32 bits for |v| < 2^57)
+__device__ __forceinline__ long long wave_sum_i64(long long v) {
+    const long long hi = v >> 24;
+    const long long a = (long long)(unsigned)wave_sum_i32((int)(v & 0xFFFFFF));
+    const long long b = (long long)(unsigned)wave_sum_i32((int)(hi & 0xFFFFFF));
+    const long long c = (long long)wave_sum_i32((int)(hi >> 24));
+    return a + ((b + (c << 24)) << 24);
+}
+// minimum over aligned groups of `width` lanes (width = 64 or 32)
+__device__ __forceinline__ int group_min_i32(int v, int width) {
+    v = row_min_i32(v);
+    const int lo = min(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16));
+    const int hi = min(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48));
+    if (width == 64) return min(lo, hi);
+    return LANE < 32 ? lo : hi;
+}
+__device__ __forceinline__ int ilog2i(int v) { return 31 - __clz(v); }
+// Full-rate multiply (v_mul_i32_i24): both factors fit 24 bits everywhere it is used (sample values,
+// filter taps, weights, block coordinates, angles, levels, quantiser scales); a plain `*` on ints
+// compiles to the quarter-rate v_mul_lo_u32.
+#define M24(a, b) __mul24((int)(a), (int)(b))
+
+// ---------------------------------------------------------------------------
+// recon tile access (CTU-local component coordinates)
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ int rec_get(int c, int x, int y) {
+    if (c == 0) return y < 0 ? SH.recYtop[x + 4] : SH.recY[y * 36 + x + 4];
+    return y < 0 ? SH.recCtop[c - 1][x + 4] : SH.recC[c - 1][y * 20 + x + 4];
+}
+__device__ __forceinline__ void rec_put(int c, int x, int y, int v) {
+    if (c == 0)
+        SH.recY[y * 36 + x + 4] = (uint8_t)v;
+    else
+        SH.recC[c - 1][y * 20 + x + 4] = (uint8_t)v;
+}
+// original sample at CTU-local component coordinates (global load; the planes are read-only
+// for the whole launch, so the loads are cacheable and need no ordering)
+// element offset of plane pc inside a picture's Y | Cb | Cr slab (integer arithmetic only: the
+// three planes are one allocation, so no pointer is ever selected per lane)
+__device__ __forceinline__ unsigned plane_off(const Ctx& c, int pc) {
+    return pc == 0 ? 0u : (pc == 1 ? (unsigned)c.WH : (unsigned)(c.WH + (c.WH >> 2)));
+}
+__device__ __forceinline__ int org_get(const Ctx& c, int pc, int x, int y) {
+    const int cs = pc ? 1 : 0;
+    const int stride = c.W >> cs;
+    return c.org[plane_off(c, pc) + (unsigned)(((c.ctu_y >> cs) + y) * stride + (c.ctu_x >> cs) + x)];
+}
+
+// ---------------------------------------------------------------------------
+// availability (ctu.rs:2083-2188, encoder_context.rs:918-956)
+// bx, by: CTU-local luma position, lg: log2 luma size
+// ---------------------------------------------------------------------------
+__device__ inline bool above_right_avail(Ctx c, int bx, int by, int lg) {
+    for (;;) {
+        const int n = 1 << lg;
+        if (c.ctu_x + bx + n >= c.W) return false;
+        if (lg == 5) return c.ctu_y > 0 && c.ctu_x + 32 < c.W;
+        const int px = bx & ~(2 * n - 1), py = by & ~(2 * n - 1);
+        if (bx == px && by == py) return c.ctu_y + by > 0;
+        if (by == py) { // top-right child: parent's
+            bx = px;
+            by = py;
+            lg += 1;
+            continue;
+        }
+        if (bx == px) return true;
+        return false;
+    }
+}
+__device__ inline bool below_left_avail(Ctx c, int bx, int by, int lg) {
+    for (;;) {
+        const int n = 1 << lg;
+        if (c.ctu_y + by + n >= c.k->H) return false;
+        if (lg == 5) return false;
+        const int px = bx & ~(2 * n - 1), py = by & ~(2 * n - 1);
+        if (px < bx) return false;
+        if (by + n < py + 2 * n) return c.ctu_x + bx > 0;
+        bx = px;
+        by = py;
+        lg += 1;
+    }
+}
+__device__ __forceinline__ bool nb_avail(Ctx c, int gx, int gy, int tn, int xn, int yn,
+                                         bool ar, bool bl) {
+    return xn >= 0 && yn >= 0 && xn < c.W && yn < c.k->H &&
+           ((xn >> 5) <= (gx >> 5) || (yn >> 5) < (gy >> 5)) && (yn >> 5) < (gy >> 5) + 1 &&
+           (xn < gx + tn || ar) && (yn < gy + tn || bl);
+}
+
+} // namespace wrenc

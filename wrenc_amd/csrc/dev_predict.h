@@ -1,0 +1,758 @@
+// dev_predict.h -- reference samples, PLANAR / DC / angular / CCLM prediction, SAD lists (intra_predictor.rs)
+// Part of the gfx950 device code of the RD-search path; see wrenc_dev.h for the overall model.
+#pragma once
+
+namespace wrenc {
+
+// ---------------------------------------------------------------------------
+// Intra prediction.  tx, ty: CTU-local luma position of the TU, tlg: log2 luma
+// size, comp: component, mode: TU-array prediction mode.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ int pdpc_w(int n_scale, int i) {
+    const int sh = (i << 1) >> n_scale;
+    return sh > 5 ? 0 : (32 >> sh);
+}
+
+// Component convention of every stage below: comp 0 = luma block, comp 1 = the chroma PAIR
+// (Cb and Cr blocks of the TU processed together: block index blk = 0/1, plane pc = comp + blk).
+//
+// Reference samples of one block into the per-plane LDS arrays: unfiltered always, plus the
+// [1 2 1]-filtered version for luma blocks of more than 32 samples (intra_predictor.rs:146-353).
+// The neighbourhood of a block does not change while its candidate modes are evaluated
+// (evaluations only write inside the block), so this runs once per block instead of once per mode.
+__device__ __forceinline__ void build_refs(Ctx c, int comp, int tx, int ty, int tlg) {
+    c = uni(c);
+    comp = uni(comp);
+    tx = uni(tx);
+    ty = uni(ty);
+    tlg = uni(tlg);
+    const int cs = comp ? 1 : 0;
+    const int nb = comp ? 2 : 1;
+    const int n = 1 << (tlg - cs);
+    const int tn = 1 << tlg;
+    const int cx = tx >> cs, cy = ty >> cs;
+    const int gx = c.ctu_x + tx, gy = c.ctu_y + ty;
+    const bool ar = above_right_avail(c, tx, ty, tlg);
+    const bool bl = below_left_avail(c, tx, ty, tlg);
+    const int st = 1 << cs;
+    // segment availabilities in substitution-scan order: BL, L, corner, A, AR (bit j = segment j)
+    int avm = 0;
+    avm |= nb_avail(c, gx, gy, tn, gx - st, gy + tn, ar, bl) ? 1 : 0;
+    avm |= nb_avail(c, gx, gy, tn, gx - st, gy, ar, bl) ? 2 : 0;
+    avm |= nb_avail(c, gx, gy, tn, gx - st, gy - st, ar, bl) ? 4 : 0;
+    avm |= nb_avail(c, gx, gy, tn, gx, gy - st, ar, bl) ? 8 : 0;
+    avm |= nb_avail(c, gx, gy, tn, gx + tn, gy - st, ar, bl) ? 16 : 0;
+    const bool any = avm != 0;
+    const int total = 4 * n + 1;
+    for (int tt = LANE; tt < nb * total; tt += 64) {
+        const int blk = tt >= total ? 1 : 0;
+        const int t = tt - blk * total;
+        const int pc = comp + blk;
+        int16_t* refL = SH.refs + (pc == 0 ? R_L0 : (pc == 1 ? R_LC0 : R_LC1));
+        int16_t* refA = SH.refs + (pc == 0 ? R_A0 : (pc == 1 ? R_AC0 : R_AC1));
+        // unified item: t <= 2n -> left index li = t (li 0 = corner, li k -> y = k-1); else above
+        int seg;
+        const bool is_left = t <= 2 * n;
+        const int li = t, ai = t - (2 * n + 1);
+        if (is_left)
+            seg = li == 0 ? 2 : (li <= n ? 1 : 0);
+        else
+            seg = ai < n ? 3 : 4;
+        int v;
+        if (!any) {
+            v = 128;
+        } else {
+            // source sample: own position if available, else nearest available in scan order
+            int sli = li, sai = ai;
+            bool src_left = is_left;
+            if (!((avm >> seg) & 1)) {
+                const int below = avm & ((1 << seg) - 1);
+                int j;
+                if (below) { // last sample (in scan order) of the nearest earlier available segment
+                    j = 31 - __clz(below);
+                    if (j == 0) { src_left = true; sli = n + 1; }
+                    else if (j == 1) { src_left = true; sli = 1; }
+                    else if (j == 2) { src_left = true; sli = 0; }
+                    else { src_left = false; sai = n - 1; }
+                } else { // first sample of the first available later segment
+                    j = __ffs(avm) - 1;
+                    if (j == 1) { src_left = true; sli = n; }
+                    else if (j == 2) { src_left = true; sli = 0; }
+                    else if (j == 3) { src_left = false; sai = 0; }
+                    else { src_left = false; sai = n; }
+                }
+            }
+            v = src_left ? rec_get(pc, cx - 1, cy + sli - 1) : rec_get(pc, cx + sai, cy - 1);
+        }
+        if (is_left)
+            refL[li] = (int16_t)v;
+        else
+            refA[ai] = (int16_t)v;
+    }
+    WSYNC();
+    // [1 2 1] filter, intra_predictor.rs:304-352 (used by modes 0, 2, 34, 66 only)
+    if (comp == 0 && n * n > 32) {
+        const int16_t* refL = SH.refs + R_L0;
+        const int16_t* refA = SH.refs + R_A0;
+        for (int t = LANE; t < total; t += 64) {
+            if (t <= 2 * n) {
+                const int li = t;
+                int v;
+                if (li == 2 * n)
+                    v = refL[li];
+                else if (li == 0)
+                    v = (refL[1] + 2 * refL[0] + refA[0] + 2) >> 2;
+                else
+                    v = (refL[li + 1] + 2 * refL[li] + refL[li - 1] + 2) >> 2;
+                SH.refs[R_LF + li] = (int16_t)v;
+            } else {
+                const int ai = t - (2 * n + 1);
+                int v;
+                if (ai == 2 * n - 1)
+                    v = refA[ai];
+                else if (ai == 0)
+                    v = (refL[0] + 2 * refA[0] + refA[1] + 2) >> 2;
+                else
+                    v = (refA[ai - 1] + 2 * refA[ai] + refA[ai + 1] + 2) >> 2;
+                SH.refs[R_AF + ai] = (int16_t)v;
+            }
+        }
+        WSYNC();
+    }
+}
+
+// CCLM model parameters (intra_predictor.rs:1604-2031); uniform across the wave
+struct CclmParams {
+    int a, k, b;
+    bool flat128;
+    bool avail_l;
+};
+
+__device__ __forceinline__ int cclm_w(Ctx c, int tx, int ty, int y, int x, bool avail_l) {
+    // padded luma window p_y_xm3_ym3 (:1766-1818): column -1 repeats column 0 when the left
+    // neighbour is unavailable; every other read hits reconstructed luma
+    if (x < 0 && !avail_l) x = 0;
+    return rec_get(0, tx + x, ty + y);
+}
+__device__ __forceinline__ int cclm_ds6(Ctx c, int tx, int ty, int sy, int sx, bool avail_l) {
+    return (cclm_w(c, tx, ty, sy, sx - 1, avail_l) + cclm_w(c, tx, ty, sy + 1, sx - 1, avail_l) +
+            cclm_w(c, tx, ty, sy, sx, avail_l) * 2 + cclm_w(c, tx, ty, sy + 1, sx, avail_l) * 2 +
+            cclm_w(c, tx, ty, sy, sx + 1, avail_l) + cclm_w(c, tx, ty, sy + 1, sx + 1, avail_l) + 4) >> 3;
+}
+
+// `comp` (plane 1 or 2) may differ per lane: everything that depends on it is per-lane data
+__device__ __forceinline__ CclmParams cclm_params(Ctx c, int comp, int tx, int ty, int tlg, int mode) {
+    c = uni(c);
+    tx = uni(tx);
+    ty = uni(ty);
+    tlg = uni(tlg);
+    mode = uni(mode);
+    CclmParams r;
+    const int tn = 1 << tlg;
+    const int tw = tn >> 1, th = tw;
+    const int cx = tx >> 1, cy = ty >> 1;
+    const int gx = c.ctu_x + tx, gy = c.ctu_y + ty;
+    const bool avail_l = nb_avail(c, gx, gy, tn, gx - 1, gy, false, false);
+    const bool avail_t = nb_avail(c, gx, gy, tn, gx, gy - 1, false, false);
+    r.avail_l = avail_l;
+    int num_top_right = 0, num_below_left = 0;
+    if (mode == T_CCLM) {
+        const bool ar = above_right_avail(c, tx, ty, tlg), bl = below_left_avail(c, tx, ty, tlg);
+        // run of available above-right samples (:1881-1893): one position per lane, then the length
+        // of the leading run of set bits
+        const bool a = LANE < tw && nb_avail(c, gx, gy, tn, gx + (tw + LANE) * 2, gy - 1, ar, bl);
+        num_top_right = min((int)__ffsll(~__ballot(a)) - 1, tw);
+    }
+    if (mode == L_CCLM) {
+        const bool ar = above_right_avail(c, tx, ty, tlg), bl = below_left_avail(c, tx, ty, tlg);
+        const bool a = LANE < th && nb_avail(c, gx, gy, tn, gx - 1, gy + (th + LANE) * 2, ar, bl);
+        num_below_left = min((int)__ffsll(~__ballot(a)) - 1, th);
+    }
+    int num_samp_t, num_samp_l;
+    if (mode == LT_CCLM) {
+        num_samp_t = avail_t ? tw : 0;
+        num_samp_l = avail_l ? th : 0;
+    } else {
+        num_samp_t = (avail_t && mode == T_CCLM) ? tw + min(num_top_right, th) : 0;
+        num_samp_l = (avail_l && mode == L_CCLM) ? th + min(num_below_left, tw) : 0;
+    }
+    r.flat128 = (num_samp_l == 0 && num_samp_t == 0);
+    r.a = 0;
+    r.k = 0;
+    r.b = 128;
+    if (r.flat128) return r;
+    const bool b_ctu_boundary = ((c.ctu_y + ty) & 31) == 0;
+    const int num_is_4 = !(avail_t && avail_l && mode == LT_CCLM) ? 1 : 0;
+    int cnt_t = 0, cnt_l = 0;
+    int y0 = 0, y1 = 0, y2 = 0, y3 = 0, c0 = 0, c1 = 0, c2 = 0, c3 = 0; // p_sel_ds_y / p_sel_c
+    // selects, not an indexed array: the four slots stay in registers
+#define CCLM_PUT(I, YY, CC)            \
+    do {                               \
+        const int i_ = (I);            \
+        const int yv_ = (YY), cv_ = (CC); \
+        y0 = i_ == 0 ? yv_ : y0;       \
+        c0 = i_ == 0 ? cv_ : c0;       \
+        y1 = i_ == 1 ? yv_ : y1;       \
+        c1 = i_ == 1 ? cv_ : c1;       \
+        y2 = i_ == 2 ? yv_ : y2;       \
+        c2 = i_ == 2 ? cv_ : c2;       \
+        y3 = i_ == 3 ? yv_ : y3;       \
+        c3 = i_ == 3 ? cv_ : c3;       \
+    } while (0)
+    if (avail_t && (mode == LT_CCLM || mode == T_CCLM)) {
+        const int start = num_samp_t >> (2 + num_is_4);
+        const int step = max(num_samp_t >> (1 + num_is_4), 1);
+        cnt_t = min((1 + num_is_4) << 1, num_samp_t);
+        for (int i = 0; i < cnt_t; ++i) {
+            const int pos = start + i * step;
+            const int sc = rec_get(comp, cx + pos, cy - 1);
+            const int sx = 2 * pos;
+            int sy;
+            if (!b_ctu_boundary)
+                sy = (cclm_w(c, tx, ty, -1, sx - 1, avail_l) + cclm_w(c, tx, ty, -2, sx - 1, avail_l) +
+                      cclm_w(c, tx, ty, -1, sx, avail_l) * 2 + cclm_w(c, tx, ty, -2, sx, avail_l) * 2 +
+                      cclm_w(c, tx, ty, -1, sx + 1, avail_l) + cclm_w(c, tx, ty, -2, sx + 1, avail_l) + 4) >> 3;
+            else
+                sy = (cclm_w(c, tx, ty, -1, sx - 1, avail_l) + cclm_w(c, tx, ty, -1, sx, avail_l) * 2 +
+                      cclm_w(c, tx, ty, -1, sx + 1, avail_l) + 2) >> 2;
+            CCLM_PUT(i, sy, sc);
+        }
+    }
+    if (avail_l && (mode == LT_CCLM || mode == L_CCLM)) {
+        const int start = num_samp_l >> (2 + num_is_4);
+        const int step = max(num_samp_l >> (1 + num_is_4), 1);
+        cnt_l = min((1 + num_is_4) << 1, num_samp_l);
+        for (int i = 0; i < cnt_l; ++i) {
+            const int pos = start + i * step;
+            CCLM_PUT(cnt_t + i, cclm_ds6(c, tx, ty, 2 * pos, -2, avail_l), rec_get(comp, cx - 1, cy + pos));
+        }
+    }
+#undef CCLM_PUT
+    // min group {0,2}, max group {1,3} and the four compare-exchanges of :1973-1986,
+    // carried out on (luma, chroma) value pairs instead of indices
+    int mnAy = y0, mnAc = c0, mnBy = y2, mnBc = c2, mxAy = y1, mxAc = c1, mxBy = y3, mxBc = c3, t;
+    if (mnAy > mnBy) { t = mnAy; mnAy = mnBy; mnBy = t; t = mnAc; mnAc = mnBc; mnBc = t; }
+    if (mxAy > mxBy) { t = mxAy; mxAy = mxBy; mxBy = t; t = mxAc; mxAc = mxBc; mxBc = t; }
+    if (mnAy > mxBy) {
+        t = mnAy; mnAy = mxAy; mxAy = t; t = mnAc; mnAc = mxAc; mxAc = t;
+        t = mnBy; mnBy = mxBy; mxBy = t; t = mnBc; mnBc = mxBc; mxBc = t;
+    }
+    if (mnBy > mxAy) { t = mnBy; mnBy = mxAy; mxAy = t; t = mnBc; mnBc = mxAc; mxAc = t; }
+    const int max_y = (mxAy + mxBy + 1) >> 1;
+    const int max_c = (mxAc + mxBc + 1) >> 1;
+    const int min_y = (mnAy + mnBy + 1) >> 1;
+    const int min_c = (mnAc + mnBc + 1) >> 1;
+    const int diff = max_y - min_y;
+    if (diff != 0) {
+        const int diff_c = max_c - min_c;
+        int x = ilog2i(diff);
+        const int norm_diff = ((diff << 4) >> x) & 15;
+        x += (norm_diff != 0) ? 1 : 0;
+        const int adc = diff_c < 0 ? -diff_c : diff_c;
+        const int y = adc > 0 ? ilog2i(adc) + 1 : 0;
+        const int div_sig = (int)((0x0111122334455670ULL >> (4 * norm_diff)) & 15); // {0,7,6,5,5,4,4,3,3,2,2,1,1,1,1,0}
+        int a = diff_c == 0 ? 0 : (diff_c * (div_sig | 8) + (1 << (y - 1))) >> y;
+        int k;
+        if (3 + x - y < 1) {
+            k = 1;
+            a = a < 0 ? -15 : (a > 0 ? 15 : 0);
+        } else {
+            k = 3 + x - y;
+        }
+        r.a = a;
+        r.k = k;
+        r.b = min_c - ((a * min_y) >> k);
+    } else {
+        r.a = 0;
+        r.k = 0;
+        r.b = min_c;
+    }
+    return r;
+}
+
+// Original sample for prediction index i (plane pc, component coordinates x, y).  A full
+// evaluation reads the picture; SAD lists read the copy of the block's originals that
+// stage_org() put into r2 (free while no transform runs), index obase + i.
+// byte offset in r2 of the staged originals (luma at +0, Cb | Cr at +1024): the last 1.5 KB, so that
+// r1 and the first 2688 bytes of r2 are one free region during SAD lists
+constexpr int kOrgStage = 2688;
+template <bool full>
+__device__ __forceinline__ int pred_org(const Ctx& c, int pc, int x, int y, int obase, int i) {
+    if (full) return org_get(c, pc, x, y);
+    return ((const uint8_t*)SH.r2)[kOrgStage + obase + i];
+}
+__device__ __forceinline__ void stage_org(const Ctx& c, int comps, int tx, int ty, int tlg) {
+    uint32_t* dst = (uint32_t*)((char*)SH.r2 + kOrgStage);
+    if (comps & 1) {
+        const int words = 1 << (2 * tlg - 2);
+        for (int w = LANE; w < words; w += 64) {
+            const int row = (4 * w) >> tlg, col = (4 * w) & ((1 << tlg) - 1);
+            dst[w] = *(const GLOBAL_AS uint32_t*)&c.org[(unsigned)((c.ctu_y + ty + row) * c.W + c.ctu_x + tx + col)];
+        }
+    }
+    if (comps & 2) {
+        const int lg = tlg - 1;
+        const int words = 1 << (2 * lg - 2); // per plane
+        for (int w = LANE; w < 2 * words; w += 64) {
+            const int pl = w >= words ? 1 : 0;
+            const int ww = w - pl * words;
+            const int row = (4 * ww) >> lg, col = (4 * ww) & ((1 << lg) - 1);
+            dst[256 + w] = *(const GLOBAL_AS uint32_t*)&c.org[plane_off(c, 1 + pl) +
+                                                             (unsigned)((((c.ctu_y + ty) >> 1) + row) * (c.W >> 1) +
+                                                                        ((c.ctu_x + tx) >> 1) + col)];
+        }
+    }
+    WSYNC();
+}
+
+// one predicted sample: accumulate |org - pred|; `full` also stores residual and prediction
+// The prediction itself is parked in the block's own area of the reconstruction tile until the
+// residual is added to it (nothing reads that area in between: the reference samples are cached, and
+// CCLM reads the luma plane while it writes chroma).  Only the final pass, which compares its
+// reconstruction with the search's, keeps the tile and parks the prediction in global scratch.
+template <bool full>
+__device__ __forceinline__ int emit_sample(const Ctx& c, int o, int i, int v, int pc, int x, int y, bool to_tile) {
+    const int d = o - v;
+    if (full) { // i already includes the block's base in r1 / the prediction scratch
+        SH.r1[i] = (int16_t)d;
+        if (to_tile)
+            rec_put(pc, x, y, v);
+        else
+            c.pred_scratch[i] = (uint8_t)v;
+    }
+    return d < 0 ? -d : d;
+}
+
+// Prediction of one luma block (comp 0) or of the Cb+Cr pair (comp 1) from the cached reference
+// samples (build_refs must have run for this block; CCLM reads the reconstructed luma instead).
+// Sample index i runs over nb*n*n: block blk = i / (n*n), then row-major inside the block.
+// full: the residual org - pred goes to r1[i] and the prediction byte to this wave's scratch
+//       (each lane later re-reads exactly the bytes it wrote).
+// Returns the lane's partial sum of |org - pred| (the SAD of block_splitter.rs:96-104).
+template <bool full>
+__device__ __forceinline__ int predict(Ctx c, int comp, int tx, int ty, int tlg, int mode, int rbase = 0,
+                                       bool to_tile = true) {
+    c = uni(c);
+    rbase = uni(rbase);
+    comp = uni(comp);
+    tx = uni(tx);
+    ty = uni(ty);
+    tlg = uni(tlg);
+    mode = uni(mode);
+    const int cs = comp ? 1 : 0;
+    const int nb = comp ? 2 : 1;
+    const int lg = tlg - cs;
+    const int n = 1 << lg;
+    const int cx = tx >> cs, cy = ty >> cs;
+    const int nn = n * n;
+    const int obase = comp ? 1024 : 0;
+    int sad = 0;
+    if (mode >= LT_CCLM) {
+        // model parameters of both planes in one pass: odd lanes derive Cr, even lanes Cb
+        const CclmParams cpv = cclm_params(c, 1 + (LANE & 1), tx, ty, tlg, mode);
+        const int a0 = __builtin_amdgcn_readlane(cpv.a, 0), a1 = __builtin_amdgcn_readlane(cpv.a, 1);
+        const int k0 = __builtin_amdgcn_readlane(cpv.k, 0), k1 = __builtin_amdgcn_readlane(cpv.k, 1);
+        const int b0 = __builtin_amdgcn_readlane(cpv.b, 0), b1 = __builtin_amdgcn_readlane(cpv.b, 1);
+        const bool flat128 = __builtin_amdgcn_readlane((int)cpv.flat128, 0) != 0;
+        const bool avail_l = __builtin_amdgcn_readlane((int)cpv.avail_l, 0) != 0;
+        for (int i = LANE; i < nb * nn; i += 64) {
+            const int blk = i >> (2 * lg);
+            const int ii = i & (nn - 1);
+            const int x = ii & (n - 1), y = ii >> lg;
+            const int o = pred_org<full>(c, comp + blk, cx + x, cy + y, obase, i); // issued early
+            int v;
+            if (flat128) {
+                v = 128;
+            } else {
+                const int ds = cclm_ds6(c, tx, ty, 2 * y, 2 * x, avail_l);
+                v = (M24(ds, blk ? a1 : a0) >> (blk ? k1 : k0)) + (blk ? b1 : b0);
+                v = min(max(v, 0), 255);
+            }
+            sad += emit_sample<full>(c, o, rbase + i, v, comp + blk, cx + x, cy + y, to_tile);
+        }
+        WSYNC();
+        return sad;
+    }
+    // luma blocks of more than 32 samples use the filtered references for modes 0, 2, 34, 66
+    const bool filt = comp == 0 && nn > 32 && (mode == 0 || mode == 2 || mode == 34 || mode == 66);
+    const int oL0 = comp == 0 ? (filt ? R_LF : R_L0) : R_LC0; // index 0 = corner
+    const int oA0 = comp == 0 ? (filt ? R_AF : R_A0) : R_AC0;
+    const int16_t* L0 = SH.refs + oL0;
+    const int16_t* A0 = SH.refs + oA0;
+    if (mode == PLANAR || mode == DC) {
+        int dcv0 = 0, dcv1 = 0;
+        if (mode == DC) {
+            int part0 = 0, part1 = 0;
+            for (int t = LANE; t < 2 * n; t += 64) {
+                part0 += t < n ? A0[t] : L0[t - n + 1];
+                if (nb == 2) part1 += t < n ? SH.refs[R_AC1 + t] : SH.refs[R_LC1 + t - n + 1];
+            }
+            dcv0 = ((wave_sum_i32(part0) + n) >> (lg + 1)) & 0xFF; // `as u8`
+            if (nb == 2) dcv1 = ((wave_sum_i32(part1) + n) >> (lg + 1)) & 0xFF;
+        }
+        const int n_scale = (2 * lg - 2) >> 2;
+        for (int i = LANE; i < nb * nn; i += 64) {
+            const int blk = i >> (2 * lg);
+            const int ii = i & (nn - 1);
+            const int x = ii & (n - 1), y = ii >> lg;
+            const int o = pred_org<full>(c, comp + blk, cx + x, cy + y, obase, i); // issued early
+            const int16_t* L = SH.refs + (blk ? R_LC1 : oL0);
+            const int16_t* A = SH.refs + (blk ? R_AC1 : oA0);
+            int v;
+            if (mode == PLANAR) {
+                const int pv = M24(n - 1 - y, A[x]) + M24(y + 1, L[n + 1]);
+                const int ph = M24(n - 1 - x, L[y + 1]) + M24(x + 1, A[n]);
+                v = ((pv + ph + n) >> (lg + 1)) & 0xFF;
+            } else {
+                v = blk ? dcv1 : dcv0;
+            }
+            const int wl = pdpc_w(n_scale, x), wt = pdpc_w(n_scale, y);
+            v = (int16_t)(M24(L[y + 1], wl) + M24(A[x], wt) + M24(64 - wt - wl, v) + 32) >> 6;
+            v = min(max(v, 0), 255);
+            sad += emit_sample<full>(c, o, rbase + i, v, comp + blk, cx + x, cy + y, to_tile);
+        }
+        WSYNC();
+        return sad;
+    }
+    // angular 2..66 (intra_predictor.rs:1287-1602), square blocks
+    const int at = c.k->ang_tab[mode];
+    const int angle = (int)(int16_t)(at & 0xFFFF);
+    const int inv_angle = at >> 16;
+    bool filter_flag = false;
+    if (!(mode == 2 || mode == 34 || mode == 66)) {
+        const int md = min(abs(mode - 50), abs(mode - 18));
+        const int thr = lg == 2 ? 24 : (lg == 3 ? 14 : (lg == 4 ? 2 : 0));
+        filter_flag = md > thr;
+    }
+    const bool do_pdpc = mode <= 18 || mode >= 50;
+    int n_scale = 0;
+    if (mode > 50 || (mode > 1 && mode < 18))
+        n_scale = min(lg - ilog2i(3 * inv_angle - 2) + 8, 2);
+    else
+        n_scale = (2 * lg - 2) >> 2;
+    // The main reference of the mode, projected once (intra_predictor.rs:1311-1420): entry idx in
+    // [-n, 2n + 3] = ref[idx] of the reference's refx / refy arrays: idx >= 0 reads the main side
+    // (0 = corner, k = sample k - 1, clamped to 2n), idx < 0 the side array at the inverse-angle
+    // projection.  It lives in the upper half of r2 (no transform runs during a prediction), so
+    // a sample's taps are consecutive LDS reads with no selects.
+    const bool vertical = mode >= 34;
+    constexpr int RM0 = 1024, RMS = 104; // int16 index of the table in r2, stride per block
+    int16_t* rm = (int16_t*)SH.r2 + RM0;
+    {
+        const int ne = 3 * n + 4;
+        for (int e = LANE; e < nb * ne; e += 64) {
+            const int blk = e >= ne ? 1 : 0;
+            const int ee = e - blk * ne;
+            const int idx = ee - n;
+            const int oL = blk ? R_LC1 : oL0, oA = blk ? R_AC1 : oA0;
+            const int k = idx >= 0 ? min(idx, 2 * n) : max(min((M24(idx, inv_angle) + 256) >> 9, n), 0);
+            const bool from_above = (idx >= 0) == vertical;
+            // k == 0 is the corner (L[0]); above sample k - 1 = A[k - 1], left sample k - 1 = L[k]
+            rm[blk * RMS + ee] = SH.refs[k == 0 ? oL : (from_above ? oA + k - 1 : oL + k)];
+        }
+        WSYNC();
+    }
+    for (int i = LANE; i < nb * nn; i += 64) {
+        const int blk = i >> (2 * lg);
+        const int ii = i & (nn - 1);
+        const int x = ii & (n - 1), y = ii >> lg;
+        const int o = pred_org<full>(c, comp + blk, cx + x, cy + y, obase, i); // issued early
+        const int16_t* L = SH.refs + (blk ? R_LC1 : oL0);
+        const int16_t* A = SH.refs + (blk ? R_AC1 : oA0);
+        int v;
+        {
+            const int along = vertical ? y : x, across = vertical ? x : y;
+            const int i_idx = M24(along + 1, angle) >> 5;
+            const int i_fact = M24(along + 1, angle) & 31;
+            const int16_t* tap = rm + blk * RMS + n + across + i_idx; // tap[t] = ref[across + i_idx + t]
+            if (comp == 0) {
+                int f0, f1, f2, f3;
+                if (filter_flag) {
+                    f0 = 16 - (i_fact >> 1);
+                    f1 = 32 - (i_fact >> 1);
+                    f2 = 16 + (i_fact >> 1);
+                    f3 = i_fact >> 1;
+                } else {
+                    const int w = *(const int*)&SHT.fc[i_fact][0];
+                    f0 = (int)(int8_t)w;
+                    f1 = (int)(int8_t)(w >> 8);
+                    f2 = (int)(int8_t)(w >> 16);
+                    f3 = w >> 24;
+                }
+                const int acc = M24(f0, tap[0]) + M24(f1, tap[1]) + M24(f2, tap[2]) + M24(f3, tap[3]);
+                v = min(max((acc + 32) >> 6, 0), 255);
+            } else {
+                // i_fact == 0 gives tap[1] itself; a convex combination of 8-bit samples needs no `& 0xFF`
+                v = (M24(32 - i_fact, tap[1]) + M24(i_fact, tap[2]) + 16) >> 5;
+            }
+        }
+        if (do_pdpc) {
+            // intra_predictor.rs:355-757; left[] = L+1, above[] = A
+            int rl = 0, rt = 0, wl = 0, wt = 0;
+            if (mode == 18 || mode == 50) {
+                const int alrs = L[0];
+                rl = (int16_t)(L[y + 1] - alrs + v);
+                rt = (int16_t)(A[x] - alrs + v);
+                wl = mode == 50 ? pdpc_w(n_scale, x) : 0;
+                wt = mode == 18 ? pdpc_w(n_scale, y) : 0;
+            } else if (mode < 18 && n_scale >= 0) {
+                const int dx_int = (M24(y + 1, inv_angle) + 256) >> 9;
+                rt = y < (3 << n_scale) ? A[x + dx_int] : 0;
+                wt = pdpc_w(n_scale, y);
+            } else if (mode > 50 && n_scale >= 0) {
+                const int dy_int = (M24(x + 1, inv_angle) + 256) >> 9;
+                rl = x < (3 << n_scale) ? L[1 + y + dy_int] : 0;
+                wl = pdpc_w(n_scale, x);
+            }
+            v = (int16_t)(M24(rl, wl) + M24(rt, wt) + M24(64 - wt - wl, v) + 32) >> 6;
+            v = min(max(v, 0), 255);
+        }
+        sad += emit_sample<full>(c, o, rbase + i, v, comp + blk, cx + x, cy + y, to_tile);
+    }
+    WSYNC();
+    return sad;
+}
+
+constexpr int kNoMode = 255; // list entry that is not evaluated (cost f32::MAX)
+
+// SADs of a LIST of angular modes (2..66) of one block: get_intra_pred_aux_cost of each entry
+// (block_splitter.rs:64-108), luma block and/or chroma pair.  Same arithmetic as predict<false>,
+// organised so that the per-mode fixed work is done once per list:
+//   * lane mi derives the parameters of entry mi (angle, inverse angle, filter / PDPC variant);
+//     the uniform loop over the entries fetches them with v_readlane;
+//   * the projected main references of ALL entries are built in one pass into r1 .. r2 (free
+//     during SAD lists), stride 4n per block;
+//   * a lane adds the SAD of entry mi into its accumulator when LANE == mi.
+// acc (lane mi): summed SAD of entry mi over the components; entries with mode kNoMode stay 0.
+__device__ __forceinline__ unsigned sad_list_angular(const Ctx& c, int comps, int tx, int ty, int tlg, int nmodes,
+                                                     unsigned long long modes_lo, unsigned long long modes_hi) {
+    unsigned acc = 0;
+    const int my_mode = LANE < nmodes ? (int)(((LANE < 8 ? modes_lo : modes_hi) >> (8 * (LANE & 7))) & 255u) : kNoMode;
+    int16_t* tab = SH.r1;                   // [entry][blk][4n] projected references
+    uint32_t* ptab = (uint32_t*)SH.decw + 32; // [entry]: inv_angle (low half) | vertical << 16 | valid << 17
+    uint32_t* ptab2 = (uint32_t*)SH.decw + 48; // [entry]: angle (low half) | flags << 16 | mode << 24
+#pragma unroll 1
+    for (int comp = 0; comp < 2; ++comp) {
+        if (!((comps >> comp) & 1)) continue;
+        const int cs = comp ? 1 : 0;
+        const int nb = comp ? 2 : 1;
+        const int lg = tlg - cs;
+        const int n = 1 << lg;
+        const int nn = n * n;
+        const int cx = tx >> cs, cy = ty >> cs;
+        const int obase = comp ? 1024 : 0;
+        const int lgs = lg + 2; // table stride 4n >= 3n + 4 per block
+        // ---- parameters of my entry (intra_predictor.rs:1287-1310, 355-372) ----
+        const bool valid = my_mode != kNoMode;
+        const int mm = valid ? my_mode : 2;
+        const int at = c.k->ang_tab[mm];
+        const int my_angle = (int)(int16_t)(at & 0xFFFF);
+        const int my_inv = at >> 16;
+        int my_flags; // bit 0 filter_flag, bits 1-2 PDPC variant (0 none, 1 mode 18/50, 2 mode < 18, 3 mode > 50), bits 4.. n_scale
+        {
+            bool filter_flag = false;
+            if (!(mm == 2 || mm == 34 || mm == 66)) {
+                const int md = min(abs(mm - 50), abs(mm - 18));
+                const int thr = lg == 2 ? 24 : (lg == 3 ? 14 : (lg == 4 ? 2 : 0));
+                filter_flag = md > thr;
+            }
+            int n_scale;
+            if (mm > 50 || (mm > 1 && mm < 18))
+                n_scale = min(lg - ilog2i(3 * my_inv - 2) + 8, 2);
+            else
+                n_scale = (2 * lg - 2) >> 2;
+            int kind = 0;
+            if (mm == 18 || mm == 50)
+                kind = 1;
+            else if (mm < 18 && n_scale >= 0)
+                kind = 2;
+            else if (mm > 50 && n_scale >= 0)
+                kind = 3;
+            my_flags = (filter_flag ? 1 : 0) | (kind << 1) | (max(n_scale, 0) << 4);
+        }
+        if (LANE < nmodes) {
+            ptab[LANE] = ((uint32_t)my_inv & 0xFFFFu) | (mm >= 34 ? 0x10000u : 0u) | (valid ? 0x20000u : 0u);
+            ptab2[LANE] = ((uint32_t)my_angle & 0xFFFFu) | ((uint32_t)my_flags << 16) | ((uint32_t)mm << 24);
+        }
+        WSYNC();
+        // ---- projected main references of every entry (intra_predictor.rs:1311-1420) ----
+        {
+            const int oL0 = comp == 0 ? R_L0 : R_LC0, oA0 = comp == 0 ? R_A0 : R_AC0; // (filtered refs: modes 2, 34, 66 below)
+            const int total = nmodes << (lgs + cs);
+            for (int e = LANE; e < total; e += 64) {
+                const int mi = e >> (lgs + cs);
+                const int blk = cs ? ((e >> lgs) & 1) : 0;
+                const int ee = e & ((1 << lgs) - 1);
+                const uint32_t pw = ptab[mi];
+                const int inv_angle = (int)(int16_t)(pw & 0xFFFF);
+                const bool vertical = (pw >> 16) & 1;
+                const int idx = ee - n;
+                int oL = blk ? R_LC1 : oL0, oA = blk ? R_AC1 : oA0;
+                if (comp == 0 && nn > 32) { // luma blocks of more than 32 samples: modes 2, 34, 66 use the filtered references
+                    const int m = (int)(((mi < 8 ? modes_lo : modes_hi) >> (8 * (mi & 7))) & 255u);
+                    if (m == 2 || m == 34 || m == 66) {
+                        oL = R_LF;
+                        oA = R_AF;
+                    }
+                }
+                const int k = idx >= 0 ? min(idx, 2 * n) : max(min((M24(idx, inv_angle) + 256) >> 9, n), 0);
+                const bool from_above = (idx >= 0) == vertical;
+                tab[e] = SH.refs[k == 0 ? oL : (from_above ? oA + k - 1 : oL + k)];
+            }
+        }
+        WSYNC();
+        if (nb * nn <= 32) {
+            // ---- small blocks (4x4 luma: 16 samples, 4x4 chroma pair: 32): 4 or 2 entries share an
+            // iteration, the entry's parameters are per-lane values ----
+            const int lgS = nb * nn == 32 ? 5 : 4;
+            const int slot = LANE >> lgS;
+            const int i = LANE & ((1 << lgS) - 1);
+            const int blk = i >> (2 * lg);
+            const int ii = i & (nn - 1);
+            const int x = ii & (n - 1), y = ii >> lg;
+            const int o = ((const uint8_t*)SH.r2)[kOrgStage + obase + i];
+            const int16_t* L = SH.refs + (blk ? R_LC1 : (comp == 0 ? R_L0 : R_LC0));
+            const int16_t* A = SH.refs + (blk ? R_AC1 : (comp == 0 ? R_A0 : R_AC0));
+#pragma unroll 1
+            for (int base = 0; base < nmodes; base += 64 >> lgS) {
+                const int mi = base + slot;
+                const uint32_t pw = ptab[min(mi, 15)], pw2 = ptab2[min(mi, 15)];
+                const bool on = mi < nmodes && ((pw >> 17) & 1);
+                const int inv_angle = (int)(int16_t)(pw & 0xFFFF);
+                const bool vertical = (pw >> 16) & 1;
+                const int angle = (int)(int16_t)(pw2 & 0xFFFF);
+                const int flags = (int)((pw2 >> 16) & 0xFF);
+                const int mode = (int)(pw2 >> 24);
+                const bool filter_flag = flags & 1;
+                const int kind = (flags >> 1) & 3;
+                const int n_scale = flags >> 4;
+                const int along = vertical ? y : x, across = vertical ? x : y;
+                const int i_idx = M24(along + 1, angle) >> 5;
+                const int i_fact = M24(along + 1, angle) & 31;
+                const int16_t* tap = tab + (((min(mi, 15) << cs) + blk) << lgs) + n + across + i_idx;
+                int v;
+                if (comp == 0) {
+                    const int w = *(const int*)&SHT.fc[i_fact][0];
+                    const int h = i_fact >> 1;
+                    const int f0 = filter_flag ? 16 - h : (int)(int8_t)w;
+                    const int f1 = filter_flag ? 32 - h : (int)(int8_t)(w >> 8);
+                    const int f2 = filter_flag ? 16 + h : (int)(int8_t)(w >> 16);
+                    const int f3 = filter_flag ? h : (w >> 24);
+                    const int a4 = M24(f0, tap[0]) + M24(f1, tap[1]) + M24(f2, tap[2]) + M24(f3, tap[3]);
+                    v = min(max((a4 + 32) >> 6, 0), 255);
+                } else {
+                    v = (M24(32 - i_fact, tap[1]) + M24(i_fact, tap[2]) + 16) >> 5;
+                }
+                if (kind != 0) { // PDPC, intra_predictor.rs:355-757; left[] = L+1, above[] = A
+                    int rl = 0, rt = 0, wl = 0, wt = 0;
+                    if (kind == 1) {
+                        const int alrs = L[0];
+                        rl = (int16_t)(L[y + 1] - alrs + v);
+                        rt = (int16_t)(A[x] - alrs + v);
+                        wl = mode == 50 ? pdpc_w(n_scale, x) : 0;
+                        wt = mode == 18 ? pdpc_w(n_scale, y) : 0;
+                    } else if (kind == 2) {
+                        const int dx_int = (M24(y + 1, inv_angle) + 256) >> 9;
+                        rt = y < (3 << n_scale) ? A[x + dx_int] : 0;
+                        wt = pdpc_w(n_scale, y);
+                    } else {
+                        const int dy_int = (M24(x + 1, inv_angle) + 256) >> 9;
+                        rl = x < (3 << n_scale) ? L[1 + y + dy_int] : 0;
+                        wl = pdpc_w(n_scale, x);
+                    }
+                    v = (int16_t)(M24(rl, wl) + M24(rt, wt) + M24(64 - wt - wl, v) + 32) >> 6;
+                    v = min(max(v, 0), 255);
+                }
+                const int d = o - v;
+                const int rs = row_sum_i32(on ? (d < 0 ? -d : d) : 0); // every lane: total of its row of 16
+                // slot totals: 16-sample slots are the rows, 32-sample slots two rows each
+                const int t0 = __builtin_amdgcn_readlane(rs, 0), t1 = __builtin_amdgcn_readlane(rs, 16),
+                          t2 = __builtin_amdgcn_readlane(rs, 32), t3 = __builtin_amdgcn_readlane(rs, 48);
+                if (lgS == 4) {
+                    acc += LANE == base ? (unsigned)t0 : (LANE == base + 1 ? (unsigned)t1 : (LANE == base + 2 ? (unsigned)t2 : (LANE == base + 3 ? (unsigned)t3 : 0u)));
+                } else {
+                    acc += LANE == base ? (unsigned)(t0 + t1) : (LANE == base + 1 ? (unsigned)(t2 + t3) : 0u);
+                }
+            }
+            WSYNC();
+            continue;
+        }
+        // ---- entry by entry: one predicted sample per lane and iteration, |org - pred| summed ----
+#pragma unroll 1
+        for (int mi = 0; mi < nmodes; ++mi) {
+            const int mode = __builtin_amdgcn_readlane(my_mode, mi);
+            if (mode == kNoMode) continue;
+            const int angle = __builtin_amdgcn_readlane(my_angle, mi);
+            const int inv_angle = __builtin_amdgcn_readlane(my_inv, mi);
+            const int flags = __builtin_amdgcn_readlane(my_flags, mi);
+            const bool filter_flag = flags & 1;
+            const int kind = (flags >> 1) & 3;
+            const int n_scale = flags >> 4;
+            const bool vertical = mode >= 34;
+            const bool filt = comp == 0 && nn > 32 && (mode == 2 || mode == 34 || mode == 66);
+            const int oL0 = comp == 0 ? (filt ? R_LF : R_L0) : R_LC0;
+            const int oA0 = comp == 0 ? (filt ? R_AF : R_A0) : R_AC0;
+            int sad = 0;
+            for (int i = LANE; i < nb * nn; i += 64) {
+                const int blk = i >> (2 * lg);
+                const int ii = i & (nn - 1);
+                const int x = ii & (n - 1), y = ii >> lg;
+                const int o = ((const uint8_t*)SH.r2)[kOrgStage + obase + i];
+                const int16_t* L = SH.refs + (blk ? R_LC1 : oL0);
+                const int16_t* A = SH.refs + (blk ? R_AC1 : oA0);
+                const int along = vertical ? y : x, across = vertical ? x : y;
+                const int i_idx = M24(along + 1, angle) >> 5;
+                const int i_fact = M24(along + 1, angle) & 31;
+                const int16_t* tap = tab + (((mi << cs) + blk) << lgs) + n + across + i_idx; // tap[t] = ref[across + i_idx + t]
+                int v;
+                if (comp == 0) {
+                    int f0, f1, f2, f3;
+                    if (filter_flag) {
+                        f0 = 16 - (i_fact >> 1);
+                        f1 = 32 - (i_fact >> 1);
+                        f2 = 16 + (i_fact >> 1);
+                        f3 = i_fact >> 1;
+                    } else {
+                        const int w = *(const int*)&SHT.fc[i_fact][0];
+                        f0 = (int)(int8_t)w;
+                        f1 = (int)(int8_t)(w >> 8);
+                        f2 = (int)(int8_t)(w >> 16);
+                        f3 = w >> 24;
+                    }
+                    const int a4 = M24(f0, tap[0]) + M24(f1, tap[1]) + M24(f2, tap[2]) + M24(f3, tap[3]);
+                    v = min(max((a4 + 32) >> 6, 0), 255);
+                } else {
+                    v = (M24(32 - i_fact, tap[1]) + M24(i_fact, tap[2]) + 16) >> 5;
+                }
+                if (kind != 0) { // PDPC, intra_predictor.rs:355-757; left[] = L+1, above[] = A
+                    int rl = 0, rt = 0, wl = 0, wt = 0;
+                    if (kind == 1) {
+                        const int alrs = L[0];
+                        rl = (int16_t)(L[y + 1] - alrs + v);
+                        rt = (int16_t)(A[x] - alrs + v);
+                        wl = mode == 50 ? pdpc_w(n_scale, x) : 0;
+                        wt = mode == 18 ? pdpc_w(n_scale, y) : 0;
+                    } else if (kind == 2) {
+                        const int dx_int = (M24(y + 1, inv_angle) + 256) >> 9;
+                        rt = y < (3 << n_scale) ? A[x + dx_int] : 0;
+                        wt = pdpc_w(n_scale, y);
+                    } else {
+                        const int dy_int = (M24(x + 1, inv_angle) + 256) >> 9;
+                        rl = x < (3 << n_scale) ? L[1 + y + dy_int] : 0;
+                        wl = pdpc_w(n_scale, x);
+                    }
+                    v = (int16_t)(M24(rl, wl) + M24(rt, wt) + M24(64 - wt - wl, v) + 32) >> 6;
+                    v = min(max(v, 0), 255);
+                }
+                const int d = o - v;
+                sad += d < 0 ? -d : d;
+            }
+            const int total = wave_sum_i32(sad);
+            acc += LANE == mi ? (unsigned)total : 0u;
+        }
+        WSYNC(); // the next component overwrites the tables
+    }
+    return acc;
+}
+
+} // namespace wrenc

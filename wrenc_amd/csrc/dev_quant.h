@@ -1,0 +1,607 @@
+// dev_quant.h -- dependent quantisation as a pooled 4-state Viterbi, forward trace + level cost, dequantisation (quantizer.rs)
+// Part of the gfx950 device code of the RD-search path; see wrenc_dev.h for the overall model.
+#pragma once
+
+namespace wrenc {
+
+// ---------------------------------------------------------------------------
+// Dependent quantisation (quantizer.rs:338-759) + level cost (block_splitter.rs:415-460)
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ long long ldq_at(Ctx c, int bits) {
+    return bits < 256 ? (long long)SHT.ldq[bits] : c.k->ldq[bits];
+}
+__device__ __forceinline__ long long lv_at(Ctx c, int a) {
+    return a < 256 ? (long long)SHT.lv[a] : c.k->lv[a];
+}
+template <int CTRL>
+__device__ __forceinline__ int dpp_quad(int v) {
+    return __builtin_amdgcn_mov_dpp(v, CTRL, 0xF, 0xF, true);
+}
+
+// Decisions of the 16 positions of one sub-block: one 16-bit mask per state (bit k = position k
+// takes a0 + 1 when it is reached in that state), two dwords.
+struct DecMasks {
+    uint32_t m01, m23;
+};
+__device__ __forceinline__ DecMasks dec_masks(const uint16_t* dec16, int p) {
+    const uint2 v = *(const uint2*)(dec16 + (p >> 4) * 4);
+    DecMasks m;
+    m.m01 = v.x;
+    m.m23 = v.y;
+    return m;
+}
+__device__ __forceinline__ int dec_nib(DecMasks m, int p) { // bit s = decision of position p in state s
+    const int k = p & 15;
+    const uint32_t t01 = m.m01 >> k, t23 = m.m23 >> k;
+    return (int)((t01 & 1u) | ((t01 >> 15) & 2u) | ((t23 & 1u) << 2) | ((t23 >> 13) & 8u));
+}
+
+// State maps {0..3} -> {0..3} are kept as one byte per state, so that composing two maps is one
+// byte permute (v_perm_b32): (g2 o g1)(s) = g2[g1[s]].
+constexpr int kMapId = 0x03020100;
+__device__ __forceinline__ int compose_map(int g2, int g1) {
+    return (int)__builtin_amdgcn_perm(0u, (uint32_t)g2, (uint32_t)g1);
+}
+// map of one position: state s goes to q_state_trans_table[s][parity of a_s] (encoder_context.rs:339),
+// a_s = a0 of the state's delta class + the position's decision in state s; the table entry is
+// (s >> 1) + 2 * (parity ^ (s & 1))
+__device__ __forceinline__ int position_map(int tc, int qd, bool dcn, int nib) {
+    int pv = 0; // bit s = parity of a_s
+    if (tc != 0) {
+        const int b0 = (qd >> 1) & 1;
+        const int b1 = dcn ? b0 : (((qd + 1) >> 1) & 1);
+        pv = nib ^ (b0 ? 3 : 0) ^ (b1 ? 12 : 0);
+    }
+    const unsigned x = (unsigned)(pv ^ 10);
+    return (int)(0x01010000u + (((x * 0x00204081u) & 0x01010101u) << 1));
+}
+
+// Which wave of the workgroup walks the pooled Viterbi.  Waves w and w + 4 share a SIMD with the same
+// two waves of the CU's other workgroup; if every workgroup walked in wave 0, one SIMD of each CU would
+// carry all the serial walks and its waves would reach every barrier last.  Spread by workgroup index.
+__device__ __forceinline__ int walker_wave() { return (int)((blockIdx.x * 2654435761u) >> 30); }
+
+// Path costs are kept in 32 bits, DOUBLED, with the tie-break of quantizer.rs:505 in the low bit.
+// Only cost DIFFERENCES between the four states decide the path, and they are bounded: any
+// state reaches any other state's continuation within two steps (q_state_trans_table is 2-step
+// complete), and one step costs at most 128*65535 + lambda_q*dq_table[1023] < 2^25 (QP 63), so
+// |C_s - C_s'| < 2^26.2.  Subtracting the quad minimum every 16 positions therefore keeps every
+// cost below 2^26.2 + 16*2^25 < 2^29.1, its double below 2^30.1.
+// A zero coefficient has no second branch; it is given the cost 2^27, which can never win
+// against branch 0 (K0 <= n0 + 2^25 <= n1 + 2^26.2 + 2^25 < n1 + 2^27) and cannot overflow.
+//
+// Walk step of state s: the two candidates are K0 = c0 + C[trans[s][par]] ("keep a0") and
+// K1 = c1 + C[trans[s][par ^ 1]] ("take a0 + 1"), par = parity of a0; K1 wins only if K1 < K0.
+// The chunk precompute stores, per position and state class, u = cost that goes with
+// C[trans[s][0]] and w = cost that goes with C[trans[s][1]], as 2*cost + tie bit such that the
+// single comparison KB < KA (KA = u + CA, KB = w + CB) is exact: choseB == pick1 ^ par.
+constexpr int kNoBranch = 1 << 27;
+
+// lambda_q * dq_table[idx] (quantizer.rs:29-31): the first 256 entries are in LDS; larger levels are
+// rare, and a wave without any takes no branch
+__device__ __forceinline__ int ldq_fast(const Ctx& c, int idx) {
+    int v = SHT.ldq[min(idx, 255)];
+    if (__ballot(idx > 255) != 0ULL) {
+        if (idx > 255) v = (int)c.k->ldq[idx];
+    }
+    return v;
+}
+
+// Chunk entry of one position (see the comment above kNoBranch): writes (u, w) of the three state
+// classes, returns the parities of a0 in the two delta classes and the state-0 "kept zero inside the
+// trailing run" flag.  Branch-free apart from the rare large-level table reads.
+//   tc, qd: coefficient and quotient of the position; dcn: the DC position (p == P - 1), whose
+//   levels wrap through i16 (quantizer.rs:378-391); tzp: p <= istar; sh / off / lsc: quantiser scale
+__device__ __forceinline__ void chunk_entry(const Ctx& c, int* en, int tc, int qd, bool dcn, bool tzp, int sh, int off,
+                                            int lsc, int ldq1, int* par0_out, int* par1_out, int* adj_out,
+                                            int* ovf) {
+    const bool nz = tc != 0;
+    int c0d[2], c1d[2], par[2];
+#pragma unroll
+    for (int d = 0; d < 2; ++d) {
+        const int a0 = (qd + (dcn ? 0 : d)) >> 1; // quantizer.rs:378 / :441
+        const int a1 = a0 + 1;
+        // 2*a - d fits i16, so the reference's `as i16` only matters for a0 = 0, d = 1 at the DC position (-1)
+        int q0 = (a0 > 0 || dcn) ? 2 * a0 - d : 0;
+        int q1 = 2 * a1 - d;
+        if (tc < 0) {
+            q0 = -q0;
+            q1 = -q1;
+        }
+        const int d0 = abs(tc - ((M24(q0, lsc) + off) >> sh)); // |q| <= 2047, lsc < 2^21
+        const int d1 = abs(tc - ((M24(q1, lsc) + off) >> sh));
+        if (nz && a1 + 1 >= 1024) *ovf = 1;
+        const int l0 = ldq_fast(c, min(a0 + 1, 1023)), l1 = ldq_fast(c, min(a1 + 1, 1023));
+        c0d[d] = nz ? 128 * d0 + l0 : ldq1;       // zero coefficient outside the trailing run: dq_table[1] (:433)
+        c1d[d] = nz ? 128 * d1 + l1 : kNoBranch;
+        par[d] = nz ? (a0 & 1) : 0;               // parity of a0 -> which successor state
+    }
+    const int a00 = qd >> 1;                      // a0 of delta class 0
+    const bool zero0 = !nz || a00 == 0;
+    // bits 0 instead of 1 for a zero kept inside the trailing run (:449-453)
+    const int c0tz = nz ? (a00 == 0 ? c0d[0] - ldq1 : c0d[0]) : 0;
+    const int c0s0 = tzp ? c0tz : c0d[0];
+    const int p0 = par[0], p1 = par[1];
+    en[0] = 2 * (p0 ? c1d[0] : c0s0) + p0;
+    en[1] = 2 * (p0 ? c0s0 : c1d[0]) + 1 - p0;
+    en[2] = 2 * (p0 ? c1d[0] : c0d[0]) + p0;
+    en[3] = 2 * (p0 ? c0d[0] : c1d[0]) + 1 - p0;
+    en[4] = 2 * (p1 ? c1d[1] : c0d[1]) + p1;
+    en[5] = 2 * (p1 ? c0d[1] : c1d[1]) + 1 - p1;
+    *par0_out = p0;
+    *par1_out = p1;
+    *adj_out = (tzp && zero0) ? 1 : 0;
+}
+
+// level-cost table (block_splitter.rs:436-458), same access pattern as ldq_fast
+__device__ __forceinline__ int lv_fast(const Ctx& c, int a) {
+    int v = SHT.lv[min(a, 255)];
+    if (__ballot(a > 255) != 0ULL) {
+        if (a > 255) v = (int)c.k->lv[a];
+    }
+    return v;
+}
+
+// One position of the forward trace (quantizer.rs:686-721) in `state`: returns the level, advances the
+// state, and accumulates the level-cost terms of the position (block_splitter.rs:436-458): the
+// table cost of a non-zero level, a bit in zmask for a zero, the first non-zero position.
+__device__ __forceinline__ int emit_level(const Ctx& c, int tc, int qd, bool dcn, int nib, int p, int j, int& state,
+                                          unsigned& zmask, long long& sum_nz, int& fnz, int& ovf) {
+    const int dl = state > 1 ? 1 : 0;
+    const bool nz = tc != 0;
+    const int a = nz ? ((qd + (dcn ? 0 : dl)) >> 1) + ((nib >> state) & 1) : 0;
+    // 2*a - dl fits i16: the reference's usize wrap + `as i16` (quantizer.rs:379,391) only shows for
+    // a = 0, dl = 1 at the DC position (-1)
+    int q = (nz && (a > 0 || dcn)) ? 2 * a - dl : 0;
+    if (tc < 0) q = -q;
+    const int qc = abs(q);
+    const bool zero = qc == 0;
+    zmask |= (zero ? 1u : 0u) << j;
+    const int aw = (qc + dl) >> 1;
+    if (!zero && aw >= 1024) ovf = 1;
+    const int lv = lv_fast(c, min(aw, 1023));
+    sum_nz += zero ? 0 : lv;
+    fnz = zero ? fnz : min(fnz, p);
+    state = (0x7D28 >> (2 * (2 * state + (a & 1)))) & 3;
+    return q;
+}
+
+// Dependent quantisation of nb transform blocks of side n (nb = 1 luma, 2 = Cb+Cr pair):
+// coefficients r1 ([blk][y][x]) -> levels in place; returns the summed level cost
+// (block_splitter.rs:436-458).  Scratch: r2, decw.  `*overflow` is set when a level needs a table
+// entry >= 1024 (the reference panics there).
+//
+// Backward pass = 4-state Viterbi equivalent of the reference's memoised DFS (SURVEY.md Q3,
+// proven equal to the literal DFS in tests/test_oracle.py).  Per chunk of positions all lanes
+// precompute the two branch costs for both values of delta = (state > 1); then ONE lane per
+// state and block walks the chunk, exchanging path costs with two DPP quad permutes.
+//   shared == true : every wave of the workgroup is in this call with blocks of the same size
+//                    (same schedule, see SHW above); wave 0 walks all WPB*nb blocks at once, one
+//                    quad of lanes per block, between two workgroup barriers per chunk.
+//                    `active == false` = this wave only keeps the barriers company.
+//   shared == false: the wave walks its own blocks in quads 0..nb-1 (final pass, tests).
+// Forward trace = composition of per-position state maps (prefix scan over lanes), then every
+// lane emits its own positions and their level costs.
+__device__ __forceinline__ long long quantize(Ctx c, int lg, int nb, bool shared, bool active, int* overflow) {
+    c = uni(c);
+    lg = uni(lg);
+    nb = uni(nb);
+    const CONST_AS DevConst* k = c.k;
+    const int n = 1 << lg;
+    const int P = n * n;
+    const int lgP = 2 * lg;
+    const int sh = 8 + lg - 5 + 1; // quantizer.rs:558-569
+    const int off = (1 << sh) >> 1;
+    const int lsc = k->lsc;
+    const CONST_AS uint16_t* scan = k->scan_idx[lg - 2];
+    int16_t* tcs = (int16_t*)SH.r2;          // [blk][p]: coefficient in reverse-scan order
+    int16_t* qds = (int16_t*)SH.r2 + 1024;   // [blk][p]: |(tc << sh) - off| / lsc
+    int32_t* cc = (int32_t*)SH.r1;           // chunk: [blk][CH][6] ints (coefficients are dead after the gather)
+    const uint16_t* dec16 = (const uint16_t*)SH.decw; // decisions: [blk][sub-block][state] 16-bit masks
+    PROF_MARK(q0_);
+    int istar0 = P, istar1 = P;
+    if (active) {
+        int first0 = P, first1 = P;
+        for (int idx = LANE; idx < nb * P; idx += 64) {
+            const int blk = idx >> lgP, p = idx & (P - 1);
+            const int tc = SH.r1[blk * P + scan[p]];
+            int S = (int)((unsigned)tc << sh) - off;
+            if (tc < 0) S = -S;
+            const int qd = tc == 0 ? 0 : (int)(((unsigned long long)(unsigned)S * k->div_magic) >> 47);
+            tcs[idx] = (int16_t)tc;
+            qds[idx] = (int16_t)qd;
+            if (tc != 0 && (qd >> 1) > 0) {
+                if (blk)
+                    first1 = min(first1, p);
+                else
+                    first0 = min(first0, p);
+            }
+        }
+        istar0 = wave_min_i32(first0);
+        if (nb == 2) istar1 = wave_min_i32(first1);
+    }
+    if (LANE == 0) {
+        SH.q_istar[0] = istar0;
+        SH.q_istar[1] = istar1;
+        SH.q_active = active ? 1 : 0;
+    }
+    PROF_MARK(q1_);
+    PROF_ADD2(PH_QPRE, q0_, q1_);
+    const int ldq1 = (int)ldq_at(c, 1);
+    const int st = LANE & 3;
+    const int delta = st > 1 ? 1 : 0;
+    const int CH = min(P, nb == 2 ? 32 : 64); // chunk positions per block
+    // which block this lane's quad walks: (wave, blk) = (quad / nb, quad % nb) in shared mode
+    const int quad = LANE >> 2;
+    const int wblk = nb == 2 ? (quad & 1) : 0;
+    const int wwave = nb == 2 ? (quad >> 1) : quad;
+    const bool walker = shared ? (WAVE == walker_wave() && wwave < WPB) : (quad < nb);
+    const Lds* tb = shared ? &SHW[wwave < WPB ? wwave : 0] : &SH;
+    const int32_t* wcc = (const int32_t*)tb->r1 + wblk * CH * 6;
+    int C = 0;
+    int ovf = 0;
+    for (int base = P - CH; base >= 0; base -= CH) {
+        PROF_MARK(qb0_);
+        WSYNC();
+        if (active) {
+            // per position and state class (0: state 0, 1: state 1, 2: states 2 and 3): (u, w) doubled,
+            // see above; per sub-block: parity masks of the two delta classes and, for state 0, whether
+            // its first position in coding order (kk == 15) keeps a zero inside the trailing run
+            const bool mine = LANE < nb * CH;
+            const int blk = LANE >= CH ? 1 : 0;
+            const int i = LANE - blk * CH;
+            const int p = base + i;
+            int par0 = 0, par1 = 0, adj = 0;
+            if (mine)
+                chunk_entry(c, cc + LANE * 6, tcs[blk * P + p], qds[blk * P + p], p == P - 1, p <= (blk ? istar1 : istar0),
+                            sh, off, lsc, ldq1, &par0, &par1, &adj, &ovf);
+            const unsigned long long b0 = __ballot(mine && par0), b1 = __ballot(mine && par1), ba = __ballot(mine && adj);
+            if (mine && (LANE & 15) == 0) {
+                uint16_t* pm = SH.q_pm[blk][i >> 4];
+                pm[0] = (uint16_t)(b0 >> LANE);
+                pm[1] = (uint16_t)(b1 >> LANE);
+                pm[2] = (uint16_t)((ba >> (LANE + 15)) & 1);
+            }
+        }
+        PROF_MARK(qb1_);
+        if (shared)
+            __syncthreads();
+        else
+            WSYNC();
+        PROF_MARK(qb2_);
+        if (walker && (!shared || tb->q_active)) {
+            const int cls = st == 0 ? 0 : (st == 1 ? 1 : 2);
+            uint16_t* wdec = (uint16_t*)const_cast<uint32_t*>(tb->decw) + wblk * (P >> 2);
+            for (int g16 = CH - 16; g16 >= 0; g16 -= 16) { // one 4x4 sub-block per iteration
+                const uint16_t* pm = tb->q_pm[wblk][g16 >> 4];
+                const unsigned parmask = pm[st > 1 ? 1 : 0];
+                const bool adj = st == 0 && pm[2] != 0;
+                // all 16 entries of the sub-block are fetched before its walk (a serial dependency
+                // chain that should not wait for LDS position by position)
+                int2 cur[16];
+#pragma unroll
+                for (int kk = 0; kk < 16; ++kk) cur[kk] = *(const int2*)&wcc[(g16 + kk) * 6 + 2 * cls];
+                unsigned bits = 0;
+#pragma unroll
+                for (int kk = 15; kk >= 0; --kk) {
+                    const int2 e = cur[kk];
+                    const int KA = e.x + dpp_quad<0xD8>(C); // C[trans[s][0]]: quad_perm [0,2,1,3]
+                    const int KB = e.y + dpp_quad<0x72>(C); // C[trans[s][1]]: quad_perm [2,0,3,1]
+                    const bool choseB = KB < KA;
+                    C = (choseB ? KB : KA) & ~1;
+                    bits = (bits << 1) | (choseB ? 1u : 0u);
+                    if (kk == 15) { // first position of a sub-block in coding order (:512-514)
+                        const bool pick1 = choseB != (((parmask >> 15) & 1) != 0);
+                        if (!pick1 && adj) C -= 2 * ldq1;
+                    }
+                }
+                bits ^= parmask; // choseB -> pick1
+                // renormalise: subtract the quad minimum (decisions depend on differences only)
+                int m = min(C, dpp_quad<0xB1>(C));  // quad_perm [1,0,3,2]
+                m = min(m, dpp_quad<0x4E>(m));      // quad_perm [2,3,0,1]
+                C -= m;
+                wdec[((base + g16) >> 4) * 4 + st] = (uint16_t)bits;
+            }
+        }
+        PROF_MARK(qb3_);
+        if (shared) __syncthreads();
+        PROF_MARK(qb4_);
+        PROF_ADD2(PH_QB_PRE, qb0_, qb1_);
+        PROF_ADD2(PH_QB_WAIT1, qb1_, qb2_);
+        PROF_ADD2(PH_QB_WALK, qb2_, qb3_);
+        PROF_ADD2(PH_QB_WAIT2, qb3_, qb4_);
+    }
+    WSYNC();
+    PROF_MARK(q2_);
+    PROF_ADD2(PH_QBACK, q1_, q2_);
+    if (!active) return 0;
+    // ---- forward trace from state 0 (quantizer.rs:686-721) + level-cost walk ----
+    // lanes are split evenly between the blocks; each lane owns `per` consecutive positions
+    const int half = nb == 2 ? 32 : 64;
+    const int blk = nb == 2 ? (LANE >> 5) : 0;
+    const int lane_in = LANE & (half - 1);
+    const int per = P >= half ? P / half : 1;
+    const int p0 = lane_in * per;
+    const bool act = p0 < P;
+    const int16_t* btcs = tcs + blk * P;
+    const int16_t* bqds = qds + blk * P;
+    const uint16_t* bdec = dec16 + blk * (P >> 2);
+    int fmap = kMapId;
+    const DecMasks dm = dec_masks(bdec, act ? p0 : 0); // a lane's positions lie in one sub-block (per divides 16)
+    if (act) {
+        for (int j = 0; j < per; ++j) {
+            const int p = p0 + j;
+            fmap = compose_map(position_map(btcs[p], bqds[p], p == P - 1, dec_nib(dm, p)), fmap);
+        }
+    }
+    // inclusive prefix composition across the lanes of a block: Hillis-Steele inside the 16-lane rows
+    // with row_shr DPP moves (lanes without a source get the identity map), then the row totals
+    // travel with row_bcast:15 / row_bcast:31 (the two blocks of a chroma pair are lanes 0..31 and
+    // 32..63, so they simply skip the last step).  No LDS-crossbar shuffles.
+    int pre = fmap;
+    pre = compose_map(pre, __builtin_amdgcn_update_dpp(kMapId, pre, 0x111, 0xF, 0xF, false)); // row_shr:1
+    pre = compose_map(pre, __builtin_amdgcn_update_dpp(kMapId, pre, 0x112, 0xF, 0xF, false)); // row_shr:2
+    pre = compose_map(pre, __builtin_amdgcn_update_dpp(kMapId, pre, 0x114, 0xF, 0xF, false)); // row_shr:4
+    pre = compose_map(pre, __builtin_amdgcn_update_dpp(kMapId, pre, 0x118, 0xF, 0xF, false)); // row_shr:8
+    pre = compose_map(pre, __builtin_amdgcn_update_dpp(kMapId, pre, 0x142, 0xA, 0xF, false)); // row_bcast:15 -> rows 1, 3
+    if (nb == 1) pre = compose_map(pre, __builtin_amdgcn_update_dpp(kMapId, pre, 0x143, 0xC, 0xF, false)); // row_bcast:31 -> rows 2, 3
+    // state after all previous lanes of the block, starting from 0
+    int entry = __builtin_amdgcn_update_dpp(0, pre, 0x138, 0xF, 0xF, false) & 3; // wave_shr:1
+    if (lane_in == 0) entry = 0;
+    long long sum_nz = 0;
+    unsigned zmask = 0;
+    int fnz = P;
+    if (act) {
+        int state = entry;
+        for (int j = 0; j < per; ++j) {
+            const int p = p0 + j;
+            SH.r1[blk * P + scan[p]] =
+                (int16_t)emit_level(c, btcs[p], bqds[p], p == P - 1, dec_nib(dm, p), p, j, state, zmask, sum_nz, fnz, ovf);
+        }
+    }
+    const int pf = group_min_i32(fnz, half); // zeros before a block's first non-zero level cost nothing
+    if (act) // zeros after the first non-zero position: positions j > pf - p0 of this lane
+        sum_nz += (long long)__popc(zmask >> min(max(pf - p0 + 1, 0), 16)) * SHT.lv[0];
+    const long long sum = wave_sum_i64(sum_nz);
+    if (__ballot(ovf != 0) != 0ULL) *overflow = 1;
+    WSYNC();
+    PROF_MARK(q3_);
+    PROF_ADD2(PH_QTRACE, q2_, q3_);
+    return sum;
+}
+
+// Dependent quantisation of the three transform blocks of one candidate in ONE pooled pass: luma
+// n0 x n0 at r1[0, P0), Cb and Cr (n0/2)^2 at r1[P0, P0 + Pc) and r1[P0 + Pc, P0 + 2 Pc), n0 = 8 or
+// 16 (search only: every wave of the workgroup is in this call with the same block size).  Same
+// algorithm as quantize(); the chroma chains are a quarter as long as the luma chain, so a chunk is
+// 64 luma + 16 + 16 chroma positions and the chroma blocks ride along for free: wave 0 walks the
+// 8 luma blocks (lanes 0..31) and the 8 Cb blocks (lanes 32..63), wave 1 the 8 Cr blocks.
+// Scratch: r2 = [scan-order coefficients | quotients | chunk entries], decw.
+__device__ __forceinline__ void quantize3(Ctx c, int lg0, bool active, int* overflow, long long* lvl_y,
+                                          long long* lvl_c) {
+    static_assert(WPB == 8, "the merged pass maps 8 waves x 3 blocks onto two walker waves");
+    c = uni(c);
+    lg0 = uni(lg0);
+    const CONST_AS DevConst* k = c.k;
+    const int lgc = lg0 - 1;
+    const int P0 = 1 << (2 * lg0), Pc = P0 >> 2, T = P0 + 2 * Pc;
+    const int sh0 = lg0 + 4, shc = lgc + 4; // 8 + lg - 5 + 1 (quantizer.rs:558-569)
+    const int lsc = k->lsc;
+    const CONST_AS uint16_t* scan0 = k->scan_idx[lg0 - 2];
+    const CONST_AS uint16_t* scanc = k->scan_idx[lgc - 2];
+    int16_t* tcs = (int16_t*)SH.r2;               // [T]: coefficient in reverse-scan order, block after block
+    int16_t* qds = (int16_t*)SH.r2 + T;           // [T]: |(tc << sh) - off| / lsc
+    constexpr int kCcByte = 1536;                 // 2 * 2 * T <= 1536 for T <= 384
+    int32_t* cc = (int32_t*)((char*)SH.r2 + kCcByte); // chunk: [96][6] ints
+    *lvl_y = 0;
+    *lvl_c = 0;
+    PROF_MARK(q0_);
+    int istar0 = P0, istar1 = Pc, istar2 = Pc;
+    if (active) {
+        int first0 = P0, first1 = Pc, first2 = Pc;
+        for (int idx = LANE; idx < T; idx += 64) {
+            const int b = idx < P0 ? 0 : (idx < P0 + Pc ? 1 : 2);
+            const int boff = b == 0 ? 0 : (b == 1 ? P0 : P0 + Pc);
+            const int p = idx - boff;
+            const int sh = b == 0 ? sh0 : shc;
+            const int off = (1 << sh) >> 1;
+            const int tc = SH.r1[boff + (b == 0 ? scan0[p] : scanc[p])];
+            int S = (int)((unsigned)tc << sh) - off;
+            if (tc < 0) S = -S;
+            const int qd = tc == 0 ? 0 : (int)(((unsigned long long)(unsigned)S * k->div_magic) >> 47);
+            tcs[idx] = (int16_t)tc;
+            qds[idx] = (int16_t)qd;
+            if (tc != 0 && (qd >> 1) > 0) {
+                if (b == 0)
+                    first0 = min(first0, p);
+                else if (b == 1)
+                    first1 = min(first1, p);
+                else
+                    first2 = min(first2, p);
+            }
+        }
+        istar0 = wave_min_i32(first0);
+        istar1 = wave_min_i32(first1);
+        istar2 = wave_min_i32(first2);
+    }
+    if (LANE == 0) SH.q_active = active ? 1 : 0;
+    PROF_MARK(q1_);
+    PROF_ADD2(PH_QPRE, q0_, q1_);
+    const int ldq1 = (int)ldq_at(c, 1);
+    const int st = LANE & 3;
+    const int cls = st == 0 ? 0 : (st == 1 ? 1 : 2);
+    // walker lanes: wave 0 lanes 0..31 luma of wave LANE/4, lanes 32..63 Cb; wave 1 lanes 0..31 Cr
+    const int wv = (WAVE - walker_wave()) & (WPB - 1); // 0 and 1: the two walker waves
+    const int wb = wv == 0 ? (LANE < 32 ? 0 : 1) : 2;
+    const bool walker = wv == 0 || (wv == 1 && LANE < 32);
+    const Lds* tb = &SHW[(LANE & 31) >> 2];
+    const int32_t* wcc = (const int32_t*)((const char*)tb->r2 + kCcByte) + (wb == 0 ? 0 : (wb == 1 ? 64 : 80)) * 6;
+    uint16_t* wdec = (uint16_t*)const_cast<uint32_t*>(tb->decw) + (wb == 0 ? 0 : (wb == 1 ? (P0 >> 2) : (P0 >> 2) + (Pc >> 2)));
+    const int wnsb = wb == 0 ? 4 : 1; // sub-blocks of the walker's block per chunk
+    int C = 0;
+    int ovf = 0;
+    const int nch = P0 >> 6;
+    for (int ch = 0; ch < nch; ++ch) {
+        const int base0 = P0 - 64 * (ch + 1), basec = Pc - 16 * (ch + 1);
+        PROF_MARK(qb0_);
+        WSYNC();
+        if (active) {
+#pragma unroll 1
+            for (int pass = 0; pass < 2; ++pass) {
+                const int e = LANE + 64 * pass;
+                const bool mine = e < 96;
+                const int b = e < 64 ? 0 : (e < 80 ? 1 : 2);
+                const int i = b == 0 ? e : ((e - 64) & 15);
+                const int p = (b == 0 ? base0 : basec) + i;
+                const int Pb = b == 0 ? P0 : Pc;
+                const int gidx = (b == 0 ? 0 : (b == 1 ? P0 : P0 + Pc)) + p;
+                int par0 = 0, par1 = 0, adj = 0;
+                if (mine) {
+                    const int sh = b == 0 ? sh0 : shc;
+                    chunk_entry(c, cc + e * 6, tcs[gidx], qds[gidx], p == Pb - 1,
+                                p <= (b == 0 ? istar0 : (b == 1 ? istar1 : istar2)), sh, (1 << sh) >> 1, lsc, ldq1, &par0,
+                                &par1, &adj, &ovf);
+                }
+                const unsigned long long b0 = __ballot(mine && par0), b1 = __ballot(mine && par1),
+                                         ba = __ballot(mine && adj);
+                if (mine && (LANE & 15) == 0) {
+                    // pass 0: luma sub-block LANE / 16; pass 1: lanes 0..15 Cb, 16..31 Cr (one sub-block each)
+                    uint16_t* pm = SH.q_pm[b][b == 0 ? (LANE >> 4) : 0];
+                    pm[0] = (uint16_t)(b0 >> LANE);
+                    pm[1] = (uint16_t)(b1 >> LANE);
+                    pm[2] = (uint16_t)((ba >> (LANE + 15)) & 1);
+                }
+            }
+        }
+        PROF_MARK(qb1_);
+        __syncthreads();
+        PROF_MARK(qb2_);
+        if (walker && tb->q_active) {
+            for (int sbi = wnsb - 1; sbi >= 0; --sbi) { // one 4x4 sub-block per iteration
+                const int g16 = sbi * 16;
+                const uint16_t* pm = tb->q_pm[wb][sbi];
+                const unsigned parmask = pm[st > 1 ? 1 : 0];
+                const bool adj = st == 0 && pm[2] != 0;
+                int2 cur[16];
+#pragma unroll
+                for (int kk = 0; kk < 16; ++kk) cur[kk] = *(const int2*)&wcc[(g16 + kk) * 6 + 2 * cls];
+                unsigned bits = 0;
+#pragma unroll
+                for (int kk = 15; kk >= 0; --kk) {
+                    const int2 en = cur[kk];
+                    const int KA = en.x + dpp_quad<0xD8>(C); // C[trans[s][0]]: quad_perm [0,2,1,3]
+                    const int KB = en.y + dpp_quad<0x72>(C); // C[trans[s][1]]: quad_perm [2,0,3,1]
+                    const bool choseB = KB < KA;
+                    C = (choseB ? KB : KA) & ~1;
+                    bits = (bits << 1) | (choseB ? 1u : 0u);
+                    if (kk == 15) { // first position of a sub-block in coding order (:512-514)
+                        const bool pick1 = choseB != (((parmask >> 15) & 1) != 0);
+                        if (!pick1 && adj) C -= 2 * ldq1;
+                    }
+                }
+                bits ^= parmask; // choseB -> pick1
+                int m = min(C, dpp_quad<0xB1>(C));
+                m = min(m, dpp_quad<0x4E>(m));
+                C -= m;
+                wdec[(((wb == 0 ? base0 : basec) + g16) >> 4) * 4 + st] = (uint16_t)bits;
+            }
+        }
+        PROF_MARK(qb3_);
+        __syncthreads();
+        PROF_MARK(qb4_);
+        PROF_ADD2(PH_QB_PRE, qb0_, qb1_);
+        PROF_ADD2(PH_QB_WAIT1, qb1_, qb2_);
+        PROF_ADD2(PH_QB_WALK, qb2_, qb3_);
+        PROF_ADD2(PH_QB_WAIT2, qb3_, qb4_);
+    }
+    WSYNC();
+    PROF_MARK(q2_);
+    PROF_ADD2(PH_QBACK, q1_, q2_);
+    if (!active) return;
+    // ---- forward trace + level cost: lanes 0..31 luma, 32..47 Cb, 48..63 Cr ----
+    const int b = LANE < 32 ? 0 : (LANE < 48 ? 1 : 2);
+    const int lane_in = b == 0 ? LANE : (LANE & 15);
+    const int Pb = b == 0 ? P0 : Pc;
+    const int per = b == 0 ? (P0 >> 5) : (Pc >> 4); // P0 / 32 = Pc / 16 * 2
+    const int boff = b == 0 ? 0 : (b == 1 ? P0 : P0 + Pc);
+    const int p0 = lane_in * per;
+    const int16_t* btcs = tcs + boff;
+    const int16_t* bqds = qds + boff;
+    const uint16_t* bdec = (const uint16_t*)SH.decw + (b == 0 ? 0 : (b == 1 ? (P0 >> 2) : (P0 >> 2) + (Pc >> 2)));
+    int fmap = kMapId;
+    const DecMasks dm = dec_masks(bdec, p0); // a lane's positions lie in one sub-block (per divides 16)
+    for (int j = 0; j < per; ++j) {
+        const int p = p0 + j;
+        fmap = compose_map(position_map(btcs[p], bqds[p], p == Pb - 1, dec_nib(dm, p)), fmap);
+    }
+    int pre = fmap;
+    pre = compose_map(pre, __builtin_amdgcn_update_dpp(kMapId, pre, 0x111, 0xF, 0xF, false)); // row_shr:1
+    pre = compose_map(pre, __builtin_amdgcn_update_dpp(kMapId, pre, 0x112, 0xF, 0xF, false)); // row_shr:2
+    pre = compose_map(pre, __builtin_amdgcn_update_dpp(kMapId, pre, 0x114, 0xF, 0xF, false)); // row_shr:4
+    pre = compose_map(pre, __builtin_amdgcn_update_dpp(kMapId, pre, 0x118, 0xF, 0xF, false)); // row_shr:8
+    pre = compose_map(pre, __builtin_amdgcn_update_dpp(kMapId, pre, 0x142, 0x2, 0xF, false)); // row_bcast:15 -> row 1 (luma)
+    int entry = __builtin_amdgcn_update_dpp(0, pre, 0x138, 0xF, 0xF, false) & 3; // wave_shr:1
+    if (lane_in == 0) entry = 0;
+    long long sum_nz = 0;
+    unsigned zmask = 0;
+    int fnz = Pb;
+    {
+        int state = entry;
+        for (int j = 0; j < per; ++j) {
+            const int p = p0 + j;
+            SH.r1[boff + (b == 0 ? scan0[p] : scanc[p])] =
+                (int16_t)emit_level(c, btcs[p], bqds[p], p == Pb - 1, dec_nib(dm, p), p, j, state, zmask, sum_nz, fnz, ovf);
+        }
+    }
+    // zeros before a block's first non-zero level cost nothing: minimum per block (rows 0-1 | 2 | 3)
+    {
+        const int rm = row_min_i32(fnz);
+        const int m0 = min(__builtin_amdgcn_readlane(rm, 0), __builtin_amdgcn_readlane(rm, 16));
+        const int m1 = __builtin_amdgcn_readlane(rm, 32), m2 = __builtin_amdgcn_readlane(rm, 48);
+        const int pf = b == 0 ? m0 : (b == 1 ? m1 : m2);
+        sum_nz += (long long)__popc(zmask >> min(max(pf - p0 + 1, 0), 16)) * SHT.lv[0];
+    }
+    // level cost of the luma block (rows 0-1) and of the chroma pair (rows 2-3), three limbs each
+    {
+        const long long hi = sum_nz >> 24;
+        const int ra = row_sum_i32((int)(sum_nz & 0xFFFFFF)), rb = row_sum_i32((int)(hi & 0xFFFFFF)),
+                  rc = row_sum_i32((int)(hi >> 24));
+        const long long ya = (long long)(unsigned)(__builtin_amdgcn_readlane(ra, 0) + __builtin_amdgcn_readlane(ra, 16));
+        const long long yb = (long long)(unsigned)(__builtin_amdgcn_readlane(rb, 0) + __builtin_amdgcn_readlane(rb, 16));
+        const long long yc = (long long)(__builtin_amdgcn_readlane(rc, 0) + __builtin_amdgcn_readlane(rc, 16));
+        const long long ca = (long long)(unsigned)(__builtin_amdgcn_readlane(ra, 32) + __builtin_amdgcn_readlane(ra, 48));
+        const long long cb = (long long)(unsigned)(__builtin_amdgcn_readlane(rb, 32) + __builtin_amdgcn_readlane(rb, 48));
+        const long long cc2 = (long long)(__builtin_amdgcn_readlane(rc, 32) + __builtin_amdgcn_readlane(rc, 48));
+        *lvl_y = ya + ((yb + (yc << 24)) << 24);
+        *lvl_c = ca + ((cb + (cc2 << 24)) << 24);
+    }
+    if (__ballot(ovf != 0) != 0ULL) *overflow = 1;
+    WSYNC();
+    PROF_MARK(q3_);
+    PROF_ADD2(PH_QTRACE, q2_, q3_);
+}
+
+// levels r1 (row-major) -> transposed dequantised coefficients in r2 (dT[x][i] = d[i][x]);
+// quantizer.rs:761-1079
+__device__ __forceinline__ void dequantize_t(Ctx c, int lg, int nb, int o1 = 0) {
+    c = uni(c);
+    lg = uni(lg);
+    nb = uni(nb);
+    o1 = uni(o1);
+    const int n = 1 << lg;
+    const int nn = n * n;
+    const int sh = 8 + lg - 5 + 1;
+    const int off = (1 << sh) >> 1;
+    const int lsc = c.k->lsc;
+    int16_t* out = (int16_t*)SH.r2;
+    for (int i = LANE; i < nb * nn; i += 64) {
+        const int blk = i >> (2 * lg), ii = i & (nn - 1);
+        const int x = ii & (n - 1), y = ii >> lg;
+        int v = (M24(SH.r1[o1 + i], lsc) + off) >> sh;
+        v = min(max(v, -32768), 32767);
+        out[blk * nn + x * n + y] = (int16_t)v;
+    }
+    WSYNC();
+}
+
+} // namespace wrenc

@@ -1,0 +1,1075 @@
+// dev_search.h -- evaluation requests and the evaluator, the leaf / CTU search state machines, CTU entry (block_splitter.rs, ctu_encoder.rs:1421-1461)
+// Part of the gfx950 device code of the RD-search path; see wrenc_dev.h for the overall model.
+#pragma once
+
+namespace wrenc {
+
+// ---------------------------------------------------------------------------
+// RD search building blocks (block_splitter.rs)
+// ---------------------------------------------------------------------------
+// Evaluation requests and the evaluator
+// ---------------------------------------------------------------------------
+enum { K_SADLIST = 0, K_FULL = 1, K_NOP = 2 };
+enum { COPY_NONE = 0, COPY_SAVE = 1, COPY_RESTORE = 2 };
+
+struct Req {
+    int kind;       // K_SADLIST: predict + SAD of a list of modes (block_splitter.rs:64-108, 476-522);
+                    // K_FULL: predict .. reconstruct (:146-185)
+    int comps;      // bit 0: luma block, bit 1: Cb+Cr pair
+    int tx, ty, tlg;
+    int ml, mc;     // K_FULL: luma / chroma mode
+    bool shared;    // quantiser: pooled Viterbi of the workgroup (search) or solo (regen, final pass)
+    bool active;    // false: walk the schedule only (keeps the workgroup's barriers aligned)
+    bool refs0, refs1; // (re)build the luma / chroma reference samples of the block first
+    bool final;     // final pass: store the levels, count reconstruction changes
+    int n;          // K_SADLIST: number of entries
+    int tree;       // tree type of the leaf that asks (diagnostic trace only)
+    // before the evaluation: save the block's reconstruction to a slot / restore it from there
+    // (the reference's cache_reconsts / restore_reconsts, block_splitter.rs:807-840, 1085-1145)
+    int pre_copy, copy_comps, copy_slot, copy_tx, copy_ty, copy_tlg;
+    unsigned long long modes_lo, modes_hi; // K_SADLIST: one byte per entry (8 + 8), the same mode for luma and chroma
+};
+
+struct Res {
+    // K_FULL: SSD and level cost of the luma block and of the chroma pair
+    uint32_t ssd_y, ssd_c;
+    long long lvl_y, lvl_c;
+    // K_SADLIST: costs of the first three entries, first minimum (strict <) and its index
+    float v0, v1, v2, vmin;
+    int imin;
+};
+
+__device__ __forceinline__ float uni_f(float v) { return __int_as_float(uni(__float_as_int(v))); }
+
+// First half of a full evaluation of one component (comp 0: luma block, 1: chroma pair): reference
+// samples, prediction, forward transform.  Residual / coefficients at r1[rbase ..], prediction bytes
+// in the tile (final pass: at pred_scratch[rbase ..]).
+__device__ __forceinline__ void full_front(const Ctx& c, const Req& q, int comp, int mode, int rbase) {
+    const int cs = comp ? 1 : 0;
+    const int nb = comp ? 2 : 1;
+    const int lg = q.tlg - cs;
+    PROF_MARK(tr0_);
+    if ((comp ? q.refs1 : q.refs0) && mode < LT_CCLM) build_refs(c, comp, q.tx, q.ty, q.tlg);
+    PROF_MARK(t0_);
+    PROF_ADD2(PH_REFS, tr0_, t0_);
+    predict<true>(c, comp, q.tx, q.ty, q.tlg, mode, rbase, !q.final);
+    PROF_MARK(t1_);
+    PROF_ADD2(PH_PREDICT, t0_, t1_);
+    fwd_dct_lg(c, lg, nb, rbase);
+    PROF_MARK(t2_);
+    PROF_ADD2(PH_FDCT, t1_, t2_);
+}
+
+// Second half: levels at r1[rbase ..] -> (final pass: store them) -> dequantise, inverse transform,
+// reconstruct into the tile; returns the SSD against the originals (block_splitter.rs:146-185)
+__device__ __forceinline__ uint32_t full_back(const Ctx& c, const PicBufs& pb, const Req& q, int comp, int rbase) {
+    const int cs = comp ? 1 : 0;
+    const int nb = comp ? 2 : 1;
+    const int lg = q.tlg - cs;
+    const int n = 1 << lg;
+    const int nn = n * n;
+    const int cx = q.tx >> cs, cy = q.ty >> cs;
+    PROF_MARK(t3_);
+    if (q.final && c.write) {
+        const int stride = c.W >> cs;
+        const size_t at = (size_t)((c.ctu_y + q.ty) >> cs) * stride + ((c.ctu_x + q.tx) >> cs);
+        GLOBAL_AS int16_t* lev0 = AS_GLOBAL(int16_t, pb.lev[0]) + plane_off(c, comp) + at;
+        GLOBAL_AS int16_t* lev1 = AS_GLOBAL(int16_t, pb.lev[0]) + plane_off(c, 2) + at;
+        for (int i = LANE; i < nb * nn; i += 64) {
+            const int blk = i >> (2 * lg), ii = i & (nn - 1);
+            (blk ? lev1 : lev0)[(size_t)(ii >> lg) * stride + (ii & (n - 1))] = SH.r1[rbase + i];
+        }
+    }
+    dequantize_t(c, lg, nb, rbase);
+    PROF_MARK(t4_);
+    inv_dct_lg(c, lg, nb, rbase);
+    PROF_MARK(t5_);
+    PROF_ADD2(PH_DEQ, t3_, t4_);
+    PROF_ADD2(PH_IDCT, t4_, t5_);
+    unsigned int part = 0;
+    int diff = 0;
+    for (int i = LANE; i < nb * nn; i += 64) {
+        const int blk = i >> (2 * lg), ii = i & (nn - 1);
+        const int x = ii & (n - 1), y = ii >> lg;
+        const int pc = comp + blk;
+        const int pred = q.final ? (int)c.pred_scratch[rbase + i] : rec_get(pc, cx + x, cy + y);
+        int v = (int16_t)(pred + (int)SH.r1[rbase + i]); // pred as i16 + res, clamp (:178)
+        v = min(max(v, 0), 255);
+        if (q.final && v != rec_get(pc, cx + x, cy + y)) ++diff;
+        rec_put(pc, cx + x, cy + y, v);
+        const int d = v - org_get(c, pc, cx + x, cy + y);
+        part += (unsigned)M24(d, d);
+    }
+    const uint32_t ssd = (uint32_t)wave_sum_i32((int)part); // <= 1024 * 255^2: fits 32 bits
+    if (q.final) {
+        const int changed = wave_sum_i32(diff);
+        if (changed && LANE == 0 && c.write) atomicAdd(c.mismatch, (unsigned long long)changed);
+    }
+    WSYNC();
+    PROF_MARK(t6_);
+    PROF_ADD2(PH_RECON, t5_, t6_);
+    return ssd;
+}
+
+// Save the reconstruction of a block (comps bit 0: luma n x n, bit 1: Cb and Cr (n/2) x (n/2)) from
+// the LDS tile to a slot in global scratch, or restore it from there.  Dwords: block corners are
+// multiples of 4 samples in every plane that takes part.
+__device__ __forceinline__ void copy_block(const Ctx& c, int mode, int comps, int slot, int tx, int ty, int tlg) {
+    GLOBAL_AS uint32_t* g = (GLOBAL_AS uint32_t*)(c.slots + slot * kSlotBytes);
+    if (comps & 1) {
+        const int words = 1 << (2 * tlg - 2);
+        for (int w = LANE; w < words; w += 64) {
+            const int row = (4 * w) >> tlg, col = (4 * w) & ((1 << tlg) - 1);
+            uint32_t* l = (uint32_t*)&SH.recY[(ty + row) * 36 + tx + col + 4];
+            if (mode == COPY_SAVE)
+                g[w] = *l;
+            else
+                *l = g[w];
+        }
+    }
+    if (comps & 2) {
+        const int lg = tlg - 1;
+        const int words = 1 << (2 * lg - 2); // per plane
+        for (int w = LANE; w < 2 * words; w += 64) {
+            const int pl = w >= words ? 1 : 0;
+            const int ww = w - pl * words;
+            const int row = (4 * ww) >> lg, col = (4 * ww) & ((1 << lg) - 1);
+            uint32_t* l = (uint32_t*)&SH.recC[pl][((ty >> 1) + row) * 20 + (tx >> 1) + col + 4];
+            if (mode == COPY_SAVE)
+                g[256 + pl * 64 + ww] = *l;
+            else
+                *l = g[256 + pl * 64 + ww];
+        }
+    }
+    WSYNC();
+}
+
+// The evaluator: every block evaluation of the search, of the regeneration and of the final pass
+// goes through this one inlined copy (the search logic below is a state machine that hands out
+// evaluation requests; no function calls in the hot path).
+__device__ __forceinline__ Res evaluate(const Ctx& c, const PicBufs& pb, const Req& q, int* overflow) {
+    Res r;
+    r.ssd_y = 0;
+    r.ssd_c = 0;
+    r.lvl_y = 0;
+    r.lvl_c = 0;
+    r.v0 = r.v1 = r.v2 = r.vmin = 3.40282347e+38f;
+    r.imin = 0;
+    if (q.pre_copy != COPY_NONE) copy_block(c, q.pre_copy, q.copy_comps, q.copy_slot, q.copy_tx, q.copy_ty, q.copy_tlg);
+    if (q.kind == K_NOP) return r;
+    if (q.kind == K_FULL) {
+        // A candidate of the search with an 8x8 or 16x16 luma block quantises its three transform
+        // blocks in one pooled pass (quantize3): both components go through the first half, then
+        // the pass, then both through the second half.  Everything else runs component by component
+        // (the two share r1 / r2).  One copy of each stage either way.
+        const bool merged = WPB == 8 && q.shared && q.comps == 3 && q.tlg <= 4;
+        const int p0 = 1 << (2 * q.tlg);
+        const int rounds = merged ? 1 : 2;
+#pragma unroll 1
+        for (int round = 0; round < rounds; ++round) {
+            const int cset = merged ? 3 : (q.comps & (1 << round));
+            if (!cset) continue;
+            if (q.active) {
+#pragma unroll 1
+                for (int comp = 0; comp < 2; ++comp)
+                    if ((cset >> comp) & 1) full_front(c, q, comp, comp ? q.mc : q.ml, (merged && comp) ? p0 : 0);
+            }
+            PROF_MARK(ts0_);
+            if (merged) {
+                quantize3(c, q.tlg, q.active, overflow, &r.lvl_y, &r.lvl_c);
+            } else {
+                const long long lvl = quantize(c, q.tlg - round, round ? 2 : 1, q.shared, q.active, overflow);
+                if (round)
+                    r.lvl_c = lvl;
+                else
+                    r.lvl_y = lvl;
+            }
+            PROF_MARK(ts1_);
+            if (!q.active) { // only kept the shared-Viterbi barriers company
+                PROF_ADD2(PH_SKIP, ts0_, ts1_);
+                continue;
+            }
+#pragma unroll 1
+            for (int comp = 0; comp < 2; ++comp) {
+                if (!((cset >> comp) & 1)) continue;
+                const uint32_t ssd = full_back(c, pb, q, comp, (merged && comp) ? p0 : 0);
+                if (comp)
+                    r.ssd_c = ssd;
+                else
+                    r.ssd_y = ssd;
+            }
+        }
+        return r;
+    }
+    // K_SADLIST: get_intra_pred_aux_cost / get_chroma_intra_pred_aux_cost of each listed mode
+    PROF_MARK(tr0_);
+    if (q.refs0 && (q.comps & 1)) build_refs(c, 0, q.tx, q.ty, q.tlg);
+    if (q.refs1 && (q.comps & 2)) build_refs(c, 1, q.tx, q.ty, q.tlg);
+    stage_org(c, q.comps, q.tx, q.ty, q.tlg);
+    PROF_MARK(t0_);
+    PROF_ADD2(PH_REFS, tr0_, t0_);
+    // SADs stay integers (< 2^20, so the f32 the reference compares is exact and ordered the same
+    // way); they become floats once, at the end.  An entry that is not evaluated costs f32::MAX.
+    constexpr unsigned kNoSad = 0xFFFFFFFFu;
+    unsigned s0 = kNoSad, s1 = kNoSad, s2 = kNoSad, smin = kNoSad;
+    const int m_first = (int)(q.modes_lo & 255u);
+    const int m_second = (int)((q.modes_lo >> 8) & 255u);
+    if ((m_first >= 2 && m_first <= 66) || (m_first == kNoMode && m_second <= 66)) {
+        // a list of angular modes (the 13 directional candidates, a step-search pair)
+        const unsigned acc = sad_list_angular(c, q.comps, q.tx, q.ty, q.tlg, q.n, q.modes_lo, q.modes_hi);
+        const int my_mode = LANE < q.n ? (int)(((LANE < 8 ? q.modes_lo : q.modes_hi) >> (8 * (LANE & 7))) & 255u) : kNoMode;
+        if (c.write && my_mode != kNoMode)
+            TRACE_REC(c.ctu_x + q.tx, c.ctu_y + q.ty, q.tlg, q.tree, (q.comps & 1) ? 0 : 2, (q.comps & 1) ? my_mode : 0, my_mode,
+                      __float_as_int((float)acc));
+        // first minimum = smallest (sad, index) pair
+        const int key = my_mode != kNoMode ? (int)((acc << 4) | (unsigned)LANE) : 0x7FFFFFFF;
+        const int kmin = wave_min_i32(key);
+        if (kmin != 0x7FFFFFFF) {
+            smin = (unsigned)kmin >> 4;
+            r.imin = kmin & 15;
+        }
+        const unsigned a0 = (unsigned)__builtin_amdgcn_readlane((int)acc, 0), a1 = (unsigned)__builtin_amdgcn_readlane((int)acc, 1),
+                       a2 = (unsigned)__builtin_amdgcn_readlane((int)acc, 2);
+        if (m_first != kNoMode) s0 = a0;
+        if (q.n > 1 && m_second != kNoMode) s1 = a1;
+        if (q.n > 2 && (int)((q.modes_lo >> 16) & 255u) != kNoMode) s2 = a2;
+    } else {
+#pragma unroll 1
+        for (int i = 0; i < q.n; ++i) {
+            const int m = (int)(((i < 8 ? q.modes_lo : q.modes_hi) >> (8 * (i & 7))) & 255u);
+            unsigned sad = kNoSad;
+            if (m != kNoMode) {
+                sad = 0;
+#pragma unroll 1
+                for (int comp = 0; comp < 2; ++comp) {
+                    if (!((q.comps >> comp) & 1)) continue;
+                    PROF_MARK(tp0_);
+                    sad += (unsigned)wave_sum_i32(predict<false>(c, comp, q.tx, q.ty, q.tlg, m));
+                    PROF_MARK(tp1_);
+                    PROF_ADD2(PH_PSZ + ((q.tlg - 2) * 2 + comp), tp0_, tp1_);
+                    PROF_ADD2(PH_PCNT + ((q.tlg - 2) * 2 + comp), 0, 1);
+                }
+            }
+            if (c.write && LANE == 0 && m != kNoMode)
+                TRACE_REC(c.ctu_x + q.tx, c.ctu_y + q.ty, q.tlg, q.tree, (q.comps & 1) ? 0 : 2, (q.comps & 1) ? m : 0, m,
+                          __float_as_int((float)sad));
+            if (i == 0) s0 = sad;
+            if (i == 1) s1 = sad;
+            if (i == 2) s2 = sad;
+            if (sad < smin) { // first minimum
+                smin = sad;
+                r.imin = i;
+            }
+        }
+    }
+    r.v0 = s0 == kNoSad ? 3.40282347e+38f : uni_f((float)s0);
+    r.v1 = s1 == kNoSad ? 3.40282347e+38f : uni_f((float)s1);
+    r.v2 = s2 == kNoSad ? 3.40282347e+38f : uni_f((float)s2);
+    r.vmin = smin == kNoSad ? 3.40282347e+38f : uni_f((float)smin);
+    PROF_MARK(t1_);
+    PROF_ADD2(PH_PREDICT, t0_, t1_);
+    return r;
+}
+
+// luma mode of the CU covering picture position (CTU-local x, y), as the search sees it
+// (SURVEY.md Q7): inside the CTU -> root CU's mode; left CTU -> its final map; else none.
+__device__ __forceinline__ int nb_luma_mode(Ctx c, int x, int y, bool* exists) {
+    if (x >= 0 && y >= 0) {
+        *exists = true;
+        return c.cu32_mode;
+    }
+    if (y >= 0 && x < 0 && c.ctu_x > 0) {
+        *exists = true;
+        return uni((int)SH.left_mode[y >> 2]);
+    }
+    *exists = false;
+    return PLANAR;
+}
+
+// mode class index for the header-bit table: 0 planar, 1..5 mpm_idx, 6..66 remainder
+// (ctu.rs:1498-1635)
+__device__ __forceinline__ int mpm_class(const Ctx& c, int bx, int by, int lg, int mode) {
+    if (mode == PLANAR) return 0;
+    const int n = 1 << lg;
+    bool le, ae;
+    int left = nb_luma_mode(c, bx - 1, by + n - 1, &le);
+    if (!le) left = PLANAR;
+    int above;
+    if (by - 1 < 0) {
+        // above the CTU: either no CU (picture edge) or forced PLANAR across the CTU row (:1518-1523)
+        above = PLANAR;
+    } else {
+        above = nb_luma_mode(c, bx + n - 1, by - 1, &ae);
+        if (!ae) above = PLANAR;
+    }
+    int k0, k1, k2, k3, k4;
+    if (left == above && left > DC) {
+        const int m = left;
+        k0 = m;
+        k1 = 2 + (m + 61) % 64;
+        k2 = 2 + (m - 1) % 64;
+        k3 = 2 + (m + 60) % 64;
+        k4 = 2 + m % 64;
+    } else if (left != above && (left > DC || above > DC)) {
+        const int mn = min(left, above), mx = max(left, above);
+        if (mn > DC) {
+            const int d = mx - mn;
+            k0 = left;
+            k1 = above;
+            if (d == 1) {
+                k2 = 2 + (mn + 61) % 64;
+                k3 = 2 + (mx - 1) % 64;
+                k4 = 2 + (mn + 60) % 64;
+            } else if (d >= 62) {
+                k2 = 2 + (mn - 1) % 64;
+                k3 = 2 + (mx + 61) % 64;
+                k4 = 2 + mn % 64;
+            } else if (d == 2) {
+                k2 = 2 + (mn - 1) % 64;
+                k3 = 2 + (mn + 61) % 64;
+                k4 = 2 + (mx - 1) % 64;
+            } else {
+                k2 = 2 + (mn + 61) % 64;
+                k3 = 2 + (mn - 1) % 64;
+                k4 = 2 + (mx + 61) % 64;
+            }
+        } else {
+            k0 = mx;
+            k1 = 2 + (mx + 61) % 64;
+            k2 = 2 + (mx - 1) % 64;
+            k3 = 2 + (mx + 60) % 64;
+            k4 = 2 + mx % 64;
+        }
+    } else {
+        k0 = DC;
+        k1 = 50;
+        k2 = 18;
+        k3 = 46;
+        k4 = 54;
+    }
+    if (k0 == mode) return 1;
+    if (k1 == mode) return 2;
+    if (k2 == mode) return 3;
+    if (k3 == mode) return 4;
+    if (k4 == mode) return 5;
+    // remainder = mode - 1 - #(candidates below mode) after sorting (:1613-1628)
+    const int smaller = (k0 < mode) + (k1 < mode) + (k2 < mode) + (k3 < mode) + (k4 < mode);
+    return 6 + (mode - 1 - smaller);
+}
+
+__device__ __forceinline__ float rd_cost(unsigned long long ssd, long long level, float lambda) {
+    // block_splitter.rs:472-473: ssd as f32 + lambda * (level as f32 / 16384.0).  Rust never
+    // contracts a*b+c into an FMA; HIP's default -ffp-contract=fast would, so contraction is
+    // switched off here (and with -ffp-contract=off on the command line).
+#pragma clang fp contract(off)
+    const float lv = (float)level * (1.0f / 16384.0f);
+    const float prod = lambda * lv;
+    return (float)ssd + prod;
+}
+
+// SSD and level cost of the luma and of the chroma pair of one evaluated candidate.  Evaluations
+// are deterministic functions of (block, mode, neighbourhood[, luma recon for CCLM]), so where the
+// reference re-runs an evaluation it has already done (block_splitter.rs:1040,1068-1075) the
+// parts are re-used and only the cost is re-assembled.
+// get_intra_pred_cost (block_splitter.rs:110-474) from already evaluated parts, modes [ml, mc, mc]
+__device__ __forceinline__ float assemble_cost(const Ctx& c, int tree, int cls, int mc, const EvalParts& e) {
+    const bool single = tree == TREE_SINGLE;
+    const int cc = (single && mc >= LT_CCLM) ? 1 + (mc - LT_CCLM) : 0;
+    const unsigned long long ssd = (unsigned long long)e.ssd_y + (single ? (unsigned long long)e.ssd_c : 0ULL);
+    const long long level = e.lvl_y + (single ? e.lvl_c : 0LL) + c.k->hb_luma[single ? 0 : 1][cc][cls];
+    return rd_cost(ssd, level, c.k->lambda_rd);
+}
+
+// get_chroma_intra_pred_cost (block_splitter.rs:524-780) from already evaluated parts
+__device__ __forceinline__ float assemble_chroma_cost(const Ctx& c, int mc, const EvalParts& e) {
+    const long long level = e.lvl_c + c.k->hb_chroma[mc >= LT_CCLM ? 1 + (mc - LT_CCLM) : 0];
+    return rd_cost((unsigned long long)e.ssd_c, level, c.k->lambda_rd_chroma);
+}
+
+__device__ __forceinline__ int pick_cclm(float lt, float t, float l) {
+    // block_splitter.rs:847-854
+    if (lt <= t && lt <= l) return LT_CCLM;
+    if (t <= l) return T_CCLM;
+    return L_CCLM;
+}
+
+__device__ __noinline__ void fill_maps(int bx, int by, int lg, int luma_mode, int chroma_mode, bool luma,
+                                       bool chroma) {
+    bx = uni(bx);
+    by = uni(by);
+    lg = uni(lg);
+    luma_mode = uni(luma_mode);
+    chroma_mode = uni(chroma_mode);
+    const int n4 = (1 << lg) >> 2;
+    if (luma)
+        for (int i = LANE; i < n4 * n4; i += 64) {
+            const int idx = ((by >> 2) + i / n4) * 8 + (bx >> 2) + i % n4;
+            SH.cu_log2[idx] = (uint8_t)lg;
+            SH.luma_mode[idx] = (uint8_t)luma_mode;
+        }
+    if (chroma) {
+        const int n8 = max(n4 >> 1, 1);
+        for (int i = LANE; i < n8 * n8; i += 64)
+            SH.chroma_mode[((by >> 3) + i / n8) * 4 + (bx >> 3) + i % n8] = (uint8_t)chroma_mode;
+    }
+    WSYNC();
+}
+
+
+// ---------------------------------------------------------------------------
+// Search control as state machines: a step function runs until it needs a block evaluated, stores
+// the request and where to continue, and returns true; the driver evaluates the block and calls
+// it again with the result.  All state lives in LDS (CtuSt / LeafSt, wave-uniform); the control
+// flow is a plain loop around a switch (reducible, all scalar branches).
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void req_full(Req& q, int comps, int tx, int ty, int tlg, int ml, int mc, bool shared,
+                                         bool active, bool refs0, bool refs1, bool final) {
+    q.kind = K_FULL;
+    q.comps = comps;
+    q.tx = tx;
+    q.ty = ty;
+    q.tlg = tlg;
+    q.ml = ml;
+    q.mc = mc;
+    q.shared = shared;
+    q.active = active;
+    q.refs0 = refs0;
+    q.refs1 = refs1;
+    q.final = final;
+    q.pre_copy = COPY_NONE;
+}
+
+__device__ __forceinline__ void req_copy(Req& q, int mode, int comps, int slot, int tx, int ty, int tlg) {
+    q.pre_copy = mode;
+    q.copy_comps = comps;
+    q.copy_slot = slot;
+    q.copy_tx = tx;
+    q.copy_ty = ty;
+    q.copy_tlg = tlg;
+}
+
+enum {
+    C_START = 0, C_PLANAR, C_DCM, C_LIST, C_PAIR_EMIT, C_PAIR, C_F0, C_F1, C_F2, C_WIN, C_CX, C_CCLM, C_DM,
+    C_DC_START, C_DC2, C_DC3, C_DC4, C_DC5
+};
+
+__device__ __forceinline__ void leaf_init(LeafSt& s, int tree, int bx, int by, int lg, int dm_mode) {
+    s.cont = (uint8_t)(tree == TREE_DUAL_CHROMA ? C_DC_START : C_START);
+    s.tree = (uint8_t)tree;
+    s.bx = (uint8_t)bx;
+    s.by = (uint8_t)by;
+    s.lg = (uint8_t)lg;
+    s.dm_mode = (uint8_t)dm_mode;
+    s.need_refs0 = 1;
+    s.need_refs1 = 1;
+    s.need_save = 0;
+    s.tile_best = 0;
+}
+
+// a new best candidate's reconstruction is saved to slot 0 by the request that follows it (before
+// anything overwrites the tile)
+__device__ __forceinline__ void leaf_attach_save(LeafSt& s, Req& q) {
+    q.pre_copy = COPY_NONE;
+    if (s.need_save) {
+        req_copy(q, COPY_SAVE, s.tree == TREE_SINGLE ? 3 : 1, 0, s.bx, s.by, s.lg);
+        s.need_save = 0;
+    }
+}
+// a request that only saves / restores a reconstruction
+__device__ __forceinline__ void leaf_copy_only(LeafSt& s, Req& q, int mode, int comps, int cont) {
+    q.kind = K_NOP;
+    req_copy(q, mode, comps, 0, s.bx, s.by, s.lg);
+    s.cont = (uint8_t)cont;
+}
+
+// full evaluation (get_intra_pred_cost, block_splitter.rs:110-474) of comps with modes [ml, mc, mc];
+// the first request of a leaf for a component also (re)builds its reference samples
+__device__ __forceinline__ void leaf_full(LeafSt& s, Req& q, int comps, int ml, int mc, bool act, int cont,
+                                          bool solo = false) {
+    const bool r0 = (comps & 1) && s.need_refs0 != 0;
+    const bool r1 = (comps & 2) && mc < LT_CCLM && s.need_refs1 != 0;
+    req_full(q, comps, s.bx, s.by, s.lg, ml, mc, !solo, act, r0, r1, false);
+    q.tree = s.tree;
+    leaf_attach_save(s, q);
+    if (act) {
+        if (r0) s.need_refs0 = 0;
+        if (r1) s.need_refs1 = 0;
+    }
+    s.op_ml = (uint8_t)ml;
+    s.op_mc = (uint8_t)mc;
+    s.op_act = act ? 1 : 0;
+    s.cont = (uint8_t)cont;
+}
+
+// SAD list (get_intra_pred_aux_cost / get_chroma_intra_pred_aux_cost) of n modes, one byte each
+__device__ __forceinline__ void leaf_sadlist(LeafSt& s, Req& q, int comps, int n, uint32_t m0, uint32_t m1, uint32_t m2,
+                                             uint32_t m3, bool chroma_refs, int cont) {
+    q.kind = K_SADLIST;
+    q.tree = s.tree;
+    q.comps = comps;
+    q.tx = s.bx;
+    q.ty = s.by;
+    q.tlg = s.lg;
+    q.n = n;
+    q.modes_lo = (unsigned long long)m0 | ((unsigned long long)m1 << 32);
+    q.modes_hi = (unsigned long long)m2 | ((unsigned long long)m3 << 32);
+    q.refs0 = (comps & 1) && s.need_refs0 != 0;
+    q.refs1 = (comps & 2) && chroma_refs && s.need_refs1 != 0;
+    if (q.refs0) s.need_refs0 = 0;
+    if (q.refs1) s.need_refs1 = 0;
+    leaf_attach_save(s, q);
+    s.cont = (uint8_t)cont;
+}
+
+__device__ __forceinline__ EvalParts res_parts(const Res& r) {
+    EvalParts e;
+    e.ssd_y = r.ssd_y;
+    e.ssd_c = r.ssd_c;
+    e.lvl_y = r.lvl_y;
+    e.lvl_c = r.lvl_c;
+    return e;
+}
+__device__ __forceinline__ void put_parts(EvalPartsU& d, const EvalParts& e) {
+    d.ssd_y = e.ssd_y;
+    d.ssd_c = e.ssd_c;
+    d.lvl_y = e.lvl_y;
+    d.lvl_c = e.lvl_c;
+}
+
+// result of a full candidate with luma mode M: running first minimum over the candidates in the
+// reference's order; a new best is saved by the next request, any other active candidate has
+// overwritten the tile
+#define LEAF_CANDIDATE(M)                 \
+    do {                                  \
+        if (val < s.best_cost) {          \
+            s.best_cost = val;            \
+            put_parts(s.e_best, rp);      \
+            s.mode = (uint8_t)(M);        \
+            s.best_cls = (uint8_t)cls;    \
+            s.need_save = 1;              \
+            s.tile_best = 1;              \
+        } else if (s.op_act) {            \
+            s.tile_best = 0;              \
+        }                                 \
+    } while (0)
+
+// One step of a leaf search: SINGLE_TREE / DUAL_TREE_LUMA blocks (block_splitter.rs:886-1078) and
+// DUAL_TREE_CHROMA blocks (:794-885; lg = luma log2 = 3).  r is the result of the request the
+// previous step made (unused at the first step).  Returns false when the leaf is decided
+// (s.cost, s.luma_mode, s.chroma_mode).  The reference's "first minimum wins" selections are kept
+// as strict-less running updates in the reference's candidate order; a candidate = one request
+// (luma block and chroma pair together, SAD candidates as one list).
+__device__ __forceinline__ bool leaf_step(const Ctx& c, LeafSt& s, const Res& r, Req& q) {
+    const int tree = s.tree;
+    const int both = tree == TREE_SINGLE ? 3 : 1;
+    int cont = s.cont;
+    // RD cost of the full evaluation that just came back (candidates of C_PLANAR .. C_F2)
+    float val = 0.0f;
+    int cls = 0;
+    const EvalParts rp = res_parts(r);
+    if (cont == C_PLANAR || cont == C_DCM || cont == C_F0 || cont == C_F1 || cont == C_F2) {
+        if (s.op_act) {
+            cls = mpm_class(c, s.bx, s.by, s.lg, s.op_ml);
+            val = uni_f(assemble_cost(c, tree, cls, s.op_mc, rp));
+            if (c.write && LANE == 0)
+                TRACE_REC(c.ctu_x + s.bx, c.ctu_y + s.by, s.lg, tree, 1, s.op_ml, s.op_mc, __float_as_int(val));
+        } else {
+            val = 3.40282347e+38f; // a skipped evaluation is f32::MAX in the reference
+        }
+    }
+    for (;;) {
+        switch (cont) {
+        case C_START: // candidates {0,1,2,7,13,18,23,29,34,39,45,50,55,60,66} (:887)
+            leaf_full(s, q, both, PLANAR, PLANAR, true, C_PLANAR);
+            return true;
+        case C_PLANAR:
+            s.best_cost = val;
+            put_parts(s.e_best, rp);
+            s.mode = PLANAR;
+            s.best_cls = (uint8_t)cls;
+            s.need_save = 1;
+            s.tile_best = 1;
+            leaf_full(s, q, both, DC, DC, true, C_DCM);
+            return true;
+        case C_DCM:
+            LEAF_CANDIDATE(DC);
+            // the 13 directional candidates: SAD, first minimum (:899-904)
+            leaf_sadlist(s, q, both, 13, 2u | (7u << 8) | (13u << 16) | (18u << 24),
+                         23u | (29u << 8) | (34u << 16) | (39u << 24), 45u | (50u << 8) | (55u << 16) | (60u << 24), 66u,
+                         true, C_LIST);
+            return true;
+        case C_LIST: {
+            // entry i of the list = candidate i + 2 of {0,1,2,7,13,18,23,29,34,39,45,50,55,60,66}, 7 bits each
+            const int j = r.imin + 2;
+            const int m = j < 8 ? (int)((0x3A5C90D0E08080ULL >> (7 * j)) & 127)
+                                : (int)((0x109E3764B53A2ULL >> (7 * (j - 8))) & 127);
+            // step_search(mode, 2, cost, aux=true) (:905-973)
+            s.cur_mode = (uint8_t)m;
+            s.cur_cost = r.vmin;
+            s.step = 2;
+            cont = C_PAIR_EMIT;
+            break;
+        }
+        case C_PAIR_EMIT: {
+            const int cm = s.cur_mode, st = s.step;
+            const int lo = !(cm < 2 + st) ? cm - st : kNoMode;
+            const int hi = !(cm + st > 66) ? cm + st : kNoMode;
+            leaf_sadlist(s, q, both, 2, (uint32_t)lo | ((uint32_t)hi << 8), 0, 0, 0, true, C_PAIR);
+            return true;
+        }
+        case C_PAIR: {
+            const float cur = s.cur_cost, c0 = r.v0, c1 = r.v1;
+            const int st = s.step;
+            const float mn = fminf(fminf(cur, c0), c1);
+            if (cur == mn) {
+            } else if (c0 == mn) {
+                s.cur_mode -= st;
+                s.cur_cost = c0;
+            } else {
+                s.cur_mode += st;
+                s.cur_cost = c1;
+            }
+            if ((st >> 1) > 0) {
+                s.step = (uint8_t)(st >> 1);
+                cont = C_PAIR_EMIT;
+                break;
+            }
+            // step_search(mode, 1, _, aux=false) (:974) on {cur, cur - 1, cur + 1}, then the minimum of
+            // {planar, DC, dir} (:975-978): first minimum of [planar, DC, cur, cur - 1, cur + 1], kept as
+            // one running best.  Out-of-range neighbours are "evaluated" inactive: the wave still
+            // walks the schedule so that the workgroup's shared Viterbi barriers stay aligned
+            const int cm = s.cur_mode;
+            leaf_full(s, q, both, cm, cm, true, C_F0);
+            return true;
+        }
+        case C_F0: {
+            const int cm = s.cur_mode;
+            LEAF_CANDIDATE(cm);
+            leaf_full(s, q, both, cm - 1, cm - 1, !(cm < 3), C_F1);
+            return true;
+        }
+        case C_F1: {
+            const int cm = s.cur_mode;
+            LEAF_CANDIDATE(cm - 1);
+            leaf_full(s, q, both, cm + 1, cm + 1, !(cm + 1 > 66), C_F2);
+            return true;
+        }
+        case C_F2: {
+            LEAF_CANDIDATE(s.cur_mode + 1);
+            s.cost = s.best_cost;
+            const int m = s.mode;
+            s.luma_mode = (uint8_t)m;
+            s.chroma_mode = (uint8_t)m;
+            // :989-1037 re-runs the winner's luma to have its reconstruction in the tile; here the
+            // winner's reconstruction comes back from slot 0 unless it is still in the tile
+            const bool in_tile = s.tile_best != 0;
+            if (tree == TREE_DUAL_LUMA) {
+                // :1073-1076 repeats the luma evaluation for planar / DC: same parts, same header bits,
+                // so the cost it assigns is the candidate's cost already in s.cost
+                if (in_tile) return false;
+                leaf_copy_only(s, q, COPY_RESTORE, 1, C_WIN);
+                return true;
+            }
+            // :1040 get_chroma_intra_pred_cost(mode) repeats the winner's chroma evaluation: re-use it
+            s.cur_cost = uni_f(assemble_chroma_cost(c, m, s.e_best.get()));
+            if (c.write && LANE == 0)
+                TRACE_REC(c.ctu_x + s.bx, c.ctu_y + s.by, s.lg, tree, 3, 0, m, __float_as_int((float)s.cur_cost));
+            leaf_sadlist(s, q, 2, 3, (uint32_t)LT_CCLM | ((uint32_t)T_CCLM << 8) | ((uint32_t)L_CCLM << 16), 0, 0, 0, false,
+                         C_CX);
+            if (!in_tile) req_copy(q, COPY_RESTORE, 1, 0, s.bx, s.by, s.lg); // (its save went out earlier)
+            return true;
+        }
+        case C_WIN:
+            return false;
+        case C_CX: {
+            const int cm = pick_cclm(r.v0, r.v1, r.v2);
+            s.cclm_mode = (uint8_t)cm;
+            leaf_full(s, q, 2, 0, cm, true, C_CCLM);
+            return true;
+        }
+        case C_CCLM: {
+            // the CCLM candidate = the winner's luma parts + the chroma parts just evaluated
+            EvalParts e = s.e_best.get();
+            e.ssd_c = rp.ssd_c;
+            e.lvl_c = rp.lvl_c;
+            const float cclm_cost = uni_f(assemble_chroma_cost(c, s.cclm_mode, e));
+            if (c.write && LANE == 0)
+                TRACE_REC(c.ctu_x + s.bx, c.ctu_y + s.by, s.lg, tree, 3, 0, s.cclm_mode, __float_as_int(cclm_cost));
+            const float cur = s.cur_cost;
+            const bool dm_wins = cur == fminf(cclm_cost, fminf(cur, 3.40282347e+38f));
+            // :1062-1072 final get_intra_pred_cost: luma = the winner; the chroma pair is the DM
+            // evaluation (its reconstruction comes back from slot 0) or the CCLM evaluation just made
+            const int m = s.mode;
+            const int bcls = s.best_cls; // mpm_class of the winner, from its candidate evaluation
+            if (dm_wins) {
+                s.cost = uni_f(assemble_cost(c, tree, bcls, m, s.e_best.get()));
+                leaf_copy_only(s, q, COPY_RESTORE, 2, C_DM);
+                return true;
+            }
+            s.chroma_mode = s.cclm_mode;
+            s.cost = uni_f(assemble_cost(c, tree, bcls, s.cclm_mode, e));
+            return false;
+        }
+        case C_DM:
+            return false;
+        // ---- DUAL_TREE_CHROMA leaf (:794-885) ----
+        case C_DC_START:
+            leaf_sadlist(s, q, 2, 3, (uint32_t)LT_CCLM | ((uint32_t)T_CCLM << 8) | ((uint32_t)L_CCLM << 16), 0, 0, 0, false,
+                         C_DC2);
+            return true;
+        case C_DC2: {
+            const int cm = pick_cclm(r.v0, r.v1, r.v2);
+            s.cclm_mode = (uint8_t)cm;
+            leaf_full(s, q, 2, 0, cm, true, C_DC3);
+            return true;
+        }
+        case C_DC3:
+            s.c0 = uni_f(assemble_chroma_cost(c, s.cclm_mode, rp));
+            if (c.write && LANE == 0)
+                TRACE_REC(c.ctu_x + s.bx, c.ctu_y + s.by, s.lg, tree, 3, 0, s.cclm_mode, __float_as_int((float)s.c0));
+            leaf_full(s, q, 2, 0, s.dm_mode, true, C_DC4);
+            req_copy(q, COPY_SAVE, 2, 0, s.bx, s.by, s.lg); // keep the CCLM reconstruction (:807-840)
+            return true;
+        case C_DC4: {
+            const float dm_cost = uni_f(assemble_chroma_cost(c, s.dm_mode, rp));
+            if (c.write && LANE == 0)
+                TRACE_REC(c.ctu_x + s.bx, c.ctu_y + s.by, s.lg, tree, 3, 0, s.dm_mode, __float_as_int(dm_cost));
+            const float cost = fminf(s.c0, fminf(dm_cost, 3.40282347e+38f));
+            s.luma_mode = 0;
+            s.cost = cost;
+            if (dm_cost == cost) {
+                s.chroma_mode = s.dm_mode;
+                return false;
+            }
+            s.chroma_mode = s.cclm_mode;
+            leaf_copy_only(s, q, COPY_RESTORE, 2, C_DC5); // :869-873 restore_reconsts
+            return true;
+        }
+        default: // C_DC5
+            return false;
+        }
+    }
+}
+
+// split_ct (block_splitter.rs:782-1154) for one CTU + the final pass (ctu_encoder.rs:1421-1461):
+// exhaustive quad-tree search as an explicit depth-first walk (level 0 = 32x32 ... level 2 = 8x8;
+// an 8x8 node's split is four DUAL_TREE_LUMA 4x4 leaves + one DUAL_TREE_CHROMA 4x4 leaf,
+// ctu.rs:1990-2063), per-level state in LDS.
+//
+// Decided blocks whose reconstruction was overwritten by later candidates come back from the
+// slots in global scratch they were saved to (copy_block): the reference's cache_reconsts /
+// restore_reconsts (block_splitter.rs:807-840, 1085-1145), with the saved planes kept in L2/HBM
+// instead of LDS.
+enum { T_START = 0, T_ENTER, T_NODE_LEAF, T_LEAF4_EMIT, T_LEAF4, T_LEAFC, T_REGEN_DONE, T_RETURN, T_FINAL_Z, T_FZ_TAIL, T_FZ_NEXT };
+
+__device__ __forceinline__ bool ctu_step(Ctx& c, const Res& r, Req& q) {
+    CtuSt& t = SH.st;
+    bool in_leaf = t.in_leaf != 0;
+    int cont = t.cont;
+    for (;;) {
+        if (in_leaf) {
+            if (leaf_step(c, t.leaf, r, q)) {
+                if (t.pend) { // the first request of a node's first child saves the unsplit candidate
+                    req_copy(q, COPY_SAVE, 3, t.pslot, t.pbx, t.pby, t.plg);
+                    t.pend = 0;
+                }
+                t.cont = (uint8_t)cont;
+                t.in_leaf = 1;
+                return true;
+            }
+            t.in_leaf = 0;
+            in_leaf = false;
+        }
+        switch (cont) {
+        case T_START:
+            t.level = 0;
+            t.bx = 0;
+            t.by = 0;
+            cont = T_ENTER;
+            break;
+        case T_ENTER: { // enter node (bx, by) at `level`: the unsplit candidate
+            const int lg = 5 - t.level;
+            t.lg = (uint8_t)lg;
+            leaf_init(t.leaf, TREE_SINGLE, t.bx, t.by, lg, 0);
+            in_leaf = true;
+            cont = T_NODE_LEAF;
+            break;
+        }
+        case T_NODE_LEAF: {
+            const float ns = t.leaf.cost;
+            const int ml = t.leaf.luma_mode, mc = t.leaf.chroma_mode;
+            const int level = t.level, lg = t.lg;
+            t.ns_cost_cur = ns;
+            t.ns_luma_cur = (uint8_t)ml;
+            t.ns_chroma_cur = (uint8_t)mc;
+            fill_maps(t.bx, t.by, lg, ml, mc, true, true);
+            if (level == 0) c.cu32_mode = ml;
+            if (t.max_depth - level == 0) {
+                t.ret = ns;
+                cont = T_RETURN;
+                break;
+            }
+            // the unsplit candidate's reconstruction goes to slot 1 + level (cache_reconsts, :1085-1100)
+            t.pend = 1;
+            t.pbx = t.bx;
+            t.pby = t.by;
+            t.plg = (uint8_t)lg;
+            t.pslot = (uint8_t)(1 + level);
+            if (LANE == 0) {
+                SH.ns_cost[level] = ns;
+                SH.ns_luma[level] = (uint8_t)ml;
+                SH.ns_chroma[level] = (uint8_t)mc;
+                SH.split_cost[level] = 0.0f;
+                SH.child[level] = 0;
+            }
+            WSYNC();
+            if (lg > 3) {
+                t.level = (uint8_t)(level + 1); // descend into child 0 (same top-left corner)
+                cont = T_ENTER;
+                break;
+            }
+            // 8x8: four DUAL_TREE_LUMA 4x4 leaves, then the DUAL_TREE_CHROMA leaf
+            t.split8 = 0.0f;
+            t.i8 = 0;
+            cont = T_LEAF4_EMIT;
+            break;
+        }
+        case T_LEAF4_EMIT: {
+            const int i8 = t.i8;
+            leaf_init(t.leaf, TREE_DUAL_LUMA, t.bx + (i8 & 1) * 4, t.by + (i8 >> 1) * 4, 2, 0);
+            in_leaf = true;
+            cont = T_LEAF4;
+            break;
+        }
+        case T_LEAF4: {
+            fill_maps(t.leaf.bx, t.leaf.by, 2, t.leaf.luma_mode, 0, true, false);
+            t.split8 = t.split8 + t.leaf.cost;
+            const int i8 = t.i8 + 1;
+            t.i8 = (uint8_t)i8;
+            if (i8 < 4) {
+                cont = T_LEAF4_EMIT;
+                break;
+            }
+            // DM = luma mode of the CU covering the parent's centre (block_splitter.rs:795-805)
+            const int bx = t.bx, by = t.by;
+            leaf_init(t.leaf, TREE_DUAL_CHROMA, bx, by, 3, uni((int)SH.luma_mode[((by + 4) >> 2) * 8 + ((bx + 4) >> 2)]));
+            in_leaf = true;
+            cont = T_LEAFC;
+            break;
+        }
+        case T_LEAFC: {
+            fill_maps(t.bx, t.by, 3, 0, t.leaf.chroma_mode, false, true);
+            const float split8 = t.split8 + t.leaf.cost;
+            if (split8 > t.ns_cost_cur) { // :1125-1145: the unsplit 8x8 wins, put it back
+                t.rbx = t.bx;
+                t.rby = t.by;
+                t.rlg = t.lg;
+                t.rl = t.ns_luma_cur;
+                t.rc = t.ns_chroma_cur;
+                q.kind = K_NOP;
+                req_copy(q, COPY_RESTORE, 3, 1 + t.level, t.rbx, t.rby, t.rlg);
+                t.cont = T_REGEN_DONE;
+                return true;
+            }
+            t.ret = split8;
+            cont = T_RETURN;
+            break;
+        }
+        case T_REGEN_DONE:
+            fill_maps(t.rbx, t.rby, t.rlg, t.rl, t.rc, true, true);
+            t.ret = uni_f(SH.ns_cost[t.level]);
+            cont = T_RETURN;
+            break;
+        case T_RETURN: { // return `ret` from the finished node at `level` to its parent
+            const int level = t.level;
+            if (level == 0) {
+                t.ctu_cost = t.ret;
+                t.z = 0;
+                cont = T_FINAL_Z;
+                break;
+            }
+            const int pl = level - 1;
+            const int psz = 1 << (5 - pl);
+            const int pbx = t.bx & ~(psz - 1), pby = t.by & ~(psz - 1);
+            // children in z-order, f32 (:1116-1123)
+            const float acc = uni_f(uni_f(SH.split_cost[pl]) + t.ret);
+            const int ch = uni((int)SH.child[pl]) + 1;
+            WSYNC();
+            if (LANE == 0) {
+                SH.split_cost[pl] = acc;
+                SH.child[pl] = (uint8_t)ch;
+            }
+            WSYNC();
+            if (ch < 4) { // next sibling
+                t.bx = (uint8_t)(pbx + (ch & 1) * (psz >> 1));
+                t.by = (uint8_t)(pby + (ch >> 1) * (psz >> 1));
+                cont = T_ENTER;
+                break;
+            }
+            // parent complete: split vs unsplit (:1125-1145)
+            t.bx = (uint8_t)pbx;
+            t.by = (uint8_t)pby;
+            t.level = (uint8_t)pl;
+            if (acc > uni_f(SH.ns_cost[pl])) {
+                t.rbx = (uint8_t)pbx;
+                t.rby = (uint8_t)pby;
+                t.rlg = (uint8_t)(5 - pl);
+                t.rl = (uint8_t)uni((int)SH.ns_luma[pl]);
+                t.rc = (uint8_t)uni((int)SH.ns_chroma[pl]);
+                q.kind = K_NOP;
+                req_copy(q, COPY_RESTORE, 3, 1 + pl, t.rbx, t.rby, t.rlg);
+                t.cont = T_REGEN_DONE;
+                return true;
+            }
+            t.ret = acc;
+            break; // cont stays T_RETURN
+        }
+        // ---- final pass (ctu_encoder.rs:1421-1461): coding order = z-order over the 4x4 units; a
+        // CU is emitted at its top-left unit (luma TB, then the chroma TBs) ----
+        case T_FINAL_Z: {
+            const int z = t.z;
+            if (z == 64) {
+                t.cont = T_START;
+                return false;
+            }
+            const int bx = 4 * ((z & 1) | ((z >> 1) & 2) | ((z >> 2) & 4));
+            const int by = 4 * (((z >> 1) & 1) | ((z >> 2) & 2) | ((z >> 3) & 4));
+            const int lg = uni((int)SH.cu_log2[(by >> 2) * 8 + (bx >> 2)]);
+            t.bx = (uint8_t)bx;
+            t.by = (uint8_t)by;
+            t.lg = (uint8_t)lg;
+            if ((bx & ((1 << lg) - 1)) == 0 && (by & ((1 << lg) - 1)) == 0) {
+                const int ml = uni((int)SH.luma_mode[(by >> 2) * 8 + (bx >> 2)]);
+                const int mc = uni((int)SH.chroma_mode[(by >> 3) * 4 + (bx >> 3)]);
+                req_full(q, lg >= 3 ? 3 : 1, bx, by, lg, ml, mc, false, true, true, true, true);
+                t.cont = T_FZ_TAIL;
+                return true;
+            }
+            cont = T_FZ_NEXT;
+            break;
+        }
+        case T_FZ_TAIL: {
+            const int bx = t.bx, by = t.by;
+            if (t.lg == 2 && (t.z & 3) == 3) { // after the fourth 4x4 luma CU: the 8x8's chroma CU
+                req_full(q, 2, bx & ~7, by & ~7, 3, 0, uni((int)SH.chroma_mode[(by >> 3) * 4 + (bx >> 3)]), false, true,
+                         true, true, true);
+                t.cont = T_FZ_NEXT;
+                return true;
+            }
+            cont = T_FZ_NEXT;
+            break;
+        }
+        default: // T_FZ_NEXT
+            t.z = (uint8_t)(t.z + 1);
+            cont = T_FINAL_Z;
+            break;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// CTU entry: load, search, final pass, store
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void load_tables(Ctx c) {
+    for (int i = threadIdx.x; i < 256; i += blockDim.x) {
+        SHT.ldq[i] = (int32_t)c.k->ldq[i];
+        SHT.lv[i] = (int32_t)c.k->lv[i];
+    }
+    for (int i = threadIdx.x; i < 128; i += blockDim.x) ((int8_t*)SHT.fc)[i] = ((const CONST_AS int8_t*)c.k->fc)[i];
+    __syncthreads();
+}
+
+
+__device__ __forceinline__ void encode_ctu(Ctx& c, const PicBufs& pb, int ctu_col, int ctu_row, int* overflow) {
+    const CONST_AS DevConst* k = c.k;
+    const int W = k->W;
+    const int Wc = W >> 1;
+    c.ctu_x = ctu_col * 32;
+    c.ctu_y = ctu_row * 32;
+    c.cu32_mode = PLANAR;
+#ifdef WRENC_PROFILE
+    if (threadIdx.x < PH_COUNT) s_prof[threadIdx.x] = 0;
+    __syncthreads();
+#endif
+    PROF_MARK(tt0_);
+    load_tables(c);
+    GLOBAL_AS uint8_t* const rec = AS_GLOBAL(uint8_t, pb.rec[0]);
+    // neighbour border of the reconstruction: row -1 (x = -4..67) and columns -4..-1
+    for (int i = LANE; i < 72; i += 64) {
+        const int gx = c.ctu_x - 4 + i, gy = c.ctu_y - 1;
+        SH.recYtop[i] = (gx >= 0 && gx < W && gy >= 0) ? rec[(size_t)gy * W + gx] : 0;
+    }
+    for (int i = LANE; i < 32 * 4; i += 64) {
+        const int y = i >> 2, x = (i & 3) - 4;
+        const int gx = c.ctu_x + x, gy = c.ctu_y + y;
+        SH.recY[y * 36 + x + 4] = gx >= 0 ? rec[(size_t)gy * W + gx] : 0;
+    }
+    for (int comp = 1; comp < 3; ++comp) {
+        for (int i = LANE; i < 40; i += 64) {
+            const int gx = (c.ctu_x >> 1) - 4 + i, gy = (c.ctu_y >> 1) - 1;
+            SH.recCtop[comp - 1][i] = (gx >= 0 && gx < Wc && gy >= 0) ? rec[plane_off(c, comp) + (size_t)gy * Wc + gx] : 0;
+        }
+        for (int i = LANE; i < 16 * 4; i += 64) {
+            const int y = i >> 2, x = (i & 3) - 4;
+            const int gx = (c.ctu_x >> 1) + x, gy = (c.ctu_y >> 1) + y;
+            SH.recC[comp - 1][y * 20 + x + 4] = gx >= 0 ? rec[plane_off(c, comp) + (size_t)gy * Wc + gx] : 0;
+        }
+    }
+    // tile.rs:49-58: planes start at zero
+    for (int i = LANE; i < 32 * 32; i += 64) SH.recY[(i >> 5) * 36 + (i & 31) + 4] = 0;
+    for (int comp = 1; comp < 3; ++comp)
+        for (int i = LANE; i < 256; i += 64) SH.recC[comp - 1][(i >> 4) * 20 + (i & 15) + 4] = 0;
+    if (LANE < 8)
+        SH.left_mode[LANE] =
+            c.ctu_x > 0 ? AS_GLOBAL(uint8_t, pb.luma_mode)[(size_t)((c.ctu_y >> 2) + LANE) * (W >> 2) + (c.ctu_x >> 2) - 1] : 0;
+    WSYNC();
+    // ---- the search + final pass: one evaluator, driven by the state machine ----
+    static_assert(sizeof(Lds) * WPB + sizeof(LdsTab) <= 81920, "two workgroups per CU need <= 80 KB each");
+    SH.st.cont = T_START;
+    SH.st.in_leaf = 0;
+    SH.st.pend = 0;
+    SH.st.max_depth = (uint8_t)k->max_depth;
+    Res r = {};
+    Req q = {};
+    for (;;) {
+        PROF_MARK(tc0_);
+        const bool more = ctu_step(c, r, q);
+        PROF_MARK(tc1_);
+        PROF_ADD2(PH_CTRL, tc0_, tc1_);
+        PROF_ADD2(PH_NSTEP, 0, 1);
+        PROF_ADD2(PH_NFULL, 0, (q.kind == K_FULL ? 1 : 0));
+        if (!more) break;
+        r = evaluate(c, pb, q, overflow);
+    }
+    const float cost = SH.st.ctu_cost;
+    // store recon + decisions
+    if (c.write) {
+        for (int i = LANE; i < 1024 / 4; i += 64) {
+            const int y = i >> 3, x4 = (i & 7) * 4;
+            *(GLOBAL_AS uint32_t*)&rec[(size_t)(c.ctu_y + y) * W + c.ctu_x + x4] = *(const uint32_t*)&SH.recY[y * 36 + x4 + 4];
+        }
+        for (int comp = 1; comp < 3; ++comp)
+            for (int i = LANE; i < 256 / 4; i += 64) {
+                const int y = i >> 2, x4 = (i & 3) * 4;
+                *(GLOBAL_AS uint32_t*)&rec[plane_off(c, comp) + (size_t)((c.ctu_y >> 1) + y) * Wc + (c.ctu_x >> 1) + x4] =
+                    *(const uint32_t*)&SH.recC[comp - 1][y * 20 + x4 + 4];
+            }
+        const int i = LANE; // 64 4x4 units
+        const size_t o = (size_t)((c.ctu_y >> 2) + (i >> 3)) * (W >> 2) + (c.ctu_x >> 2) + (i & 7);
+        AS_GLOBAL(uint8_t, pb.cu_log2)[o] = SH.cu_log2[i];
+        AS_GLOBAL(uint8_t, pb.luma_mode)[o] = SH.luma_mode[i];
+        if (i < 16) {
+            const size_t oc = (size_t)((c.ctu_y >> 3) + (i >> 2)) * (W >> 3) + (c.ctu_x >> 3) + (i & 3);
+            AS_GLOBAL(uint8_t, pb.chroma_mode)[oc] = SH.chroma_mode[i];
+        }
+        if (i == 0) AS_GLOBAL(float, pb.ctu_cost)[ctu_row * k->ctu_cols + ctu_col] = cost;
+    }
+#ifdef WRENC_PROFILE
+    PROF_MARK(tt1_);
+    PROF_ADD2(PH_TOTAL, tt0_, tt1_);
+    __syncthreads();
+    if (threadIdx.x < PH_COUNT) atomicAdd(&g_prof[threadIdx.x], s_prof[threadIdx.x]);
+#endif
+}
+
+} // namespace wrenc
