@@ -45,6 +45,17 @@ def measured_traffic(batch, width, height, qp, depth):
     return (2.0 * t["fetch_size_kb_per_launch"] + t["write_size_kb_per_launch"]) * 1024.0
 
 
+def measured_issue_bound():
+    """What actually bounds the kernel (it is nowhere near HBM): VALU busy fraction of a SIMD and the
+    wave-instructions per CTU from the committed SQ counter passes; reported next to the roofline."""
+    try:
+        t = json.load(open(TRAFFIC_FILE))
+        return {"valu_busy_frac_of_simd": t["valu_busy_frac_of_simd"], "valu_insts_per_ctu": t["valu_insts_per_ctu"],
+                "salu_insts_per_ctu": t["salu_insts_per_ctu"], "source": t["sq_source"]}
+    except (OSError, ValueError, KeyError):
+        return None
+
+
 
 def cpu_baseline(width, height, qp, depth, rows=None):
     """Oracle on one host core over a bounded sample of the same workload."""
@@ -170,6 +181,7 @@ def main():
                          # an encode call runs 4 HIP streams of launches side by side (pictures are
                          # independent); the whole-GPU rate is the step's bytes over its wall time
                          "concurrent_streams": 4,
+                         "issue_bound": measured_issue_bound(),
                          "aggregate_GBs": ALGO_BYTES_PER_PIXEL * pix * total_frames / dt / 1e9},
         }
         if world == 1 and not args.no_cpu_baseline:
