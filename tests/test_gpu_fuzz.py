@@ -1,0 +1,60 @@
+"""Seeded random sweep: picture size (multiples of 32 up to 160x128), QP 18..51, depth 0..3 and a random
+mixture of the content generators, each case bit-exact against the CPU oracle.  Meant to reach corners
+no hand-written case thinks of (odd combinations of block sizes at picture edges, saturated levels,
+CCLM next to angular modes, ...)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+KEYS = ("cu_log2_size", "luma_mode", "chroma_mode", "lev_y", "lev_cb", "lev_cr", "rec_y", "rec_cb", "rec_cr",
+        "ctu_cost")
+KINDS = ["flat", "ramp", "stripes30", "stripes75", "stripes120", "stripes165", "checker", "noise", "cclm", "extremes"]
+
+
+def _case(seed):
+    from test_gpu_content import _content
+    rng = np.random.default_rng(1000 + seed)
+    w, h = 32 * int(rng.integers(1, 6)), 32 * int(rng.integers(1, 5))
+    qp, depth = int(rng.integers(18, 52)), int(rng.integers(0, 4))
+    # per-CTU mixture of two content kinds, plus a little noise so that neighbouring CTUs differ
+    ka, kb = rng.choice(len(KINDS), 2)
+    ya, cba, cra = _content(KINDS[ka], w, h, seed)
+    yb, cbb, crb = _content(KINDS[kb], w, h, seed + 1)
+    pick = rng.integers(0, 2, (h // 32, w // 32)).astype(bool)
+    m = np.kron(pick, np.ones((32, 32), bool))
+    mc = np.kron(pick, np.ones((16, 16), bool))
+    y = np.where(m, ya, yb).astype(np.int32) + rng.integers(-3, 4, (h, w))
+    cb = np.where(mc, cba, cbb).astype(np.int32) + rng.integers(-2, 3, (h // 2, w // 2))
+    cr = np.where(mc, cra, crb).astype(np.int32) + rng.integers(-2, 3, (h // 2, w // 2))
+    if qp < 24:  # keep levels inside the reference's 1024-entry tables (it panics beyond them)
+        y, cb, cr = 128 + (y - 128) // 3, 128 + (cb - 128) // 3, 128 + (cr - 128) // 3
+    clip = lambda a: np.ascontiguousarray(np.clip(a, 0, 255), dtype=np.uint8)
+    return clip(y), clip(cb), clip(cr), qp, depth
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_random_case_matches_oracle(built, seed):
+    from wrenc_amd import gpu
+    from oracle import pyoracle as po
+    y, cb, cr, qp, depth = _case(seed)
+    h, w = y.shape
+    try:
+        ref = po.encode_picture(y, cb, cr, qp, depth)
+    except ValueError:
+        ref = None  # a level reached 1024: the reference panics there, the GPU must report it too
+    enc = gpu.Encoder(w, h, qp=qp, max_split_depth=depth)
+    if ref is None:
+        with pytest.raises(gpu.WrencGpuError) as ei:
+            enc.encode_picture(y, cb, cr)
+        assert ei.value.code == -6
+        enc.close()
+        return
+    got = enc.encode_picture(y, cb, cr)
+    assert enc.final_pass_mismatches() == 0
+    enc.close()
+    for k in KEYS:
+        if not np.array_equal(got[k], ref[k]):
+            bad = np.argwhere(got[k] != ref[k])
+            raise AssertionError("seed %d %dx%d qp%d d%d: %s differs at %d positions, first %s" % (
+                seed, w, h, qp, depth, k, len(bad), bad[0]))
