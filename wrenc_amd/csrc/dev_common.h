@@ -260,7 +260,7 @@ __shared__ unsigned long long s_prof[PH_COUNT];
 
 // Diagnostic build (-DWRENC_TRACE, never the product library): every candidate evaluation of the
 // search is appended to a device buffer, 8 ints per record, in the layout of the oracle's trace
-// (oracle/wrenc_oracle.h: x, y, log2 size, tree, kind, luma mode, chroma mode, f32 bits).
+// (x, y, log2 size, tree, kind, luma mode, chroma mode, f32 bits; the CPU checker records the same layout).
 #ifdef WRENC_TRACE
 constexpr unsigned kTraceMax = 1u << 19;
 __device__ unsigned int g_trace_n;
