@@ -166,6 +166,13 @@ __device__ __forceinline__ int emit_level(const Ctx& c, int tc, int qd, bool dcn
     return q;
 }
 
+// bits = 2 * bits + (kb < ka): the compare sets VCC, v_addc shifts it in (one instruction instead of
+// a select and an or)
+__device__ __forceinline__ unsigned shift_in_less(unsigned bits, int kb, int ka) {
+    asm("v_cmp_lt_i32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(bits) : "v"(kb), "v"(ka) : "vcc");
+    return bits;
+}
+
 // Dependent quantisation of nb transform blocks of side n (nb = 1 luma, 2 = Cb+Cr pair):
 // coefficients r1 ([blk][y][x]) -> levels in place; returns the summed level cost
 // (block_splitter.rs:436-458).  Scratch: r2, decw.  `*overflow` is set when a level needs a table
@@ -287,10 +294,10 @@ __device__ __forceinline__ long long quantize(Ctx c, int lg, int nb, bool shared
                     const int2 e = cur[kk];
                     const int KA = e.x + dpp_quad<0xD8>(C); // C[trans[s][0]]: quad_perm [0,2,1,3]
                     const int KB = e.y + dpp_quad<0x72>(C); // C[trans[s][1]]: quad_perm [2,0,3,1]
-                    const bool choseB = KB < KA;
-                    C = (choseB ? KB : KA) & ~1;
-                    bits = (bits << 1) | (choseB ? 1u : 0u);
+                    C = min(KA, KB) & ~1;
+                    bits = shift_in_less(bits, KB, KA);
                     if (kk == 15) { // first position of a sub-block in coding order (:512-514)
+                        const bool choseB = KB < KA;
                         const bool pick1 = choseB != (((parmask >> 15) & 1) != 0);
                         if (!pick1 && adj) C -= 2 * ldq1;
                     }
@@ -491,10 +498,10 @@ __device__ __forceinline__ void quantize3(Ctx c, int lg0, bool active, int* over
                     const int2 en = cur[kk];
                     const int KA = en.x + dpp_quad<0xD8>(C); // C[trans[s][0]]: quad_perm [0,2,1,3]
                     const int KB = en.y + dpp_quad<0x72>(C); // C[trans[s][1]]: quad_perm [2,0,3,1]
-                    const bool choseB = KB < KA;
-                    C = (choseB ? KB : KA) & ~1;
-                    bits = (bits << 1) | (choseB ? 1u : 0u);
+                    C = min(KA, KB) & ~1;
+                    bits = shift_in_less(bits, KB, KA);
                     if (kk == 15) { // first position of a sub-block in coding order (:512-514)
+                        const bool choseB = KB < KA;
                         const bool pick1 = choseB != (((parmask >> 15) & 1) != 0);
                         if (!pick1 && adj) C -= 2 * ldq1;
                     }
