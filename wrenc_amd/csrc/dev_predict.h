@@ -513,6 +513,57 @@ __device__ __forceinline__ int predict(Ctx c, int comp, int tx, int ty, int tlg,
     return sad;
 }
 
+// SADs of the three CCLM modes of a chroma pair (get_chroma_intra_pred_aux_cost of LT_CCLM, T_CCLM,
+// L_CCLM, block_splitter.rs:476-522, 847-854): the down-sampled luma of a sample is the same for
+// the three modes, so it is computed once and the three linear models are applied to it.
+// Returns the SAD of mode m (0 LT, 1 T, 2 L) in lane m.
+__device__ __forceinline__ unsigned sad_list_cclm(const Ctx& c, int tx, int ty, int tlg) {
+    const int lg = tlg - 1;
+    const int n = 1 << lg;
+    const int nn = n * n;
+    const int cx = tx >> 1, cy = ty >> 1;
+    // model parameters: odd lanes derive Cr, even lanes Cb (cclm_params), then made scalar
+    int a[3][2], k[3][2], b[3][2];
+    bool flat[3], avail_l = false;
+#pragma unroll
+    for (int m = 0; m < 3; ++m) {
+        const int mode = m == 0 ? LT_CCLM : (m == 1 ? T_CCLM : L_CCLM);
+        const CclmParams cp = cclm_params(c, 1 + (LANE & 1), tx, ty, tlg, mode);
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) {
+            a[m][pl] = __builtin_amdgcn_readlane(cp.a, pl);
+            k[m][pl] = __builtin_amdgcn_readlane(cp.k, pl);
+            b[m][pl] = __builtin_amdgcn_readlane(cp.b, pl);
+        }
+        flat[m] = __builtin_amdgcn_readlane((int)cp.flat128, 0) != 0;
+        avail_l = __builtin_amdgcn_readlane((int)cp.avail_l, 0) != 0; // the same for the three modes
+    }
+    int s0 = 0, s1 = 0, s2 = 0;
+    for (int i = LANE; i < 2 * nn; i += 64) {
+        const int blk = i >> (2 * lg);
+        const int ii = i & (nn - 1);
+        const int x = ii & (n - 1), y = ii >> lg;
+        const int o = ((const uint8_t*)SH.r2)[kOrgStage + 1024 + i];
+        const int ds = cclm_ds6(c, tx, ty, 2 * y, 2 * x, avail_l);
+#pragma unroll
+        for (int m = 0; m < 3; ++m) {
+            int v = 128;
+            if (!flat[m]) v = min(max((M24(ds, blk ? a[m][1] : a[m][0]) >> (blk ? k[m][1] : k[m][0])) + (blk ? b[m][1] : b[m][0]), 0), 255);
+            const int d = o - v;
+            const int ad = d < 0 ? -d : d;
+            if (m == 0)
+                s0 += ad;
+            else if (m == 1)
+                s1 += ad;
+            else
+                s2 += ad;
+        }
+    }
+    const unsigned t0 = (unsigned)wave_sum_i32(s0), t1 = (unsigned)wave_sum_i32(s1), t2 = (unsigned)wave_sum_i32(s2);
+    WSYNC();
+    return LANE == 0 ? t0 : (LANE == 1 ? t1 : (LANE == 2 ? t2 : 0u));
+}
+
 constexpr int kNoMode = 255; // list entry that is not evaluated (cost f32::MAX)
 
 // SADs of a LIST of angular modes (2..66) of one block: get_intra_pred_aux_cost of each entry

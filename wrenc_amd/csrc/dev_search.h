@@ -233,6 +233,25 @@ __device__ __forceinline__ Res evaluate(const Ctx& c, const PicBufs& pb, const R
         if (m_first != kNoMode) s0 = a0;
         if (q.n > 1 && m_second != kNoMode) s1 = a1;
         if (q.n > 2 && (int)((q.modes_lo >> 16) & 255u) != kNoMode) s2 = a2;
+    } else if (q.comps == 2 && q.n == 3 && (unsigned)q.modes_lo == ((unsigned)LT_CCLM | ((unsigned)T_CCLM << 8) | ((unsigned)L_CCLM << 16))) {
+        // the three CCLM modes of a chroma pair, one sample pass
+        const unsigned acc = sad_list_cclm(c, q.tx, q.ty, q.tlg);
+        s0 = (unsigned)__builtin_amdgcn_readlane((int)acc, 0);
+        s1 = (unsigned)__builtin_amdgcn_readlane((int)acc, 1);
+        s2 = (unsigned)__builtin_amdgcn_readlane((int)acc, 2);
+        if (c.write && LANE < 3)
+            TRACE_REC(c.ctu_x + q.tx, c.ctu_y + q.ty, q.tlg, q.tree, 2, 0, LANE == 0 ? LT_CCLM : (LANE == 1 ? T_CCLM : L_CCLM),
+                      __float_as_int((float)acc));
+        smin = s0;
+        r.imin = 0;
+        if (s1 < smin) {
+            smin = s1;
+            r.imin = 1;
+        }
+        if (s2 < smin) {
+            smin = s2;
+            r.imin = 2;
+        }
     } else {
 #pragma unroll 1
         for (int i = 0; i < q.n; ++i) {
