@@ -27,9 +27,10 @@ class _PicOut(C.Structure):
 
 
 def build(force=False):
-    src = os.path.join(_HERE, "wrenc_oracle.cpp")
-    if force or not os.path.exists(_SO) or (
-            os.path.exists(src) and os.path.getmtime(src) > os.path.getmtime(_SO)):
+    srcs = [os.path.join(_HERE, f) for f in ("wrenc_oracle.cpp", "wrenc_oracle.h", "vvc_parse.cpp", "vvc_parse.h",
+                                            "vvc_ctx_init.inc")]
+    if force or not os.path.exists(_SO) or any(
+            os.path.exists(f) and os.path.getmtime(f) > os.path.getmtime(_SO) for f in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-s"])
     return _SO
 
@@ -178,3 +179,41 @@ def dct64():
     m = np.zeros((64, 64), np.int16)
     lib().wro_dct64(_p(m))
     return m
+
+
+class _StreamInfo(C.Structure):
+    _fields_ = [("width", C.c_int), ("height", C.c_int), ("init_qp", C.c_int), ("n_pictures", C.c_int)]
+
+
+def parse_stream_info(stream):
+    """Parameter sets of a byte stream written by wrenc_amd.bitstream (vvc_parse.h)."""
+    buf = np.frombuffer(bytes(stream), np.uint8)
+    info = _StreamInfo()
+    rc = lib().wro_parse_stream_info(_p(buf), C.c_size_t(buf.size), C.byref(info))
+    if rc != 0:
+        raise ValueError("wro_parse_stream_info failed: %d" % rc)
+    return {"width": info.width, "height": info.height, "init_qp": info.init_qp, "n_pictures": info.n_pictures}
+
+
+def parse_picture(stream, index=0):
+    """CABAC-decode picture `index` of the stream back into a record (no reconstruction)."""
+    buf = np.frombuffer(bytes(stream), np.uint8)
+    info = parse_stream_info(stream)
+    w, h = info["width"], info["height"]
+    out = {
+        "lev_y": np.zeros((h, w), np.int16),
+        "lev_cb": np.zeros((h // 2, w // 2), np.int16),
+        "lev_cr": np.zeros((h // 2, w // 2), np.int16),
+        "cu_log2_size": np.zeros((h // 4, w // 4), np.uint8),
+        "luma_mode": np.zeros((h // 4, w // 4), np.uint8),
+        "chroma_mode": np.zeros((h // 8, w // 8), np.uint8),
+    }
+    po = _PicOut(None, None, None, _p(out["lev_y"]), _p(out["lev_cb"]), _p(out["lev_cr"]), _p(out["cu_log2_size"]),
+                 _p(out["luma_mode"]), _p(out["chroma_mode"]), None)
+    poc, qp = C.c_int(), C.c_int()
+    rc = lib().wro_parse_picture(_p(buf), C.c_size_t(buf.size), int(index), C.byref(poc), C.byref(qp), C.byref(po))
+    if rc != 0:
+        raise ValueError("wro_parse_picture failed: %d" % rc)
+    out["poc_lsb"] = poc.value
+    out["slice_qp"] = qp.value
+    return out

@@ -1,0 +1,93 @@
+"""ctypes binding of the host bitstream writer (include/wrenc_bitstream.h, wrenc_amd/csrc/host).
+
+Turns the record the device search returns (gpu.Encoder.download) into the reference's byte
+stream: parameter sets once (main.rs:223-260), then per picture a picture-header NAL and one
+IDR slice NAL (main.rs:294-385).  CPU code, as in the reference: CABAC is serial per picture.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "host", "libwrenc_host.so")
+EXPORTED_SYMBOLS = ("wrenc_bs_picture_bound", "wrenc_bs_write_parameter_sets", "wrenc_bs_write_picture",
+                    "wrenc_bs_last_slice_data_bits")
+
+OK, EINVAL, ENOSPC, EDATA = 0, -1, -2, -3
+
+
+class BitstreamError(RuntimeError):
+    def __init__(self, code, what):
+        RuntimeError.__init__(self, "%s failed with %d (%s)" % (
+            what, code, {EINVAL: "bad argument", ENOSPC: "buffer too small", EDATA: "inconsistent record"}.get(code, "?")))
+        self.code = code
+
+
+class _Record(C.Structure):
+    _fields_ = [("cu_log2_size", C.c_void_p), ("luma_mode", C.c_void_p), ("chroma_mode", C.c_void_p),
+                ("lev_y", C.c_void_p), ("lev_cb", C.c_void_p), ("lev_cr", C.c_void_p)]
+
+
+_lib = None
+
+
+def load_library():
+    """The writer has no Python or CPU-oracle fallback: a missing library is an error."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError("%s is missing: run `python -c 'import __graft_entry__ as g; g.build()'`" % LIB_PATH)
+        lib = C.CDLL(LIB_PATH)
+        lib.wrenc_bs_picture_bound.restype = C.c_size_t
+        lib.wrenc_bs_picture_bound.argtypes = [C.c_int, C.c_int]
+        lib.wrenc_bs_write_parameter_sets.restype = C.c_int
+        lib.wrenc_bs_write_parameter_sets.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t,
+                                                      C.POINTER(C.c_size_t)]
+        lib.wrenc_bs_write_picture.restype = C.c_int
+        lib.wrenc_bs_write_picture.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(_Record), C.c_void_p,
+                                               C.c_size_t, C.POINTER(C.c_size_t)]
+        lib.wrenc_bs_last_slice_data_bits.restype = C.c_longlong
+        _lib = lib
+    return _lib
+
+
+def write_parameter_sets(width, height, qp):
+    """VPS + SPS + PPS NAL units (bytes)."""
+    lib = load_library()
+    buf = np.zeros(4096, np.uint8)
+    n = C.c_size_t()
+    rc = lib.wrenc_bs_write_parameter_sets(width, height, qp, buf.ctypes.data, buf.size, C.byref(n))
+    if rc != OK:
+        raise BitstreamError(rc, "wrenc_bs_write_parameter_sets")
+    return buf[:n.value].tobytes()
+
+
+def _plane(rec, key, shape, dtype):
+    a = np.ascontiguousarray(rec[key], dtype=dtype)
+    if a.shape != shape:
+        raise ValueError("%s has shape %r, expected %r" % (key, a.shape, shape))
+    return a
+
+
+def write_picture(width, height, qp, poc, rec):
+    """Picture header NAL + IDR slice NAL (bytes) of one picture from its search record: a dict with
+    cu_log2_size, luma_mode, chroma_mode, lev_y, lev_cb, lev_cr as gpu.Encoder.download returns them."""
+    lib = load_library()
+    w, h = int(width), int(height)
+    arrs = [_plane(rec, "cu_log2_size", (h // 4, w // 4), np.uint8), _plane(rec, "luma_mode", (h // 4, w // 4), np.uint8),
+            _plane(rec, "chroma_mode", (h // 8, w // 8), np.uint8), _plane(rec, "lev_y", (h, w), np.int16),
+            _plane(rec, "lev_cb", (h // 2, w // 2), np.int16), _plane(rec, "lev_cr", (h // 2, w // 2), np.int16)]
+    r = _Record(*[a.ctypes.data for a in arrs])
+    cap = lib.wrenc_bs_picture_bound(w, h)
+    buf = np.empty(cap, np.uint8)
+    n = C.c_size_t()
+    rc = lib.wrenc_bs_write_picture(w, h, int(qp), int(poc), C.byref(r), buf.ctypes.data, cap, C.byref(n))
+    if rc != OK:
+        raise BitstreamError(rc, "wrenc_bs_write_picture")
+    return buf[:n.value].tobytes()
+
+
+def last_slice_data_bits():
+    """CABAC bits of the CTU data of this thread's last write_picture call."""
+    return int(load_library().wrenc_bs_last_slice_data_bits())

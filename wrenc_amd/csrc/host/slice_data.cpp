@@ -1,0 +1,535 @@
+// slice_data.cpp -- CTU syntax of one all-intra picture, from the search record to CABAC bins.
+//
+// Restates, for the syntax that is live under the reference's parameter sets,
+//   coding_tree           ctu_encoder.rs:227-438   (quadtree only; 8x8 -> 4x4 opens a local dual tree,
+//                                                   ctu.rs:1960-2064)
+//   coding_unit           ctu_encoder.rs:440-1323  (MPM signalling ctu.rs:1498-1635, chroma ctu.rs:1637-1741)
+//   transform_unit        ctu_encoder.rs:1463-1784
+//   residual_coding       ctu_encoder.rs:1786-2269 (dependent quantisation levels, three coding passes)
+// with the context selection of bool_coder.rs:2053-2400,2659-2740 and the binarisations of
+// bool_coder.rs:1133-1465.  The reference walks its CT/CU/TU object graph; here the same walk runs over
+// the flat maps the device returns (include/wrenc_bitstream.h).
+#include "slice_data.h"
+
+#include <cstdlib>
+#include <cstring>
+
+namespace wrenc_host {
+
+namespace {
+
+enum Tree { SINGLE_TREE = 0, DUAL_TREE_LUMA = 1, DUAL_TREE_CHROMA = 2 };
+enum { PLANAR = 0, DC = 1, ANG18 = 18, ANG46 = 46, ANG50 = 50, ANG54 = 54, LT_CCLM = 81 };
+
+// 6.5.2 up-right diagonal scan of a (1 << lw) x (1 << lh) block (the reference's table ctu.rs:14-81)
+struct Scan {
+    uint8_t x[64], y[64];
+};
+void make_scan(int lw, int lh, Scan& s) {
+    const int w = 1 << lw, h = 1 << lh;
+    int i = 0, x = 0, y = 0;
+    while (i < w * h) {
+        while (y >= 0) {
+            if (x < w && y < h) {
+                s.x[i] = (uint8_t)x;
+                s.y[i] = (uint8_t)y;
+                ++i;
+            }
+            --y;
+            ++x;
+        }
+        y = x;
+        x = 0;
+    }
+}
+struct Scans {
+    Scan s[4]; // square blocks of side 1, 2, 4, 8
+    Scans() {
+        for (int l = 0; l < 4; ++l) make_scan(l, l, s[l]);
+    }
+};
+const Scans kScans;
+
+const int kQStateTrans[4][2] = {{0, 2}, {2, 0}, {1, 3}, {3, 1}}; // encoder_context.rs:339
+const int kRiceParams[32] = {0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 1, 1, 1, 2, 2,
+                             2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 3, 3, 3, 3}; // cabac_contexts.rs:919
+
+class PictureCoder {
+public:
+    PictureCoder(int width, int height, int qp, const wrenc_bs_record& rec, BitWriter& bw)
+        : W_(width), H_(height), qp_(qp), r_(rec), cabac_(bw) {}
+
+    // slice_encoder.rs:343-404: CTUs in raster order, CABAC initialised at the first one
+    // (ctu_encoder.rs:38-47), end_of_slice_one_bit after the last
+    int run() {
+        cabac_.start(qp_);
+        for (int y = 0; y < H_; y += 32)
+            for (int x = 0; x < W_; x += 32) {
+                const int rc = coding_tree(x, y, 5);
+                if (rc) return rc;
+            }
+        cabac_.finish();
+        return WRENC_BS_OK;
+    }
+
+private:
+    int leaf_lg(int x, int y) const { return r_.cu_log2_size[(size_t)(y >> 2) * (W_ >> 2) + (x >> 2)]; }
+    int luma_mode(int x, int y) const { return r_.luma_mode[(size_t)(y >> 2) * (W_ >> 2) + (x >> 2)]; }
+
+    // ctu_encoder.rs:227-438
+    int coding_tree(int x0, int y0, int lg) {
+        const int leaf = leaf_lg(x0, y0);
+        if (leaf > lg || leaf < 2) return WRENC_BS_EDATA;
+        const bool split = leaf < lg;
+        // split_cu_flag (:284-296): only the quadtree split is allowed (MTT depth 0), so ctxSetIdx is 0;
+        // condL / condA compare the neighbouring leaf's size with this block's (bool_coder.rs:2712-2741)
+        const int cond_l = x0 > 0 && leaf_lg(x0 - 1, y0) < lg;
+        const int cond_a = y0 > 0 && leaf_lg(x0, y0 - 1) < lg;
+        cabac_.encode(CTX_SPLIT_CU + cond_l + cond_a, split);
+        if (lg == 5) qp_delta_coded_ = false; // quantisation group = CTU (:304-309, cu_qp_delta_subdiv 0)
+        if (!split) return coding_unit(x0, y0, lg, SINGLE_TREE);
+        if (lg > 3) {
+            for (int i = 0; i < 4; ++i) {
+                const int rc = coding_tree(x0 + ((i & 1) << (lg - 1)), y0 + ((i >> 1) << (lg - 1)), lg - 1);
+                if (rc) return rc;
+            }
+            return WRENC_BS_OK;
+        }
+        // 8x8 -> four 4x4 luma blocks, then the 4x4 chroma block of the whole 8x8 (local dual tree,
+        // modeTypeCondition 1: nothing is signalled for it; 4x4 luma and the chroma tree cannot split)
+        if (leaf != 2) return WRENC_BS_EDATA;
+        for (int i = 0; i < 4; ++i) {
+            const int rc = coding_unit(x0 + ((i & 1) << 2), y0 + ((i >> 1) << 2), 2, DUAL_TREE_LUMA);
+            if (rc) return rc;
+        }
+        return coding_unit(x0, y0, 3, DUAL_TREE_CHROMA);
+    }
+
+    // candModeList of 8.4.2 as ctu.rs:1498-1598 builds it
+    void mpm_list(int x0, int y0, int size, int cand[5]) const {
+        const int left = x0 > 0 ? luma_mode(x0 - 1, y0 + size - 1) : PLANAR;
+        const int above = (y0 > 0 && y0 - 1 >= ((y0 >> 5) << 5)) ? luma_mode(x0 + size - 1, y0 - 1) : PLANAR;
+        if (left == above && left > DC) {
+            cand[0] = left;
+            cand[1] = 2 + (left + 61) % 64;
+            cand[2] = 2 + (left - 1) % 64;
+            cand[3] = 2 + (left + 60) % 64;
+            cand[4] = 2 + left % 64;
+        } else if (left != above && (left > DC || above > DC)) {
+            const int mn = left < above ? left : above, mx = left < above ? above : left;
+            if (mn > DC) {
+                const int d = mx - mn;
+                cand[0] = left;
+                cand[1] = above;
+                if (d == 1) {
+                    cand[2] = 2 + (mn + 61) % 64;
+                    cand[3] = 2 + (mx - 1) % 64;
+                    cand[4] = 2 + (mn + 60) % 64;
+                } else if (d >= 62) {
+                    cand[2] = 2 + (mn - 1) % 64;
+                    cand[3] = 2 + (mx + 61) % 64;
+                    cand[4] = 2 + mn % 64;
+                } else if (d == 2) {
+                    cand[2] = 2 + (mn - 1) % 64;
+                    cand[3] = 2 + (mn + 61) % 64;
+                    cand[4] = 2 + (mx - 1) % 64;
+                } else {
+                    cand[2] = 2 + (mn + 61) % 64;
+                    cand[3] = 2 + (mn - 1) % 64;
+                    cand[4] = 2 + (mx + 61) % 64;
+                }
+            } else {
+                cand[0] = mx;
+                cand[1] = 2 + (mx + 61) % 64;
+                cand[2] = 2 + (mx - 1) % 64;
+                cand[3] = 2 + (mx + 60) % 64;
+                cand[4] = 2 + mx % 64;
+            }
+        } else {
+            cand[0] = DC;
+            cand[1] = ANG50;
+            cand[2] = ANG18;
+            cand[3] = ANG46;
+            cand[4] = ANG54;
+        }
+    }
+
+    // ctu_encoder.rs:440-1323 (intra, I slice)
+    int coding_unit(int x0, int y0, int lg, Tree tree) {
+        const int size = 1 << lg;
+        for (int y = y0; y < y0 + size && tree != DUAL_TREE_CHROMA; y += 4)
+            for (int x = x0; x < x0 + size; x += 4)
+                if (leaf_lg(x, y) != lg) return WRENC_BS_EDATA; // the size map is not a quadtree
+        if (tree != DUAL_TREE_CHROMA) {
+            const int mode = luma_mode(x0, y0);
+            if (mode > 66) return WRENC_BS_EDATA;
+            // intra_luma_mpm_flag / not_planar / mpm_idx / mpm_remainder (:755-804)
+            if (mode == PLANAR) {
+                cabac_.encode(CTX_MPM_FLAG, 1);
+                cabac_.encode(CTX_NOT_PLANAR + 1, 0); // ctxInc = !intra_subpartitions_mode_flag
+            } else {
+                int cand[5];
+                mpm_list(x0, y0, size, cand);
+                int idx = -1;
+                for (int i = 0; i < 5 && idx < 0; ++i)
+                    if (cand[i] == mode) idx = i;
+                if (idx >= 0) {
+                    cabac_.encode(CTX_MPM_FLAG, 1);
+                    cabac_.encode(CTX_NOT_PLANAR + 1, 1);
+                    for (int i = 0; i < idx; ++i) cabac_.bypass(1); // TR cMax 4, all bins bypass
+                    if (idx < 4) cabac_.bypass(0);
+                } else {
+                    cabac_.encode(CTX_MPM_FLAG, 0);
+                    int rem = mode - 1; // planar is the first most probable mode
+                    for (int i = 0; i < 5; ++i) rem -= cand[i] < mode;
+                    // truncated binary, cMax 60: 3 short codewords of 5 bits, the rest 6 bits
+                    if (rem < 3)
+                        cabac_.bypass_bits((uint32_t)rem, 5);
+                    else
+                        cabac_.bypass_bits((uint32_t)rem + 3, 6);
+                }
+            }
+        }
+        if (tree != DUAL_TREE_LUMA) {
+            const int cm = r_.chroma_mode[(size_t)(y0 >> 3) * (W_ >> 3) + (x0 >> 3)];
+            // the chroma tree of an 8x8 takes its direct mode from the luma block covering the centre
+            // (block_splitter.rs:795-805)
+            const int luma_ref = tree == SINGLE_TREE ? luma_mode(x0, y0) : luma_mode(x0 + size / 2, y0 + size / 2);
+            if (cm >= LT_CCLM) {
+                if (cm > LT_CCLM + 2) return WRENC_BS_EDATA;
+                cabac_.encode(CTX_CCLM_FLAG, 1);
+                const int idx = cm - LT_CCLM; // TR cMax 2: first bin coded, second bypass
+                cabac_.encode(CTX_CCLM_IDX, idx > 0);
+                if (idx > 0) cabac_.bypass(idx > 1);
+            } else {
+                cabac_.encode(CTX_CCLM_FLAG, 0);
+                // intra_chroma_pred_mode (Table 20, ctu.rs:1682-1737): the search only ever picks the
+                // direct mode (4); the other four values are accepted for completeness
+                int v = -1;
+                static const int kFixed[4] = {PLANAR, ANG50, ANG18, DC};
+                if (cm == luma_ref) {
+                    v = 4;
+                } else {
+                    for (int i = 0; i < 4; ++i)
+                        if (cm == kFixed[i] || (cm == 66 && luma_ref == kFixed[i])) v = i;
+                }
+                if (v < 0) return WRENC_BS_EDATA;
+                if (v == 4) {
+                    cabac_.encode(CTX_CHROMA_PRED, 0);
+                } else {
+                    cabac_.encode(CTX_CHROMA_PRED, 1);
+                    cabac_.bypass_bits((uint32_t)v, 2);
+                }
+            }
+        }
+        mts_dc_only_ = true; // :1211-1214
+        mts_zero_out_ = true;
+        const int rc = transform_unit(x0, y0, lg, tree);
+        if (rc) return rc;
+        // mts_idx = 0 (:1299-1318): one context-coded bin
+        if (tree != DUAL_TREE_CHROMA && mts_zero_out_ && !mts_dc_only_) cabac_.encode(CTX_MTS_IDX, 0);
+        return WRENC_BS_OK;
+    }
+
+    const int16_t* plane(int c) const { return c == 0 ? r_.lev_y : (c == 1 ? r_.lev_cb : r_.lev_cr); }
+    int stride(int c) const { return c ? W_ >> 1 : W_; }
+
+    bool any_level(int c, int tx, int ty, int lg) const {
+        const int16_t* p = plane(c) + (size_t)ty * stride(c) + tx;
+        for (int y = 0; y < (1 << lg); ++y, p += stride(c))
+            for (int x = 0; x < (1 << lg); ++x)
+                if (p[x]) return true;
+        return false;
+    }
+
+    // ctu_encoder.rs:1463-1784
+    int transform_unit(int x0, int y0, int lg, Tree tree) {
+        const bool chroma = tree != DUAL_TREE_LUMA, luma = tree != DUAL_TREE_CHROMA;
+        const bool cbf_y = luma && any_level(0, x0, y0, lg);
+        const bool cbf_cb = chroma && any_level(1, x0 >> 1, y0 >> 1, lg - 1);
+        const bool cbf_cr = chroma && any_level(2, x0 >> 1, y0 >> 1, lg - 1);
+        if (chroma) {
+            cabac_.encode(CTX_CB_CBF, cbf_cb);          // ctxInc 0 (no BDPCM)
+            cabac_.encode(CTX_CR_CBF + cbf_cb, cbf_cr); // ctxInc = tu_cb_coded_flag
+        }
+        if (luma) cabac_.encode(CTX_Y_CBF, cbf_y); // ctxInc 0 (no ISP, no BDPCM)
+        // cu_qp_delta_abs = 0, once per quantisation group (:1603-1637)
+        if ((cbf_y || cbf_cb || cbf_cr) && luma && !qp_delta_coded_) {
+            cabac_.encode(CTX_QP_DELTA_ABS, 0);
+            qp_delta_coded_ = true;
+        }
+        for (int c = 0; c < 3; ++c) {
+            if (!(c == 0 ? cbf_y : (c == 1 ? cbf_cb : cbf_cr))) continue;
+            cabac_.encode(CTX_TS_FLAG + (c != 0), 0); // transform_skip_flag = 0 (:1693-1775)
+            const int rc = c == 0 ? residual(0, x0, y0, lg) : residual(c, x0 >> 1, y0 >> 1, lg - 1);
+            if (rc) return rc;
+        }
+        return WRENC_BS_OK;
+    }
+
+    // locNumSig / locSumAbsPass1 of 9.3.4.2.8 (bool_coder.rs:2152-2244): the five already-coded neighbours
+    void local_template(int xc, int yc, int tw, int& num_sig, int& sum_p1) const {
+        num_sig = 0;
+        sum_p1 = 0;
+        const auto add = [&](int x, int y) {
+            const int v = p1_[y * 32 + x];
+            sum_p1 += v;
+            num_sig += v > 0;
+        };
+        if (xc < tw - 1) {
+            add(xc + 1, yc);
+            if (xc < tw - 2) add(xc + 2, yc);
+            if (yc < tw - 1) add(xc + 1, yc + 1);
+        }
+        if (yc < tw - 1) {
+            add(xc, yc + 1);
+            if (yc < tw - 2) add(xc, yc + 2);
+        }
+    }
+
+    // bool_coder.rs:1133-1174 (9.3.3.2)
+    int rice_param(int base_level, int xc, int yc, int tw) const {
+        int s = 0;
+        if (xc < tw - 1) {
+            s += abs_[yc * 32 + xc + 1];
+            if (xc < tw - 2) s += abs_[yc * 32 + xc + 2];
+            if (yc < tw - 1) s += abs_[(yc + 1) * 32 + xc + 1];
+        }
+        if (yc < tw - 1) {
+            s += abs_[(yc + 1) * 32 + xc];
+            if (yc < tw - 2) s += abs_[(yc + 2) * 32 + xc];
+        }
+        s -= base_level * 5;
+        return kRiceParams[s < 0 ? 0 : (s > 31 ? 31 : s)];
+    }
+
+    // abs_remainder / dec_abs_level (bool_coder.rs:1384-1465): truncated Rice prefix with cMax 6 << k, then
+    // limited Exp-Golomb of order k + 1 (maxPreExtLen 11, truncSuffixLen 15, :1305-1331); all bypass
+    void code_remainder(int val, int k) {
+        const int c_max = 6 << k;
+        const int pv = val < c_max ? val : c_max;
+        const int pre = pv >> k;
+        if (pre < 6) {
+            for (int i = 0; i < pre; ++i) cabac_.bypass(1);
+            cabac_.bypass(0);
+            if (k > 0) cabac_.bypass_bits((uint32_t)(pv - (pre << k)), k);
+            return;
+        }
+        for (int i = 0; i < 6; ++i) cabac_.bypass(1);
+        int sym = val - c_max;
+        const int kk = k + 1;
+        const int code_value = sym >> kk;
+        int pre_ext = 0;
+        while (pre_ext < 11 && code_value > (2 << pre_ext) - 2) {
+            ++pre_ext;
+            cabac_.bypass(1);
+        }
+        int escape;
+        if (pre_ext == 11) {
+            escape = 15;
+        } else {
+            cabac_.bypass(0);
+            escape = pre_ext + kk;
+        }
+        sym -= ((1 << pre_ext) - 1) << kk;
+        cabac_.bypass_bits((uint32_t)sym, escape);
+    }
+
+    // last_sig_coeff_{x,y}_prefix: truncated unary, cMax = 2 * log2 - 1 (bool_coder.rs:713-740), context
+    // (binIdx >> ctxShift) + ctxOffset (:2053-2083)
+    void code_last_prefix(int base, int c, int lg, int prefix) {
+        static const int kOffsetY[6] = {0, 0, 3, 6, 10, 15};
+        int off, shift;
+        if (c == 0) {
+            off = kOffsetY[lg - 1];
+            shift = (lg + 1) >> 2;
+        } else {
+            off = 20;
+            shift = (1 << lg) >> 3;
+            shift = shift > 2 ? 2 : shift;
+        }
+        const int c_max = (lg << 1) - 1;
+        for (int i = 0; i < prefix; ++i) cabac_.encode(base + (i >> shift) + off, 1);
+        if (prefix < c_max) cabac_.encode(base + (prefix >> shift) + off, 0);
+    }
+
+    // (prefix, suffix) of a last-significant coordinate (ctu_encoder.rs:1818-1851)
+    static void split_last(int v, int& prefix, int& suffix) {
+        if (v <= 3) {
+            prefix = v;
+            suffix = 0;
+            return;
+        }
+        int bits = 1, p;
+        for (;;) {
+            p = v >> bits;
+            suffix = v - (p << bits);
+            if (p < 4) break;
+            ++bits;
+        }
+        prefix = ((bits + 1) << 1) + (p & 1);
+    }
+
+    // ctu_encoder.rs:1786-2269; tx, ty, lg in samples of component c
+    int residual(int c, int tx, int ty, int lg) {
+        const int tw = 1 << lg;
+        const int16_t* lev = plane(c) + (size_t)ty * stride(c) + tx;
+        const int st = stride(c);
+        for (int y = 0; y < tw; ++y) {
+            memset(&abs_[y * 32], 0, sizeof(int) * tw);
+            memset(&p1_[y * 32], 0, sizeof(int) * tw);
+        }
+        const Scan& sbs = kScans.s[lg - 2]; // sub-blocks of the TB
+        const Scan& cs = kScans.s[2];       // coefficients of a 4x4 sub-block
+        const int n_sb = 1 << (2 * (lg - 2));
+        // last significant coefficient in scan order (ctu.rs:867-899)
+        int last_sb = -1, last_pos = 0;
+        for (int i = n_sb - 1; i >= 0 && last_sb < 0; --i)
+            for (int n = 15; n >= 0; --n)
+                if (lev[(size_t)((sbs.y[i] << 2) + cs.y[n]) * st + (sbs.x[i] << 2) + cs.x[n]]) {
+                    last_sb = i;
+                    last_pos = n;
+                    break;
+                }
+        if (last_sb < 0) return WRENC_BS_EDATA;
+        const int last_x = (sbs.x[last_sb] << 2) + cs.x[last_pos], last_y = (sbs.y[last_sb] << 2) + cs.y[last_pos];
+        int px, sx, py, sy;
+        split_last(last_x, px, sx);
+        split_last(last_y, py, sy);
+        code_last_prefix(CTX_LAST_X, c, lg, px);
+        code_last_prefix(CTX_LAST_Y, c, lg, py);
+        if (px > 3) cabac_.bypass_bits((uint32_t)sx, (px >> 1) - 1);
+        if (py > 3) cabac_.bypass_bits((uint32_t)sy, (py >> 1) - 1);
+
+        if ((last_sb > 0 || last_pos > 0) && c == 0) mts_dc_only_ = false; // :1945-1947
+        int rem_bins = ((1 << (2 * lg)) * 7) >> 2;
+        int q_state = 0;
+        for (int i = last_sb; i >= 0; --i) {
+            const int start_q = q_state;
+            const int xs = sbs.x[i], ys = sbs.y[i];
+            const int x_off = xs << 2, y_off = ys << 2;
+            // AbsLevel of the sub-block from TransCoeffLevel: (|q| + (state > 1)) / 2 along the state
+            // walk (:1968-1985); the parity check is the reference's release assert
+            int a[16];
+            bool sb_coded = (xs | ys) == 0; // (:1994) the DC sub-block counts as coded
+            {
+                int q = q_state;
+                for (int n = 15; n >= 0; --n) {
+                    const int v = lev[(size_t)(y_off + cs.y[n]) * st + x_off + cs.x[n]];
+                    const int av = v < 0 ? -v : v;
+                    if (av && (av & 1) != (q > 1)) return WRENC_BS_EDATA;
+                    a[n] = (av + (q > 1)) >> 1;
+                    sb_coded |= av != 0;
+                    q = kQStateTrans[q][a[n] & 1];
+                }
+            }
+            bool infer_dc = false;
+            if (i < last_sb && i > 0) {
+                // sb_coded_flag: context from the right and lower sub-blocks (bool_coder.rs:2102-2150)
+                int csbf = 0;
+                if (xs < (tw >> 2) - 1) csbf += any_level_sb(lev, st, xs + 1, ys);
+                if (ys < (tw >> 2) - 1) csbf += any_level_sb(lev, st, xs, ys + 1);
+                cabac_.encode(CTX_SB_CODED + (c ? 2 : 0) + (csbf > 0), sb_coded);
+                infer_dc = true;
+            }
+            if (sb_coded && (xs > 3 || ys > 3) && c == 0) mts_zero_out_ = false; // :2008-2010
+            const int first_pos_mode0 = i == last_sb ? last_pos : 15;
+            int first_pos_mode1 = first_pos_mode0;
+            // pass 1: sig_coeff_flag, abs_level_gtx_flag[0], par_level_flag, abs_level_gtx_flag[1]
+            for (int n = first_pos_mode0; n >= 0; --n) {
+                if (rem_bins < 4) break;
+                const int xc = x_off + cs.x[n], yc = y_off + cs.y[n];
+                const bool sig = a[n] > 0;
+                const bool is_last = xc == last_x && yc == last_y;
+                int num_sig = 0, sum_p1 = 0;
+                const int d = xc + yc;
+                bool have_template = false;
+                if (sb_coded && (n > 0 || !infer_dc) && !is_last) {
+                    local_template(xc, yc, tw, num_sig, sum_p1);
+                    have_template = true;
+                    const int s = (sum_p1 + 1) >> 1;
+                    const int qs = q_state > 1 ? q_state - 1 : 0;
+                    const int inc = c == 0 ? 12 * qs + (s < 3 ? s : 3) + (d < 2 ? 8 : (d < 5 ? 4 : 0))
+                                           : 36 + 8 * qs + (s < 3 ? s : 3) + (d < 2 ? 4 : 0);
+                    cabac_.encode(CTX_SIG + inc, sig);
+                    --rem_bins;
+                    if (sig) infer_dc = false;
+                }
+                const bool gt1 = a[n] > 1, gt3 = a[n] > 3, par = a[n] > 1 && (a[n] & 1);
+                if (sig) {
+                    if (!have_template) local_template(xc, yc, tw, num_sig, sum_p1);
+                    int off = sum_p1 - num_sig;
+                    off = off > 4 ? 4 : off;
+                    int inc;
+                    if (is_last)
+                        inc = c == 0 ? 0 : 21;
+                    else if (c == 0)
+                        inc = 1 + off + (d == 0 ? 15 : (d < 3 ? 10 : (d < 10 ? 5 : 0)));
+                    else
+                        inc = 22 + off + (d == 0 ? 5 : 0);
+                    cabac_.encode(CTX_GTX + inc, gt1);
+                    --rem_bins;
+                    if (gt1) {
+                        cabac_.encode(CTX_PAR + inc, par);
+                        --rem_bins;
+                        cabac_.encode(CTX_GTX + 32 + inc, gt3);
+                        --rem_bins;
+                    }
+                }
+                const int pass1 = (int)sig + (int)par + (int)gt1 + 2 * (int)gt3;
+                p1_[yc * 32 + xc] = pass1;
+                q_state = kQStateTrans[q_state][pass1 & 1];
+                first_pos_mode1 = n - 1;
+            }
+            // pass 2: abs_remainder of the coefficients pass 1 covered
+            for (int n = first_pos_mode0; n > first_pos_mode1; --n) {
+                const int xc = x_off + cs.x[n], yc = y_off + cs.y[n];
+                if (a[n] > 3) code_remainder((a[n] - p1_[yc * 32 + xc]) >> 1, rice_param(4, xc, yc, tw));
+                abs_[yc * 32 + xc] = a[n];
+            }
+            // pass 3: dec_abs_level of what the bin budget left out (ctu.rs:739-782)
+            for (int n = first_pos_mode1; n >= 0; --n) {
+                const int xc = x_off + cs.x[n], yc = y_off + cs.y[n];
+                abs_[yc * 32 + xc] = a[n];
+                if (sb_coded) {
+                    const int k = rice_param(0, xc, yc, tw);
+                    const int zero_pos = (q_state < 2 ? 1 : 2) << k;
+                    const int dec = a[n] == 0 ? zero_pos : (a[n] <= zero_pos ? a[n] - 1 : a[n]);
+                    code_remainder(dec, k);
+                }
+                q_state = kQStateTrans[q_state][a[n] & 1];
+            }
+            // signs, bypass
+            for (int n = 15; n >= 0; --n)
+                if (a[n] > 0) cabac_.bypass(lev[(size_t)(y_off + cs.y[n]) * st + x_off + cs.x[n]] < 0);
+            // the state at the start of the next sub-block is the one after all 16 positions (:2254-2267)
+            q_state = start_q;
+            for (int n = 15; n >= 0; --n) q_state = kQStateTrans[q_state][a[n] & 1];
+        }
+        return WRENC_BS_OK;
+    }
+
+    static int any_level_sb(const int16_t* lev, int st, int xs, int ys) {
+        const int16_t* p = lev + (size_t)(ys << 2) * st + (xs << 2);
+        for (int y = 0; y < 4; ++y, p += st)
+            if (p[0] | p[1] | p[2] | p[3]) return 1;
+        return 0;
+    }
+
+    const int W_, H_, qp_;
+    const wrenc_bs_record& r_;
+    CabacEncoder cabac_;
+    bool qp_delta_coded_ = false;
+    bool mts_dc_only_ = true, mts_zero_out_ = true;
+    int abs_[32 * 32]; // AbsLevel of the current TB, row stride 32
+    int p1_[32 * 32];  // AbsLevelPass1
+};
+
+} // namespace
+
+int write_slice_data(int width, int height, int qp, const wrenc_bs_record& rec, BitWriter& bw) {
+    PictureCoder coder(width, height, qp, rec, bw);
+    return coder.run();
+}
+
+} // namespace wrenc_host
