@@ -194,6 +194,35 @@ def test_random_records_round_trip(built, seed, qp, amp):
             assert not (body[i] == 0 and body[i + 1] == 0 and body[i + 2] <= 2), (k, i)
 
 
+def test_production_arithmetic_coder_writes_the_bit_serial_coders_bytes(built):
+    """cabac.h holds two encoders: the bit-at-a-time form of bool_coder.rs:136-296 and the register /
+    byte-output form the product runs.  Same bins in, same bytes out, over records that exercise long
+    carry chains (dense noise) and almost-empty pictures."""
+    from wrenc_amd import bitstream as bs
+    from oracle import pyoracle as po
+    spec = C.CDLL(os.path.join(os.path.dirname(bs.LIB_PATH), "libwrenc_host_spec.so"))
+    spec.wrenc_bs_picture_bound.restype = C.c_size_t
+    cases = [("noise", 64, 64, 22, 3, 1), ("noise", 64, 64, 4, 2, 2), ("flat", 64, 64, 40, 1, 3), ("cclm", 96, 64, 30, 3, 4),
+             ("checker", 64, 96, 37, 2, 5)]
+    records = []
+    for kind, w, h, qp, depth, seed in cases:
+        y, cb, cr = content(kind, w, h, seed)
+        records.append((w, h, qp, po.encode_picture(y, cb, cr, qp, depth)))
+    rng = np.random.default_rng(99)
+    for qp, amp in ((30, 500), (10, 30000), (50, 20000)):
+        records.append((96, 64, qp, _random_record(rng, 96, 64, qp, amp)))
+    for w, h, qp, rec in records:
+        want = bs.write_picture(w, h, qp, 2, rec)
+        arrs = [np.ascontiguousarray(rec[k]) for k in REC_KEYS]
+        r = bs._Record(*[a.ctypes.data for a in arrs])
+        cap = spec.wrenc_bs_picture_bound(w, h)
+        buf = np.zeros(cap, np.uint8)
+        n = C.c_size_t()
+        rc = spec.wrenc_bs_write_picture(w, h, qp, 2, C.byref(r), C.c_void_p(buf.ctypes.data), C.c_size_t(cap), C.byref(n))
+        assert rc == 0
+        assert buf[:n.value].tobytes() == want
+
+
 def test_multi_picture_stream_and_qp_below_26(built):
     from wrenc_amd import bitstream as bs
     from oracle import pyoracle as po

@@ -1,0 +1,138 @@
+"""Command line of the encoder: the reference's `wrenc` options (main.rs:85-115) over the MI355X search
+and the host bitstream writer.
+
+    python -m wrenc_amd.cli -i in.yuv -o out.vvc --input-size 1920x1088 --output-size 1920x1088 \
+        --num-pictures 30 --qp 32 --max-split-depth 2 [--reconst rec.yuv]
+
+Flow of main.rs:223-402: VPS, SPS, PPS once; then per picture read Y, Cb, Cr (8-bit 4:2:0 at the output
+size), search + final pass (on the GPU, `--batch` pictures at a time: they are independent IDR pictures),
+picture header NAL + slice NAL, optionally the reconstruction.  `-` means stdin / stdout.  Like the
+reference, every failure prints `error: ...` on stderr and ends the process with status 0
+(main.rs:127-133,171-191).  There is no CPU path: without an MI355X the command fails.
+"""
+import argparse
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+
+
+def _die(msg):
+    sys.stderr.write("error: %s\n" % msg)
+    sys.exit(0)     # main.rs:132: process::exit(0) on every error
+
+
+def _size(text, what):
+    parts = text.split("x")
+    try:
+        w, h = [int(p) for p in parts]
+    except ValueError:
+        w = h = -1
+    if len(parts) != 2 or w <= 0 or h <= 0:
+        _die("Invalid %s: %s" % (what, text))
+    return w, h
+
+
+def _read_exact(f, n):
+    buf = bytearray()
+    while len(buf) < n:
+        chunk = f.read(n - len(buf))
+        if not chunk:
+            return None
+        buf += chunk
+    return bytes(buf)
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser(prog="wrenc_amd", description="VVC all-intra encoder (MI355X search, host CABAC)")
+    ap.add_argument("-i", "--input", required=True, help="Path to input raw video")
+    ap.add_argument("-o", "--output", required=True, help="Path to output bitstream")
+    ap.add_argument("-r", "--reconst", help="Path to reconstructed frames")
+    ap.add_argument("--input-size", required=True, help="Input video resolution (WIDTHxHEIGHT)")
+    ap.add_argument("--output-size", required=True, help="Output video resolution (WIDTHxHEIGHT)")
+    ap.add_argument("--num-pictures", required=True, type=int, help="Number of pictures to encode")
+    ap.add_argument("--qp", type=int, help="Fixed quantization parameter for entire video stream")
+    ap.add_argument("--max-split-depth", type=int, default=3, help="Max split depth of coding trees to search")
+    ap.add_argument("--extra-params", help="Extra parameters (PARAM1=VAL1[,PARAM2=VAL2,...])")
+    ap.add_argument("--batch", type=int, default=64, help="pictures searched per GPU call (not in the reference)")
+    ap.add_argument("--device", type=int, default=0, help="HIP device ordinal (not in the reference)")
+    ap.add_argument("--threads", type=int, default=8, help="host threads writing slices (not in the reference)")
+    a = ap.parse_args(argv)
+
+    _size(a.input_size, "input-size")           # parsed and otherwise unused, as in main.rs:164-174
+    w, h = _size(a.output_size, "output-size")
+    qp = 26 if a.qp is None else a.qp           # ctu.rs:382 default when --qp is absent
+    if a.extra_params:
+        for item in a.extra_params.split(","):
+            if len(item.split("=")) != 2:
+                _die("Invalid extra-params: %s" % a.extra_params)
+        _die("extra-params (the RD-model tuning knobs of block_splitter.rs:21-53,187-375) are not supported: "
+             "this build resolves the reference's default constants only")
+    if w % 32 or h % 32:
+        _die("output-size must be a multiple of the 32x32 CTU (picture.rs:178-181): %dx%d" % (w, h))
+    if not 0 <= qp <= 63 or not 0 <= a.max_split_depth <= 3 or a.num_pictures < 0:
+        _die("qp must be 0..63, max-split-depth 0..3")
+
+    from . import bitstream, gpu
+    try:
+        fin = sys.stdin.buffer if a.input == "-" else open(a.input, "rb")
+    except OSError as e:
+        _die("failed to open input file: %s" % e)
+    try:
+        fout = sys.stdout.buffer if a.output == "-" else open(a.output, "wb")
+    except OSError as e:
+        _die("failed to open output file: %s" % e)
+    frec = None
+    if a.reconst:
+        try:
+            frec = open(a.reconst, "wb")
+        except OSError as e:
+            _die("failed to open reconst file: %s" % e)
+
+    batch = max(1, min(a.batch, max(a.num_pictures, 1)))
+    try:
+        enc = gpu.Encoder(w, h, qp=qp, max_split_depth=a.max_split_depth, device=a.device, n_slots=batch)
+    except (gpu.WrencGpuError, ImportError, OSError) as e:
+        _die(str(e))
+
+    fout.write(bitstream.write_parameter_sets(w, h, qp))
+    ysz, csz = w * h, (w // 2) * (h // 2)
+    poc = 0
+    pool = ThreadPoolExecutor(max_workers=max(1, a.threads))
+    try:
+        while poc < a.num_pictures:
+            n = 0
+            for s in range(min(batch, a.num_pictures - poc)):
+                raw = _read_exact(fin, ysz + 2 * csz)
+                if raw is None:
+                    _die("input ended after %d of %d pictures" % (poc + n, a.num_pictures))
+                buf = np.frombuffer(raw, np.uint8)
+                enc.upload(s, buf[:ysz].reshape(h, w), buf[ysz:ysz + csz].reshape(h // 2, w // 2),
+                           buf[ysz + csz:].reshape(h // 2, w // 2))
+                n += 1
+            enc.encode(0, n)
+            enc.sync()
+            recs = [enc.download(s) for s in range(n)]
+            # pictures are independent: their slices are written in parallel (the C call drops the GIL)
+            nals = list(pool.map(lambda t: bitstream.write_picture(w, h, qp, poc + t[0], t[1]), enumerate(recs)))
+            for s in range(n):
+                fout.write(nals[s])
+                if frec is not None:
+                    for k in ("rec_y", "rec_cb", "rec_cr"):     # main.rs:387-399
+                        frec.write(recs[s][k].tobytes())
+            poc += n
+    except (gpu.WrencGpuError, bitstream.BitstreamError) as e:
+        _die(str(e))
+    finally:
+        pool.shutdown()
+        enc.close()
+        fout.flush()
+        if frec is not None:
+            frec.close()
+        if fout is not sys.stdout.buffer:
+            fout.close()
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

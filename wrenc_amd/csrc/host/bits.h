@@ -23,6 +23,14 @@ public:
     void put(uint64_t v, int len) {
         for (int i = len - 1; i >= 0; --i) bit((v >> i) & 1);
     }
+    // one whole byte at a byte boundary
+    void byte(uint8_t v) {
+        if (n_ == 0)
+            bytes_.push_back(v);
+        else
+            put(v, 8);
+    }
+    void reserve(size_t n) { bytes_.reserve(n); }
     // bool_coder.rs:62-73
     void ue(uint64_t v) {
         if (v == 0) {

@@ -112,11 +112,15 @@ inline void init_models(CtxModel* m, int slice_qp) {
     }
 }
 
+#ifdef WRENC_CABAC_SPEC_ENGINE
+// The arithmetic encoder exactly as the reference (and clause 9.3.5 of the specification) words it: one
+// output bit at a time with an outstanding-bit counter.  Built only for tests/test_bitstream.py, which
+// checks that the production engine below writes the same bytes.
 class CabacEncoder {
 public:
     explicit CabacEncoder(BitWriter& bw) : bw_(bw) {}
 
-    // bool_coder.rs:1106-1111 + :38-47 of ctu_encoder.rs (first CTU of the picture)
+    // bool_coder.rs:1106-1111 + ctu_encoder.rs:38-47 (first CTU of the picture)
     void start(int slice_qp) {
         init_models(m_, slice_qp);
         range_ = 510;
@@ -161,7 +165,7 @@ public:
         for (int i = n - 1; i >= 0; --i) bypass((v >> i) & 1);
     }
 
-    // end_of_slice_one_bit = 1: bool_coder.rs:218-235 (terminate, flush, the last written bit doubles as
+    // end_of_slice_one_bit = 1: bool_coder.rs:218-235 (terminate, flush; the last written bit doubles as
     // rbsp_stop_one_bit)
     void finish() {
         range_ -= 2;
@@ -211,5 +215,106 @@ private:
     bool first_ = true;
     uint32_t outstanding_ = 0;
 };
+#else
+// Production engine: the same interval arithmetic (bool_coder.rs:136-296) with the low end of the interval
+// kept in a 32-bit register and whole bytes leaving it, the carry resolved through a count of buffered
+// 0xff bytes instead of one outstanding bit at a time.  It writes the same bit sequence as the
+// bit-serial form above (tests/test_bitstream.py builds both and compares).  bits_left_ starts at 23, not
+// 24: that is the reference's suppressed first output bit (cabac_first_bit_flag, bool_coder.rs:174-180).
+class CabacEncoder {
+public:
+    explicit CabacEncoder(BitWriter& bw) : bw_(bw) {}
+
+    void start(int slice_qp) {
+        init_models(m_, slice_qp);
+        range_ = 510;
+        low_ = 0;
+        bits_left_ = 23;
+        buffered_byte_ = 0xff;
+        num_buffered_ = 0;
+    }
+
+    void encode(int ctx, int bin) {
+        CtxModel& c = m_[ctx];
+        const uint32_t q = range_ >> 5;
+        const uint32_t p = (uint32_t)c.s1 + 16u * c.s0;
+        const uint32_t mps = p >> 14;
+        const uint32_t lps = ((q * ((mps ? 32767u - p : p) >> 9)) >> 1) + 4;
+        // Both outcomes are computed and selected without a branch (the bin value is the least predictable
+        // thing in the encoder).  LPS: the interval moves up by the MPS part and shrinks to lps, which
+        // needs clz(lps) - 23 shifts to come back to 256..511 (lps is 4..236).  MPS: the interval shrinks by
+        // lps and never needs more than one shift.
+        const uint32_t r_mps = range_ - lps;
+        const bool is_lps = (uint32_t)bin != mps;
+        const int nb = is_lps ? __builtin_clz(lps) - 23 : (int)(r_mps < 256);
+        low_ = (low_ + (is_lps ? r_mps : 0u)) << nb;
+        range_ = (is_lps ? lps : r_mps) << nb;
+        bits_left_ -= nb;
+        if (bits_left_ < 12) write_out();
+        c.s0 = (uint16_t)(c.s0 - (c.s0 >> c.shift0) + ((1023 * bin) >> c.shift0));
+        c.s1 = (uint16_t)(c.s1 - (c.s1 >> c.shift1) + ((16383 * bin) >> c.shift1));
+    }
+
+    void bypass(int bin) {
+        low_ <<= 1;
+        if (bin) low_ += range_;
+        if (--bits_left_ < 12) write_out();
+    }
+    void bypass_bits(uint32_t v, int n) {
+        while (n > 0) { // at most 8 at a time keeps low_ inside its 32 bits
+            const int k = n > 8 ? 8 : n;
+            n -= k;
+            low_ = (low_ << k) + range_ * ((v >> n) & ((1u << k) - 1));
+            bits_left_ -= k;
+            if (bits_left_ < 12) write_out();
+        }
+    }
+
+    // end_of_slice_one_bit = 1, flush, and the bit equal to one that ends the slice data
+    void finish() {
+        range_ -= 2;
+        low_ = (low_ + range_) << 7;
+        range_ = 2 << 7;
+        bits_left_ -= 7;
+        if (bits_left_ < 12) write_out();
+        if (low_ >> (32 - bits_left_)) { // a carry into the bytes still held back
+            bw_.byte((uint8_t)(buffered_byte_ + 1));
+            for (; num_buffered_ > 1; --num_buffered_) bw_.byte(0x00);
+            low_ -= 1u << (32 - bits_left_);
+        } else {
+            if (num_buffered_ > 0) bw_.byte((uint8_t)buffered_byte_);
+            for (; num_buffered_ > 1; --num_buffered_) bw_.byte(0xff);
+        }
+        bw_.put(low_ >> 8, 24 - bits_left_);
+        bw_.bit(true);
+    }
+
+private:
+    void write_out() {
+        const uint32_t lead = low_ >> (24 - bits_left_);
+        bits_left_ += 8;
+        low_ &= 0xffffffffu >> bits_left_;
+        if (lead == 0xff) {
+            ++num_buffered_;
+        } else if (num_buffered_ > 0) {
+            const uint32_t carry = lead >> 8;
+            bw_.byte((uint8_t)(buffered_byte_ + carry));
+            buffered_byte_ = lead & 0xff;
+            const uint8_t fill = (uint8_t)(0xff + carry);
+            for (; num_buffered_ > 1; --num_buffered_) bw_.byte(fill);
+        } else {
+            num_buffered_ = 1;
+            buffered_byte_ = lead;
+        }
+    }
+
+    BitWriter& bw_;
+    CtxModel m_[CTX_COUNT];
+    uint32_t range_ = 510, low_ = 0;
+    int bits_left_ = 23;
+    uint32_t buffered_byte_ = 0xff;
+    int num_buffered_ = 0;
+};
+#endif
 
 } // namespace wrenc_host

@@ -234,20 +234,28 @@ private:
     const int16_t* plane(int c) const { return c == 0 ? r_.lev_y : (c == 1 ? r_.lev_cb : r_.lev_cr); }
     int stride(int c) const { return c ? W_ >> 1 : W_; }
 
-    bool any_level(int c, int tx, int ty, int lg) const {
-        const int16_t* p = plane(c) + (size_t)ty * stride(c) + tx;
-        for (int y = 0; y < (1 << lg); ++y, p += stride(c))
-            for (int x = 0; x < (1 << lg); ++x)
-                if (p[x]) return true;
-        return false;
+    // bit (ys * 8 + xs) is set when the 4x4 sub-block (xs, ys) of the TB holds a level (get_sb_coded_flag,
+    // ctu.rs:724-737); zero means the coded flag of the TB is zero (ctu.rs:902-950)
+    uint64_t sb_mask(int c, int tx, int ty, int lg) const {
+        const int st = stride(c), tw = 1 << lg;
+        const int16_t* p = plane(c) + (size_t)ty * st + tx;
+        uint64_t mask = 0;
+        for (int y = 0; y < tw; ++y, p += st)
+            for (int x = 0; x < tw; x += 4) {
+                uint64_t four;
+                memcpy(&four, p + x, sizeof(four));
+                if (four) mask |= 1ull << ((y >> 2) * 8 + (x >> 2));
+            }
+        return mask;
     }
 
     // ctu_encoder.rs:1463-1784
     int transform_unit(int x0, int y0, int lg, Tree tree) {
         const bool chroma = tree != DUAL_TREE_LUMA, luma = tree != DUAL_TREE_CHROMA;
-        const bool cbf_y = luma && any_level(0, x0, y0, lg);
-        const bool cbf_cb = chroma && any_level(1, x0 >> 1, y0 >> 1, lg - 1);
-        const bool cbf_cr = chroma && any_level(2, x0 >> 1, y0 >> 1, lg - 1);
+        const uint64_t m_y = luma ? sb_mask(0, x0, y0, lg) : 0;
+        const uint64_t m_cb = chroma ? sb_mask(1, x0 >> 1, y0 >> 1, lg - 1) : 0;
+        const uint64_t m_cr = chroma ? sb_mask(2, x0 >> 1, y0 >> 1, lg - 1) : 0;
+        const bool cbf_y = m_y != 0, cbf_cb = m_cb != 0, cbf_cr = m_cr != 0;
         if (chroma) {
             cabac_.encode(CTX_CB_CBF, cbf_cb);          // ctxInc 0 (no BDPCM)
             cabac_.encode(CTX_CR_CBF + cbf_cb, cbf_cr); // ctxInc = tu_cb_coded_flag
@@ -259,47 +267,31 @@ private:
             qp_delta_coded_ = true;
         }
         for (int c = 0; c < 3; ++c) {
-            if (!(c == 0 ? cbf_y : (c == 1 ? cbf_cb : cbf_cr))) continue;
+            const uint64_t m = c == 0 ? m_y : (c == 1 ? m_cb : m_cr);
+            if (!m) continue;
             cabac_.encode(CTX_TS_FLAG + (c != 0), 0); // transform_skip_flag = 0 (:1693-1775)
-            const int rc = c == 0 ? residual(0, x0, y0, lg) : residual(c, x0 >> 1, y0 >> 1, lg - 1);
+            const int rc = c == 0 ? residual(0, x0, y0, lg, m) : residual(c, x0 >> 1, y0 >> 1, lg - 1, m);
             if (rc) return rc;
         }
         return WRENC_BS_OK;
     }
 
-    // locNumSig / locSumAbsPass1 of 9.3.4.2.8 (bool_coder.rs:2152-2244): the five already-coded neighbours
-    void local_template(int xc, int yc, int tw, int& num_sig, int& sum_p1) const {
-        num_sig = 0;
-        sum_p1 = 0;
-        const auto add = [&](int x, int y) {
-            const int v = p1_[y * 32 + x];
-            sum_p1 += v;
-            num_sig += v > 0;
-        };
-        if (xc < tw - 1) {
-            add(xc + 1, yc);
-            if (xc < tw - 2) add(xc + 2, yc);
-            if (yc < tw - 1) add(xc + 1, yc + 1);
-        }
-        if (yc < tw - 1) {
-            add(xc, yc + 1);
-            if (yc < tw - 2) add(xc, yc + 2);
-        }
+    // The two per-TB arrays of 9.3.4.2.8 / 9.3.3.2 are kept with a row stride of kS and two zero columns
+    // and rows after the TB, so the five-neighbour templates need no bounds tests (the tests of
+    // bool_coder.rs:1133-1174,2152-2244 only ever exclude positions outside the TB, which read as zero
+    // here).  tpl_ packs AbsLevelPass1 with "is significant" in bit 8: one sum gives locSumAbsPass1 (low
+    // byte, at most 5 * 5) and locNumSig (bits 8..10).
+    enum { kS = 36 };
+
+    int template_sum(int xc, int yc) const {
+        const int* t = &tpl_[yc * kS + xc];
+        return t[1] + t[2] + t[kS] + t[kS + 1] + t[2 * kS];
     }
 
     // bool_coder.rs:1133-1174 (9.3.3.2)
-    int rice_param(int base_level, int xc, int yc, int tw) const {
-        int s = 0;
-        if (xc < tw - 1) {
-            s += abs_[yc * 32 + xc + 1];
-            if (xc < tw - 2) s += abs_[yc * 32 + xc + 2];
-            if (yc < tw - 1) s += abs_[(yc + 1) * 32 + xc + 1];
-        }
-        if (yc < tw - 1) {
-            s += abs_[(yc + 1) * 32 + xc];
-            if (yc < tw - 2) s += abs_[(yc + 2) * 32 + xc];
-        }
-        s -= base_level * 5;
+    int rice_param(int base_level, int xc, int yc) const {
+        const int* t = &abs_[yc * kS + xc];
+        int s = t[1] + t[2] + t[kS] + t[kS + 1] + t[2 * kS] - base_level * 5;
         return kRiceParams[s < 0 ? 0 : (s > 31 ? 31 : s)];
     }
 
@@ -370,28 +362,23 @@ private:
         prefix = ((bits + 1) << 1) + (p & 1);
     }
 
-    // ctu_encoder.rs:1786-2269; tx, ty, lg in samples of component c
-    int residual(int c, int tx, int ty, int lg) {
+    // ctu_encoder.rs:1786-2269; tx, ty, lg in samples of component c; mask = sb_mask of the TB
+    int residual(int c, int tx, int ty, int lg, uint64_t mask) {
         const int tw = 1 << lg;
         const int16_t* lev = plane(c) + (size_t)ty * stride(c) + tx;
         const int st = stride(c);
-        for (int y = 0; y < tw; ++y) {
-            memset(&abs_[y * 32], 0, sizeof(int) * tw);
-            memset(&p1_[y * 32], 0, sizeof(int) * tw);
+        for (int y = 0; y < tw + 2; ++y) {
+            memset(&abs_[y * kS], 0, sizeof(int) * (tw + 2));
+            memset(&tpl_[y * kS], 0, sizeof(int) * (tw + 2));
         }
         const Scan& sbs = kScans.s[lg - 2]; // sub-blocks of the TB
         const Scan& cs = kScans.s[2];       // coefficients of a 4x4 sub-block
         const int n_sb = 1 << (2 * (lg - 2));
         // last significant coefficient in scan order (ctu.rs:867-899)
-        int last_sb = -1, last_pos = 0;
-        for (int i = n_sb - 1; i >= 0 && last_sb < 0; --i)
-            for (int n = 15; n >= 0; --n)
-                if (lev[(size_t)((sbs.y[i] << 2) + cs.y[n]) * st + (sbs.x[i] << 2) + cs.x[n]]) {
-                    last_sb = i;
-                    last_pos = n;
-                    break;
-                }
+        int last_sb = n_sb - 1, last_pos = 15;
+        while (last_sb >= 0 && !((mask >> (sbs.y[last_sb] * 8 + sbs.x[last_sb])) & 1)) --last_sb;
         if (last_sb < 0) return WRENC_BS_EDATA;
+        while (!lev[(size_t)((sbs.y[last_sb] << 2) + cs.y[last_pos]) * st + (sbs.x[last_sb] << 2) + cs.x[last_pos]]) --last_pos;
         const int last_x = (sbs.x[last_sb] << 2) + cs.x[last_pos], last_y = (sbs.y[last_sb] << 2) + cs.y[last_pos];
         int px, sx, py, sy;
         split_last(last_x, px, sx);
@@ -404,49 +391,57 @@ private:
         if ((last_sb > 0 || last_pos > 0) && c == 0) mts_dc_only_ = false; // :1945-1947
         int rem_bins = ((1 << (2 * lg)) * 7) >> 2;
         int q_state = 0;
+        const int sb_ctx = CTX_SB_CODED + (c ? 2 : 0);
+        const int sbw = tw >> 2;
         for (int i = last_sb; i >= 0; --i) {
-            const int start_q = q_state;
             const int xs = sbs.x[i], ys = sbs.y[i];
             const int x_off = xs << 2, y_off = ys << 2;
-            // AbsLevel of the sub-block from TransCoeffLevel: (|q| + (state > 1)) / 2 along the state
-            // walk (:1968-1985); the parity check is the reference's release assert
-            int a[16];
-            bool sb_coded = (xs | ys) == 0; // (:1994) the DC sub-block counts as coded
-            {
-                int q = q_state;
-                for (int n = 15; n >= 0; --n) {
-                    const int v = lev[(size_t)(y_off + cs.y[n]) * st + x_off + cs.x[n]];
-                    const int av = v < 0 ? -v : v;
-                    if (av && (av & 1) != (q > 1)) return WRENC_BS_EDATA;
-                    a[n] = (av + (q > 1)) >> 1;
-                    sb_coded |= av != 0;
-                    q = kQStateTrans[q][a[n] & 1];
-                }
-            }
+            const bool sb_coded = ((mask >> (ys * 8 + xs)) & 1) || i == 0; // (:1994) the DC sub-block counts as coded
             bool infer_dc = false;
             if (i < last_sb && i > 0) {
                 // sb_coded_flag: context from the right and lower sub-blocks (bool_coder.rs:2102-2150)
                 int csbf = 0;
-                if (xs < (tw >> 2) - 1) csbf += any_level_sb(lev, st, xs + 1, ys);
-                if (ys < (tw >> 2) - 1) csbf += any_level_sb(lev, st, xs, ys + 1);
-                cabac_.encode(CTX_SB_CODED + (c ? 2 : 0) + (csbf > 0), sb_coded);
+                if (xs < sbw - 1) csbf |= (int)((mask >> (ys * 8 + xs + 1)) & 1);
+                if (ys < sbw - 1) csbf |= (int)((mask >> ((ys + 1) * 8 + xs)) & 1);
+                cabac_.encode(sb_ctx + csbf, sb_coded);
                 infer_dc = true;
             }
-            if (sb_coded && (xs > 3 || ys > 3) && c == 0) mts_zero_out_ = false; // :2008-2010
+            // An uncoded sub-block ends here.  Sixteen zero levels leave the quantiser state where it was
+            // (0->0, 1->2->1, 2->1->2, 3->3) and take nothing from the bin budget, so the passes of
+            // :2014-2253 would have no effect.
+            if (!sb_coded) continue;
+            // AbsLevel of the sub-block from TransCoeffLevel: (|q| + (state > 1)) / 2 along the state
+            // walk (:1968-1985); the parity check is the reference's release assert.  The state this
+            // walk ends in is the one the next sub-block starts from (:2254-2267).
+            int a[16];
+            uint32_t signs = 0;
+            int n_signs = 0, next_q = q_state;
+            for (int n = 15; n >= 0; --n) {
+                const int v = lev[(size_t)(y_off + cs.y[n]) * st + x_off + cs.x[n]];
+                const int av = v < 0 ? -v : v;
+                if (av) {
+                    if ((av & 1) != (next_q > 1)) return WRENC_BS_EDATA;
+                    signs = (signs << 1) | (uint32_t)(v < 0);
+                    ++n_signs;
+                }
+                a[n] = (av + (next_q > 1)) >> 1;
+                next_q = kQStateTrans[next_q][a[n] & 1];
+            }
+            if ((xs > 3 || ys > 3) && c == 0) mts_zero_out_ = false; // :2008-2010
             const int first_pos_mode0 = i == last_sb ? last_pos : 15;
             int first_pos_mode1 = first_pos_mode0;
+            bool any_gt3 = false;
             // pass 1: sig_coeff_flag, abs_level_gtx_flag[0], par_level_flag, abs_level_gtx_flag[1]
             for (int n = first_pos_mode0; n >= 0; --n) {
                 if (rem_bins < 4) break;
                 const int xc = x_off + cs.x[n], yc = y_off + cs.y[n];
-                const bool sig = a[n] > 0;
+                const int an = a[n];
+                const bool sig = an > 0;
                 const bool is_last = xc == last_x && yc == last_y;
-                int num_sig = 0, sum_p1 = 0;
                 const int d = xc + yc;
-                bool have_template = false;
-                if (sb_coded && (n > 0 || !infer_dc) && !is_last) {
-                    local_template(xc, yc, tw, num_sig, sum_p1);
-                    have_template = true;
+                const int tsum = template_sum(xc, yc);
+                const int sum_p1 = tsum & 255, num_sig = tsum >> 8;
+                if ((n > 0 || !infer_dc) && !is_last) {
                     const int s = (sum_p1 + 1) >> 1;
                     const int qs = q_state > 1 ? q_state - 1 : 0;
                     const int inc = c == 0 ? 12 * qs + (s < 3 ? s : 3) + (d < 2 ? 8 : (d < 5 ? 4 : 0))
@@ -455,9 +450,8 @@ private:
                     --rem_bins;
                     if (sig) infer_dc = false;
                 }
-                const bool gt1 = a[n] > 1, gt3 = a[n] > 3, par = a[n] > 1 && (a[n] & 1);
+                int pass1 = 0;
                 if (sig) {
-                    if (!have_template) local_template(xc, yc, tw, num_sig, sum_p1);
                     int off = sum_p1 - num_sig;
                     off = off > 4 ? 4 : off;
                     int inc;
@@ -467,53 +461,45 @@ private:
                         inc = 1 + off + (d == 0 ? 15 : (d < 3 ? 10 : (d < 10 ? 5 : 0)));
                     else
                         inc = 22 + off + (d == 0 ? 5 : 0);
+                    const bool gt1 = an > 1;
                     cabac_.encode(CTX_GTX + inc, gt1);
                     --rem_bins;
+                    pass1 = 1;
                     if (gt1) {
-                        cabac_.encode(CTX_PAR + inc, par);
-                        --rem_bins;
+                        const bool gt3 = an > 3;
+                        cabac_.encode(CTX_PAR + inc, an & 1);
                         cabac_.encode(CTX_GTX + 32 + inc, gt3);
-                        --rem_bins;
+                        rem_bins -= 2;
+                        pass1 = 2 + (an & 1) + 2 * (int)gt3;
+                        any_gt3 |= gt3;
                     }
+                    tpl_[yc * kS + xc] = pass1 | 256;
                 }
-                const int pass1 = (int)sig + (int)par + (int)gt1 + 2 * (int)gt3;
-                p1_[yc * 32 + xc] = pass1;
                 q_state = kQStateTrans[q_state][pass1 & 1];
                 first_pos_mode1 = n - 1;
             }
             // pass 2: abs_remainder of the coefficients pass 1 covered
             for (int n = first_pos_mode0; n > first_pos_mode1; --n) {
+                if (!a[n]) continue;
                 const int xc = x_off + cs.x[n], yc = y_off + cs.y[n];
-                if (a[n] > 3) code_remainder((a[n] - p1_[yc * 32 + xc]) >> 1, rice_param(4, xc, yc, tw));
-                abs_[yc * 32 + xc] = a[n];
+                if (any_gt3 && a[n] > 3)
+                    code_remainder((a[n] - (tpl_[yc * kS + xc] & 255)) >> 1, rice_param(4, xc, yc));
+                abs_[yc * kS + xc] = a[n];
             }
             // pass 3: dec_abs_level of what the bin budget left out (ctu.rs:739-782)
             for (int n = first_pos_mode1; n >= 0; --n) {
                 const int xc = x_off + cs.x[n], yc = y_off + cs.y[n];
-                abs_[yc * 32 + xc] = a[n];
-                if (sb_coded) {
-                    const int k = rice_param(0, xc, yc, tw);
-                    const int zero_pos = (q_state < 2 ? 1 : 2) << k;
-                    const int dec = a[n] == 0 ? zero_pos : (a[n] <= zero_pos ? a[n] - 1 : a[n]);
-                    code_remainder(dec, k);
-                }
+                const int k = rice_param(0, xc, yc);
+                const int zero_pos = (q_state < 2 ? 1 : 2) << k;
+                code_remainder(a[n] == 0 ? zero_pos : (a[n] <= zero_pos ? a[n] - 1 : a[n]), k);
+                abs_[yc * kS + xc] = a[n];
                 q_state = kQStateTrans[q_state][a[n] & 1];
             }
-            // signs, bypass
-            for (int n = 15; n >= 0; --n)
-                if (a[n] > 0) cabac_.bypass(lev[(size_t)(y_off + cs.y[n]) * st + x_off + cs.x[n]] < 0);
-            // the state at the start of the next sub-block is the one after all 16 positions (:2254-2267)
-            q_state = start_q;
-            for (int n = 15; n >= 0; --n) q_state = kQStateTrans[q_state][a[n] & 1];
+            // signs of the sub-block in scan order, bypass
+            if (n_signs) cabac_.bypass_bits(signs, n_signs);
+            q_state = next_q;
         }
         return WRENC_BS_OK;
-    }
-
-    static int any_level_sb(const int16_t* lev, int st, int xs, int ys) {
-        const int16_t* p = lev + (size_t)(ys << 2) * st + (xs << 2);
-        for (int y = 0; y < 4; ++y, p += st)
-            if (p[0] | p[1] | p[2] | p[3]) return 1;
-        return 0;
     }
 
     const int W_, H_, qp_;
@@ -521,8 +507,8 @@ private:
     CabacEncoder cabac_;
     bool qp_delta_coded_ = false;
     bool mts_dc_only_ = true, mts_zero_out_ = true;
-    int abs_[32 * 32]; // AbsLevel of the current TB, row stride 32
-    int p1_[32 * 32];  // AbsLevelPass1
+    int abs_[34 * kS]; // AbsLevel of the current TB
+    int tpl_[34 * kS]; // AbsLevelPass1 | significant << 8
 };
 
 } // namespace
