@@ -1,0 +1,89 @@
+"""Command line (wrenc_amd/cli.py): the reference's options (main.rs:85-115) and its error behaviour
+(message on stderr, exit status 0: main.rs:127-133)."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from content import content
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(args, stdin=None):
+    return subprocess.run([sys.executable, "-m", "wrenc_amd.cli"] + args, cwd=ROOT, input=stdin, capture_output=True,
+                          timeout=600)
+
+
+def test_argument_errors_print_and_exit_zero(built, tmp_path):
+    out = str(tmp_path / "o.vvc")
+    base = ["-i", str(tmp_path / "missing.yuv"), "-o", out, "--num-pictures", "1", "--qp", "32"]
+    r = _run(base + ["--input-size", "64x64", "--output-size", "64by64"])
+    assert r.returncode == 0 and b"error: Invalid output-size: 64by64" in r.stderr
+    r = _run(base + ["--input-size", "x", "--output-size", "64x64"])
+    assert r.returncode == 0 and b"error: Invalid input-size: x" in r.stderr
+    r = _run(base + ["--input-size", "64x64", "--output-size", "64x64", "--extra-params", "a"])
+    assert r.returncode == 0 and b"error: Invalid extra-params: a" in r.stderr
+    r = _run(base + ["--input-size", "64x64", "--output-size", "64x60"])
+    assert r.returncode == 0 and b"multiple of the 32x32 CTU" in r.stderr
+    r = _run(base + ["--input-size", "64x64", "--output-size", "64x64"])
+    assert r.returncode == 0 and b"error: failed to open input file" in r.stderr
+    assert not os.path.exists(out) or os.path.getsize(out) == 0
+
+
+def test_without_a_gpu_the_command_fails_loudly(built, tmp_path):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    src = tmp_path / "in.yuv"
+    src.write_bytes(bytes(64 * 64 * 3 // 2))
+    r = _run(["-i", str(src), "-o", str(tmp_path / "o.vvc"), "--input-size", "64x64", "--output-size", "64x64",
+              "--num-pictures", "1", "--qp", "32"])
+    assert r.returncode == 0 and r.stderr.startswith(b"error: ")      # no CPU fallback
+
+
+@pytest.mark.gpu
+def test_encodes_a_sequence_like_the_reference_binary(built, tmp_path):
+    """3 pictures through files, then 2 through stdin/stdout: the stream parses, every picture decodes to the
+    record of a direct encode, and --reconst holds the decoder-side reconstruction (the reference's
+    integration test compares exactly these two files)."""
+    from wrenc_amd import gpu
+    from oracle import pyoracle as po
+    w, h, qp, depth = 96, 64, 30, 2
+    frames = [content(k, w, h, i) for i, k in enumerate(("cclm", "stripes20", "noise"))]
+    raw = b"".join(p.tobytes() for f in frames for p in f)
+    src, out, rec = tmp_path / "in.yuv", tmp_path / "out.vvc", tmp_path / "rec.yuv"
+    src.write_bytes(raw)
+    r = _run(["-i", str(src), "-o", str(out), "-r", str(rec), "--input-size", "%dx%d" % (w, h), "--output-size",
+              "%dx%d" % (w, h), "--num-pictures", "3", "--qp", str(qp), "--max-split-depth", str(depth), "--batch", "2"])
+    assert r.returncode == 0 and r.stderr == b"", r.stderr
+    stream = out.read_bytes()
+    assert po.parse_stream_info(stream) == {"width": w, "height": h, "init_qp": qp, "n_pictures": 3}
+    recon = np.frombuffer(rec.read_bytes(), np.uint8)
+    per = w * h * 3 // 2
+    assert recon.size == 3 * per
+    enc = gpu.Encoder(w, h, qp=qp, max_split_depth=depth)
+    for i, f in enumerate(frames):
+        want = enc.encode_picture(*f)
+        back = po.parse_picture(stream, i)
+        assert back["poc_lsb"] == i and back["slice_qp"] == qp
+        for k in ("cu_log2_size", "luma_mode", "chroma_mode", "lev_y", "lev_cb", "lev_cr"):
+            assert np.array_equal(back[k], want[k]), (i, k)
+        ry, rcb, rcr = po.reconstruct_from_record(back, qp)
+        got = recon[i * per:(i + 1) * per]
+        assert np.array_equal(got[:w * h], ry.ravel())
+        assert np.array_equal(got[w * h:w * h + w * h // 4], rcb.ravel())
+        assert np.array_equal(got[w * h + w * h // 4:], rcr.ravel())
+    enc.close()
+    r = _run(["-i", "-", "-o", "-", "--input-size", "%dx%d" % (w, h), "--output-size", "%dx%d" % (w, h),
+              "--num-pictures", "2", "--qp", str(qp), "--max-split-depth", str(depth)], stdin=raw)
+    assert r.returncode == 0 and po.parse_stream_info(r.stdout)["n_pictures"] == 2
+    two = po.parse_picture(r.stdout, 1)
+    one = po.parse_picture(stream, 1)
+    assert all(np.array_equal(two[k], one[k]) for k in ("lev_y", "luma_mode"))
+    # input shorter than --num-pictures asks for
+    r = _run(["-i", str(src), "-o", str(out), "--input-size", "%dx%d" % (w, h), "--output-size", "%dx%d" % (w, h),
+              "--num-pictures", "4", "--qp", str(qp)])
+    assert r.returncode == 0 and b"error: input ended after 3 of 4 pictures" in r.stderr
