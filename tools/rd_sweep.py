@@ -1,0 +1,95 @@
+#!/usr/bin/env python3
+"""RD-curve sweep (BASELINE.json configs[2]): encode the same pictures at several QPs
+with the full CT-partition search, write the real bitstream, and report bytes, PSNR / SSIM of the
+reconstruction and the rates of the two stages.  The result list follows the shape of the reference's
+tools/evaluation/evaluate_mp.py:78-120 (title, qp, bytes, duration, metrics.{psnr,ssim}.summary), without
+ffmpeg / VTM: PSNR and SSIM are computed here from the encoder's reconstruction, which the stream parser
+tests show is what a decoder rebuilds.
+
+    python tools/rd_sweep.py [--width 3840 --height 2176 --frames 8 --depth 3 --qps 22,27,32,37] [--out file.json]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def psnr(a, b):
+    mse = np.mean((a.astype(np.float64) - b.astype(np.float64)) ** 2)
+    return 100.0 if mse == 0 else 10.0 * np.log10(255.0 * 255.0 / mse)   # evaluate_mp.py:108 caps inf at 100
+
+
+def ssim(a, b):
+    """Wang et al. SSIM, 11x11 Gaussian window (sigma 1.5), mean over the plane."""
+    from scipy.ndimage import gaussian_filter
+    a, b = a.astype(np.float64), b.astype(np.float64)
+    f = lambda x: gaussian_filter(x, 1.5, truncate=3.5)
+    mu_a, mu_b = f(a), f(b)
+    va, vb, cov = f(a * a) - mu_a ** 2, f(b * b) - mu_b ** 2, f(a * b) - mu_a * mu_b
+    c1, c2 = (0.01 * 255) ** 2, (0.03 * 255) ** 2
+    return float(np.mean(((2 * mu_a * mu_b + c1) * (2 * cov + c2)) / ((mu_a ** 2 + mu_b ** 2 + c1) * (va + vb + c2))))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--width", type=int, default=3840)
+    ap.add_argument("--height", type=int, default=2176)
+    ap.add_argument("--frames", type=int, default=8)
+    ap.add_argument("--depth", type=int, default=3)
+    ap.add_argument("--qps", default="22,27,32,37")
+    ap.add_argument("--threads", type=int, default=8)
+    ap.add_argument("--out")
+    a = ap.parse_args()
+    from wrenc_amd import bitstream, gpu, synth
+    w, h, n = a.width, a.height, a.frames
+    frames = [synth.synth_textured_frame(w, h, f) for f in range(n)]
+    results = []
+    pool = ThreadPoolExecutor(max_workers=a.threads)
+    for qp in [int(q) for q in a.qps.split(",")]:
+        enc = gpu.Encoder(w, h, qp=qp, max_split_depth=a.depth, n_slots=n)
+        for s in range(n):
+            enc.upload(s, *frames[s])
+        enc.sync()
+        t0 = time.perf_counter()
+        enc.encode(0, n)
+        enc.sync()
+        t_search = time.perf_counter() - t0
+        recs = [enc.download(s) for s in range(n)]
+        mism = enc.final_pass_mismatches()
+        enc.close()
+        t0 = time.perf_counter()
+        nals = list(pool.map(lambda t: bitstream.write_picture(w, h, qp, t[0], t[1]), enumerate(recs)))
+        t_write = time.perf_counter() - t0
+        total = len(bitstream.write_parameter_sets(w, h, qp)) + sum(len(x) for x in nals)
+        per_frame = []
+        for f in range(n):
+            py, pu, pv = (psnr(frames[f][c], recs[f][k]) for c, k in enumerate(("rec_y", "rec_cb", "rec_cr")))
+            per_frame.append({"n": f + 1, "psnr_y": py, "psnr_u": pu, "psnr_v": pv, "psnr_avg": (4 * py + pu + pv) / 6,
+                              "ssim_y": ssim(frames[f][0], recs[f]["rec_y"]), "bytes": len(nals[f])})
+        summ = {k: float(np.mean([p[k] for p in per_frame])) for k in ("psnr_y", "psnr_u", "psnr_v", "psnr_avg", "ssim_y")}
+        results.append({
+            "title": "synth_textured_%dx%d[wrenc_amd@max_split_depth=%d,qp=%d]" % (w, h, a.depth, qp), "qp": qp,
+            "bytes": total, "duration": t_search + t_write, "frames": n,
+            "bits_per_pixel": 8.0 * total / (n * w * h),
+            "search_fps": n / t_search, "bitstream_fps_%d_threads" % a.threads: n / t_write,
+            "final_pass_mismatches": mism,
+            "metrics": {"psnr": {"summary": {k: summ[k] for k in ("psnr_y", "psnr_u", "psnr_v", "psnr_avg")}},
+                        "ssim": {"summary": {"ssim_y": summ["ssim_y"]}}, "per_frame": per_frame}})
+        print("qp %2d  %9d bytes  %.4f bpp  PSNR-Y %.2f dB  SSIM-Y %.4f  search %.1f fps  writer %.1f fps" % (
+            qp, total, results[-1]["bits_per_pixel"], summ["psnr_y"], summ["ssim_y"], n / t_search, n / t_write), flush=True)
+    pool.shutdown()
+    doc = {"config": {"width": w, "height": h, "frames": n, "max_split_depth": a.depth, "content": "synth_textured_frame"},
+           "results": results}
+    if a.out:
+        json.dump(doc, open(a.out, "w"), indent=1)
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
