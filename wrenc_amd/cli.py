@@ -12,6 +12,7 @@ reference, every failure prints `error: ...` on stderr and ends the process with
 """
 import argparse
 import sys
+import time
 from concurrent.futures import ThreadPoolExecutor
 
 import numpy as np
@@ -57,6 +58,7 @@ def main(argv=None):
     ap.add_argument("--batch", type=int, default=64, help="pictures searched per GPU call (not in the reference)")
     ap.add_argument("--device", type=int, default=0, help="HIP device ordinal (not in the reference)")
     ap.add_argument("--threads", type=int, default=8, help="host threads writing slices (not in the reference)")
+    ap.add_argument("--verbose", action="store_true", help="print the end-to-end rate on stderr (not in the reference)")
     a = ap.parse_args(argv)
 
     _size(a.input_size, "input-size")           # parsed and otherwise unused, as in main.rs:164-174
@@ -97,30 +99,44 @@ def main(argv=None):
 
     fout.write(bitstream.write_parameter_sets(w, h, qp))
     ysz, csz = w * h, (w // 2) * (h // 2)
-    poc = 0
     pool = ThreadPoolExecutor(max_workers=max(1, a.threads))
-    try:
-        while poc < a.num_pictures:
-            n = 0
-            for s in range(min(batch, a.num_pictures - poc)):
-                raw = _read_exact(fin, ysz + 2 * csz)
-                if raw is None:
-                    _die("input ended after %d of %d pictures" % (poc + n, a.num_pictures))
-                buf = np.frombuffer(raw, np.uint8)
-                enc.upload(s, buf[:ysz].reshape(h, w), buf[ysz:ysz + csz].reshape(h // 2, w // 2),
-                           buf[ysz + csz:].reshape(h // 2, w // 2))
-                n += 1
+    t_start = time.perf_counter()
+    stats = {"pictures": 0, "bytes": 0}
+
+    def submit(first_poc):
+        """Read and upload the next batch and start its search (asynchronous); returns its size."""
+        n = 0
+        for s in range(min(batch, a.num_pictures - first_poc)):
+            raw = _read_exact(fin, ysz + 2 * csz)
+            if raw is None:
+                _die("input ended after %d of %d pictures" % (first_poc + n, a.num_pictures))
+            buf = np.frombuffer(raw, np.uint8)
+            enc.upload(s, buf[:ysz].reshape(h, w), buf[ysz:ysz + csz].reshape(h // 2, w // 2),
+                       buf[ysz + csz:].reshape(h // 2, w // 2))
+            n += 1
+        if n:
             enc.encode(0, n)
+        return n
+
+    try:
+        poc = 0
+        n = submit(0) if a.num_pictures > 0 else 0
+        while n:
             enc.sync()
             recs = [enc.download(s) for s in range(n)]
+            first, done = poc, n
+            poc += n
+            # the next batch is searched on the GPU while this one is entropy coded on the host
+            n = submit(poc) if poc < a.num_pictures else 0
             # pictures are independent: their slices are written in parallel (the C call drops the GIL)
-            nals = list(pool.map(lambda t: bitstream.write_picture(w, h, qp, poc + t[0], t[1]), enumerate(recs)))
-            for s in range(n):
+            nals = list(pool.map(lambda t: bitstream.write_picture(w, h, qp, first + t[0], t[1]), enumerate(recs)))
+            for s in range(done):
                 fout.write(nals[s])
+                stats["bytes"] += len(nals[s])
                 if frec is not None:
                     for k in ("rec_y", "rec_cb", "rec_cr"):     # main.rs:387-399
                         frec.write(recs[s][k].tobytes())
-            poc += n
+            stats["pictures"] += done
     except (gpu.WrencGpuError, bitstream.BitstreamError) as e:
         _die(str(e))
     finally:
@@ -131,6 +147,10 @@ def main(argv=None):
             frec.close()
         if fout is not sys.stdout.buffer:
             fout.close()
+    if a.verbose:
+        dt = time.perf_counter() - t_start
+        sys.stderr.write("%d pictures, %d bytes, %.2f s, %.1f pictures/s (file to stream, %d host threads)\n" % (
+            stats["pictures"], stats["bytes"], dt, stats["pictures"] / max(dt, 1e-9), a.threads))
     return 0
 
 
