@@ -96,8 +96,9 @@ void wrenc_gpu_destroy(wrenc_gpu_ctx* ctx);
 const char* wrenc_gpu_last_error(const wrenc_gpu_ctx* ctx); /* ctx may be NULL: create errors */
 
 /* Copy one picture's planes (host memory, given strides in bytes) into slot `slot`
- * (asynchronous on the context's stream; the host buffers must stay valid until
- * wrenc_gpu_sync or wrenc_gpu_download of that slot). Replaces main.rs:318-350 +
+ * (asynchronous on the context's copy stream, behind any search still reading the slot;
+ * the host buffers must stay valid until wrenc_gpu_sync or wrenc_gpu_download of that
+ * slot). Uploads overlap the search of other slots.  Replaces main.rs:318-350 +
  * picture.rs:169-196. */
 int wrenc_gpu_upload(wrenc_gpu_ctx* ctx, int slot, const uint8_t* y, const uint8_t* cb,
                      const uint8_t* cr, size_t stride_y, size_t stride_c);
@@ -110,7 +111,9 @@ int wrenc_gpu_encode(wrenc_gpu_ctx* ctx, int first_slot, int n_pictures);
 /* Wait for everything queued on the context. */
 int wrenc_gpu_sync(wrenc_gpu_ctx* ctx);
 
-/* Copy a finished slot's results to host memory (blocking). */
+/* Copy a slot's results to host memory (blocking).  Waits for the wrenc_gpu_encode call
+ * that searched the slot and for nothing queued after it, so with two sets of slots the
+ * read-back of one set overlaps the search of the other. */
 int wrenc_gpu_download(wrenc_gpu_ctx* ctx, int slot, wrenc_gpu_picture* out);
 
 /* Convenience: upload + encode + download of a single picture through slot 0. */

@@ -24,7 +24,7 @@ with open(src, "wb") as f:
 r = subprocess.run([sys.executable, "-m", "wrenc_amd.cli", "-i", src, "-o", out, "--input-size", "%dx%d" % (w, h),
                     "--output-size", "%dx%d" % (w, h), "--num-pictures", str(n), "--qp", "32", "--max-split-depth", "2",
                     "--batch", str(batch), "--threads", str(threads), "--verbose"], cwd=ROOT, capture_output=True)
-print("textured" if textured else "smooth", "N", n, "batch", batch, "threads", threads, "|", r.stderr.decode().strip(),
+print("textured" if textured else "smooth", "N", n, "batch", batch, "threads", threads, "|", r.stderr.decode().strip().replace("\n", " | "),
       "| stream", os.path.getsize(out), "bytes", flush=True)
 os.remove(src)
 os.remove(out)

@@ -92,8 +92,9 @@ def main(argv=None):
             _die("failed to open reconst file: %s" % e)
 
     batch = max(1, min(a.batch, max(a.num_pictures, 1)))
+    halves = 2 if a.num_pictures > batch else 1     # two sets of slots: one is searched while the other is read back
     try:
-        enc = gpu.Encoder(w, h, qp=qp, max_split_depth=a.max_split_depth, device=a.device, n_slots=batch)
+        enc = gpu.Encoder(w, h, qp=qp, max_split_depth=a.max_split_depth, device=a.device, n_slots=halves * batch)
     except (gpu.WrencGpuError, ImportError, OSError) as e:
         _die(str(e))
 
@@ -101,42 +102,64 @@ def main(argv=None):
     ysz, csz = w * h, (w // 2) * (h // 2)
     pool = ThreadPoolExecutor(max_workers=max(1, a.threads))
     t_start = time.perf_counter()
-    stats = {"pictures": 0, "bytes": 0}
+    stats = {"pictures": 0, "bytes": 0, "read_upload": 0.0, "wait_gpu": 0.0, "download": 0.0, "write": 0.0}
+    want = None if frec is not None else ("lev_y", "lev_cb", "lev_cr", "cu_log2_size", "luma_mode", "chroma_mode")
 
-    def submit(first_poc):
-        """Read and upload the next batch and start its search (asynchronous); returns its size."""
+    def submit(first_poc, base):
+        """Read and upload the next batch into slots base.. and start its search (asynchronous); returns its size."""
         n = 0
+        t0 = time.perf_counter()
         for s in range(min(batch, a.num_pictures - first_poc)):
             raw = _read_exact(fin, ysz + 2 * csz)
             if raw is None:
                 _die("input ended after %d of %d pictures" % (first_poc + n, a.num_pictures))
             buf = np.frombuffer(raw, np.uint8)
-            enc.upload(s, buf[:ysz].reshape(h, w), buf[ysz:ysz + csz].reshape(h // 2, w // 2),
+            enc.upload(base + s, buf[:ysz].reshape(h, w), buf[ysz:ysz + csz].reshape(h // 2, w // 2),
                        buf[ysz + csz:].reshape(h // 2, w // 2))
             n += 1
         if n:
-            enc.encode(0, n)
+            enc.encode(base, n)
+        stats["read_upload"] += time.perf_counter() - t0
         return n
 
+    def flush(batch_out):
+        if batch_out is None:
+            return
+        futures, recs = batch_out
+        t0 = time.perf_counter()
+        for t, fut in enumerate(futures):
+            nal = fut.result()
+            fout.write(nal)
+            stats["bytes"] += len(nal)
+            if frec is not None:
+                for k in ("rec_y", "rec_cb", "rec_cr"):     # main.rs:387-399
+                    frec.write(recs[t][k].tobytes())
+        stats["write"] += time.perf_counter() - t0
+        stats["pictures"] += len(futures)
+
+    pending = None
     try:
-        poc = 0
-        n = submit(0) if a.num_pictures > 0 else 0
+        poc, base = 0, 0
+        n = submit(0, 0) if a.num_pictures > 0 else 0
         while n:
-            enc.sync()
-            recs = [enc.download(s) for s in range(n)]
-            first, done = poc, n
+            first, done, dbase = poc, n, base
             poc += n
-            # the next batch is searched on the GPU while this one is entropy coded on the host
-            n = submit(poc) if poc < a.num_pictures else 0
-            # pictures are independent: their slices are written in parallel (the C call drops the GIL)
-            nals = list(pool.map(lambda t: bitstream.write_picture(w, h, qp, first + t[0], t[1]), enumerate(recs)))
-            for s in range(done):
-                fout.write(nals[s])
-                stats["bytes"] += len(nals[s])
-                if frec is not None:
-                    for k in ("rec_y", "rec_cb", "rec_cr"):     # main.rs:387-399
-                        frec.write(recs[s][k].tobytes())
-            stats["pictures"] += done
+            base = (batch - base) if halves == 2 else 0
+            # the next batch is queued behind the current one: the GPU searches it while this batch is read
+            # back (the library's copy stream waits for this batch's search only) and entropy coded
+            t0 = time.perf_counter()
+            if halves == 1:
+                enc.sync()
+            n = submit(poc, base) if poc < a.num_pictures else 0
+            t1 = time.perf_counter()
+            recs = [enc.download(dbase + s, want) for s in range(done)]
+            stats["download"] += time.perf_counter() - t1
+            # pictures are independent: their slices are written in parallel (the C call drops the GIL), and
+            # collected one batch later so that the writing overlaps the next read-back
+            futures = [pool.submit(bitstream.write_picture, w, h, qp, first + t, recs[t]) for t in range(done)]
+            flush(pending)
+            pending = (futures, recs)
+        flush(pending)
     except (gpu.WrencGpuError, bitstream.BitstreamError) as e:
         _die(str(e))
     finally:
@@ -151,6 +174,8 @@ def main(argv=None):
         dt = time.perf_counter() - t_start
         sys.stderr.write("%d pictures, %d bytes, %.2f s, %.1f pictures/s (file to stream, %d host threads)\n" % (
             stats["pictures"], stats["bytes"], dt, stats["pictures"] / max(dt, 1e-9), a.threads))
+        sys.stderr.write("host time: read+upload %.2f s, waiting for the GPU + download %.2f s, waiting for slices %.2f s\n" % (
+            stats["read_upload"], stats["download"], stats["write"]))
     return 0
 
 

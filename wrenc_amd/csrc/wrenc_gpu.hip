@@ -198,7 +198,13 @@ void diag_scan(int lw, int lh, uint8_t (*out)[2]) { // ctu.rs:54-77
 
 struct wrenc_gpu_ctx {
     wrenc_gpu_config cfg;
-    hipStream_t stream = nullptr;              // uploads, downloads, lane 0 of the encode
+    hipStream_t stream = nullptr;              // lane 0 of the encode; timing events
+    hipStream_t copy_stream = nullptr;         // uploads and downloads: they overlap the search of other slots
+    hipEvent_t ev_uploaded = nullptr;          // end of the uploads an encode call has to wait for
+    bool uploads_pending = false;
+    std::vector<hipEvent_t> enc_events;        // ring: one "this encode call is done" event per call in flight
+    size_t enc_event_next = 0;
+    std::vector<hipEvent_t> slot_event;        // per slot: the event of the encode call that last searched it
     std::vector<hipStream_t> lanes;            // extra encode lanes (pictures are independent)
     std::vector<hipEvent_t> lane_done;
     hipEvent_t ev_fork = nullptr;
@@ -387,6 +393,7 @@ void wrenc_gpu_destroy(wrenc_gpu_ctx* ctx) {
     (void)hipSetDevice(ctx->cfg.device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     for (hipStream_t st : ctx->lanes) (void)hipStreamSynchronize(st);
+    if (ctx->copy_stream) (void)hipStreamSynchronize(ctx->copy_stream);
     for (PicBufs& b : ctx->slots) {
         // planes 1 and 2 point into plane 0's slab
         if (b.org[0]) (void)hipFree((void*)b.org[0]);
@@ -409,6 +416,9 @@ void wrenc_gpu_destroy(wrenc_gpu_ctx* ctx) {
     for (hipStream_t st : ctx->lanes) (void)hipStreamDestroy(st);
     for (hipEvent_t e : ctx->lane_done) (void)hipEventDestroy(e);
     if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
+    if (ctx->ev_uploaded) (void)hipEventDestroy(ctx->ev_uploaded);
+    for (hipEvent_t e : ctx->enc_events) (void)hipEventDestroy(e);
+    if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -450,6 +460,13 @@ int wrenc_gpu_create(const wrenc_gpu_config* cfg, wrenc_gpu_ctx** out) {
     } while (0)
     CREATE_TRY(hipSetDevice(cfg->device));
     CREATE_TRY(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+    CREATE_TRY(hipEventCreateWithFlags(&ctx->ev_uploaded, hipEventDisableTiming));
+    for (int i = 0; i < 8; ++i) {
+        hipEvent_t e = nullptr;
+        CREATE_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        ctx->enc_events.push_back(e);
+    }
+    ctx->slot_event.assign((size_t)cfg->n_slots, nullptr);
     CREATE_TRY(hipEventCreate(&ctx->ev_fork));
     for (int i = 1; i < kEncodeLanes; ++i) {
         hipStream_t st = nullptr;
@@ -459,6 +476,10 @@ int wrenc_gpu_create(const wrenc_gpu_config* cfg, wrenc_gpu_ctx** out) {
         CREATE_TRY(hipEventCreate(&e));
         ctx->lane_done.push_back(e);
     }
+    // Created after the encode lanes on purpose: the runtime deals streams onto its hardware queues in
+    // creation order (4 per process unless GPU_MAX_HW_QUEUES says otherwise), and two lanes on one queue
+    // would run one after the other.  With 4 queues the copy stream shares lane 0's.
+    CREATE_TRY(hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
     CREATE_TRY(hipEventCreate(&ctx->ev_begin));
     CREATE_TRY(hipEventCreate(&ctx->ev_end));
     {
@@ -512,9 +533,13 @@ int wrenc_gpu_upload(wrenc_gpu_ctx* ctx, int slot, const uint8_t* y, const uint8
     if (stride_y < w || stride_c < w / 2) return fail(ctx, WRENC_GPU_EINVAL, "stride smaller than row");
     HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
     PicBufs& b = ctx->slots[slot];
-    HIP_TRY(ctx, hipMemcpy2DAsync((void*)b.org[0], w, y, stride_y, w, h, hipMemcpyHostToDevice, ctx->stream));
-    HIP_TRY(ctx, hipMemcpy2DAsync((void*)b.org[1], w / 2, cb, stride_c, w / 2, h / 2, hipMemcpyHostToDevice, ctx->stream));
-    HIP_TRY(ctx, hipMemcpy2DAsync((void*)b.org[2], w / 2, cr, stride_c, w / 2, h / 2, hipMemcpyHostToDevice, ctx->stream));
+    // the planes may still be read by a search in flight on this slot
+    if (ctx->slot_event[slot]) HIP_TRY(ctx, hipStreamWaitEvent(ctx->copy_stream, ctx->slot_event[slot], 0));
+    hipStream_t cs = ctx->copy_stream;
+    HIP_TRY(ctx, hipMemcpy2DAsync((void*)b.org[0], w, y, stride_y, w, h, hipMemcpyHostToDevice, cs));
+    HIP_TRY(ctx, hipMemcpy2DAsync((void*)b.org[1], w / 2, cb, stride_c, w / 2, h / 2, hipMemcpyHostToDevice, cs));
+    HIP_TRY(ctx, hipMemcpy2DAsync((void*)b.org[2], w / 2, cr, stride_c, w / 2, h / 2, hipMemcpyHostToDevice, cs));
+    ctx->uploads_pending = true;
     ctx->state[slot] = 1;
     return WRENC_GPU_OK;
 }
@@ -540,6 +565,11 @@ int wrenc_gpu_encode(wrenc_gpu_ctx* ctx, int first_slot, int n_pictures) {
         hipEvent_t e;
         HIP_TRY(ctx, hipEventCreate(&e));
         ctx->ev_pool.push_back(e);
+    }
+    if (ctx->uploads_pending) {
+        HIP_TRY(ctx, hipEventRecord(ctx->ev_uploaded, ctx->copy_stream));
+        HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_uploaded, 0));
+        ctx->uploads_pending = false;
     }
     HIP_TRY(ctx, hipEventRecord(ctx->ev_begin, ctx->stream));
     HIP_TRY(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
@@ -575,15 +605,22 @@ int wrenc_gpu_encode(wrenc_gpu_ctx* ctx, int first_slot, int n_pictures) {
         HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->lane_done[l - 1], 0));
     }
     HIP_TRY(ctx, hipEventRecord(ctx->ev_end, ctx->stream));
+    // downloads of these slots wait for this call only, not for searches queued after it
+    hipEvent_t done = ctx->enc_events[ctx->enc_event_next++ % ctx->enc_events.size()];
+    HIP_TRY(ctx, hipEventRecord(done, ctx->stream));
     ctx->last_launches = launches;
     ctx->stats_valid = true;
-    for (int s = first_slot; s < first_slot + n_pictures; ++s) ctx->state[s] = 2;
+    for (int s = first_slot; s < first_slot + n_pictures; ++s) {
+        ctx->state[s] = 2;
+        ctx->slot_event[s] = done;
+    }
     return WRENC_GPU_OK;
 }
 
 int wrenc_gpu_sync(wrenc_gpu_ctx* ctx) {
     if (!ctx) return WRENC_GPU_EINVAL;
     HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->copy_stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     for (hipStream_t st : ctx->lanes) HIP_TRY(ctx, hipStreamSynchronize(st));
     int ovf = 0;
@@ -601,18 +638,25 @@ int wrenc_gpu_download(wrenc_gpu_ctx* ctx, int slot, wrenc_gpu_picture* out) {
     const wrenc_gpu_config& c = ctx->cfg;
     uint8_t* rec[3] = {out->rec_y, out->rec_cb, out->rec_cr};
     int16_t* lev[3] = {out->lev_y, out->lev_cb, out->lev_cr};
+    // on the copy stream, behind the encode call that searched this slot and nothing later
+    hipStream_t cs = ctx->copy_stream;
+    if (ctx->slot_event[slot]) HIP_TRY(ctx, hipStreamWaitEvent(cs, ctx->slot_event[slot], 0));
     for (int k = 0; k < 3; ++k) {
-        if (rec[k]) HIP_TRY(ctx, hipMemcpyAsync(rec[k], b.rec[k], plane_bytes(c, k, 1), hipMemcpyDeviceToHost, ctx->stream));
-        if (lev[k]) HIP_TRY(ctx, hipMemcpyAsync(lev[k], b.lev[k], plane_bytes(c, k, 2), hipMemcpyDeviceToHost, ctx->stream));
+        if (rec[k]) HIP_TRY(ctx, hipMemcpyAsync(rec[k], b.rec[k], plane_bytes(c, k, 1), hipMemcpyDeviceToHost, cs));
+        if (lev[k]) HIP_TRY(ctx, hipMemcpyAsync(lev[k], b.lev[k], plane_bytes(c, k, 2), hipMemcpyDeviceToHost, cs));
     }
     const size_t n4 = (size_t)(c.width / 4) * (c.height / 4), n8 = (size_t)(c.width / 8) * (c.height / 8);
-    if (out->cu_log2_size) HIP_TRY(ctx, hipMemcpyAsync(out->cu_log2_size, b.cu_log2, n4, hipMemcpyDeviceToHost, ctx->stream));
-    if (out->luma_mode) HIP_TRY(ctx, hipMemcpyAsync(out->luma_mode, b.luma_mode, n4, hipMemcpyDeviceToHost, ctx->stream));
-    if (out->chroma_mode) HIP_TRY(ctx, hipMemcpyAsync(out->chroma_mode, b.chroma_mode, n8, hipMemcpyDeviceToHost, ctx->stream));
+    if (out->cu_log2_size) HIP_TRY(ctx, hipMemcpyAsync(out->cu_log2_size, b.cu_log2, n4, hipMemcpyDeviceToHost, cs));
+    if (out->luma_mode) HIP_TRY(ctx, hipMemcpyAsync(out->luma_mode, b.luma_mode, n4, hipMemcpyDeviceToHost, cs));
+    if (out->chroma_mode) HIP_TRY(ctx, hipMemcpyAsync(out->chroma_mode, b.chroma_mode, n8, hipMemcpyDeviceToHost, cs));
     if (out->ctu_cost)
         HIP_TRY(ctx, hipMemcpyAsync(out->ctu_cost, b.ctu_cost, sizeof(float) * ctx->ctu_cols * ctx->ctu_rows,
-                                    hipMemcpyDeviceToHost, ctx->stream));
-    return wrenc_gpu_sync(ctx);
+                                    hipMemcpyDeviceToHost, cs));
+    int ovf = 0;
+    HIP_TRY(ctx, hipMemcpyAsync(&ovf, ctx->d_overflow, sizeof(int), hipMemcpyDeviceToHost, cs));
+    HIP_TRY(ctx, hipStreamSynchronize(cs));
+    if (ovf) return fail(ctx, WRENC_GPU_ELEVEL, "a quantised level reached 1024 (reference panics: block_splitter.rs:453)");
+    return WRENC_GPU_OK;
 }
 
 int wrenc_gpu_encode_picture(wrenc_gpu_ctx* ctx, const uint8_t* y, const uint8_t* cb, const uint8_t* cr,

@@ -9,6 +9,11 @@ import os
 
 import numpy as np
 
+# The HIP runtime gives a process 4 hardware queues per device by default; the context uses 4 encode lanes
+# plus one copy stream, and the copy stream only overlaps the search if it has a queue of its own.  Must be
+# in the environment before the runtime initialises (first HIP call of the process).
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("WRENC_GPU_LIB", os.path.join(_HERE, "csrc", "libwrenc_gpu.so"))
 
@@ -159,9 +164,12 @@ class Encoder:
     def sync(self):
         self._check(self.lib.wrenc_gpu_sync(self.ctx))
 
-    def download(self, slot):
+    def download(self, slot, keys=None):
+        """All planes of the record, or only `keys` (the C ABI skips NULL pointers)."""
         out = alloc_picture(self.width, self.height)
-        pic = Picture(*[_p(out[k]) for k in _PIC_KEYS])
+        if keys is not None:
+            out = {k: v for k, v in out.items() if k in keys}
+        pic = Picture(*[_p(out[k]) if k in out else None for k in _PIC_KEYS])
         self._check(self.lib.wrenc_gpu_download(self.ctx, slot, C.byref(pic)))
         return out
 
