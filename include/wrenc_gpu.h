@@ -116,6 +116,12 @@ int wrenc_gpu_sync(wrenc_gpu_ctx* ctx);
  * read-back of one set overlaps the search of the other. */
 int wrenc_gpu_download(wrenc_gpu_ctx* ctx, int slot, wrenc_gpu_picture* out);
 
+/* Page-locked host memory for the planes handed to wrenc_gpu_upload / wrenc_gpu_download: transfers from
+ * and to it run at PCIe rate and truly asynchronously (pageable buffers are staged by the runtime at a
+ * fraction of that).  Optional: any host memory works.  Free with wrenc_gpu_free_host before destroy. */
+void* wrenc_gpu_alloc_host(wrenc_gpu_ctx* ctx, size_t bytes);
+void wrenc_gpu_free_host(wrenc_gpu_ctx* ctx, void* p);
+
 /* Convenience: upload + encode + download of a single picture through slot 0. */
 int wrenc_gpu_encode_picture(wrenc_gpu_ctx* ctx, const uint8_t* y, const uint8_t* cb,
                              const uint8_t* cr, wrenc_gpu_picture* out);

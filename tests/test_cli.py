@@ -1,5 +1,6 @@
-"""Command line (wrenc_amd/cli.py): the reference's options (main.rs:85-115) and its error behaviour
-(message on stderr, exit status 0: main.rs:127-133)."""
+"""Command lines (the native program wrenc_amd/csrc/host/wrenc and its Python twin wrenc_amd/cli.py): the
+reference's options (main.rs:85-115) and its error behaviour (message on stderr, exit status 0:
+main.rs:127-133)."""
 import os
 import subprocess
 import sys
@@ -12,40 +13,47 @@ from content import content
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _run(args, stdin=None):
-    return subprocess.run([sys.executable, "-m", "wrenc_amd.cli"] + args, cwd=ROOT, input=stdin, capture_output=True,
-                          timeout=600)
+NATIVE = os.path.join(ROOT, "wrenc_amd", "csrc", "host", "wrenc")
+FRONT_ENDS = ["native", "python"]
 
 
-def test_argument_errors_print_and_exit_zero(built, tmp_path):
+def _run(front, args, stdin=None):
+    cmd = [NATIVE] if front == "native" else [sys.executable, "-m", "wrenc_amd.cli"]
+    return subprocess.run(cmd + args, cwd=ROOT, input=stdin, capture_output=True, timeout=600)
+
+
+@pytest.mark.parametrize("front", FRONT_ENDS)
+def test_argument_errors_print_and_exit_zero(built, tmp_path, front):
     out = str(tmp_path / "o.vvc")
     base = ["-i", str(tmp_path / "missing.yuv"), "-o", out, "--num-pictures", "1", "--qp", "32"]
-    r = _run(base + ["--input-size", "64x64", "--output-size", "64by64"])
+    r = _run(front, base + ["--input-size", "64x64", "--output-size", "64by64"])
     assert r.returncode == 0 and b"error: Invalid output-size: 64by64" in r.stderr
-    r = _run(base + ["--input-size", "x", "--output-size", "64x64"])
+    r = _run(front, base + ["--input-size", "x", "--output-size", "64x64"])
     assert r.returncode == 0 and b"error: Invalid input-size: x" in r.stderr
-    r = _run(base + ["--input-size", "64x64", "--output-size", "64x64", "--extra-params", "a"])
+    r = _run(front, base + ["--input-size", "64x64", "--output-size", "64x64", "--extra-params", "a"])
     assert r.returncode == 0 and b"error: Invalid extra-params: a" in r.stderr
-    r = _run(base + ["--input-size", "64x64", "--output-size", "64x60"])
+    r = _run(front, base + ["--input-size", "64x64", "--output-size", "64x60"])
     assert r.returncode == 0 and b"multiple of the 32x32 CTU" in r.stderr
-    r = _run(base + ["--input-size", "64x64", "--output-size", "64x64"])
+    r = _run(front, base + ["--input-size", "64x64", "--output-size", "64x64"])
     assert r.returncode == 0 and b"error: failed to open input file" in r.stderr
     assert not os.path.exists(out) or os.path.getsize(out) == 0
 
 
-def test_without_a_gpu_the_command_fails_loudly(built, tmp_path):
+@pytest.mark.parametrize("front", FRONT_ENDS)
+def test_without_a_gpu_the_command_fails_loudly(built, tmp_path, front):
     import torch
     if torch.cuda.is_available():
         pytest.skip("a GPU is present")
     src = tmp_path / "in.yuv"
     src.write_bytes(bytes(64 * 64 * 3 // 2))
-    r = _run(["-i", str(src), "-o", str(tmp_path / "o.vvc"), "--input-size", "64x64", "--output-size", "64x64",
+    r = _run(front, ["-i", str(src), "-o", str(tmp_path / "o.vvc"), "--input-size", "64x64", "--output-size", "64x64",
               "--num-pictures", "1", "--qp", "32"])
     assert r.returncode == 0 and r.stderr.startswith(b"error: ")      # no CPU fallback
 
 
 @pytest.mark.gpu
-def test_encodes_a_sequence_like_the_reference_binary(built, tmp_path):
+@pytest.mark.parametrize("front", FRONT_ENDS)
+def test_encodes_a_sequence_like_the_reference_binary(built, tmp_path, front):
     """3 pictures through files, then 2 through stdin/stdout: the stream parses, every picture decodes to the
     record of a direct encode, and --reconst holds the decoder-side reconstruction (the reference's
     integration test compares exactly these two files)."""
@@ -56,7 +64,7 @@ def test_encodes_a_sequence_like_the_reference_binary(built, tmp_path):
     raw = b"".join(p.tobytes() for f in frames for p in f)
     src, out, rec = tmp_path / "in.yuv", tmp_path / "out.vvc", tmp_path / "rec.yuv"
     src.write_bytes(raw)
-    r = _run(["-i", str(src), "-o", str(out), "-r", str(rec), "--input-size", "%dx%d" % (w, h), "--output-size",
+    r = _run(front, ["-i", str(src), "-o", str(out), "-r", str(rec), "--input-size", "%dx%d" % (w, h), "--output-size",
               "%dx%d" % (w, h), "--num-pictures", "3", "--qp", str(qp), "--max-split-depth", str(depth), "--batch", "2"])
     assert r.returncode == 0 and r.stderr == b"", r.stderr
     stream = out.read_bytes()
@@ -77,13 +85,34 @@ def test_encodes_a_sequence_like_the_reference_binary(built, tmp_path):
         assert np.array_equal(got[w * h:w * h + w * h // 4], rcb.ravel())
         assert np.array_equal(got[w * h + w * h // 4:], rcr.ravel())
     enc.close()
-    r = _run(["-i", "-", "-o", "-", "--input-size", "%dx%d" % (w, h), "--output-size", "%dx%d" % (w, h),
+    r = _run(front, ["-i", "-", "-o", "-", "--input-size", "%dx%d" % (w, h), "--output-size", "%dx%d" % (w, h),
               "--num-pictures", "2", "--qp", str(qp), "--max-split-depth", str(depth)], stdin=raw)
     assert r.returncode == 0 and po.parse_stream_info(r.stdout)["n_pictures"] == 2
     two = po.parse_picture(r.stdout, 1)
     one = po.parse_picture(stream, 1)
     assert all(np.array_equal(two[k], one[k]) for k in ("lev_y", "luma_mode"))
     # input shorter than --num-pictures asks for
-    r = _run(["-i", str(src), "-o", str(out), "--input-size", "%dx%d" % (w, h), "--output-size", "%dx%d" % (w, h),
+    r = _run(front, ["-i", str(src), "-o", str(out), "--input-size", "%dx%d" % (w, h), "--output-size", "%dx%d" % (w, h),
               "--num-pictures", "4", "--qp", str(qp)])
     assert r.returncode == 0 and b"error: input ended after 3 of 4 pictures" in r.stderr
+
+
+@pytest.mark.gpu
+def test_native_and_python_front_ends_write_the_same_bytes(built, tmp_path):
+    """7 pictures in batches of 2 (both front ends alternate two sets of slots, the last batch is short) and
+    in one batch of 7: four identical streams and reconstructions."""
+    w, h = 64, 96
+    frames = [content(k, w, h, i) for i, k in enumerate(("cclm", "noise", "ramp", "checker", "stripes70", "flat", "extremes"))]
+    src = tmp_path / "in.yuv"
+    src.write_bytes(b"".join(p.tobytes() for f in frames for p in f))
+    outs = []
+    for front in FRONT_ENDS:
+        for batch in ("2", "7"):
+            out, rec = tmp_path / ("%s%s.vvc" % (front, batch)), tmp_path / ("%s%s.yuv" % (front, batch))
+            r = _run(front, ["-i", str(src), "-o", str(out), "-r", str(rec), "--input-size", "64x96", "--output-size", "64x96",
+                             "--num-pictures", "7", "--qp", "27", "--max-split-depth", "3", "--batch", batch, "--threads", "3"])
+            assert r.returncode == 0 and r.stderr == b"", r.stderr
+            outs.append((out.read_bytes(), rec.read_bytes()))
+    assert len(outs[0][0]) > 1000 and len(outs[0][1]) == 7 * w * h * 3 // 2
+    for o in outs[1:]:
+        assert o == outs[0]

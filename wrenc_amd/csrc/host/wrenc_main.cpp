@@ -1,0 +1,306 @@
+// wrenc_main.cpp -- the encoder as a native program with the reference's command line (main.rs:85-115).
+//
+//   wrenc -i in.yuv -o out.vvc --input-size 1920x1088 --output-size 1920x1088 --num-pictures 30
+//         --qp 32 --max-split-depth 2 [--reconst rec.yuv]
+//
+// Flow of main.rs:117-402 over the two C ABIs of this repository (include/wrenc_gpu.h for the search and
+// the final pass on the MI355X, include/wrenc_bitstream.h for everything written to the stream): VPS, SPS,
+// PPS once; then pictures in batches (they are independent IDR pictures, main.rs:296): read Y, Cb, Cr at
+// the output size, upload, search, read the record back, write picture header NAL + slice NAL, and the
+// reconstruction when asked for.  Two sets of device slots and of page-locked host buffers alternate, so
+// the GPU searches batch k+1 while batch k is read back and entropy coded on a pool of host threads.
+// `-` is stdin / stdout.  Every failure prints `error: ...` on stderr and exits with status 0, as the
+// reference does (main.rs:127-133).  Options the reference does not have: --batch, --threads, --device,
+// --verbose.  Links only against the two C ABIs: no HIP, no Python.
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../../include/wrenc_bitstream.h"
+#include "../../../include/wrenc_gpu.h"
+
+namespace {
+
+[[noreturn]] void die(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    fputs("error: ", stderr);
+    vfprintf(stderr, fmt, ap);
+    fputc('\n', stderr);
+    va_end(ap);
+    exit(0); // main.rs:132: process::exit(0) on every error
+}
+
+bool parse_size(const char* text, int& w, int& h) {
+    char tail = 0;
+    return sscanf(text, "%dx%d%c", &w, &h, &tail) == 2 && w > 0 && h > 0;
+}
+
+bool read_exact(FILE* f, uint8_t* dst, size_t n) {
+    size_t got = 0;
+    while (got < n) {
+        const size_t r = fread(dst + got, 1, n - got, f);
+        if (r == 0) return false;
+        got += r;
+    }
+    return true;
+}
+
+// A fixed set of worker threads running index ranges (the slices of one batch).
+class Pool {
+public:
+    explicit Pool(int n) {
+        for (int i = 0; i < n; ++i) threads_.emplace_back([this] { work(); });
+    }
+    ~Pool() {
+        {
+            std::lock_guard<std::mutex> g(m_);
+            stop_ = true;
+        }
+        cv_.notify_all();
+        for (std::thread& t : threads_) t.join();
+    }
+    // run fn(0..count-1) on the workers; returns at once
+    void start(int count, std::function<void(int)> fn) {
+        std::lock_guard<std::mutex> g(m_);
+        fn_ = std::move(fn);
+        count_ = count;
+        next_ = 0;
+        done_ = 0;
+        cv_.notify_all();
+    }
+    void wait() {
+        std::unique_lock<std::mutex> g(m_);
+        idle_.wait(g, [this] { return done_ == count_; });
+    }
+
+private:
+    void work() {
+        std::unique_lock<std::mutex> g(m_);
+        for (;;) {
+            cv_.wait(g, [this] { return stop_ || next_ < count_; });
+            if (stop_) return;
+            const int i = next_++;
+            g.unlock();
+            fn_(i);
+            g.lock();
+            if (++done_ == count_) idle_.notify_all();
+        }
+    }
+    std::vector<std::thread> threads_;
+    std::mutex m_;
+    std::condition_variable cv_, idle_;
+    std::function<void(int)> fn_;
+    int count_ = 0, next_ = 0, done_ = 0;
+    bool stop_ = false;
+};
+
+struct HostSet { // page-locked planes of one batch
+    uint8_t* in = nullptr;      // batch x (Y | Cb | Cr)
+    uint8_t* rec = nullptr;     // batch x (Y | Cb | Cr), only with --reconst
+    int16_t* lev = nullptr;     // batch x (Y | Cb | Cr) levels
+    uint8_t* maps = nullptr;    // batch x (cu_log2_size | luma_mode | chroma_mode)
+    std::vector<std::vector<uint8_t>> nal; // per picture
+    std::vector<int> status;
+    int count = 0, first_poc = 0;       // the batch being searched / read back in this set
+    int bs_count = 0, bs_first_poc = 0; // the batch whose slices are being written from this set
+};
+
+} // namespace
+
+int main(int argc, char** argv) {
+    const char *input = nullptr, *output = nullptr, *reconst = nullptr, *in_size = nullptr, *out_size = nullptr,
+               *extra = nullptr;
+    long num_pictures = -1;
+    int qp = 26; // ctu.rs:382 when --qp is absent
+    int depth = 3, batch = 64, n_threads = 8, device = 0;
+    bool verbose = false;
+    for (int i = 1; i < argc; ++i) {
+        const std::string a = argv[i];
+        const auto val = [&]() -> const char* {
+            if (i + 1 >= argc) die("option %s needs a value", a.c_str());
+            return argv[++i];
+        };
+        if (a == "-i" || a == "--input") input = val();
+        else if (a == "-o" || a == "--output") output = val();
+        else if (a == "-r" || a == "--reconst") reconst = val();
+        else if (a == "--input-size") in_size = val();
+        else if (a == "--output-size") out_size = val();
+        else if (a == "--num-pictures") num_pictures = atol(val());
+        else if (a == "--qp") qp = atoi(val());
+        else if (a == "--max-split-depth") depth = atoi(val());
+        else if (a == "--extra-params") extra = val();
+        else if (a == "--batch") batch = atoi(val());
+        else if (a == "--threads") n_threads = atoi(val());
+        else if (a == "--device") device = atoi(val());
+        else if (a == "--verbose") verbose = true;
+        else die("unknown option %s", a.c_str());
+    }
+    if (!input || !output || !in_size || !out_size || num_pictures < 0)
+        die("the following options are required: --input --output --input-size --output-size --num-pictures");
+    int w = 0, h = 0, iw = 0, ih = 0;
+    if (!parse_size(in_size, iw, ih)) die("Invalid input-size: %s", in_size); // parsed, otherwise unused (main.rs:164-174)
+    if (!parse_size(out_size, w, h)) die("Invalid output-size: %s", out_size);
+    if (extra) {
+        std::string e = extra;
+        size_t pos = 0;
+        while (pos <= e.size()) {
+            const size_t end = e.find(',', pos) == std::string::npos ? e.size() : e.find(',', pos);
+            const std::string item = e.substr(pos, end - pos);
+            if (item.find('=') == std::string::npos || item.find('=') != item.rfind('='))
+                die("Invalid extra-params: %s", extra);
+            pos = end + 1;
+        }
+        die("extra-params (the RD-model tuning knobs of block_splitter.rs:21-53,187-375) are not supported: this build "
+            "resolves the reference's default constants only");
+    }
+    if (w % 32 || h % 32) die("output-size must be a multiple of the 32x32 CTU (picture.rs:178-181): %dx%d", w, h);
+    if (qp < 0 || qp > 63 || depth < 0 || depth > 3) die("qp must be 0..63, max-split-depth 0..3");
+    if (batch < 1) batch = 1;
+    if (num_pictures > 0 && batch > num_pictures) batch = (int)num_pictures;
+    if (n_threads < 1) n_threads = 1;
+
+    FILE* fin = strcmp(input, "-") ? fopen(input, "rb") : stdin;
+    if (!fin) die("failed to open input file: %s", strerror(errno));
+    FILE* fout = strcmp(output, "-") ? fopen(output, "wb") : stdout;
+    if (!fout) die("failed to open output file: %s", strerror(errno));
+    FILE* frec = nullptr;
+    if (reconst && !(frec = fopen(reconst, "wb"))) die("failed to open reconst file: %s", strerror(errno));
+
+    const int halves = num_pictures > batch ? 2 : 1;
+    wrenc_gpu_config cfg;
+    if (wrenc_gpu_default_config(&cfg, w, h, qp, depth)) die("%s", wrenc_gpu_last_error(nullptr));
+    cfg.device = device;
+    cfg.n_slots = halves * batch;
+    wrenc_gpu_ctx* ctx = nullptr;
+    if (wrenc_gpu_create(&cfg, &ctx)) die("%s", wrenc_gpu_last_error(nullptr)); // no CPU path: fails without an MI355X
+    const auto gpu_check = [&](int rc) {
+        if (rc) die("%s", wrenc_gpu_last_error(ctx));
+    };
+
+    const size_t ysz = (size_t)w * h, csz = ysz / 4, pic = ysz + 2 * csz;
+    const size_t n4 = ysz / 16, n8 = ysz / 64, maps = 2 * n4 + n8;
+    std::vector<HostSet> sets((size_t)halves);
+    for (HostSet& s : sets) {
+        s.in = (uint8_t*)wrenc_gpu_alloc_host(ctx, pic * batch);
+        s.lev = (int16_t*)wrenc_gpu_alloc_host(ctx, pic * batch * sizeof(int16_t));
+        s.maps = (uint8_t*)wrenc_gpu_alloc_host(ctx, maps * batch);
+        if (frec) s.rec = (uint8_t*)wrenc_gpu_alloc_host(ctx, pic * batch);
+        if (!s.in || !s.lev || !s.maps || (frec && !s.rec)) die("%s", wrenc_gpu_last_error(ctx));
+        s.nal.resize((size_t)batch);
+        s.status.assign((size_t)batch, 0);
+    }
+
+    {
+        uint8_t hdr[512];
+        size_t n = 0;
+        if (wrenc_bs_write_parameter_sets(w, h, qp, hdr, sizeof(hdr), &n)) die("parameter sets do not fit");
+        fwrite(hdr, 1, n, fout);
+    }
+
+    const auto t_start = std::chrono::steady_clock::now();
+    long poc = 0, pictures = 0;
+    unsigned long long bytes = 0;
+    // read + upload the next batch into slot set `half` and start its search; returns the batch size
+    const auto submit = [&](int half) -> int {
+        HostSet& s = sets[(size_t)half];
+        s.count = 0;
+        s.first_poc = (int)poc;
+        for (int k = 0; k < batch && poc + k < num_pictures; ++k) {
+            uint8_t* p = s.in + pic * k;
+            if (!read_exact(fin, p, pic)) die("input ended after %ld of %ld pictures", poc + k, num_pictures);
+            gpu_check(wrenc_gpu_upload(ctx, half * batch + k, p, p + ysz, p + ysz + csz, (size_t)w, (size_t)w / 2));
+            ++s.count;
+        }
+        if (s.count) gpu_check(wrenc_gpu_encode(ctx, half * batch, s.count));
+        poc += s.count;
+        return s.count;
+    };
+    Pool pool(n_threads);
+    const size_t bound = wrenc_bs_picture_bound(w, h);
+    // slices of batch `half` on the pool; flush() collects them in picture order
+    const auto start_slices = [&](int half) {
+        HostSet& s = sets[(size_t)half];
+        s.bs_count = s.count;
+        s.bs_first_poc = s.first_poc;
+        pool.start(s.bs_count, [&s, w, h, qp, pic, ysz, csz, maps, n4, bound](int k) {
+            const uint8_t* m = s.maps + maps * k;
+            const int16_t* l = s.lev + pic * k;
+            const wrenc_bs_record rec = {m, m + n4, m + 2 * n4, l, l + ysz, l + ysz + csz};
+            std::vector<uint8_t>& out = s.nal[(size_t)k];
+            out.resize(bound);
+            size_t n = 0;
+            s.status[(size_t)k] = wrenc_bs_write_picture(w, h, qp, s.bs_first_poc + k, &rec, out.data(), out.size(), &n);
+            out.resize(s.status[(size_t)k] ? 0 : n);
+        });
+    };
+    const auto flush = [&](int half) {
+        HostSet& s = sets[(size_t)half];
+        pool.wait();
+        for (int k = 0; k < s.bs_count; ++k) {
+            if (s.status[(size_t)k]) die("wrenc_bs_write_picture failed with %d on picture %d", s.status[(size_t)k], s.bs_first_poc + k);
+            fwrite(s.nal[(size_t)k].data(), 1, s.nal[(size_t)k].size(), fout);
+            bytes += s.nal[(size_t)k].size();
+            if (frec) fwrite(s.rec + pic * k, 1, pic, frec); // main.rs:387-399
+        }
+        pictures += s.bs_count;
+    };
+
+    // Per batch k: start the search of k+1, read k back (waits for the search of k only), collect the slices
+    // of k-1 (they were written while k was searched), start the slices of k.  With --reconst the
+    // reconstruction planes of k-1 are written before the read-back of k+1 reuses their buffers.
+    int half = 0, pending = -1;
+    int n = num_pictures > 0 ? submit(0) : 0;
+    while (n) {
+        const int cur = half;
+        half = halves == 2 ? 1 - half : 0;
+        HostSet& s = sets[(size_t)cur];
+        const int done = s.count;
+        if (halves == 2)
+            n = poc < num_pictures ? submit(half) : 0;
+        else
+            gpu_check(wrenc_gpu_sync(ctx));
+        for (int k = 0; k < done; ++k) {
+            uint8_t* m = s.maps + maps * k;
+            int16_t* l = s.lev + pic * k;
+            uint8_t* r = frec ? s.rec + pic * k : nullptr;
+            wrenc_gpu_picture out = {r, r ? r + ysz : nullptr, r ? r + ysz + csz : nullptr, l, l + ysz, l + ysz + csz,
+                                     m, m + n4, m + 2 * n4, nullptr};
+            gpu_check(wrenc_gpu_download(ctx, cur * batch + k, &out));
+        }
+        if (pending >= 0) flush(pending);
+        start_slices(cur);
+        pending = cur;
+        if (halves == 1) { // a single set: nothing can overlap
+            flush(pending);
+            pending = -1;
+            n = poc < num_pictures ? submit(0) : 0;
+        }
+    }
+    if (pending >= 0) flush(pending);
+    fflush(fout);
+    if (frec) fclose(frec);
+    if (fout != stdout) fclose(fout);
+    if (verbose) {
+        const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
+        fprintf(stderr, "%ld pictures, %llu bytes, %.2f s, %.1f pictures/s (file to stream, %d host threads)\n", pictures,
+                bytes, dt, pictures / (dt > 0 ? dt : 1e-9), n_threads);
+    }
+    for (HostSet& s : sets) {
+        wrenc_gpu_free_host(ctx, s.in);
+        wrenc_gpu_free_host(ctx, s.lev);
+        wrenc_gpu_free_host(ctx, s.maps);
+        wrenc_gpu_free_host(ctx, s.rec);
+    }
+    wrenc_gpu_destroy(ctx);
+    return 0;
+}

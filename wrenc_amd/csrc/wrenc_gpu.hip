@@ -659,6 +659,20 @@ int wrenc_gpu_download(wrenc_gpu_ctx* ctx, int slot, wrenc_gpu_picture* out) {
     return WRENC_GPU_OK;
 }
 
+void* wrenc_gpu_alloc_host(wrenc_gpu_ctx* ctx, size_t bytes) {
+    if (!ctx || bytes == 0) return nullptr;
+    void* p = nullptr;
+    if (hipSetDevice(ctx->cfg.device) != hipSuccess || hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) {
+        (void)fail(ctx, WRENC_GPU_ENOMEM, "hipHostMalloc failed");
+        return nullptr;
+    }
+    return p;
+}
+
+void wrenc_gpu_free_host(wrenc_gpu_ctx* ctx, void* p) {
+    if (ctx && p) (void)hipHostFree(p);
+}
+
 int wrenc_gpu_encode_picture(wrenc_gpu_ctx* ctx, const uint8_t* y, const uint8_t* cb, const uint8_t* cr,
                              wrenc_gpu_picture* out) {
     if (!ctx) return WRENC_GPU_EINVAL;

@@ -20,7 +20,7 @@ LIB_PATH = os.environ.get("WRENC_GPU_LIB", os.path.join(_HERE, "csrc", "libwrenc
 EXPORTED_SYMBOLS = [
     "wrenc_gpu_default_config", "wrenc_gpu_create", "wrenc_gpu_destroy", "wrenc_gpu_last_error",
     "wrenc_gpu_upload", "wrenc_gpu_encode", "wrenc_gpu_sync", "wrenc_gpu_download",
-    "wrenc_gpu_encode_picture", "wrenc_gpu_last_encode_stats", "wrenc_gpu_final_pass_mismatches",
+    "wrenc_gpu_alloc_host", "wrenc_gpu_free_host", "wrenc_gpu_encode_picture", "wrenc_gpu_last_encode_stats", "wrenc_gpu_final_pass_mismatches",
     "wrenc_gpu_test_fwd_dct", "wrenc_gpu_test_inv_dct", "wrenc_gpu_test_quantize",
     "wrenc_gpu_test_dequantize",
 ]
