@@ -91,6 +91,13 @@ typedef struct wrenc_gpu_picture {
 int wrenc_gpu_default_config(wrenc_gpu_config* cfg, int width, int height, int qp,
                              int max_split_depth);
 
+/* Re-resolve cfg's tables with the reference's --extra-params string "K1=V1,K2=V2" (main.rs:202-217):
+ * the RD-model tuning knobs of block_splitter.rs:21-53,187-375,594-693,775 and quantizer.rs:16-19,650-683.
+ * Keys of the code path that is live (dependent quantisation + trellis) take effect; other keys are accepted
+ * and ignored, as in the reference.  WRENC_GPU_EINVAL (text in wrenc_gpu_last_error(NULL)) for an item that
+ * is not KEY=VALUE or a live key whose value is not a number.  NULL or "" gives the defaults again. */
+int wrenc_gpu_config_extra_params(wrenc_gpu_config* cfg, const char* extra_params);
+
 int wrenc_gpu_create(const wrenc_gpu_config* cfg, wrenc_gpu_ctx** out);
 void wrenc_gpu_destroy(wrenc_gpu_ctx* ctx);
 const char* wrenc_gpu_last_error(const wrenc_gpu_ctx* ctx); /* ctx may be NULL: create errors */

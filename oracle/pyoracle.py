@@ -55,6 +55,18 @@ def _p(a):
     return a.ctypes.data_as(C.c_void_p)
 
 
+def set_extra_params(text):
+    """The reference's --extra-params string for every later call in this process (None / "" = defaults)."""
+    rc = lib().wro_set_extra_params((text or "").encode())
+    if rc != 0:
+        raise ValueError("Invalid extra-params: %s" % text)
+
+
+def lambda_rd_chroma(qp):
+    lib().wro_lambda_rd_chroma.restype = C.c_float
+    return float(lib().wro_lambda_rd_chroma(int(qp)))
+
+
 def encode_picture(y, cb, cr, qp, max_split_depth):
     """Run search + final pass of one picture. Returns a dict of numpy arrays."""
     h, w = y.shape

@@ -16,7 +16,9 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <memory>
+#include <string>
 #include <vector>
 
 namespace {
@@ -157,22 +159,62 @@ struct RdConst {
     float cclm_mode_idx_offset = 2.1f;      // :336
     float non_cclm_offset = 0.89f;          // :352
     float cclm_offset = 0.53f;              // :368
+    float chroma_lambda_mul = 1.1282581f;   // :775-778: extra-param "a" replaces lambda_mul in the chroma cost
 };
 
+// --extra-params of the reference (main.rs:202-217): key -> text; read where the reference reads them
+static std::map<std::string, std::string> g_extra;
+static int g_extra_gen = 0; // bumped by wro_set_extra_params: cached constants are rebuilt
+static double xp_f64(const char* key, double dflt) {
+    auto it = g_extra.find(key);
+    return it == g_extra.end() ? dflt : strtod(it->second.c_str(), nullptr);
+}
+static float xp_f32(const char* key, float dflt) {
+    auto it = g_extra.find(key);
+    return it == g_extra.end() ? dflt : strtof(it->second.c_str(), nullptr);
+}
+
 static void init_rd(RdConst& r, int qp) {
+    r = RdConst();
     r.qp = qp;
-    const double lv_pow = 0.48592678233563835, lv_off = 0.15150746310196822;
+    // block_splitter.rs:29-52, quantizer.rs:16-21
+    const double lv_pow = xp_f64("lv_pow_dq_trellis", 0.48592678233563835);
+    const double lv_off = xp_f64("lv_offset_dq_trellis", 0.15150746310196822);
+    const double dq_pow = xp_f64("quant_lv_pow", 0.5004010166085378);
     for (int i = 0; i < 1024; ++i) {
         r.lv[i] = (int64_t)(std::pow((double)i + lv_off, lv_pow) * 16384.0);
-        r.dq[i] = (int64_t)std::pow((double)(i * 16384), 0.5004010166085378);
+        r.dq[i] = (int64_t)std::pow((double)(i * 16384), dq_pow);
     }
-    // quantizer.rs:683  (2.0f64.powf(qp/qp_div) * lambda_mul) as i64 + lambda_offset
-    r.lambda_q = (int64_t)(std::pow(2.0, (double)qp / 5.218413785332902) * 1.2709404305806742) + 11;
+    // quantizer.rs:650-683  (2.0f64.powf(qp/qp_div) * lambda_mul) as i64 + lambda_offset
+    const auto off = g_extra.find("quant_lambda_offset_trellis");
+    r.lambda_q = (int64_t)(std::pow(2.0, (double)qp / xp_f64("quant_qp_div_trellis", 5.218413785332902)) *
+                           xp_f64("quant_lambda_mul_trellis", 1.2709404305806742)) +
+                 (off == g_extra.end() ? 11 : strtoll(off->second.c_str(), nullptr, 10));
+    // block_splitter.rs:187-375,594-693: the dep-quant + trellis variants are the live ones
+    r.non_planar_offset = xp_f32("non_planar_offset_dq_trellis", r.non_planar_offset);
+    r.mpm_idx_offset = xp_f32("mpm_idx_offset_dq_trellis", r.mpm_idx_offset);
+    r.mpm_remainder_mult = xp_f32("mpm_remainder_mult_dq_trellis", r.mpm_remainder_mult);
+    r.mpm_remainder_offset = xp_f32("mpm_remainder_offset_dq_trellis", r.mpm_remainder_offset);
+    r.planar_offset = xp_f32("planer_offset_dq_trellis", r.planar_offset);
+    r.header_bits = xp_f32("header_bits_dq_trellis", r.header_bits);
+    r.chroma_header_bits = xp_f32("chroma_header_bits_dq_trellis", r.chroma_header_bits);
+    r.qp_div = xp_f32("qp_div_dq_trellis", r.qp_div);
+    r.lambda_mul = xp_f32("lambda_mul_dq_trellis", r.lambda_mul);
+    r.cclm_pow = xp_f32("cclm_pow", r.cclm_pow);
+    r.mpm_idx_pow = xp_f32("mpm_idx_pow", r.mpm_idx_pow);
+    r.mpm_remainder_pow = xp_f32("mpm_remainder_pow", r.mpm_remainder_pow);
+    r.cclm_mode_idx_offset = xp_f32("cclm_mode_idx_offset_dq_trellis", r.cclm_mode_idx_offset);
+    r.non_cclm_offset = xp_f32("non_cclm_offset_dq_trellis", r.non_cclm_offset);
+    r.cclm_offset = xp_f32("cclm_offset_dq_trellis", r.cclm_offset);
+    r.chroma_lambda_mul = xp_f32("a", r.lambda_mul);
 }
 
 // block_splitter.rs:472 / :775-778
 static inline float rd_lambda(const RdConst& r) {
     return std::pow(2.0f, (float)r.qp / r.qp_div) * r.lambda_mul;
+}
+static inline float rd_lambda_chroma(const RdConst& r) {
+    return std::pow(2.0f, (float)r.qp / r.qp_div) * r.chroma_lambda_mul;
 }
 
 // block_splitter.rs:377-406
@@ -1555,7 +1597,7 @@ struct Splitter {
         int64_t sum = 0;
         for (int c = 1; c < 3; ++c) sum += level_cost(p.rd, cu->lev[c].data(), ilog2(cu->csize(1)));
         const int64_t level = sum + hb;
-        const float lambda = rd_lambda(p.rd);
+        const float lambda = rd_lambda_chroma(p.rd);
         return trace_put(cu->x, cu->y, cu->w, ct->tree, 3, 0, m, (float)ssd + lambda * ((float)level / 16384.0f));
     }
 
@@ -1976,6 +2018,35 @@ int wro_reconstruct_from_record(const wro_params* prm, const wro_picture_out* re
 
 long wro_last_final_pass_mismatches(void) { return g_last_final_mismatch; }
 
+// main.rs:202-217: "K1=V1,K2=V2"; an empty string or NULL restores the defaults.  Returns 0, or -1 when an
+// item is not KEY=VALUE (the reference prints "Invalid extra-params" and exits).
+int wro_set_extra_params(const char* text) {
+    ++g_extra_gen;
+    g_extra.clear();
+    if (!text || !*text) return 0;
+    std::string t = text;
+    size_t pos = 0;
+    while (pos <= t.size()) {
+        size_t end = t.find(',', pos);
+        if (end == std::string::npos) end = t.size();
+        const std::string item = t.substr(pos, end - pos);
+        const size_t eq = item.find('=');
+        if (eq == std::string::npos || item.find('=', eq + 1) != std::string::npos) {
+            g_extra.clear();
+            return -1;
+        }
+        g_extra[item.substr(0, eq)] = item.substr(eq + 1);
+        pos = end + 1;
+    }
+    return 0;
+}
+
+float wro_lambda_rd_chroma(int qp) {
+    RdConst rd;
+    init_rd(rd, qp);
+    return rd_lambda_chroma(rd);
+}
+
 void wro_trace_enable(int on) {
     g_trace_on = on != 0;
     g_trace.clear();
@@ -2002,20 +2073,22 @@ void wro_inv_dct(const int16_t* deq, int log2n, int16_t* res) {
 void wro_quantize(const int16_t* coef, int log2n, int qp, int16_t* levels) {
     init_tables();
     static thread_local RdConst rd;
-    static thread_local int rd_qp = -1;
-    if (rd_qp != qp) {
+    static thread_local int rd_qp = -1, rd_gen = -1;
+    if (rd_qp != qp || rd_gen != g_extra_gen) {
         init_rd(rd, qp);
         rd_qp = qp;
+        rd_gen = g_extra_gen;
     }
     quantize(rd, coef, log2n, qp, levels);
 }
 void wro_quantize_viterbi(const int16_t* coef, int log2n, int qp, int16_t* levels) {
     init_tables();
     static thread_local RdConst rd;
-    static thread_local int rd_qp = -1;
-    if (rd_qp != qp) {
+    static thread_local int rd_qp = -1, rd_gen = -1;
+    if (rd_qp != qp || rd_gen != g_extra_gen) {
         init_rd(rd, qp);
         rd_qp = qp;
+        rd_gen = g_extra_gen;
     }
     quantize_viterbi(rd, coef, log2n, qp, levels);
 }
@@ -2025,10 +2098,10 @@ void wro_dequantize(const int16_t* levels, int log2n, int qp, int16_t* deq) {
 int64_t wro_level_cost(const int16_t* levels, int log2n) {
     init_tables();
     static thread_local RdConst rd;
-    static thread_local bool ready = false;
-    if (!ready) {
+    static thread_local int rd_gen = -1;
+    if (rd_gen != g_extra_gen) {
         init_rd(rd, 32);
-        ready = true;
+        rd_gen = g_extra_gen;
     }
     return level_cost(rd, levels, log2n);
 }
@@ -2043,13 +2116,13 @@ void wro_tables(int qp, int64_t* lv, int64_t* dq, int64_t* lambda_q, float* lamb
 int64_t wro_header_bits(int tree, int non_planar, int mpm_flag, int mpm_idx, int mpm_rem,
                         int cclm_flag, int cclm_idx) {
     RdConst rd;
-    rd.qp = 32;
+    init_rd(rd, 32);
     return header_bits_luma(rd, tree, non_planar != 0, mpm_flag != 0, mpm_idx, mpm_rem, cclm_flag != 0,
                             cclm_idx);
 }
 int64_t wro_chroma_header_bits(int cclm_flag, int cclm_idx) {
     RdConst rd;
-    rd.qp = 32;
+    init_rd(rd, 32);
     return header_bits_chroma(rd, cclm_flag != 0, cclm_idx);
 }
 void wro_dct64(int16_t* m) {

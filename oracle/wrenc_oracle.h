@@ -91,6 +91,12 @@ int64_t wro_header_bits(int tree, int non_planar, int mpm_flag, int mpm_idx,
 // chroma cost function header bits (block_splitter.rs:695-712)
 int64_t wro_chroma_header_bits(int cclm_flag, int cclm_idx);
 
+// --extra-params of the reference (main.rs:202-217; the RD-model knobs of block_splitter.rs:21-53,187-375,
+// 594-693,775 and quantizer.rs:16-19,650-683): applies to every later call in this process; NULL or ""
+// restores the defaults.  Returns -1 on an item that is not KEY=VALUE.
+int wro_set_extra_params(const char* text);
+float wro_lambda_rd_chroma(int qp);
+
 // Trace of every candidate evaluation of the search (block_splitter.rs:64-108, 110-474, 476-522,
 // 524-780): enable, run wro_encode_picture, read.  A record is 8 int32 words: x, y (luma, picture
 // coordinates of the CU), log2 size, tree type (0 single, 1 dual luma, 2 dual chroma), kind

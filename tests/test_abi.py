@@ -52,6 +52,50 @@ def test_default_config_matches_oracle_tables(built):
         assert hc[cc] == po.chroma_header_bits(int(cc > 0), max(cc - 1, 0))
 
 
+EXTRA = ("lv_pow_dq_trellis=0.52,lv_offset_dq_trellis=0.2,quant_lv_pow=0.49,quant_qp_div_trellis=5.0,"
+         "quant_lambda_mul_trellis=1.4,quant_lambda_offset_trellis=7,qp_div_dq_trellis=4.2,lambda_mul_dq_trellis=1.3,"
+         "non_planar_offset_dq_trellis=2.0,mpm_idx_offset_dq_trellis=1.5,mpm_remainder_mult_dq_trellis=0.6,"
+         "mpm_remainder_offset_dq_trellis=2.1,planer_offset_dq_trellis=1.1,header_bits_dq_trellis=1.0,"
+         "chroma_header_bits_dq_trellis=1.5,cclm_pow=0.5,mpm_idx_pow=0.45,mpm_remainder_pow=0.3,"
+         "cclm_mode_idx_offset_dq_trellis=2.4,non_cclm_offset_dq_trellis=0.7,cclm_offset_dq_trellis=0.6,a=0.9,"
+         "lv_pow_dq=0.1,header_bits=9.0,some_future_knob=1")
+
+
+def test_extra_params_resolve_like_the_oracle(built):
+    """--extra-params (main.rs:202-217): every live key moves the product's tables exactly as it moves the
+    oracle's; dead and unknown keys change nothing; malformed items are rejected."""
+    from wrenc_amd import gpu
+    from oracle import pyoracle as po
+    try:
+        for qp in (22, 32, 37):
+            po.set_extra_params(EXTRA)
+            cfg = gpu.default_config(64, 64, qp, 2, extra_params=EXTRA)
+            lv, dq, lq, lr = po.tables(qp)
+            assert np.array_equal(np.array(cfg.lv_table), lv) and np.array_equal(np.array(cfg.dq_table), dq)
+            assert cfg.lambda_q == lq and cfg.lambda_rd == lr
+            assert cfg.lambda_rd_chroma == po.lambda_rd_chroma(qp) != lr
+            hb = np.array(cfg.header_bits_luma).reshape(2, 4, 67)
+            for tree, cc, cls in [(0, 0, 0), (0, 0, 3), (0, 2, 40), (1, 0, 5), (1, 0, 66), (0, 3, 6), (0, 1, 1)]:
+                want = po.header_bits(tree, int(cls > 0), int(cls <= 5), cls - 1 if 1 <= cls <= 5 else 0,
+                                      cls - 6 if cls > 5 else 0, int(cc > 0), max(cc - 1, 0))
+                assert hb[tree, cc, cls] == want, (tree, cc, cls)
+            for cc in range(4):
+                assert cfg.header_bits_chroma[cc] == po.chroma_header_bits(int(cc > 0), max(cc - 1, 0))
+            default = gpu.default_config(64, 64, qp, 2)
+            assert cfg.lambda_q != default.lambda_q and cfg.lambda_rd != default.lambda_rd
+            assert not np.array_equal(np.array(cfg.lv_table), np.array(default.lv_table))
+            only_dead = gpu.default_config(64, 64, qp, 2, extra_params="lv_pow_dq=0.1,header_bits=9.0,x=y")
+            assert bytes(only_dead) == bytes(default)
+    finally:
+        po.set_extra_params(None)
+    for bad in ("a", "a=1=2", "qp_div_dq_trellis=abc", "a=1,,b=2", "quant_lambda_offset_trellis=1.5"):
+        with pytest.raises(gpu.WrencGpuError):
+            gpu.default_config(64, 64, 32, 2, extra_params=bad)
+    with pytest.raises(ValueError):
+        po.set_extra_params("novalue")
+    po.set_extra_params(None)
+
+
 def test_create_rejects_bad_arguments_and_never_falls_back(built):
     from wrenc_amd import gpu
     lib = gpu.load_library()

@@ -98,6 +98,31 @@ def test_encodes_a_sequence_like_the_reference_binary(built, tmp_path, front):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("front", FRONT_ENDS)
+def test_extra_params_reach_the_encoder(built, tmp_path, front):
+    from wrenc_amd import gpu
+    from oracle import pyoracle as po
+    w, h, qp = 64, 64, 30
+    f = content("noise", w, h, 2)
+    src = tmp_path / "in.yuv"
+    src.write_bytes(b"".join(p.tobytes() for p in f))
+    extra = "a=0.05,lambda_mul_dq_trellis=3.0,quant_lambda_mul_trellis=3.0,unknown_knob=3"
+    base = ["-i", str(src), "--input-size", "64x64", "--output-size", "64x64", "--num-pictures", "1", "--qp", str(qp)]
+    r = _run(front, base + ["-o", str(tmp_path / "x.vvc"), "--extra-params", extra])
+    assert r.returncode == 0 and r.stderr == b"", r.stderr
+    enc = gpu.Encoder(w, h, qp=qp, max_split_depth=3, extra_params=extra)
+    want = enc.encode_picture(*f)
+    enc.close()
+    back = po.parse_picture((tmp_path / "x.vvc").read_bytes(), 0)
+    for k in ("cu_log2_size", "luma_mode", "chroma_mode", "lev_y", "lev_cb", "lev_cr"):
+        assert np.array_equal(back[k], want[k]), k
+    r = _run(front, base + ["-o", str(tmp_path / "y.vvc")])
+    assert (tmp_path / "y.vvc").read_bytes() != (tmp_path / "x.vvc").read_bytes()
+    r = _run(front, base + ["-o", str(tmp_path / "z.vvc"), "--extra-params", "qp_div_dq_trellis=fast"])
+    assert r.returncode == 0 and r.stderr.startswith(b"error: ")
+
+
+@pytest.mark.gpu
 def test_native_and_python_front_ends_write_the_same_bytes(built, tmp_path):
     """7 pictures in batches of 2 (both front ends alternate two sets of slots, the last batch is short) and
     in one batch of 7: four identical streams and reconstructions."""

@@ -67,9 +67,7 @@ def main(argv=None):
     if a.extra_params:
         for item in a.extra_params.split(","):
             if len(item.split("=")) != 2:
-                _die("Invalid extra-params: %s" % a.extra_params)
-        _die("extra-params (the RD-model tuning knobs of block_splitter.rs:21-53,187-375) are not supported: "
-             "this build resolves the reference's default constants only")
+                _die("Invalid extra-params: %s" % a.extra_params)     # main.rs:205-215
     if w % 32 or h % 32:
         _die("output-size must be a multiple of the 32x32 CTU (picture.rs:178-181): %dx%d" % (w, h))
     if not 0 <= qp <= 63 or not 0 <= a.max_split_depth <= 3 or a.num_pictures < 0:
@@ -94,7 +92,8 @@ def main(argv=None):
     batch = max(1, min(a.batch, max(a.num_pictures, 1)))
     halves = 2 if a.num_pictures > batch else 1     # two sets of slots: one is searched while the other is read back
     try:
-        enc = gpu.Encoder(w, h, qp=qp, max_split_depth=a.max_split_depth, device=a.device, n_slots=halves * batch)
+        enc = gpu.Encoder(w, h, qp=qp, max_split_depth=a.max_split_depth, device=a.device, n_slots=halves * batch,
+                          extra_params=a.extra_params)
     except (gpu.WrencGpuError, ImportError, OSError) as e:
         _die(str(e))
 

@@ -160,8 +160,6 @@ int main(int argc, char** argv) {
                 die("Invalid extra-params: %s", extra);
             pos = end + 1;
         }
-        die("extra-params (the RD-model tuning knobs of block_splitter.rs:21-53,187-375) are not supported: this build "
-            "resolves the reference's default constants only");
     }
     if (w % 32 || h % 32) die("output-size must be a multiple of the 32x32 CTU (picture.rs:178-181): %dx%d", w, h);
     if (qp < 0 || qp > 63 || depth < 0 || depth > 3) die("qp must be 0..63, max-split-depth 0..3");
@@ -179,6 +177,7 @@ int main(int argc, char** argv) {
     const int halves = num_pictures > batch ? 2 : 1;
     wrenc_gpu_config cfg;
     if (wrenc_gpu_default_config(&cfg, w, h, qp, depth)) die("%s", wrenc_gpu_last_error(nullptr));
+    if (extra && wrenc_gpu_config_extra_params(&cfg, extra)) die("%s", wrenc_gpu_last_error(nullptr));
     cfg.device = device;
     cfg.n_slots = halves * batch;
     wrenc_gpu_ctx* ctx = nullptr;

@@ -327,6 +327,68 @@ int run_block_test(wrenc_gpu_ctx* ctx, const int16_t* in, int log2n, int count, 
 
 extern "C" {
 
+// The RD-model constants the reference reads from --extra-params, with its defaults for the live
+// (dependent quantisation + trellis) variants: block_splitter.rs:29-44,187-375,594-693,775 and
+// quantizer.rs:16-19,650-683.  Types follow the reference's parse::<f64> / <f32> / <i64>.
+struct RdParams {
+    double lv_pow = 0.48592678233563835, lv_offset = 0.15150746310196822;               // lv_dq_trellis_table
+    double quant_lv_pow = 0.5004010166085378;                                            // dq_table
+    double quant_qp_div = 5.218413785332902, quant_lambda_mul = 1.2709404305806742;      // lambda of the trellis
+    long long quant_lambda_offset = 11;
+    float qp_div = 4.4043665f, lambda_mul = 1.1282581f;
+    float non_planar_offset = 2.2153597f, mpm_idx_offset = 1.3660221f, mpm_remainder_mult = 0.5007182f,
+          mpm_remainder_offset = 2.2973304f, planar_offset = 0.9626864f, header_bits = 1.1772872f,
+          chroma_header_bits = 1.309252f, cclm_pow = 0.4587651f, mpm_idx_pow = 0.40271285f,
+          mpm_remainder_pow = 0.34385094f, cclm_mode_idx_offset = 2.1f, non_cclm_offset = 0.89f, cclm_offset = 0.53f;
+    bool has_a = false; // "a" replaces lambda_mul in the chroma cost function (block_splitter.rs:775-778)
+    float a = 0.0f;
+};
+
+static void resolve_config(wrenc_gpu_config* cfg, const RdParams& p) {
+    const int qp = cfg->qp;
+    // block_splitter.rs:29-53 (lv_dq_trellis), quantizer.rs:16-25
+    for (int i = 0; i < 1024; ++i) {
+        cfg->lv_table[i] = (int64_t)(std::pow((double)i + p.lv_offset, p.lv_pow) * 16384.0);
+        cfg->dq_table[i] = (int64_t)std::pow((double)(i * 16384), p.quant_lv_pow);
+    }
+    // quantizer.rs:650-683
+    cfg->lambda_q = (int64_t)(std::pow(2.0, (double)qp / p.quant_qp_div) * p.quant_lambda_mul) + p.quant_lambda_offset;
+    // block_splitter.rs:289-309,472
+    cfg->lambda_rd = std::pow(2.0f, (float)qp / p.qp_div) * p.lambda_mul;
+    cfg->lambda_rd_chroma = std::pow(2.0f, (float)qp / p.qp_div) * (p.has_a ? p.a : p.lambda_mul); // :775-778
+    // block_splitter.rs:187-406 (dep-quant + trellis variants)
+    for (int tree = 0; tree < 2; ++tree)
+        for (int cc = 0; cc < 4; ++cc)
+            for (int cls = 0; cls < 67; ++cls) {
+                float cclm_bits;
+                if (cc > 0)
+                    cclm_bits = p.cclm_offset + std::pow((float)(cc - 1) + p.cclm_mode_idx_offset, p.cclm_pow);
+                else if (tree == 1)
+                    cclm_bits = 0.0f;
+                else
+                    cclm_bits = p.non_cclm_offset;
+                float mode_bits;
+                if (cls == 0) {
+                    mode_bits = p.planar_offset;
+                } else {
+                    float t;
+                    if (cls <= 5)
+                        t = std::pow((float)(cls - 1) + p.mpm_idx_offset, p.mpm_idx_pow);
+                    else
+                        t = p.mpm_remainder_mult * std::pow((float)(cls - 6) + p.mpm_remainder_offset, p.mpm_remainder_pow);
+                    mode_bits = p.non_planar_offset + t;
+                }
+                mode_bits = mode_bits + cclm_bits;
+                const float hb = tree == 0 ? p.header_bits + mode_bits : p.header_bits / 3.0f + mode_bits;
+                cfg->header_bits_luma[tree][cc][cls] = (int64_t)(hb * 16384.0f);
+            }
+    for (int cc = 0; cc < 4; ++cc) {
+        const float mode_bits =
+            cc > 0 ? p.cclm_offset + std::pow((float)(cc - 1) + p.cclm_mode_idx_offset, p.cclm_pow) : p.non_cclm_offset;
+        cfg->header_bits_chroma[cc] = (int64_t)((p.chroma_header_bits + mode_bits) * 16384.0f);
+    }
+}
+
 int wrenc_gpu_default_config(wrenc_gpu_config* cfg, int width, int height, int qp, int max_split_depth) {
     if (!cfg) return WRENC_GPU_EINVAL;
     memset(cfg, 0, sizeof(*cfg));
@@ -336,53 +398,61 @@ int wrenc_gpu_default_config(wrenc_gpu_config* cfg, int width, int height, int q
     cfg->max_split_depth = max_split_depth;
     cfg->device = 0;
     cfg->n_slots = 1;
-    // block_splitter.rs:29-53 (lv_dq_trellis), quantizer.rs:16-25
-    for (int i = 0; i < 1024; ++i) {
-        cfg->lv_table[i] = (int64_t)(std::pow((double)i + 0.15150746310196822, 0.48592678233563835) * 16384.0);
-        cfg->dq_table[i] = (int64_t)std::pow((double)(i * 16384), 0.5004010166085378);
+    resolve_config(cfg, RdParams());
+    return WRENC_GPU_OK;
+}
+
+int wrenc_gpu_config_extra_params(wrenc_gpu_config* cfg, const char* extra_params) {
+    if (!cfg) return WRENC_GPU_EINVAL;
+    RdParams p;
+    const struct { const char* key; double* f64; float* f32; long long* i64; } live[] = {
+        {"lv_pow_dq_trellis", &p.lv_pow, nullptr, nullptr},
+        {"lv_offset_dq_trellis", &p.lv_offset, nullptr, nullptr},
+        {"quant_lv_pow", &p.quant_lv_pow, nullptr, nullptr},
+        {"quant_qp_div_trellis", &p.quant_qp_div, nullptr, nullptr},
+        {"quant_lambda_mul_trellis", &p.quant_lambda_mul, nullptr, nullptr},
+        {"quant_lambda_offset_trellis", nullptr, nullptr, &p.quant_lambda_offset},
+        {"qp_div_dq_trellis", nullptr, &p.qp_div, nullptr},
+        {"lambda_mul_dq_trellis", nullptr, &p.lambda_mul, nullptr},
+        {"non_planar_offset_dq_trellis", nullptr, &p.non_planar_offset, nullptr},
+        {"mpm_idx_offset_dq_trellis", nullptr, &p.mpm_idx_offset, nullptr},
+        {"mpm_remainder_mult_dq_trellis", nullptr, &p.mpm_remainder_mult, nullptr},
+        {"mpm_remainder_offset_dq_trellis", nullptr, &p.mpm_remainder_offset, nullptr},
+        {"planer_offset_dq_trellis", nullptr, &p.planar_offset, nullptr}, // sic
+        {"header_bits_dq_trellis", nullptr, &p.header_bits, nullptr},
+        {"chroma_header_bits_dq_trellis", nullptr, &p.chroma_header_bits, nullptr},
+        {"cclm_pow", nullptr, &p.cclm_pow, nullptr},
+        {"mpm_idx_pow", nullptr, &p.mpm_idx_pow, nullptr},
+        {"mpm_remainder_pow", nullptr, &p.mpm_remainder_pow, nullptr},
+        {"cclm_mode_idx_offset_dq_trellis", nullptr, &p.cclm_mode_idx_offset, nullptr},
+        {"non_cclm_offset_dq_trellis", nullptr, &p.non_cclm_offset, nullptr},
+        {"cclm_offset_dq_trellis", nullptr, &p.cclm_offset, nullptr},
+        {"a", nullptr, &p.a, nullptr},
+    };
+    const std::string text = extra_params ? extra_params : "";
+    size_t pos = 0;
+    while (!text.empty() && pos <= text.size()) {
+        size_t end = text.find(',', pos);
+        if (end == std::string::npos) end = text.size();
+        const std::string item = text.substr(pos, end - pos);
+        const size_t eq = item.find('=');
+        if (eq == std::string::npos || item.find('=', eq + 1) != std::string::npos)
+            return fail(nullptr, WRENC_GPU_EINVAL, "Invalid extra-params: " + text); // main.rs:205-215
+        const std::string key = item.substr(0, eq), val = item.substr(eq + 1);
+        for (const auto& l : live) {
+            if (key != l.key) continue;
+            char* rest = nullptr;
+            if (l.f64) *l.f64 = strtod(val.c_str(), &rest);
+            if (l.f32) *l.f32 = strtof(val.c_str(), &rest);
+            if (l.i64) *l.i64 = strtoll(val.c_str(), &rest, 10);
+            if (val.empty() || (rest && *rest)) // the reference's parse().unwrap() panics here
+                return fail(nullptr, WRENC_GPU_EINVAL, "extra-params: " + key + " has no numeric value: " + val);
+            if (key == "a") p.has_a = true;
+        }
+        // any other key is stored and never read by the live code path, as in the reference
+        pos = end + 1;
     }
-    // quantizer.rs:650-683
-    cfg->lambda_q = (int64_t)(std::pow(2.0, (double)qp / 5.218413785332902) * 1.2709404305806742) + 11;
-    // block_splitter.rs:289-309,472
-    const float qp_div = 4.4043665f, lambda_mul = 1.1282581f;
-    cfg->lambda_rd = std::pow(2.0f, (float)qp / qp_div) * lambda_mul;
-    cfg->lambda_rd_chroma = cfg->lambda_rd; // block_splitter.rs:775-778 without extra-param "a"
-    // block_splitter.rs:187-406 (dep-quant + trellis defaults)
-    const float non_planar_offset = 2.2153597f, mpm_idx_offset = 1.3660221f, mpm_remainder_mult = 0.5007182f,
-                mpm_remainder_offset = 2.2973304f, planar_offset = 0.9626864f, header_bits = 1.1772872f,
-                chroma_header_bits = 1.309252f, cclm_pow = 0.4587651f, mpm_idx_pow = 0.40271285f,
-                mpm_remainder_pow = 0.34385094f, cclm_mode_idx_offset = 2.1f, non_cclm_offset = 0.89f,
-                cclm_offset = 0.53f;
-    for (int tree = 0; tree < 2; ++tree)
-        for (int cc = 0; cc < 4; ++cc)
-            for (int cls = 0; cls < 67; ++cls) {
-                float cclm_bits;
-                if (cc > 0)
-                    cclm_bits = cclm_offset + std::pow((float)(cc - 1) + cclm_mode_idx_offset, cclm_pow);
-                else if (tree == 1)
-                    cclm_bits = 0.0f;
-                else
-                    cclm_bits = non_cclm_offset;
-                float mode_bits;
-                if (cls == 0) {
-                    mode_bits = planar_offset;
-                } else {
-                    float t;
-                    if (cls <= 5)
-                        t = std::pow((float)(cls - 1) + mpm_idx_offset, mpm_idx_pow);
-                    else
-                        t = mpm_remainder_mult * std::pow((float)(cls - 6) + mpm_remainder_offset, mpm_remainder_pow);
-                    mode_bits = non_planar_offset + t;
-                }
-                mode_bits = mode_bits + cclm_bits;
-                const float hb = tree == 0 ? header_bits + mode_bits : header_bits / 3.0f + mode_bits;
-                cfg->header_bits_luma[tree][cc][cls] = (int64_t)(hb * 16384.0f);
-            }
-    for (int cc = 0; cc < 4; ++cc) {
-        const float mode_bits =
-            cc > 0 ? cclm_offset + std::pow((float)(cc - 1) + cclm_mode_idx_offset, cclm_pow) : non_cclm_offset;
-        cfg->header_bits_chroma[cc] = (int64_t)((chroma_header_bits + mode_bits) * 16384.0f);
-    }
+    resolve_config(cfg, p);
     return WRENC_GPU_OK;
 }
 

@@ -18,7 +18,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("WRENC_GPU_LIB", os.path.join(_HERE, "csrc", "libwrenc_gpu.so"))
 
 EXPORTED_SYMBOLS = [
-    "wrenc_gpu_default_config", "wrenc_gpu_create", "wrenc_gpu_destroy", "wrenc_gpu_last_error",
+    "wrenc_gpu_default_config", "wrenc_gpu_config_extra_params", "wrenc_gpu_create", "wrenc_gpu_destroy", "wrenc_gpu_last_error",
     "wrenc_gpu_upload", "wrenc_gpu_encode", "wrenc_gpu_sync", "wrenc_gpu_download",
     "wrenc_gpu_alloc_host", "wrenc_gpu_free_host", "wrenc_gpu_encode_picture", "wrenc_gpu_last_encode_stats", "wrenc_gpu_final_pass_mismatches",
     "wrenc_gpu_test_fwd_dct", "wrenc_gpu_test_inv_dct", "wrenc_gpu_test_quantize",
@@ -87,11 +87,16 @@ def load_library():
     return _lib
 
 
-def default_config(width, height, qp, max_split_depth, device=0, n_slots=1):
+def default_config(width, height, qp, max_split_depth, device=0, n_slots=1, extra_params=None):
     cfg = Config()
-    rc = load_library().wrenc_gpu_default_config(C.byref(cfg), width, height, qp, max_split_depth)
+    lib = load_library()
+    rc = lib.wrenc_gpu_default_config(C.byref(cfg), width, height, qp, max_split_depth)
     if rc:
         raise WrencGpuError(rc, "default_config")
+    if extra_params:
+        rc = lib.wrenc_gpu_config_extra_params(C.byref(cfg), extra_params.encode())
+        if rc:
+            raise WrencGpuError(rc, lib.wrenc_gpu_last_error(None).decode())
     cfg.device = device
     cfg.n_slots = n_slots
     return cfg
@@ -124,10 +129,10 @@ class Encoder:
     """One context = one GPU.  Mirrors the picture-granular call surface a C++
     SliceEncoder::encode uses in place of the per-CTU split_ct loop."""
 
-    def __init__(self, width, height, qp=26, max_split_depth=3, device=0, n_slots=1, config=None):
+    def __init__(self, width, height, qp=26, max_split_depth=3, device=0, n_slots=1, config=None, extra_params=None):
         self.lib = load_library()
         self.cfg = config if config is not None else default_config(width, height, qp, max_split_depth,
-                                                                     device, n_slots)
+                                                                     device, n_slots, extra_params)
         self.width, self.height = self.cfg.width, self.cfg.height
         self.ctx = C.c_void_p()
         rc = self.lib.wrenc_gpu_create(C.byref(self.cfg), C.byref(self.ctx))
