@@ -579,7 +579,10 @@ __device__ __forceinline__ unsigned sad_list_angular(const Ctx& c, int comps, in
                                                      unsigned long long modes_lo, unsigned long long modes_hi) {
     unsigned acc = 0;
     const int my_mode = LANE < nmodes ? (int)(((LANE < 8 ? modes_lo : modes_hi) >> (8 * (LANE & 7))) & 255u) : kNoMode;
-    int16_t* tab = SH.r1;                   // [entry][blk][4n] projected references
+    // [entry][blk][4n] projected references as bytes, each XOR 0x80 (= ref - 128 as a signed byte) so that
+    // the interpolation filters run as one v_dot4_i32_i8 over four packed taps: sum(c * (ref - 128)) + 128 *
+    // sum(c), and both luma filters sum to 64, the chroma filter to 32
+    uint8_t* tab = (uint8_t*)SH.r1;
     uint32_t* ptab = (uint32_t*)SH.decw + 32; // [entry]: inv_angle (low half) | vertical << 16 | valid << 17
     uint32_t* ptab2 = (uint32_t*)SH.decw + 48; // [entry]: angle (low half) | flags << 16 | mode << 24
 #pragma unroll 1
@@ -648,7 +651,7 @@ __device__ __forceinline__ unsigned sad_list_angular(const Ctx& c, int comps, in
                 }
                 const int k = idx >= 0 ? min(idx, 2 * n) : max(min((M24(idx, inv_angle) + 256) >> 9, n), 0);
                 const bool from_above = (idx >= 0) == vertical;
-                tab[e] = SH.refs[k == 0 ? oL : (from_above ? oA + k - 1 : oL + k)];
+                tab[e] = (uint8_t)(SH.refs[k == 0 ? oL : (from_above ? oA + k - 1 : oL + k)] ^ 0x80);
             }
         }
         WSYNC();
@@ -680,19 +683,15 @@ __device__ __forceinline__ unsigned sad_list_angular(const Ctx& c, int comps, in
                 const int along = vertical ? y : x, across = vertical ? x : y;
                 const int i_idx = M24(along + 1, angle) >> 5;
                 const int i_fact = M24(along + 1, angle) & 31;
-                const int16_t* tap = tab + (((min(mi, 15) << cs) + blk) << lgs) + n + across + i_idx;
+                const int ta = (((min(mi, 15) << cs) + blk) << lgs) + n + across + i_idx; // taps = ref[across + i_idx + 0..3]
+                const uint32_t* tp = (const uint32_t*)(tab + (ta & ~3));
+                const int taps = (int)__builtin_amdgcn_alignbyte(tp[1], tp[0], ta & 3);
                 int v;
                 if (comp == 0) {
-                    const int w = *(const int*)&SHT.fc[i_fact][0];
-                    const int h = i_fact >> 1;
-                    const int f0 = filter_flag ? 16 - h : (int)(int8_t)w;
-                    const int f1 = filter_flag ? 32 - h : (int)(int8_t)(w >> 8);
-                    const int f2 = filter_flag ? 16 + h : (int)(int8_t)(w >> 16);
-                    const int f3 = filter_flag ? h : (w >> 24);
-                    const int a4 = M24(f0, tap[0]) + M24(f1, tap[1]) + M24(f2, tap[2]) + M24(f3, tap[3]);
-                    v = min(max((a4 + 32) >> 6, 0), 255);
+                    const int w = filter_flag ? 0x00102010 + (i_fact >> 1) * 0x0100FEFF : *(const int*)&SHT.fc[i_fact][0];
+                    v = min(max(__builtin_amdgcn_sdot4(w, taps, 8192 + 32, false) >> 6, 0), 255);
                 } else {
-                    v = (M24(32 - i_fact, tap[1]) + M24(i_fact, tap[2]) + 16) >> 5;
+                    v = __builtin_amdgcn_sdot4(((32 - i_fact) << 8) | (i_fact << 16), taps, 4096 + 16, false) >> 5;
                 }
                 if (kind != 0) { // PDPC, intra_predictor.rs:355-757; left[] = L+1, above[] = A
                     int rl = 0, rt = 0, wl = 0, wt = 0;
@@ -754,26 +753,15 @@ __device__ __forceinline__ unsigned sad_list_angular(const Ctx& c, int comps, in
                 const int along = vertical ? y : x, across = vertical ? x : y;
                 const int i_idx = M24(along + 1, angle) >> 5;
                 const int i_fact = M24(along + 1, angle) & 31;
-                const int16_t* tap = tab + (((mi << cs) + blk) << lgs) + n + across + i_idx; // tap[t] = ref[across + i_idx + t]
+                const int ta = (((mi << cs) + blk) << lgs) + n + across + i_idx; // taps = ref[across + i_idx + 0..3]
+                const uint32_t* tp = (const uint32_t*)(tab + (ta & ~3));
+                const int taps = (int)__builtin_amdgcn_alignbyte(tp[1], tp[0], ta & 3);
                 int v;
                 if (comp == 0) {
-                    int f0, f1, f2, f3;
-                    if (filter_flag) {
-                        f0 = 16 - (i_fact >> 1);
-                        f1 = 32 - (i_fact >> 1);
-                        f2 = 16 + (i_fact >> 1);
-                        f3 = i_fact >> 1;
-                    } else {
-                        const int w = *(const int*)&SHT.fc[i_fact][0];
-                        f0 = (int)(int8_t)w;
-                        f1 = (int)(int8_t)(w >> 8);
-                        f2 = (int)(int8_t)(w >> 16);
-                        f3 = w >> 24;
-                    }
-                    const int a4 = M24(f0, tap[0]) + M24(f1, tap[1]) + M24(f2, tap[2]) + M24(f3, tap[3]);
-                    v = min(max((a4 + 32) >> 6, 0), 255);
+                    const int w = filter_flag ? 0x00102010 + (i_fact >> 1) * 0x0100FEFF : *(const int*)&SHT.fc[i_fact][0];
+                    v = min(max(__builtin_amdgcn_sdot4(w, taps, 8192 + 32, false) >> 6, 0), 255);
                 } else {
-                    v = (M24(32 - i_fact, tap[1]) + M24(i_fact, tap[2]) + 16) >> 5;
+                    v = __builtin_amdgcn_sdot4(((32 - i_fact) << 8) | (i_fact << 16), taps, 4096 + 16, false) >> 5;
                 }
                 if (kind != 0) { // PDPC, intra_predictor.rs:355-757; left[] = L+1, above[] = A
                     int rl = 0, rt = 0, wl = 0, wt = 0;
