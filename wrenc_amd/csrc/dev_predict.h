@@ -436,8 +436,10 @@ __device__ __forceinline__ int predict(Ctx c, int comp, int tx, int ty, int tlg,
     // projection.  It lives in the upper half of r2 (no transform runs during a prediction), so
     // a sample's taps are consecutive LDS reads with no selects.
     const bool vertical = mode >= 34;
-    constexpr int RM0 = 1024, RMS = 104; // int16 index of the table in r2, stride per block
-    int16_t* rm = (int16_t*)SH.r2 + RM0;
+    // Bytes, each XOR 0x80 (ref - 128 as a signed byte): the filters run as one v_dot4_i32_i8 over four
+    // packed taps, see sad_list_angular.
+    constexpr int RM0 = 2048, RMS = 104; // byte offset of the table in r2, stride per block
+    uint8_t* rm = (uint8_t*)SH.r2 + RM0;
     {
         const int ne = 3 * n + 4;
         for (int e = LANE; e < nb * ne; e += 64) {
@@ -448,7 +450,7 @@ __device__ __forceinline__ int predict(Ctx c, int comp, int tx, int ty, int tlg,
             const int k = idx >= 0 ? min(idx, 2 * n) : max(min((M24(idx, inv_angle) + 256) >> 9, n), 0);
             const bool from_above = (idx >= 0) == vertical;
             // k == 0 is the corner (L[0]); above sample k - 1 = A[k - 1], left sample k - 1 = L[k]
-            rm[blk * RMS + ee] = SH.refs[k == 0 ? oL : (from_above ? oA + k - 1 : oL + k)];
+            rm[blk * RMS + ee] = (uint8_t)(SH.refs[k == 0 ? oL : (from_above ? oA + k - 1 : oL + k)] ^ 0x80);
         }
         WSYNC();
     }
@@ -464,26 +466,15 @@ __device__ __forceinline__ int predict(Ctx c, int comp, int tx, int ty, int tlg,
             const int along = vertical ? y : x, across = vertical ? x : y;
             const int i_idx = M24(along + 1, angle) >> 5;
             const int i_fact = M24(along + 1, angle) & 31;
-            const int16_t* tap = rm + blk * RMS + n + across + i_idx; // tap[t] = ref[across + i_idx + t]
+            const int ta = blk * RMS + n + across + i_idx; // taps = ref[across + i_idx + 0..3]
+            const uint32_t* tp = (const uint32_t*)(rm + (ta & ~3));
+            const int taps = (int)__builtin_amdgcn_alignbyte(tp[1], tp[0], ta & 3);
             if (comp == 0) {
-                int f0, f1, f2, f3;
-                if (filter_flag) {
-                    f0 = 16 - (i_fact >> 1);
-                    f1 = 32 - (i_fact >> 1);
-                    f2 = 16 + (i_fact >> 1);
-                    f3 = i_fact >> 1;
-                } else {
-                    const int w = *(const int*)&SHT.fc[i_fact][0];
-                    f0 = (int)(int8_t)w;
-                    f1 = (int)(int8_t)(w >> 8);
-                    f2 = (int)(int8_t)(w >> 16);
-                    f3 = w >> 24;
-                }
-                const int acc = M24(f0, tap[0]) + M24(f1, tap[1]) + M24(f2, tap[2]) + M24(f3, tap[3]);
-                v = min(max((acc + 32) >> 6, 0), 255);
+                const int w = filter_flag ? 0x00102010 + (i_fact >> 1) * 0x0100FEFF : *(const int*)&SHT.fc[i_fact][0];
+                v = min(max(__builtin_amdgcn_sdot4(w, taps, 8192 + 32, false) >> 6, 0), 255);
             } else {
-                // i_fact == 0 gives tap[1] itself; a convex combination of 8-bit samples needs no `& 0xFF`
-                v = (M24(32 - i_fact, tap[1]) + M24(i_fact, tap[2]) + 16) >> 5;
+                // i_fact == 0 gives the second tap itself; a convex combination of 8-bit samples needs no clamp
+                v = __builtin_amdgcn_sdot4(((32 - i_fact) << 8) | (i_fact << 16), taps, 4096 + 16, false) >> 5;
             }
         }
         if (do_pdpc) {
