@@ -13,7 +13,7 @@ KINDS = ["flat", "ramp", "stripes30", "stripes75", "stripes120", "stripes165", "
 
 
 def _case(seed):
-    from test_gpu_content import _content
+    from content import content as _content
     rng = np.random.default_rng(1000 + seed)
     w, h = 32 * int(rng.integers(1, 6)), 32 * int(rng.integers(1, 5))
     qp, depth = int(rng.integers(18, 52)), int(rng.integers(0, 4))
@@ -58,3 +58,11 @@ def test_random_case_matches_oracle(built, seed):
             bad = np.argwhere(got[k] != ref[k])
             raise AssertionError("seed %d %dx%d qp%d d%d: %s differs at %d positions, first %s" % (
                 seed, w, h, qp, depth, k, len(bad), bad[0]))
+    # and through the host bitstream writer: the stream decodes to the same record and reconstruction
+    from wrenc_amd import bitstream as bs
+    stream = bs.write_parameter_sets(w, h, qp) + bs.write_picture(w, h, qp, seed, got)
+    back = po.parse_picture(stream, 0)
+    for k in ("cu_log2_size", "luma_mode", "chroma_mode", "lev_y", "lev_cb", "lev_cr"):
+        assert np.array_equal(back[k], got[k]), (seed, k)
+    ry, rcb, rcr = po.reconstruct_from_record(back, qp)
+    assert np.array_equal(ry, got["rec_y"]) and np.array_equal(rcb, got["rec_cb"]) and np.array_equal(rcr, got["rec_cr"])
