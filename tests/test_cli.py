@@ -138,6 +138,17 @@ def test_native_and_python_front_ends_write_the_same_bytes(built, tmp_path):
                              "--num-pictures", "7", "--qp", "27", "--max-split-depth", "3", "--batch", batch, "--threads", "3"])
             assert r.returncode == 0 and r.stderr == b"", r.stderr
             outs.append((out.read_bytes(), rec.read_bytes()))
+    # the native program over two contexts (here both on device 0: batches alternate between them)
+    for batch in ("1", "2", "3"):
+        out, rec = tmp_path / ("multi%s.vvc" % batch), tmp_path / ("multi%s.yuv" % batch)
+        r = _run("native", ["-i", str(src), "-o", str(out), "-r", str(rec), "--input-size", "64x96", "--output-size", "64x96",
+                            "--num-pictures", "7", "--qp", "27", "--max-split-depth", "3", "--batch", batch, "--devices", "0,0",
+                            "--verbose"])
+        assert r.returncode == 0 and b"2 GPU context(s)" in r.stderr, r.stderr
+        outs.append((out.read_bytes(), rec.read_bytes()))
     assert len(outs[0][0]) > 1000 and len(outs[0][1]) == 7 * w * h * 3 // 2
     for o in outs[1:]:
         assert o == outs[0]
+    r = _run("native", ["-i", str(src), "-o", str(tmp_path / "x.vvc"), "--input-size", "64x96", "--output-size", "64x96",
+                        "--num-pictures", "7", "--devices", "0,x"])
+    assert r.returncode == 0 and b"error: Invalid devices: 0,x" in r.stderr

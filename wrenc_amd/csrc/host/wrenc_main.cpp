@@ -11,7 +11,7 @@
 // the GPU searches batch k+1 while batch k is read back and entropy coded on a pool of host threads.
 // `-` is stdin / stdout.  Every failure prints `error: ...` on stderr and exits with status 0, as the
 // reference does (main.rs:127-133).  Options the reference does not have: --batch, --threads, --device,
-// --verbose.  Links only against the two C ABIs: no HIP, no Python.
+// --devices (several GPUs of the node, batches in turn), --verbose.  Links only against the two C ABIs: no HIP, no Python.
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
@@ -104,7 +104,9 @@ private:
     bool stop_ = false;
 };
 
-struct HostSet { // page-locked planes of one batch
+struct HostSet { // one (device, slot set) unit: page-locked planes of one batch
+    wrenc_gpu_ctx* ctx = nullptr;
+    int base = 0;               // first slot of the set in its context
     uint8_t* in = nullptr;      // batch x (Y | Cb | Cr)
     uint8_t* rec = nullptr;     // batch x (Y | Cb | Cr), only with --reconst
     int16_t* lev = nullptr;     // batch x (Y | Cb | Cr) levels
@@ -124,6 +126,7 @@ int main(int argc, char** argv) {
     int qp = 26; // ctu.rs:382 when --qp is absent
     int depth = 3, batch = 64, n_threads = 8, device = 0;
     bool verbose = false;
+    const char* device_list = nullptr;
     for (int i = 1; i < argc; ++i) {
         const std::string a = argv[i];
         const auto val = [&]() -> const char* {
@@ -142,6 +145,7 @@ int main(int argc, char** argv) {
         else if (a == "--batch") batch = atoi(val());
         else if (a == "--threads") n_threads = atoi(val());
         else if (a == "--device") device = atoi(val());
+        else if (a == "--devices") device_list = val();
         else if (a == "--verbose") verbose = true;
         else die("unknown option %s", a.c_str());
     }
@@ -166,6 +170,17 @@ int main(int argc, char** argv) {
     if (batch < 1) batch = 1;
     if (num_pictures > 0 && batch > num_pictures) batch = (int)num_pictures;
     if (n_threads < 1) n_threads = 1;
+    std::vector<int> devices;
+    if (device_list) { // "0,1,2,3": HIP device ordinals, one context each (an ordinal may repeat)
+        for (const char* p = device_list; *p;) {
+            char* end = nullptr;
+            const long d = strtol(p, &end, 10);
+            if (end == p || d < 0 || (*end && *end != ',')) die("Invalid devices: %s", device_list);
+            devices.push_back((int)d);
+            p = *end ? end + 1 : end;
+        }
+    }
+    if (devices.empty()) devices.push_back(device);
 
     FILE* fin = strcmp(input, "-") ? fopen(input, "rb") : stdin;
     if (!fin) die("failed to open input file: %s", strerror(errno));
@@ -174,30 +189,42 @@ int main(int argc, char** argv) {
     FILE* frec = nullptr;
     if (reconst && !(frec = fopen(reconst, "wb"))) die("failed to open reconst file: %s", strerror(errno));
 
-    const int halves = num_pictures > batch ? 2 : 1;
+    // One context per entry of --devices (default: --device).  Every context gets two sets of slots; a (device,
+    // set) pair is a "unit", and batches go to the units in turn: d0/s0, d1/s0, .., d0/s1, d1/s1, .. so that
+    // consecutive batches run on different GPUs and every GPU always has a batch queued behind the one it is
+    // searching.  Pictures are independent IDRs (main.rs:296): no data moves between GPUs.
+    const int n_dev = (int)devices.size();
+    const int per_dev = num_pictures > (long)batch * n_dev ? 2 : 1;
     wrenc_gpu_config cfg;
     if (wrenc_gpu_default_config(&cfg, w, h, qp, depth)) die("%s", wrenc_gpu_last_error(nullptr));
     if (extra && wrenc_gpu_config_extra_params(&cfg, extra)) die("%s", wrenc_gpu_last_error(nullptr));
-    cfg.device = device;
-    cfg.n_slots = halves * batch;
-    wrenc_gpu_ctx* ctx = nullptr;
-    if (wrenc_gpu_create(&cfg, &ctx)) die("%s", wrenc_gpu_last_error(nullptr)); // no CPU path: fails without an MI355X
-    const auto gpu_check = [&](int rc) {
-        if (rc) die("%s", wrenc_gpu_last_error(ctx));
-    };
+    cfg.n_slots = per_dev * batch;
+    std::vector<wrenc_gpu_ctx*> ctxs;
+    for (int d : devices) {
+        cfg.device = d;
+        wrenc_gpu_ctx* ctx = nullptr;
+        if (wrenc_gpu_create(&cfg, &ctx)) die("%s", wrenc_gpu_last_error(nullptr)); // no CPU path: fails without an MI355X
+        ctxs.push_back(ctx);
+    }
 
     const size_t ysz = (size_t)w * h, csz = ysz / 4, pic = ysz + 2 * csz;
     const size_t n4 = ysz / 16, n8 = ysz / 64, maps = 2 * n4 + n8;
-    std::vector<HostSet> sets((size_t)halves);
-    for (HostSet& s : sets) {
-        s.in = (uint8_t*)wrenc_gpu_alloc_host(ctx, pic * batch);
-        s.lev = (int16_t*)wrenc_gpu_alloc_host(ctx, pic * batch * sizeof(int16_t));
-        s.maps = (uint8_t*)wrenc_gpu_alloc_host(ctx, maps * batch);
-        if (frec) s.rec = (uint8_t*)wrenc_gpu_alloc_host(ctx, pic * batch);
-        if (!s.in || !s.lev || !s.maps || (frec && !s.rec)) die("%s", wrenc_gpu_last_error(ctx));
+    std::vector<HostSet> units((size_t)(per_dev * n_dev));
+    for (size_t u = 0; u < units.size(); ++u) {
+        HostSet& s = units[u];
+        s.ctx = ctxs[u % (size_t)n_dev];
+        s.base = (int)(u / (size_t)n_dev) * batch;
+        s.in = (uint8_t*)wrenc_gpu_alloc_host(s.ctx, pic * batch);
+        s.lev = (int16_t*)wrenc_gpu_alloc_host(s.ctx, pic * batch * sizeof(int16_t));
+        s.maps = (uint8_t*)wrenc_gpu_alloc_host(s.ctx, maps * batch);
+        if (frec) s.rec = (uint8_t*)wrenc_gpu_alloc_host(s.ctx, pic * batch);
+        if (!s.in || !s.lev || !s.maps || (frec && !s.rec)) die("%s", wrenc_gpu_last_error(s.ctx));
         s.nal.resize((size_t)batch);
         s.status.assign((size_t)batch, 0);
     }
+    const auto gpu_check = [](HostSet& s, int rc) {
+        if (rc) die("%s", wrenc_gpu_last_error(s.ctx));
+    };
 
     {
         uint8_t hdr[512];
@@ -209,26 +236,23 @@ int main(int argc, char** argv) {
     const auto t_start = std::chrono::steady_clock::now();
     long poc = 0, pictures = 0;
     unsigned long long bytes = 0;
-    // read + upload the next batch into slot set `half` and start its search; returns the batch size
-    const auto submit = [&](int half) -> int {
-        HostSet& s = sets[(size_t)half];
+    // read + upload the next batch into the unit's slots and start its search (asynchronous)
+    const auto submit = [&](HostSet& s) {
         s.count = 0;
         s.first_poc = (int)poc;
         for (int k = 0; k < batch && poc + k < num_pictures; ++k) {
             uint8_t* p = s.in + pic * k;
             if (!read_exact(fin, p, pic)) die("input ended after %ld of %ld pictures", poc + k, num_pictures);
-            gpu_check(wrenc_gpu_upload(ctx, half * batch + k, p, p + ysz, p + ysz + csz, (size_t)w, (size_t)w / 2));
+            gpu_check(s, wrenc_gpu_upload(s.ctx, s.base + k, p, p + ysz, p + ysz + csz, (size_t)w, (size_t)w / 2));
             ++s.count;
         }
-        if (s.count) gpu_check(wrenc_gpu_encode(ctx, half * batch, s.count));
+        if (s.count) gpu_check(s, wrenc_gpu_encode(s.ctx, s.base, s.count));
         poc += s.count;
-        return s.count;
     };
     Pool pool(n_threads);
     const size_t bound = wrenc_bs_picture_bound(w, h);
-    // slices of batch `half` on the pool; flush() collects them in picture order
-    const auto start_slices = [&](int half) {
-        HostSet& s = sets[(size_t)half];
+    // slices of the unit's batch on the pool; flush() collects them in picture order
+    const auto start_slices = [&](HostSet& s) {
         s.bs_count = s.count;
         s.bs_first_poc = s.first_poc;
         pool.start(s.bs_count, [&s, w, h, qp, pic, ysz, csz, maps, n4, bound](int k) {
@@ -242,8 +266,7 @@ int main(int argc, char** argv) {
             out.resize(s.status[(size_t)k] ? 0 : n);
         });
     };
-    const auto flush = [&](int half) {
-        HostSet& s = sets[(size_t)half];
+    const auto flush = [&](HostSet& s) {
         pool.wait();
         for (int k = 0; k < s.bs_count; ++k) {
             if (s.status[(size_t)k]) die("wrenc_bs_write_picture failed with %d on picture %d", s.status[(size_t)k], s.bs_first_poc + k);
@@ -254,52 +277,49 @@ int main(int argc, char** argv) {
         pictures += s.bs_count;
     };
 
-    // Per batch k: start the search of k+1, read k back (waits for the search of k only), collect the slices
-    // of k-1 (they were written while k was searched), start the slices of k.  With --reconst the
-    // reconstruction planes of k-1 are written before the read-back of k+1 reuses their buffers.
-    int half = 0, pending = -1;
-    int n = num_pictures > 0 ? submit(0) : 0;
-    while (n) {
-        const int cur = half;
-        half = halves == 2 ? 1 - half : 0;
-        HostSet& s = sets[(size_t)cur];
-        const int done = s.count;
-        if (halves == 2)
-            n = poc < num_pictures ? submit(half) : 0;
-        else
-            gpu_check(wrenc_gpu_sync(ctx));
-        for (int k = 0; k < done; ++k) {
+    // Fill every unit, then go round: read the oldest batch back (waits for its search only), collect the
+    // slices of the batch before it (written meanwhile), start this batch's slices, and give the unit the next
+    // batch.  With --reconst the planes of a batch are written out before its unit is read back into again.
+    for (HostSet& s : units)
+        if (poc < num_pictures) submit(s);
+    HostSet* pending = nullptr;
+    for (size_t head = 0; units[head].count > 0; head = (head + 1) % units.size()) {
+        HostSet& s = units[head];
+        for (int k = 0; k < s.count; ++k) {
             uint8_t* m = s.maps + maps * k;
             int16_t* l = s.lev + pic * k;
             uint8_t* r = frec ? s.rec + pic * k : nullptr;
             wrenc_gpu_picture out = {r, r ? r + ysz : nullptr, r ? r + ysz + csz : nullptr, l, l + ysz, l + ysz + csz,
                                      m, m + n4, m + 2 * n4, nullptr};
-            gpu_check(wrenc_gpu_download(ctx, cur * batch + k, &out));
+            gpu_check(s, wrenc_gpu_download(s.ctx, s.base + k, &out));
         }
-        if (pending >= 0) flush(pending);
-        start_slices(cur);
-        pending = cur;
-        if (halves == 1) { // a single set: nothing can overlap
-            flush(pending);
-            pending = -1;
-            n = poc < num_pictures ? submit(0) : 0;
+        if (pending) flush(*pending);
+        start_slices(s);
+        pending = &s;
+        s.count = 0;
+        if (poc < num_pictures) {
+            if (units.size() == 1) { // a single unit: its slices must be out before its buffers are refilled
+                flush(s);
+                pending = nullptr;
+            }
+            submit(s);
         }
     }
-    if (pending >= 0) flush(pending);
+    if (pending) flush(*pending);
     fflush(fout);
     if (frec) fclose(frec);
     if (fout != stdout) fclose(fout);
     if (verbose) {
         const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
-        fprintf(stderr, "%ld pictures, %llu bytes, %.2f s, %.1f pictures/s (file to stream, %d host threads)\n", pictures,
-                bytes, dt, pictures / (dt > 0 ? dt : 1e-9), n_threads);
+        fprintf(stderr, "%ld pictures, %llu bytes, %.2f s, %.1f pictures/s (file to stream, %d GPU context(s), %d host threads)\n",
+                pictures, bytes, dt, pictures / (dt > 0 ? dt : 1e-9), n_dev, n_threads);
     }
-    for (HostSet& s : sets) {
-        wrenc_gpu_free_host(ctx, s.in);
-        wrenc_gpu_free_host(ctx, s.lev);
-        wrenc_gpu_free_host(ctx, s.maps);
-        wrenc_gpu_free_host(ctx, s.rec);
+    for (HostSet& s : units) {
+        wrenc_gpu_free_host(s.ctx, s.in);
+        wrenc_gpu_free_host(s.ctx, s.lev);
+        wrenc_gpu_free_host(s.ctx, s.maps);
+        wrenc_gpu_free_host(s.ctx, s.rec);
     }
-    wrenc_gpu_destroy(ctx);
+    for (wrenc_gpu_ctx* ctx : ctxs) wrenc_gpu_destroy(ctx);
     return 0;
 }
