@@ -331,3 +331,17 @@ def test_parser_rejects_damaged_streams(built):
         assert any(not np.array_equal(back[k], rec[k]) for k in REC_KEYS)
     except ValueError:
         pass
+
+
+def test_streams_match_the_recorded_hashes(built):
+    """Regression pin (tests/golden/make_stream_hashes.py): the bytes written for eight oracle records have
+    not changed since they were recorded."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_stream_hashes", os.path.join(ROOT, "tests", "golden", "make_stream_hashes.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    want = json.load(open(os.path.join(ROOT, "tests", "golden", "stream_hashes.json")))
+    assert len(want) == len(mod.CASES)
+    for case in mod.CASES:
+        sha, n = mod.stream_hash(*case)
+        assert want["%s_%dx%d_qp%d_d%d" % case] == {"sha256": sha, "bytes": n}, case
