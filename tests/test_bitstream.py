@@ -279,7 +279,16 @@ def test_error_paths(built):
         bs.write_parameter_sets(64, 60, 32)
     y, cb, cr = content("noise", 32, 32, 3)
     rec = po.encode_picture(y, cb, cr, 30, 3)
-    assert len(bs.write_picture(32, 32, 30, 0, rec)) > 20
+    whole = bs.write_picture(32, 32, 30, 0, rec)
+    assert len(whole) > 20
+    # too small a buffer: the size that is needed comes back, and a buffer of that size is enough
+    arrs = [np.ascontiguousarray(rec[k]) for k in REC_KEYS]
+    r = bs._Record(*[a.ctypes.data for a in arrs])
+    small = np.zeros(len(whole), np.uint8)
+    assert lib.wrenc_bs_write_picture(32, 32, 30, 0, C.byref(r), small.ctypes.data, 10, C.byref(n)) == bs.ENOSPC
+    assert n.value == len(whole)
+    assert lib.wrenc_bs_write_picture(32, 32, 30, 0, C.byref(r), small.ctypes.data, n.value, C.byref(n)) == bs.OK
+    assert small.tobytes() == whole
     with pytest.raises(ValueError):
         bs.write_picture(64, 32, 30, 0, rec)             # planes of the wrong shape
     # a level whose parity contradicts the quantiser state (the reference asserts, ctu_encoder.rs:1975)

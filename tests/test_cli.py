@@ -149,6 +149,13 @@ def test_native_and_python_front_ends_write_the_same_bytes(built, tmp_path):
     assert len(outs[0][0]) > 1000 and len(outs[0][1]) == 7 * w * h * 3 // 2
     for o in outs[1:]:
         assert o == outs[0]
+    # no pictures: the parameter sets alone
+    for front in FRONT_ENDS:
+        r = _run(front, ["-i", str(src), "-o", str(tmp_path / "e.vvc"), "--input-size", "64x96", "--output-size", "64x96",
+                         "--num-pictures", "0", "--qp", "27"])
+        assert r.returncode == 0 and r.stderr == b"", r.stderr
+        assert (tmp_path / "e.vvc").read_bytes() == outs[0][0][:len((tmp_path / "e.vvc").read_bytes())]
+        assert 60 < len((tmp_path / "e.vvc").read_bytes()) < 200
     r = _run("native", ["-i", str(src), "-o", str(tmp_path / "x.vvc"), "--input-size", "64x96", "--output-size", "64x96",
                         "--num-pictures", "7", "--devices", "0,x"])
     assert r.returncode == 0 and b"error: Invalid devices: 0,x" in r.stderr

@@ -79,10 +79,16 @@ def write_picture(width, height, qp, poc, rec):
             _plane(rec, "chroma_mode", (h // 8, w // 8), np.uint8), _plane(rec, "lev_y", (h, w), np.int16),
             _plane(rec, "lev_cb", (h // 2, w // 2), np.int16), _plane(rec, "lev_cr", (h // 2, w // 2), np.int16)]
     r = _Record(*[a.ctypes.data for a in arrs])
-    cap = lib.wrenc_bs_picture_bound(w, h)
+    # wrenc_bs_picture_bound is the proven worst case (12 bytes per luma sample); real pictures need a small
+    # fraction, and the writer reports the size it needs when the buffer is too small
+    cap = min(lib.wrenc_bs_picture_bound(w, h), w * h // 2 + 65536)
     buf = np.empty(cap, np.uint8)
     n = C.c_size_t()
     rc = lib.wrenc_bs_write_picture(w, h, int(qp), int(poc), C.byref(r), buf.ctypes.data, cap, C.byref(n))
+    if rc == ENOSPC:
+        cap = n.value
+        buf = np.empty(cap, np.uint8)
+        rc = lib.wrenc_bs_write_picture(w, h, int(qp), int(poc), C.byref(r), buf.ctypes.data, cap, C.byref(n))
     if rc != OK:
         raise BitstreamError(rc, "wrenc_bs_write_picture")
     return buf[:n.value].tobytes()

@@ -113,6 +113,7 @@ struct HostSet { // one (device, slot set) unit: page-locked planes of one batch
     uint8_t* maps = nullptr;    // batch x (cu_log2_size | luma_mode | chroma_mode)
     std::vector<std::vector<uint8_t>> nal; // per picture
     std::vector<int> status;
+    std::vector<size_t> len;
     int count = 0, first_poc = 0;       // the batch being searched / read back in this set
     int bs_count = 0, bs_first_poc = 0; // the batch whose slices are being written from this set
 };
@@ -221,6 +222,7 @@ int main(int argc, char** argv) {
         if (!s.in || !s.lev || !s.maps || (frec && !s.rec)) die("%s", wrenc_gpu_last_error(s.ctx));
         s.nal.resize((size_t)batch);
         s.status.assign((size_t)batch, 0);
+        s.len.assign((size_t)batch, 0);
     }
     const auto gpu_check = [](HostSet& s, int rc) {
         if (rc) die("%s", wrenc_gpu_last_error(s.ctx));
@@ -250,28 +252,35 @@ int main(int argc, char** argv) {
         poc += s.count;
     };
     Pool pool(n_threads);
-    const size_t bound = wrenc_bs_picture_bound(w, h);
+    const size_t first_guess = ysz / 2 + 65536;
     // slices of the unit's batch on the pool; flush() collects them in picture order
     const auto start_slices = [&](HostSet& s) {
         s.bs_count = s.count;
         s.bs_first_poc = s.first_poc;
-        pool.start(s.bs_count, [&s, w, h, qp, pic, ysz, csz, maps, n4, bound](int k) {
+        pool.start(s.bs_count, [&s, w, h, qp, pic, ysz, csz, maps, n4, first_guess](int k) {
             const uint8_t* m = s.maps + maps * k;
             const int16_t* l = s.lev + pic * k;
             const wrenc_bs_record rec = {m, m + n4, m + 2 * n4, l, l + ysz, l + ysz + csz};
             std::vector<uint8_t>& out = s.nal[(size_t)k];
-            out.resize(bound);
+            // wrenc_bs_picture_bound is the proven worst case (12 bytes per luma sample); real pictures need a
+            // small fraction, and the writer reports the size it needs when the buffer is too small
+            if (out.size() < first_guess) out.resize(first_guess);
             size_t n = 0;
-            s.status[(size_t)k] = wrenc_bs_write_picture(w, h, qp, s.bs_first_poc + k, &rec, out.data(), out.size(), &n);
-            out.resize(s.status[(size_t)k] ? 0 : n);
+            int rc = wrenc_bs_write_picture(w, h, qp, s.bs_first_poc + k, &rec, out.data(), out.size(), &n);
+            if (rc == WRENC_BS_ENOSPC) {
+                out.resize(n);
+                rc = wrenc_bs_write_picture(w, h, qp, s.bs_first_poc + k, &rec, out.data(), out.size(), &n);
+            }
+            s.status[(size_t)k] = rc;
+            s.len[(size_t)k] = rc ? 0 : n;
         });
     };
     const auto flush = [&](HostSet& s) {
         pool.wait();
         for (int k = 0; k < s.bs_count; ++k) {
             if (s.status[(size_t)k]) die("wrenc_bs_write_picture failed with %d on picture %d", s.status[(size_t)k], s.bs_first_poc + k);
-            fwrite(s.nal[(size_t)k].data(), 1, s.nal[(size_t)k].size(), fout);
-            bytes += s.nal[(size_t)k].size();
+            fwrite(s.nal[(size_t)k].data(), 1, s.len[(size_t)k], fout);
+            bytes += s.len[(size_t)k];
             if (frec) fwrite(s.rec + pic * k, 1, pic, frec); // main.rs:387-399
         }
         pictures += s.bs_count;
