@@ -95,6 +95,7 @@ static const CtxInit kCtxInit[CTX_COUNT] = {
 struct CtxModel {
     uint16_t s0, s1;       // 10-bit fast and 14-bit slow probability estimates
     uint8_t shift0, shift1;
+    uint16_t add0, add1;   // 1023 >> shift0, 16383 >> shift1: what a bin equal to one adds to each estimate
 };
 
 // bool_coder.rs:1073-1093 (and :142-144 for the two adaptation rates)
@@ -109,6 +110,8 @@ inline void init_models(CtxModel* m, int slice_qp) {
         m[i].s1 = (uint16_t)(pre << 7);
         m[i].shift0 = (uint8_t)((kCtxInit[i].shift_idx >> 2) + 2);
         m[i].shift1 = (uint8_t)((kCtxInit[i].shift_idx & 3) + 3 + m[i].shift0);
+        m[i].add0 = (uint16_t)(1023 >> m[i].shift0);
+        m[i].add1 = (uint16_t)(16383 >> m[i].shift1);
     }
 }
 
@@ -234,7 +237,7 @@ public:
         num_buffered_ = 0;
     }
 
-    void encode(int ctx, int bin) {
+    __attribute__((always_inline)) void encode(int ctx, int bin) {
         CtxModel& c = m_[ctx];
         const uint32_t q = range_ >> 5;
         const uint32_t p = (uint32_t)c.s1 + 16u * c.s0;
@@ -250,9 +253,9 @@ public:
         low_ = (low_ + (is_lps ? r_mps : 0u)) << nb;
         range_ = (is_lps ? lps : r_mps) << nb;
         bits_left_ -= nb;
-        if (bits_left_ < 12) write_out();
-        c.s0 = (uint16_t)(c.s0 - (c.s0 >> c.shift0) + ((1023 * bin) >> c.shift0));
-        c.s1 = (uint16_t)(c.s1 - (c.s1 >> c.shift1) + ((16383 * bin) >> c.shift1));
+        if (__builtin_expect(bits_left_ < 12, 0)) write_out();
+        c.s0 = (uint16_t)(c.s0 - (c.s0 >> c.shift0) + (bin ? c.add0 : 0));
+        c.s1 = (uint16_t)(c.s1 - (c.s1 >> c.shift1) + (bin ? c.add1 : 0));
     }
 
     void bypass(int bin) {
@@ -290,7 +293,7 @@ public:
     }
 
 private:
-    void write_out() {
+    __attribute__((noinline)) void write_out() {
         const uint32_t lead = low_ >> (24 - bits_left_);
         bits_left_ += 8;
         low_ &= 0xffffffffu >> bits_left_;
