@@ -139,6 +139,7 @@ class Encoder:
         if rc:
             raise WrencGpuError(rc, self.lib.wrenc_gpu_last_error(None).decode())
         self._keep = {}
+        self._pinned = []
 
     def _check(self, rc):
         if rc:
@@ -146,6 +147,11 @@ class Encoder:
 
     def close(self):
         if self.ctx:
+            self.lib.wrenc_gpu_free_host.restype = None
+            self.lib.wrenc_gpu_free_host.argtypes = [C.c_void_p, C.c_void_p]
+            for ptr in self._pinned:
+                self.lib.wrenc_gpu_free_host(self.ctx, ptr)
+            self._pinned = []
             self.lib.wrenc_gpu_destroy(self.ctx)
             self.ctx = C.c_void_p()
 
@@ -169,9 +175,38 @@ class Encoder:
     def sync(self):
         self._check(self.lib.wrenc_gpu_sync(self.ctx))
 
-    def download(self, slot, keys=None):
-        """All planes of the record, or only `keys` (the C ABI skips NULL pointers)."""
-        out = alloc_picture(self.width, self.height)
+    def alloc_host(self, nbytes):
+        """A page-locked uint8 array (wrenc_gpu_alloc_host): transfers from / to it run at PCIe rate.  Freed
+        by close(); do not use it afterwards."""
+        self.lib.wrenc_gpu_alloc_host.restype = C.c_void_p
+        self.lib.wrenc_gpu_alloc_host.argtypes = [C.c_void_p, C.c_size_t]
+        ptr = self.lib.wrenc_gpu_alloc_host(self.ctx, nbytes)
+        if not ptr:
+            raise WrencGpuError(-3, self.lib.wrenc_gpu_last_error(self.ctx).decode())
+        self._pinned.append(ptr)
+        return np.ctypeslib.as_array((C.c_uint8 * nbytes).from_address(ptr))
+
+    def alloc_picture_host(self, keys=None):
+        """alloc_picture() in page-locked memory (optionally only `keys`)."""
+        shapes = alloc_picture(8, 8)
+        w, h = self.width, self.height
+        dims = {"rec_y": (h, w), "rec_cb": (h // 2, w // 2), "rec_cr": (h // 2, w // 2), "lev_y": (h, w),
+                "lev_cb": (h // 2, w // 2), "lev_cr": (h // 2, w // 2), "cu_log2_size": (h // 4, w // 4),
+                "luma_mode": (h // 4, w // 4), "chroma_mode": (h // 8, w // 8), "ctu_cost": ((h // 32) * (w // 32),)}
+        out = {}
+        for k in _PIC_KEYS:
+            if keys is not None and k not in keys:
+                continue
+            dt = shapes[k].dtype
+            n = int(np.prod(dims[k])) * dt.itemsize
+            out[k] = self.alloc_host(n).view(dt).reshape(dims[k])
+        return out
+
+    def download(self, slot, keys=None, out=None):
+        """All planes of the record, or only `keys` (the C ABI skips NULL pointers); `out` = arrays to fill
+        (e.g. from alloc_picture_host) instead of fresh ones."""
+        if out is None:
+            out = alloc_picture(self.width, self.height)
         if keys is not None:
             out = {k: v for k, v in out.items() if k in keys}
         pic = Picture(*[_p(out[k]) if k in out else None for k in _PIC_KEYS])
