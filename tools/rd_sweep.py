@@ -44,6 +44,7 @@ def main():
     ap.add_argument("--depth", type=int, default=3)
     ap.add_argument("--qps", default="22,27,32,37")
     ap.add_argument("--threads", type=int, default=8)
+    ap.add_argument("--extra-params", help="the reference's RD-model knobs, K1=V1,K2=V2")
     ap.add_argument("--out")
     a = ap.parse_args()
     from wrenc_amd import bitstream, gpu, synth
@@ -52,7 +53,7 @@ def main():
     results = []
     pool = ThreadPoolExecutor(max_workers=a.threads)
     for qp in [int(q) for q in a.qps.split(",")]:
-        enc = gpu.Encoder(w, h, qp=qp, max_split_depth=a.depth, n_slots=n)
+        enc = gpu.Encoder(w, h, qp=qp, max_split_depth=a.depth, n_slots=n, extra_params=a.extra_params)
         for s in range(n):
             enc.upload(s, *frames[s])
         enc.sync()
@@ -84,7 +85,8 @@ def main():
         print("qp %2d  %9d bytes  %.4f bpp  PSNR-Y %.2f dB  SSIM-Y %.4f  search %.1f fps  writer %.1f fps" % (
             qp, total, results[-1]["bits_per_pixel"], summ["psnr_y"], summ["ssim_y"], n / t_search, n / t_write), flush=True)
     pool.shutdown()
-    doc = {"config": {"width": w, "height": h, "frames": n, "max_split_depth": a.depth, "content": "synth_textured_frame"},
+    doc = {"config": {"width": w, "height": h, "frames": n, "max_split_depth": a.depth, "content": "synth_textured_frame",
+                      "extra_params": a.extra_params},
            "results": results}
     if a.out:
         json.dump(doc, open(a.out, "w"), indent=1)
