@@ -22,4 +22,7 @@ g++ -O1 -g -std=c++17 -ffp-contract=off -fsanitize=address,undefined -fno-omit-f
     "$R/oracle/vvc_parse.cpp" "$R/oracle/wrenc_oracle.cpp" 2> "$T/build.log" || { cat "$T/build.log"; exit 1; }
 # QP of the stream is fixed to 32 in the harness's writer calls; the record's own QP only shaped its levels
 "$T/harness" "$T" "$W" "$H"
+g++ -O1 -g -std=c++17 -ffp-contract=off -mavx2 -fsanitize=address,undefined -fno-omit-frame-pointer -fno-sanitize-recover=undefined \
+    -o "$T/oracle_search" "$R/tools/sanitize/oracle_search.cpp" "$R/oracle/wrenc_oracle.cpp" "$R/oracle/vvc_parse.cpp"
+"$T/oracle_search"
 rm -rf "$T"
