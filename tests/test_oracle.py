@@ -41,6 +41,41 @@ def test_dct_matrix_equals_reference_rows_in_use():
     assert all(k == 11 for k, _ in bad) and len(bad) == 4
 
 
+def _ints(text):
+    return [int(x) for x in re.findall(r"-?\d+", text)]
+
+
+def _c_table(path, name):
+    txt = open(path).read()
+    i = txt.index(name)
+    i = txt.index("=", i)
+    return _ints(txt[i:txt.index("};", i)])
+
+
+@pytest.mark.skipif(not os.path.exists("/root/reference/src/common.rs"), reason="reference not mounted")
+def test_prediction_tables_equal_the_reference_source():
+    """intraPredAngle (common.rs:145), the cubic filter fC (:153) and the Gaussian filter fG (:188), as the
+    reference's source text holds them, against the oracle's and the device code's copies."""
+    root = os.path.dirname(HERE)
+    txt = open("/root/reference/src/common.rs").read()
+
+    def ref_table(name):
+        i = txt.index("pub const %s" % name)
+        i = txt.index("= [", i)
+        return _ints(txt[i:txt.index("];", i)])
+
+    angle, fc, fg = ref_table("INTRA_ANGLE_TABLE"), ref_table("F_C"), ref_table("F_G")
+    assert len(angle) == 95 and len(fc) == 128 and len(fg) == 128
+    assert fg == [v for p in range(32) for v in (16 - (p >> 1), 32 - (p >> 1), 16 + (p >> 1), p >> 1)]   # both copies compute it
+    for path in (os.path.join(root, "oracle", "wrenc_oracle.cpp"), os.path.join(root, "wrenc_amd", "csrc", "wrenc_gpu.hip")):
+        assert _c_table(path, "kIntraAngle[95]") == angle, path
+        assert _c_table(path, "kFC[32][4]") == fc, path
+    ls = open("/root/reference/src/quantizer.rs").read()
+    i = ls.index("=", ls.index("const LEVEL_SCALE"))
+    assert _ints(ls[i:ls.index("];", i)])[:6] == [40, 45, 51, 57, 64, 72]
+    assert _c_table(os.path.join(root, "wrenc_amd", "csrc", "wrenc_gpu.hip"), "level_scale[6]") == [40, 45, 51, 57, 64, 72]
+
+
 def test_tables_sanity_values():
     """Values derived from the formulas in SURVEY.md 8c."""
     expect = {22: (34, 9216), 27: (56, 16384), 32: (100, 29184), 37: (184, 52224)}
