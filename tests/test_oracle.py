@@ -74,6 +74,15 @@ def test_prediction_tables_equal_the_reference_source():
     i = ls.index("=", ls.index("const LEVEL_SCALE"))
     assert _ints(ls[i:ls.index("];", i)])[:6] == [40, 45, 51, 57, 64, 72]
     assert _c_table(os.path.join(root, "wrenc_amd", "csrc", "wrenc_gpu.hip"), "level_scale[6]") == [40, 45, 51, 57, 64, 72]
+    # dependent-quantisation state machine (encoder_context.rs:339): oracle, host writer, stream parser (the device walk
+    # has it folded into its lane permutations, dev_quant.h:295-296, and is covered by the parity tests)
+    ec = open("/root/reference/src/encoder_context.rs").read()
+    i = ec.index("q_state_trans_table: [[0")
+    trans = _ints(ec[i + len("q_state_trans_table:"):ec.index("]],", i)])
+    assert trans == [0, 2, 2, 0, 1, 3, 3, 1]
+    for rel, name in (("oracle/wrenc_oracle.cpp", "kQStateTrans[4][2]"), ("wrenc_amd/csrc/host/slice_data.cpp", "kQStateTrans[4][2]"),
+                      ("oracle/vvc_parse.cpp", "kTrans[4][2]")):
+        assert _c_table(os.path.join(root, rel), name) == trans, rel
 
 
 def test_tables_sanity_values():
