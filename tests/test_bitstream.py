@@ -354,3 +354,49 @@ def test_streams_match_the_recorded_hashes(built):
     for case in mod.CASES:
         sha, n = mod.stream_hash(*case)
         assert want["%s_%dx%d_qp%d_d%d" % case] == {"sha256": sha, "bytes": n}, case
+
+
+@pytest.mark.skipif(not os.path.exists("/root/reference/src/sps.rs"), reason="reference not mounted")
+def test_parameter_set_defaults_still_read_as_assumed():
+    """headers.cpp writes the parameter sets from the defaults of the reference's constructors.  Every default that
+    decides a written value or a taken branch is listed here next to where the reference sets it; the test fails if
+    the reference's source no longer says so."""
+    src = "/root/reference/src/"
+    assumed = {
+        "main.rs": ["VideoParameterSet::new(8,", "SequenceParameterSet::new(1, 8,", "PictureParameterSet::new(1, &sps",
+                    "write_byte_stream_nal_unit_bits(1, NALUnitType::VPS_NUT, 0", "write_byte_stream_nal_unit_bits(9, NALUnitType::SPS_NUT, 0",
+                    "write_byte_stream_nal_unit_bits(9, NALUnitType::PPS_NUT, 0", "let nuh_layer_id = 9;", "NALUnitType::IDR_W_RADL"],
+        "vps.rs": ["max_layers: 1,", "max_sublayers: 1,", "VpsLayer::new(9)", "each_layer_is_an_ols: false,", "num_ptls: 1,",
+                   "default_ptl_dpb_hrd_max_tid_flag: true,", "general_timing_hrd_parameters: None,", "ptl_max_tids: vec![1, 2],",
+                   "extension_data: vec![],"],
+        "ptl.rs": ["general_level_idc: 0,", "general_profile_idc: 0,", "general_constraints_info: None,", "ptl_num_sub_profiles: 0,"],
+        "dpb.rs": ["max_tid: 1,", "max_dec_pic_buffering: 8,", "max_num_reorder_pics: 4,", "max_latency_increase: 1,"],
+        "reference_picture.rs": ["num_ref_entries: 3,", "abs_delta_poc_st: vec![0, 2, 3],", "strp_entry_sign_flag: vec![lx == 0; 3],",
+                                 "num_ref_pic_list: 1,", "st_ref_pic_flag: vec![true; 3],"],
+        "sps.rs": ["max_sublayers: 1,", "chroma_format: ChromaFormat::YCbCr420,", "log2_ctu_size: 5,", "ptl_dpb_hrd_params_present_flag: true,",
+                   "conformance_window: None,", "subpic_info: None,", "bitdepth: 8,", "log2_max_pic_order_cnt_lsb: 4,",
+                   "log2_min_luma_coding_block_size: 2,", "transform_skip_enabled_flag: true,", "log2_transform_skip_max_size: 5,",
+                   "bdpcm_enabled_flag: false,", "mts_enabled_flag: true,", "explicit_mts_intra_enabled_flag: true,",
+                   "explicit_mts_inter_enabled_flag: true,", "lfnst_enabled_flag: false,", "joint_cbcr_enabled_flag: false,",
+                   "same_qp_table_for_chroma_flag: true,", "QpTable::new(bit_depth, 63, 0)", "sao_enabled_flag: false,",
+                   "alf_enabled_flag: false,", "idr_rpl_present_flag: false,", "rpl1_same_as_rpl0_flag: false,",
+                   "six_minus_max_num_merge_cand: 0,", "log2_parallel_merge_level: 2,", "cclm_enabled_flag: true,",
+                   "palette_enabled_flag: false,", "min_qp_prime_ts: 0,", "ibc_enabled_flag: false,", "ladf_parameters: None,",
+                   "dep_quant_enabled_flag: true,", "sign_data_hiding_enabled_flag: false,", "vui_parameters_present_flag: false,"],
+        "partition.rs": ["log2_diff_min_qt_min_cb_intra_slice_luma: 0,", "max_mtt_hierarchy_depth_intra_slice_luma: 0,",
+                         "qtbtt_dual_tree_intra_flag: false,", "max_mtt_hierarchy_depth_inter_slice: 0,"],
+        "pps.rs": ["no_pic_partition_flag: true,", "cabac_init_present_flag: false,", "num_ref_idx_default_active: [3, 3],",
+                   "qp.max(26)", "cu_qp_delta_enabled_flag: true,", "chroma_tool_offsets_present_flag: false,",
+                   "deblocking_filter_control_present_flag: true,", "deblocking_filter_override_enabled_flag: false,",
+                   "deblocking_filter_disabled_flag: true,", "picture_header_extension_present_flag: false,"],
+        "picture_header.rs": ["gdr_or_irap_pic_flag: true,", "non_ref_pic_flag: false,", "gdr_pic_flag: false,", "inter_slice_allowed_flag: !intra,",
+                              "pic_order_cnt_lsb: poc & 0b1111,", "cu_qp_delta_subdiv_intra_slice: 0,"],
+        "slice_header.rs": ["ph_in_sh: None,", "slice_type: SliceType::I,", "no_output_of_prior_pics_flag: false,", "qp - ectx.slice_qp_y",
+                            "dep_quant_used_flag: true,"],
+        "nal.rs": ["let header_bytes: [u8; 3] = [0, 0, 0];", "let start_code_prefix_one_3bytes: [u8; 3] = [0, 0, 1];",
+                   "while idx + 3 < bytes.len()", "bytes[idx + 2] <= 3"],
+    }
+    for name, items in assumed.items():
+        txt = open(src + name).read()
+        for item in items:
+            assert item in txt, (name, item)
