@@ -33,7 +33,13 @@ def _case(seed):
     return clip(y), clip(cb), clip(cr), qp, depth
 
 
-@pytest.mark.parametrize("seed", range(40))
+import os
+
+# WRENC_FUZZ_SEEDS=a:b widens the sweep for a one-off soak (the default 40 cases run in the suite)
+_LO, _HI = [int(v) for v in os.environ.get("WRENC_FUZZ_SEEDS", "0:40").split(":")]
+
+
+@pytest.mark.parametrize("seed", range(_LO, _HI))
 def test_random_case_matches_oracle(built, seed):
     from wrenc_amd import gpu
     from oracle import pyoracle as po
