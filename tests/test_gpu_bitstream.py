@@ -53,3 +53,36 @@ def test_full_size_picture_round_trips_and_rate_tracks_the_estimate(built):
     assert 0 < bits <= 8 * len(stream)
     nz = sum(int(np.count_nonzero(got[k])) for k in ("lev_y", "lev_cb", "lev_cr"))
     assert nz > 0 and 0.5 < bits / nz < 40      # a few bits per significant level
+
+
+@pytest.mark.parametrize("kind,w,h,qp,depth", [("cclm", 128, 64, 32, 2), ("noise", 64, 64, 27, 3), ("stripes20", 96, 64, 22, 1)])
+def test_stream_bytes_equal_the_cpu_paths(built, kind, w, h, qp, depth):
+    """BASELINE.json's metric: the .vvc written from the device's record is byte-identical to the one written from
+    the CPU oracle's record of the same input."""
+    from wrenc_amd import bitstream as bs, gpu
+    from oracle import pyoracle as po
+    y, cb, cr = content(kind, w, h, 33)
+    enc = gpu.Encoder(w, h, qp=qp, max_split_depth=depth)
+    got = enc.encode_picture(y, cb, cr)
+    enc.close()
+    ref = po.encode_picture(y, cb, cr, qp, depth)
+    assert bs.write_picture(w, h, qp, 4, got) == bs.write_picture(w, h, qp, 4, ref)
+
+
+def test_config1_1080p_stream_byte_exact_vs_cpu(built):
+    """BASELINE.json configs[1]: one whole 1920x1088 picture at QP32, max-split-depth 2: the device's record equals the
+    CPU oracle's (every plane, every CTU cost) and the two .vvc streams are the same bytes."""
+    from wrenc_amd import bitstream as bs, gpu, synth
+    from oracle import pyoracle as po
+    w, h, qp, depth = 1920, 1088, 32, 2
+    y, cb, cr = synth.synth_frame(w, h, 3)
+    enc = gpu.Encoder(w, h, qp=qp, max_split_depth=depth)
+    got = enc.encode_picture(y, cb, cr)
+    assert enc.final_pass_mismatches() == 0
+    enc.close()
+    ref = po.encode_picture(y, cb, cr, qp, depth)
+    for k in ("cu_log2_size", "luma_mode", "chroma_mode", "lev_y", "lev_cb", "lev_cr", "rec_y", "rec_cb", "rec_cr", "ctu_cost"):
+        assert np.array_equal(got[k], ref[k]), k
+    a = bs.write_parameter_sets(w, h, qp) + bs.write_picture(w, h, qp, 0, got)
+    b = bs.write_parameter_sets(w, h, qp) + bs.write_picture(w, h, qp, 0, ref)
+    assert a == b and len(a) > 10_000
