@@ -17,6 +17,6 @@ with open("/tmp/e2e_in.yuv", "wb") as f:
         f.write(frames[i % 8])
 PY
 echo -n "native ${W}x${H} depth $DEPTH textured=$X N=$N batch=$B threads=$T | "
-GPU_MAX_HW_QUEUES=${GPU_MAX_HW_QUEUES:-8} "$R/wrenc_amd/csrc/host/wrenc" -i /tmp/e2e_in.yuv -o /tmp/e2e_out.vvc --input-size ${W}x${H} \
+"$R/wrenc_amd/csrc/host/wrenc" -i /tmp/e2e_in.yuv -o /tmp/e2e_out.vvc --input-size ${W}x${H} \
   --output-size ${W}x${H} --num-pictures "$N" --qp 32 --max-split-depth $DEPTH --batch "$B" --threads "$T" --verbose 2>&1
 rm -f /tmp/e2e_in.yuv /tmp/e2e_out.vvc

@@ -4,7 +4,7 @@
 set -e
 R=$(cd "$(dirname "$0")/.." && pwd)
 N=${1:-6000}; D=${2:-0,0}
-python3 - "$N" "$R" <<'PY' | GPU_MAX_HW_QUEUES=8 "$R/wrenc_amd/csrc/host/wrenc" -i - -o - --input-size 1920x1088 --output-size 1920x1088 \
+python3 - "$N" "$R" <<'PY' | "$R/wrenc_amd/csrc/host/wrenc" -i - -o - --input-size 1920x1088 --output-size 1920x1088 \
     --num-pictures "$N" --qp 32 --max-split-depth 2 --batch 256 --threads 16 --devices "$D" --verbose > /tmp/soak.vvc
 import sys
 sys.path.insert(0, sys.argv[2])

@@ -121,6 +121,9 @@ struct HostSet { // one (device, slot set) unit: page-locked planes of one batch
 } // namespace
 
 int main(int argc, char** argv) {
+    // 4 encode lanes + 1 copy stream per context: more hardware queues than the HIP runtime's default of 4 let the
+    // read-back overlap the search (must be in the environment before the first HIP call; an explicit setting wins)
+    setenv("GPU_MAX_HW_QUEUES", "8", 0);
     const char *input = nullptr, *output = nullptr, *reconst = nullptr, *in_size = nullptr, *out_size = nullptr,
                *extra = nullptr;
     long num_pictures = -1;
