@@ -1,7 +1,6 @@
 import os, sys, time, ctypes as C
 os.environ["WRENC_GPU_LIB"]=os.path.abspath("scratch/libwrenc_gpu_prof.so")
 sys.path.insert(0,'.')
-import numpy as np
 from wrenc_amd import gpu, synth
 w,h,qp,depth=1920,1088,32,int(sys.argv[1]) if len(sys.argv)>1 else 2
 B=int(sys.argv[2]) if len(sys.argv)>2 else 16

@@ -15,8 +15,6 @@ import sys
 import time
 from concurrent.futures import ThreadPoolExecutor
 
-import numpy as np
-
 
 def _die(msg):
     sys.stderr.write("error: %s\n" % msg)
@@ -110,7 +108,7 @@ def main(argv=None):
         _die(str(e))
     pool = ThreadPoolExecutor(max_workers=max(1, a.threads))
     t_start = time.perf_counter()
-    stats = {"pictures": 0, "bytes": 0, "read_upload": 0.0, "wait_gpu": 0.0, "download": 0.0, "write": 0.0}
+    stats = {"pictures": 0, "bytes": 0, "read_upload": 0.0, "download": 0.0, "write": 0.0}
     want = None if frec is not None else ("lev_y", "lev_cb", "lev_cr", "cu_log2_size", "luma_mode", "chroma_mode")
 
     def submit(first_poc, base):
