@@ -133,8 +133,15 @@ void wrenc_gpu_free_host(wrenc_gpu_ctx* ctx, void* p);
 int wrenc_gpu_encode_picture(wrenc_gpu_ctx* ctx, const uint8_t* y, const uint8_t* cb,
                              const uint8_t* cr, wrenc_gpu_picture* out);
 
+/* Per-launch timing (two HIP events around every kernel launch) is OFF by default: the product path
+ * (CLI, native program) never reads it.  bench.py / profiling switch it on.  While it is on, an encode
+ * call first waits for the previous call's end event (the events are re-recorded), so consecutive calls
+ * do not overlap: measurement mode only. */
+int wrenc_gpu_stats_enable(wrenc_gpu_ctx* ctx, int on);
+
 /* Device time (ms, HIP events on the context's own stream) and launch count of
- * the search kernel during the last wrenc_gpu_encode call; valid after sync. */
+ * the search kernel during the last wrenc_gpu_encode call (waits for its end).  WRENC_GPU_ESTATE unless
+ * timing was on (wrenc_gpu_stats_enable) when that call was queued. */
 int wrenc_gpu_last_encode_stats(wrenc_gpu_ctx* ctx, float* total_ms, float* kernel_ms_sum,
                                 int* n_launches);
 
@@ -155,6 +162,16 @@ int wrenc_gpu_test_quantize(wrenc_gpu_ctx* ctx, const int16_t* coef, int log2n, 
                                                                            block_splitter.rs:415-460 */
 int wrenc_gpu_test_dequantize(wrenc_gpu_ctx* ctx, const int16_t* levels, int log2n, int count,
                               int16_t* deq);                            /* quantizer.rs:761 */
+
+/* Intra prediction of single blocks (intra_predictor.rs:56-144: reference-sample build :146-353, PLANAR
+ * :759-1146, DC :1148-1285, ANGULAR 2..66 :1287-1602, PDPC :355-757, CCLM :1604-2055) in the environment of
+ * given reconstruction planes of the context's picture size.  items: n_items x 5 int32 {x, y (luma, picture
+ * coordinates, multiples of the size), log2 luma size 2..5, comp (0 = luma block, 1 = Cb+Cr pair of the block,
+ * log2 size >= 3), mode (0..66, or 81..83 for comp 1)}.  out: the predicted samples, item after item (luma
+ * n x n; pair: Cb (n/2)^2 then Cr (n/2)^2); out_bytes must equal their total. */
+int wrenc_gpu_test_predict(wrenc_gpu_ctx* ctx, const uint8_t* rec_y, const uint8_t* rec_cb,
+                           const uint8_t* rec_cr, int n_items, const int32_t* items, uint8_t* out,
+                           size_t out_bytes);
 
 #ifdef __cplusplus
 }

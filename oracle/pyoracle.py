@@ -11,6 +11,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_HERE, "libwrenc_oracle.so")
+_SPEC_SO = os.path.join(_HERE, "libwrenc_specdec.so")
 
 
 class _Params(C.Structure):
@@ -29,8 +30,11 @@ class _PicOut(C.Structure):
 def build(force=False):
     srcs = [os.path.join(_HERE, f) for f in ("wrenc_oracle.cpp", "wrenc_oracle.h", "vvc_parse.cpp", "vvc_parse.h",
                                             "vvc_ctx_init.inc")]
-    if force or not os.path.exists(_SO) or any(
-            os.path.exists(f) and os.path.getmtime(f) > os.path.getmtime(_SO) for f in srcs):
+    stale = force
+    for so, deps in ((_SO, srcs), (_SPEC_SO, [os.path.join(_HERE, "spec_decoder.cpp")])):
+        stale = stale or not os.path.exists(so) or any(
+            os.path.exists(f) and os.path.getmtime(f) > os.path.getmtime(so) for f in deps)
+    if stale:
         subprocess.check_call(["make", "-C", _HERE, "-s"])
     return _SO
 
@@ -111,6 +115,66 @@ def reconstruct_from_record(rec, qp, max_split_depth=3):
     if rc != 0:
         raise ValueError("wro_reconstruct_from_record failed: %d" % rc)
     return y, cb, cr
+
+
+def predict_blocks(rec_y, rec_cb, rec_cr, items, qp=32):
+    """items: (n, 6) int32 {x, y, log2 luma size, tree type, component, mode}; returns the list of predicted
+    blocks of that component (wro_predict_blocks)."""
+    items = np.ascontiguousarray(items, np.int32).reshape(-1, 6)
+    h, w = rec_y.shape
+    sizes = [((1 << int(q[2])) >> (1 if q[4] else 0)) for q in items]
+    out = np.zeros(int(sum(s * s for s in sizes)), np.uint8)
+    planes = [np.ascontiguousarray(a, np.uint8) for a in (rec_y, rec_cb, rec_cr)]
+    prm = _Params(w, h, qp, 3)
+    rc = lib().wro_predict_blocks(C.byref(prm), _p(planes[0]), _p(planes[1]), _p(planes[2]), len(items), _p(items), _p(out))
+    if rc != 0:
+        raise ValueError("wro_predict_blocks failed: %d" % rc)
+    res, at = [], 0
+    for s in sizes:
+        res.append(out[at:at + s * s].reshape(s, s))
+        at += s * s
+    return res
+
+
+_spec_lib = None
+
+
+def spec_lib():
+    """libwrenc_specdec.so: the decoder written from H.266 alone (spec_decoder.cpp), nothing shared with the oracle."""
+    global _spec_lib
+    if _spec_lib is None:
+        build()
+        _spec_lib = C.CDLL(_SPEC_SO)
+        _spec_lib.wsd_decode_record.restype = C.c_int
+    return _spec_lib
+
+
+def spec_decode_record(rec, qp):
+    """Reconstruction of a picture from its record (cu_log2_size, luma_mode, chroma_mode, lev_*) by the
+    independent spec decoder; returns (y, cb, cr)."""
+    h4, w4 = rec["cu_log2_size"].shape
+    h, w = h4 * 4, w4 * 4
+    a = {k: np.ascontiguousarray(rec[k]) for k in ("cu_log2_size", "luma_mode", "chroma_mode", "lev_y", "lev_cb", "lev_cr")}
+    assert a["lev_y"].dtype == np.int16 and a["cu_log2_size"].dtype == np.uint8
+    y = np.zeros((h, w), np.uint8)
+    cb = np.zeros((h // 2, w // 2), np.uint8)
+    cr = np.zeros((h // 2, w // 2), np.uint8)
+    rc = spec_lib().wsd_decode_record(w, h, int(qp), _p(a["cu_log2_size"]), _p(a["luma_mode"]), _p(a["chroma_mode"]),
+                                      _p(a["lev_y"]), _p(a["lev_cb"]), _p(a["lev_cr"]), _p(y), _p(cb), _p(cr))
+    if rc != 0:
+        raise ValueError("wsd_decode_record failed: %d" % rc)
+    return y, cb, cr
+
+
+def spec_trans_matrix():
+    m = np.zeros((64, 64), np.int16)
+    spec_lib().wsd_trans_matrix(_p(m))
+    return m
+
+
+def debug_perturb(which):
+    """Deliberate misreading of one constant inside the oracle (wro_debug_perturb); 0 switches it off."""
+    lib().wro_debug_perturb(int(which))
 
 
 def fwd_dct(res):

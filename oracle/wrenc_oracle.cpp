@@ -48,6 +48,9 @@ static inline size_t tbl(size_t i) {
     return i;
 }
 static bool g_tables_ready = false;
+// Test hook (wro_debug_perturb): a deliberate misreading of one constant, to prove that the independent
+// spec decoder notices what the oracle + GPU pair cannot notice about themselves.  0 = none.
+static int g_perturb = 0;
 
 // intraPredAngle for predModeIntra -14..80 (H.266 Table 24; common.rs:145)
 static const int kIntraAngle[95] = {
@@ -313,7 +316,7 @@ static void inv_dct(const int16_t* deq, int log2n, int16_t* res) {
         }
     // :2569-2580
     for (int k = 0; k < n * n; ++k) {
-        int32_t c = (v[k] + 64) >> 7;
+        int32_t c = (v[k] + (g_perturb == 4 ? 63 : 64)) >> 7;
         v[k] = std::min(std::max(c, -32768), 32767);
     }
     // stage 2 horizontal (:2663-2671): it[y][x] = sum_i T[i][x]*v[y][i]
@@ -333,7 +336,7 @@ static void inv_dct(const int16_t* deq, int log2n, int16_t* res) {
 
 // quantizer.rs:617-622 + derive_ls :326-333, flat m == 16 (:571-583)
 static inline int32_t level_scale(int qp) {
-    return (int32_t)((16 * kLevelScale0[(qp + 1) % 6]) << ((qp + 1) / 6));
+    return (int32_t)((16 * (kLevelScale0[(qp + 1) % 6] + (g_perturb == 3 ? 1 : 0))) << ((qp + 1) / 6));
 }
 // quantizer.rs:558-569: bit_depth + rect(0) + (log2w+log2h)/2 - 5 + dep_quant(1)
 static inline int quant_bd_shift(int log2n) { return 8 + log2n - 5 + 1; }
@@ -1113,7 +1116,7 @@ struct Predictor {
                 int16_t v = (int16_t)(ref_l[y][x] * w_l[x]);
                 v = (int16_t)(v + (int16_t)(ref_t[y][x] * w_ty));
                 v = (int16_t)(v + (int16_t)((int16_t)(neg_w_ty - w_l[x]) * (int16_t)tp));
-                v = (int16_t)(v + 32);
+                v = (int16_t)(v + (g_perturb == 1 ? 31 : 32));
                 v = (int16_t)(v >> 6);
                 tp = (uint8_t)std::min<int>(std::max<int>(v, 0), 255);
             }
@@ -1372,7 +1375,7 @@ struct Predictor {
             for (int x = 0; x < tw; ++x) {
                 const int sx = 2 * x, sy = 2 * y;
                 pds[(size_t)y * tw + x] = (Wn(sy, sx - 1) + Wn(sy + 1, sx - 1) + Wn(sy, sx) * 2 +
-                                          Wn(sy + 1, sx) * 2 + Wn(sy, sx + 1) + Wn(sy + 1, sx + 1) + 4) >> 3;
+                                          Wn(sy + 1, sx) * 2 + Wn(sy, sx + 1) + Wn(sy + 1, sx + 1) + (g_perturb == 2 ? 3 : 4)) >> 3;
             }
         long sel_y[4] = {0, 0, 0, 0}, sel_c[4] = {0, 0, 0, 0};
         if (num_samp_t > 0) {
@@ -2016,6 +2019,73 @@ int wro_reconstruct_from_record(const wro_params* prm, const wro_picture_out* re
     return 0;
 }
 
+// Prediction of single blocks in the environment of a picture whose reconstruction planes are given
+// (kernel-level parity of intra_predictor.rs:56-144 with every mode / size / availability pattern).
+// An item is 6 ints: x, y (luma, picture coordinates, multiples of the size), log2 luma size, tree type
+// (0 single, 1 dual luma [4x4], 2 dual chroma [8x8 luma area]), component, mode; `out` receives the
+// component's predicted block (row-major), items back to back.  The CT chain from the CTU root down to
+// the block is made by quad-tree splits, since the availability walkers (ctu.rs:2083-2188) follow it.
+int wro_predict_blocks(const wro_params* prm, const uint8_t* rec_y, const uint8_t* rec_cb, const uint8_t* rec_cr,
+                       int n_items, const int32_t* items, uint8_t* out) {
+    init_tables();
+    if (!prm || (prm->width & 31) || (prm->height & 31) || prm->width <= 0 || prm->height <= 0) return -1;
+    Picture p;
+    p.W = prm->width;
+    p.H = prm->height;
+    p.qp = prm->qp;
+    p.max_depth = 3;
+    init_rd(p.rd, p.qp);
+    p.stride[0] = p.W;
+    p.stride[1] = p.stride[2] = p.W / 2;
+    const uint8_t* src[3] = {rec_y, rec_cb, rec_cr};
+    for (int c = 0; c < 3; ++c) {
+        const size_t n = (size_t)p.stride[c] * (c == 0 ? p.H : p.H / 2);
+        p.org[c].assign(n, 0);
+        p.pred[c].assign(n, 0);
+        p.rec[c].assign(src[c], src[c] + n);
+    }
+    p.ctu_cols = p.W / 32;
+    p.ctu_rows = p.H / 32;
+    for (int r = 0; r < p.ctu_rows; ++r)
+        for (int c = 0; c < p.ctu_cols; ++c) p.ctu_root.push_back(nullptr);
+    Splitter sp(p);
+    size_t at = 0;
+    for (int it = 0; it < n_items; ++it) {
+        const int32_t* q = items + 6 * it;
+        const int x = q[0], y = q[1], lg = q[2], tree = q[3], c = q[4], mode = q[5];
+        const int n = 1 << lg;
+        if (lg < 2 || lg > 5 || x < 0 || y < 0 || x + n > p.W || y + n > p.H || (x & (n - 1)) || (y & (n - 1))) return -2;
+        if ((tree == 1 && lg != 2) || (tree == 2 && lg != 3) || (tree == 0 && lg == 2)) return -2;
+        Node* node = p.new_node(x & ~31, y & ~31, 32, 0, SINGLE_TREE, MODE_TYPE_ALL, nullptr);
+        p.ctu_root[(size_t)(y >> 5) * p.ctu_cols + (x >> 5)] = node;
+        const int target = tree == 2 ? 8 : n;
+        while (node->w > target) {
+            sp.split(node);
+            Node* next = nullptr;
+            for (int i = 0; i < 4; ++i) {
+                Node* ch = node->cts[(size_t)i];
+                if (x >= ch->x && x < ch->x + ch->w && y >= ch->y && y < ch->y + ch->h) next = ch;
+            }
+            node = next;
+        }
+        if (tree == 2) {
+            sp.split(node);
+            node = node->cts[4];
+        }
+        CU* cu = node->cus[0];
+        if (!cu->active(c)) return -3;
+        const int m[3] = {c == 0 ? mode : PLANAR, mode, mode};
+        cu->tu_ipm[0] = m[0]; // prediction reads the TU array
+        cu->tu_ipm[1] = m[1];
+        cu->tu_ipm[2] = m[2];
+        sp.ip.predict(cu, c);
+        const int tw = cu->csize(c), tx = cu->cx(c), ty = cu->cy(c);
+        for (int yy = 0; yy < tw; ++yy)
+            for (int xx = 0; xx < tw; ++xx) out[at++] = p.pred[c][(size_t)(ty + yy) * p.stride[c] + tx + xx];
+    }
+    return 0;
+}
+
 long wro_last_final_pass_mismatches(void) { return g_last_final_mismatch; }
 
 // main.rs:202-217: "K1=V1,K2=V2"; an empty string or NULL restores the defaults.  Returns 0, or -1 when an
@@ -2046,6 +2116,8 @@ float wro_lambda_rd_chroma(int qp) {
     init_rd(rd, qp);
     return rd_lambda_chroma(rd);
 }
+
+void wro_debug_perturb(int which) { g_perturb = which; }
 
 void wro_trace_enable(int on) {
     g_trace_on = on != 0;

@@ -58,6 +58,12 @@ int wro_encode_picture(const wro_params* p, const uint8_t* y, const uint8_t* cb,
 int wro_reconstruct_from_record(const wro_params* p, const wro_picture_out* record, uint8_t* out_y,
                                 uint8_t* out_cb, uint8_t* out_cr);
 
+// Kernel-level parity of the prediction (intra_predictor.rs:56-144): predicted blocks in the environment of
+// given reconstruction planes.  Item = 6 ints {x, y, log2 luma size, tree type, component, mode}; out =
+// the component's blocks back to back.  See the definition for the details.
+int wro_predict_blocks(const wro_params* p, const uint8_t* rec_y, const uint8_t* rec_cb, const uint8_t* rec_cr,
+                       int n_items, const int32_t* items, uint8_t* out);
+
 // Final-pass consistency: number of samples where the final pass recon differs
 // from the recon the search left in the planes (expected 0).
 long wro_last_final_pass_mismatches(void);
@@ -96,6 +102,13 @@ int64_t wro_chroma_header_bits(int cclm_flag, int cclm_idx);
 // restores the defaults.  Returns -1 on an item that is not KEY=VALUE.
 int wro_set_extra_params(const char* text);
 float wro_lambda_rd_chroma(int qp);
+
+// Test hook: make the oracle misread ONE constant on purpose (0 none; 1 PDPC rounding offset 32 -> 31,
+// intra_predictor.rs:747-752; 2 CCLM down-sampling offset 4 -> 3, :1855-1868; 3 the level-scale entry + 1,
+// quantizer.rs:8,617-622; 4 inverse-transform first-stage offset 64 -> 63, transformer.rs:2569-2580).  The
+// perturbed oracle stays self-consistent (its own decoder-side reconstruction still agrees with it); the
+// independent spec decoder (spec_decoder.cpp) must disagree.  tests/test_spec_decoder.py.
+void wro_debug_perturb(int which);
 
 // Trace of every candidate evaluation of the search (block_splitter.rs:64-108, 110-474, 476-522,
 // 524-780): enable, run wro_encode_picture, read.  A record is 8 int32 words: x, y (luma, picture

@@ -112,6 +112,8 @@ def test_stream_decodes_to_the_encoder_reconstruction(built, kind, w, h, qp, dep
     _, back = _roundtrip(rec, w, h, qp, poc=5)
     ry, rcb, rcr = po.reconstruct_from_record(back, qp)
     assert np.array_equal(ry, rec["rec_y"]) and np.array_equal(rcb, rec["rec_cb"]) and np.array_equal(rcr, rec["rec_cr"])
+    sy, scb, scr = po.spec_decode_record(back, qp)          # the decoder that shares no code with the oracle
+    assert np.array_equal(sy, rec["rec_y"]) and np.array_equal(scb, rec["rec_cb"]) and np.array_equal(scr, rec["rec_cr"])
 
 
 def _random_record(rng, w, h, qp, amp):

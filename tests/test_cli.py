@@ -48,7 +48,7 @@ def test_without_a_gpu_the_command_fails_loudly(built, tmp_path, front):
     src.write_bytes(bytes(64 * 64 * 3 // 2))
     r = _run(front, ["-i", str(src), "-o", str(tmp_path / "o.vvc"), "--input-size", "64x64", "--output-size", "64x64",
               "--num-pictures", "1", "--qp", "32"])
-    assert r.returncode == 0 and r.stderr.startswith(b"error: ")      # no CPU fallback
+    assert r.returncode == 101 and r.stderr.startswith(b"error: ")    # no CPU fallback, and not a success status
 
 
 @pytest.mark.gpu
@@ -79,7 +79,9 @@ def test_encodes_a_sequence_like_the_reference_binary(built, tmp_path, front):
         assert back["poc_lsb"] == i and back["slice_qp"] == qp
         for k in ("cu_log2_size", "luma_mode", "chroma_mode", "lev_y", "lev_cb", "lev_cr"):
             assert np.array_equal(back[k], want[k]), (i, k)
-        ry, rcb, rcr = po.reconstruct_from_record(back, qp)
+        ry, rcb, rcr = po.spec_decode_record(back, qp)      # the decoder written from H.266 alone
+        oy, ocb, ocr = po.reconstruct_from_record(back, qp)
+        assert np.array_equal(ry, oy) and np.array_equal(rcb, ocb) and np.array_equal(rcr, ocr)
         got = recon[i * per:(i + 1) * per]
         assert np.array_equal(got[:w * h], ry.ravel())
         assert np.array_equal(got[w * h:w * h + w * h // 4], rcb.ravel())
@@ -119,7 +121,7 @@ def test_extra_params_reach_the_encoder(built, tmp_path, front):
     r = _run(front, base + ["-o", str(tmp_path / "y.vvc")])
     assert (tmp_path / "y.vvc").read_bytes() != (tmp_path / "x.vvc").read_bytes()
     r = _run(front, base + ["-o", str(tmp_path / "z.vvc"), "--extra-params", "qp_div_dq_trellis=fast"])
-    assert r.returncode == 0 and r.stderr.startswith(b"error: ")
+    assert r.returncode == 101 and r.stderr.startswith(b"error: ")     # the reference's parse().unwrap() panics
 
 
 @pytest.mark.gpu
@@ -159,3 +161,20 @@ def test_native_and_python_front_ends_write_the_same_bytes(built, tmp_path):
     r = _run("native", ["-i", str(src), "-o", str(tmp_path / "x.vvc"), "--input-size", "64x96", "--output-size", "64x96",
                         "--num-pictures", "7", "--devices", "0,x"])
     assert r.returncode == 0 and b"error: Invalid devices: 0,x" in r.stderr
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("front", FRONT_ENDS)
+def test_a_failure_inside_the_search_is_not_status_zero(built, tmp_path, front):
+    """argument / I/O errors exit 0 like the reference (main.rs:127-133), but where the reference
+    panics -- here a quantised level that overflows the 1024-entry rate tables (block_splitter.rs:453), reported by
+    the library as WRENC_GPU_ELEVEL -- the status is 101 (Rust's panic status), never 0 with a truncated stream."""
+    yy, xx = np.indices((32, 32))
+    y = (((xx + yy) & 1) * 255).astype(np.uint8)
+    c = (((xx[:16, :16] + yy[:16, :16]) & 1) * 255).astype(np.uint8)
+    src = tmp_path / "in.yuv"
+    src.write_bytes(y.tobytes() + c.tobytes() + c.tobytes())
+    r = _run(front, ["-i", str(src), "-o", str(tmp_path / "o.vvc"), "--input-size", "32x32", "--output-size", "32x32",
+              "--num-pictures", "1", "--qp", "0", "--max-split-depth", "2"])
+    assert r.returncode == 101, (r.returncode, r.stderr)
+    assert b"error: " in r.stderr and b"1024" in r.stderr

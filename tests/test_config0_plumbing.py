@@ -22,7 +22,7 @@ def test_cif_30_pictures_depth0_stream(built):
         assert back["poc_lsb"] == f & 15
         for k in ("cu_log2_size", "luma_mode", "chroma_mode", "lev_y", "lev_cb", "lev_cr"):
             assert np.array_equal(back[k], recs[f][k]), (f, k)
-        ry, rcb, rcr = po.reconstruct_from_record(back, qp)
+        ry, rcb, rcr = po.spec_decode_record(back, qp)      # independent decoder (oracle/spec_decoder.cpp)
         assert np.array_equal(ry, recs[f]["rec_y"]) and np.array_equal(rcb, recs[f]["rec_cb"])
         assert np.array_equal(rcr, recs[f]["rec_cr"])
     assert 20_000 < len(stream) < 3_000_000

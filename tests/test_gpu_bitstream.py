@@ -1,7 +1,8 @@
 """The device's search record through the host bitstream writer and back through the test-side parser:
 the stream must decode to exactly the record the GPU produced, and reconstructing from the decoded
 record must give the GPU's reconstruction (the reference's integration test, scripts/intergration_test.sh,
-with oracle/vvc_parse.cpp + wro_reconstruct_from_record standing in for VTM)."""
+with oracle/vvc_parse.cpp + oracle/spec_decoder.cpp -- a decoder written from H.266 that shares no code with
+the oracle -- standing in for VTM; the oracle's own wro_reconstruct_from_record is checked alongside)."""
 import numpy as np
 import pytest
 
@@ -23,6 +24,9 @@ def _decode_and_compare(got, w, h, qp, poc):
         assert np.array_equal(back[k], got[k]), k
     ry, rcb, rcr = po.reconstruct_from_record(back, qp)
     assert np.array_equal(ry, got["rec_y"]) and np.array_equal(rcb, got["rec_cb"]) and np.array_equal(rcr, got["rec_cr"])
+    # and through the decoder written from H.266 alone (oracle/spec_decoder.cpp shares no code with the oracle)
+    sy, scb, scr = po.spec_decode_record(back, qp)
+    assert np.array_equal(sy, got["rec_y"]) and np.array_equal(scb, got["rec_cb"]) and np.array_equal(scr, got["rec_cr"])
     return stream, bits
 
 

@@ -33,6 +33,8 @@ def test_1080p_depth2_properties(built):
         assert np.array_equal(ry, rec["rec_y"])
         assert np.array_equal(rcb, rec["rec_cb"])
         assert np.array_equal(rcr, rec["rec_cr"])
+        sy, scb, scr = po.spec_decode_record(rec, qp)             # ... and by the independent spec decoder
+        assert np.array_equal(sy, rec["rec_y"]) and np.array_equal(scb, rec["rec_cb"]) and np.array_equal(scr, rec["rec_cr"])
     # the first two CTU rows depend on nothing below them: they must equal the oracle on the crop
     ref = po.encode_picture(y[:64], cb[:32], cr[:32], qp, depth)
     for k in KEYS:
@@ -43,10 +45,23 @@ def test_1080p_depth2_properties(built):
     assert len(np.unique(a["cu_log2_size"])) >= 2 and np.count_nonzero(a["chroma_mode"] >= 81) > 0
 
 
-def test_2160p_depth3_decoder_check(built):
+def _top_rows_equal_oracle(rec, y, cb, cr, qp, depth, rows=32):
+    """CTU rows depend on nothing below them: the top `rows` luma rows must equal the oracle's encode of the crop."""
+    from oracle import pyoracle as po
+    w = y.shape[1]
+    ref = po.encode_picture(y[:rows], cb[:rows // 2], cr[:rows // 2], qp, depth)
+    for k, scale in (("cu_log2_size", 4), ("luma_mode", 4), ("chroma_mode", 8), ("lev_y", 1), ("lev_cb", 2), ("lev_cr", 2),
+                     ("rec_y", 1), ("rec_cb", 2), ("rec_cr", 2)):
+        assert np.array_equal(rec[k][:rows // scale], ref[k]), k
+    assert np.array_equal(rec["ctu_cost"][:(rows // 32) * (w // 32)], ref["ctu_cost"])
+
+
+@pytest.mark.parametrize("qp", [22, 27, 32, 37])
+def test_2160p_depth3_decoder_check(built, qp):
+    """BASELINE.json configs[2]: 3840x2176, the four QPs of the RD sweep, full search (max-split-depth 3)."""
     from wrenc_amd import gpu, synth
     from oracle import pyoracle as po
-    w, h, qp, depth = 3840, 2176, 27, 3
+    w, h, depth = 3840, 2176, 3
     y, cb, cr = synth.synth_textured_frame(w, h, 11)
     enc = gpu.Encoder(w, h, qp=qp, max_split_depth=depth)
     rec = enc.encode_picture(y, cb, cr)
@@ -54,9 +69,12 @@ def test_2160p_depth3_decoder_check(built):
     enc.close()
     ry, rcb, rcr = po.reconstruct_from_record(rec, qp, depth)
     assert np.array_equal(ry, rec["rec_y"]) and np.array_equal(rcb, rec["rec_cb"]) and np.array_equal(rcr, rec["rec_cr"])
+    sy, scb, scr = po.spec_decode_record(rec, qp)             # the decoder that shares no code with the oracle
+    assert np.array_equal(sy, rec["rec_y"]) and np.array_equal(scb, rec["rec_cb"]) and np.array_equal(scr, rec["rec_cr"])
+    _top_rows_equal_oracle(rec, y, cb, cr, qp, depth, rows=64)
     assert set(np.unique(rec["cu_log2_size"])) >= {2, 3, 4}      # the 8x8 -> 4x4 local dual tree is exercised
     psnr = 10 * np.log10(255.0 ** 2 / np.mean((rec["rec_y"].astype(np.float64) - y) ** 2))
-    assert psnr > 30.0
+    assert psnr > {22: 38.0, 27: 35.0, 32: 32.0, 37: 29.0}[qp]
 
 
 def test_level_overflow_is_reported(built):
@@ -76,22 +94,24 @@ def test_level_overflow_is_reported(built):
     enc.close()
 
 
-def test_4320p_depth2_decoder_check(built):
-    """The largest configuration of SURVEY.md 8d (7680x4320, 32400 CTUs): decoder-side reconstruction of
-    the record equals the encoder's, the final pass reproduces the search, and the picture's first CTU
-    row equals the oracle's encode of that row alone (a CTU row depends on nothing below it)."""
+@pytest.mark.parametrize("depth,tex", [(3, 1), (2, 0)])
+def test_4320p_decoder_check(built, depth, tex):
+    """BASELINE.json configs[4] (7680x4320 QP32 max-split-depth 3; 32400 CTUs) and the depth-2 variant:
+    decoder-side reconstruction of the record equals the encoder's, the final pass reproduces the search, and
+    the picture's first CTU row equals the oracle's encode of that row alone (a CTU row depends on nothing
+    below it)."""
     from wrenc_amd import gpu, synth
     from oracle import pyoracle as po
-    w, h, qp, depth = 7680, 4320, 32, 2
-    y, cb, cr = synth.synth_frame(w, h, 5)
+    w, h, qp = 7680, 4320, 32
+    y, cb, cr = (synth.synth_textured_frame if tex else synth.synth_frame)(w, h, 5)
     enc = gpu.Encoder(w, h, qp=qp, max_split_depth=depth)
     rec = enc.encode_picture(y, cb, cr)
     assert enc.final_pass_mismatches() == 0
     enc.close()
     ry, rcb, rcr = po.reconstruct_from_record(rec, qp, depth)
     assert np.array_equal(ry, rec["rec_y"]) and np.array_equal(rcb, rec["rec_cb"]) and np.array_equal(rcr, rec["rec_cr"])
-    ref = po.encode_picture(y[:32], cb[:16], cr[:16], qp, depth)
-    for k, scale in (("cu_log2_size", 4), ("luma_mode", 4), ("chroma_mode", 8), ("lev_y", 1), ("lev_cb", 2), ("lev_cr", 2),
-                     ("rec_y", 1), ("rec_cb", 2), ("rec_cr", 2)):
-        assert np.array_equal(rec[k][:32 // scale], ref[k]), k
-    assert np.array_equal(rec["ctu_cost"][:w // 32], ref["ctu_cost"])
+    sy, scb, scr = po.spec_decode_record(rec, qp)
+    assert np.array_equal(sy, rec["rec_y"]) and np.array_equal(scb, rec["rec_cb"]) and np.array_equal(scr, rec["rec_cr"])
+    _top_rows_equal_oracle(rec, y, cb, cr, qp, depth, rows=32)
+    if depth == 3:
+        assert set(np.unique(rec["cu_log2_size"])) >= {2, 3, 4}

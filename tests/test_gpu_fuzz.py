@@ -72,3 +72,5 @@ def test_random_case_matches_oracle(built, seed):
         assert np.array_equal(back[k], got[k]), (seed, k)
     ry, rcb, rcr = po.reconstruct_from_record(back, qp)
     assert np.array_equal(ry, got["rec_y"]) and np.array_equal(rcb, got["rec_cb"]) and np.array_equal(rcr, got["rec_cr"])
+    sy, scb, scr = po.spec_decode_record(back, qp)          # the decoder that shares no code with the oracle
+    assert np.array_equal(sy, got["rec_y"]) and np.array_equal(scb, got["rec_cb"]) and np.array_equal(scr, got["rec_cr"])

@@ -1,0 +1,65 @@
+"""The multi-group, multi-lane split of one encode call against the oracle: an encode call
+deals its pictures to workgroups of WPB = 8 pictures and the workgroups to up to 4 HIP streams ("lanes");
+the last workgroup is padded with waves that compute and never store.  19 pictures = 3 workgroups on 3 lanes
+with 5 padding waves; 33 pictures = 5 workgroups on 4 lanes with 7 padding waves.  The pictures of a
+workgroup are of DIFFERENT content kinds, so its 8 waves walk the pooled Viterbi's barriers with different
+data.  Every slot's full record (ctu_cost included) must equal the oracle's and the stream bytes the CPU path's."""
+import numpy as np
+import pytest
+
+from content import content
+
+pytestmark = pytest.mark.gpu
+
+KEYS = ("cu_log2_size", "luma_mode", "chroma_mode", "lev_y", "lev_cb", "lev_cr", "rec_y", "rec_cb", "rec_cr", "ctu_cost")
+KINDS = ["flat", "ramp", "stripes20", "stripes110", "checker", "noise", "cclm", "extremes", "stripes65"]
+
+
+def _frame(i, w, h):
+    from wrenc_amd import synth
+    if i % 3 == 2:
+        return synth.synth_textured_frame(w, h, i)
+    if i % 11 == 10:
+        return synth.synth_frame(w, h, i)
+    return content(KINDS[i % len(KINDS)], w, h, 1000 + i)
+
+
+@pytest.mark.parametrize("n_pictures,w,h,qp,depth,first_slot", [(19, 96, 64, 32, 2, 0), (33, 64, 64, 27, 3, 2), (9, 64, 96, 37, 1, 1)])
+def test_every_slot_of_a_multi_group_call_equals_the_oracle(built, n_pictures, w, h, qp, depth, first_slot):
+    from wrenc_amd import bitstream as bs, gpu
+    from oracle import pyoracle as po
+    frames = [_frame(i, w, h) for i in range(n_pictures)]
+    enc = gpu.Encoder(w, h, qp=qp, max_split_depth=depth, n_slots=first_slot + n_pictures)
+    for s, f in enumerate(frames):
+        enc.upload(first_slot + s, *f)
+    enc.encode(first_slot, n_pictures)
+    enc.sync()
+    assert enc.final_pass_mismatches() == 0
+    for s, f in enumerate(frames):
+        got = enc.download(first_slot + s)
+        ref = po.encode_picture(*f, qp, depth)
+        for k in KEYS:
+            assert np.array_equal(got[k], ref[k]), (s, k)
+        assert bs.write_picture(w, h, qp, s, got) == bs.write_picture(w, h, qp, s, ref), s
+    enc.close()
+
+
+def test_two_calls_in_flight_on_disjoint_slots(built):
+    """Two encode calls queued back to back (the double-buffered front ends do this): each keeps its own
+    workgroups' scratch regions and its slots' results."""
+    from wrenc_amd import gpu
+    from oracle import pyoracle as po
+    w, h, qp, depth = 64, 64, 32, 2
+    frames = [_frame(i, w, h) for i in range(20)]
+    enc = gpu.Encoder(w, h, qp=qp, max_split_depth=depth, n_slots=20)
+    for s, f in enumerate(frames):
+        enc.upload(s, *f)
+    enc.encode(0, 11)
+    enc.encode(11, 9)
+    enc.sync()
+    for s in (0, 7, 10, 11, 19):
+        got = enc.download(s)
+        ref = po.encode_picture(*frames[s], qp, depth)
+        for k in KEYS:
+            assert np.array_equal(got[k], ref[k]), (s, k)
+    enc.close()

@@ -168,6 +168,8 @@ def test_golden_fixture(path):
     # decoder-side reconstruction of the record equals the encoder's reconstruction
     ry, rcb, rcr = po.reconstruct_from_record(out, int(g["qp"]), int(g["depth"]))
     assert np.array_equal(ry, out["rec_y"]) and np.array_equal(rcb, out["rec_cb"]) and np.array_equal(rcr, out["rec_cr"])
+    sy, scb, scr = po.spec_decode_record(out, int(g["qp"]))
+    assert np.array_equal(sy, out["rec_y"]) and np.array_equal(scb, out["rec_cb"]) and np.array_equal(scr, out["rec_cr"])
 
 
 def test_edge_cases_single_ctu_and_flat():

@@ -1,6 +1,6 @@
 #!/bin/bash
 # File-to-stream rate of the native program on the GPU box: e2e_native.sh [N=1024] [batch=256] [threads=16] [textured=0]
-set -e
+set -e -o pipefail
 R=$(cd "$(dirname "$0")/.." && pwd)
 N=${1:-1024}; B=${2:-256}; T=${3:-16}; X=${4:-0}
 W=${W:-1920}; H=${H:-1088}; DEPTH=${DEPTH:-2}   # environment: other picture sizes / depths

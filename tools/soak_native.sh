@@ -1,7 +1,7 @@
 #!/bin/bash
 # Soak: N synthetic 1080p pictures piped into the native program (stdin -> stdout), two contexts on device 0.
 # soak_native.sh [N=6000] [devices=0,0]
-set -e
+set -e -o pipefail
 R=$(cd "$(dirname "$0")/.." && pwd)
 N=${1:-6000}; D=${2:-0,0}
 python3 - "$N" "$R" <<'PY' | "$R/wrenc_amd/csrc/host/wrenc" -i - -o - --input-size 1920x1088 --output-size 1920x1088 \

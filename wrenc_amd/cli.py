@@ -7,8 +7,10 @@ and the host bitstream writer.
 Flow of main.rs:223-402: VPS, SPS, PPS once; then per picture read Y, Cb, Cr (8-bit 4:2:0 at the output
 size), search + final pass (on the GPU, `--batch` pictures at a time: they are independent IDR pictures),
 picture header NAL + slice NAL, optionally the reconstruction.  `-` means stdin / stdout.  Like the
-reference, every failure prints `error: ...` on stderr and ends the process with status 0
-(main.rs:127-133,171-191).  There is no CPU path: without an MI355X the command fails.
+reference, argument and I/O errors print `error: ...` on stderr and end the process with status 0
+(main.rs:127-133,171-191); a failure inside the search or the stream writer (HIP error, a level that
+overflows the rate tables: the reference panics there, block_splitter.rs:453) ends it with status 101,
+Rust's panic status.  There is no CPU path: without an MI355X the command fails.
 """
 import argparse
 import sys
@@ -18,7 +20,12 @@ from concurrent.futures import ThreadPoolExecutor
 
 def _die(msg):
     sys.stderr.write("error: %s\n" % msg)
-    sys.exit(0)     # main.rs:132: process::exit(0) on every error
+    sys.exit(0)     # main.rs:132: process::exit(0) on argument and I/O errors
+
+
+def _fatal(msg):
+    sys.stderr.write("error: %s\n" % msg)
+    sys.exit(101)   # where the reference panics (a truncated stream must not come with status 0)
 
 
 def _size(text, what):
@@ -95,7 +102,7 @@ def main(argv=None):
         enc = gpu.Encoder(w, h, qp=qp, max_split_depth=a.max_split_depth, device=a.device, n_slots=halves * batch,
                           extra_params=a.extra_params)
     except (gpu.WrencGpuError, ImportError, OSError) as e:
-        _die(str(e))
+        _fatal(str(e))    # no device / a non-numeric extra-params value (parse().unwrap() panics in the reference)
 
     fout.write(bitstream.write_parameter_sets(w, h, qp))
     ysz, csz = w * h, (w // 2) * (h // 2)
@@ -105,7 +112,7 @@ def main(argv=None):
         stage_in = [enc.alloc_host(ysz + 2 * csz) for _ in range(halves * batch)]
         stage_out = [enc.alloc_picture_host(keys_wanted) for _ in range(halves * batch)]
     except gpu.WrencGpuError as e:
-        _die(str(e))
+        _fatal(str(e))
     pool = ThreadPoolExecutor(max_workers=max(1, a.threads))
     t_start = time.perf_counter()
     stats = {"pictures": 0, "bytes": 0, "read_upload": 0.0, "download": 0.0, "write": 0.0}
@@ -168,7 +175,7 @@ def main(argv=None):
         fout.flush()
         stats["seconds"] = time.perf_counter() - t_start     # before the page-locked buffers are released
     except (gpu.WrencGpuError, bitstream.BitstreamError) as e:
-        _die(str(e))
+        _fatal(str(e))
     finally:
         pool.shutdown()
         enc.close()

@@ -9,8 +9,10 @@
 // the output size, upload, search, read the record back, write picture header NAL + slice NAL, and the
 // reconstruction when asked for.  Two sets of device slots and of page-locked host buffers alternate, so
 // the GPU searches batch k+1 while batch k is read back and entropy coded on a pool of host threads.
-// `-` is stdin / stdout.  Every failure prints `error: ...` on stderr and exits with status 0, as the
-// reference does (main.rs:127-133).  Options the reference does not have: --batch, --threads, --device,
+// `-` is stdin / stdout.  Argument and I/O errors print `error: ...` on stderr and exit with status 0, as the
+// reference does (main.rs:127-133); a failure inside the search or the stream writer (a HIP error, a level
+// that overflows the rate tables, ...) is where the reference panics (block_splitter.rs:453): status 101,
+// Rust's panic status, so that a truncated stream never comes with a success status.  Options the reference does not have: --batch, --threads, --device,
 // --devices (several GPUs of the node, batches in turn), --verbose.  Links only against the two C ABIs: no HIP, no Python.
 #include <atomic>
 #include <chrono>
@@ -25,6 +27,8 @@
 #include <thread>
 #include <vector>
 
+#include <unistd.h>
+
 #include "../../../include/wrenc_bitstream.h"
 #include "../../../include/wrenc_gpu.h"
 
@@ -37,7 +41,19 @@ namespace {
     vfprintf(stderr, fmt, ap);
     fputc('\n', stderr);
     va_end(ap);
-    exit(0); // main.rs:132: process::exit(0) on every error
+    exit(0); // main.rs:132: process::exit(0) on argument and I/O errors
+}
+
+// failures of the two libraries: the reference panics there (exit status 101)
+[[noreturn]] void fatal(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    fputs("error: ", stderr);
+    vfprintf(stderr, fmt, ap);
+    fputc('\n', stderr);
+    va_end(ap);
+    fflush(nullptr);
+    _exit(101);
 }
 
 bool parse_size(const char* text, int& w, int& h) {
@@ -200,14 +216,15 @@ int main(int argc, char** argv) {
     const int n_dev = (int)devices.size();
     const int per_dev = num_pictures > (long)batch * n_dev ? 2 : 1;
     wrenc_gpu_config cfg;
-    if (wrenc_gpu_default_config(&cfg, w, h, qp, depth)) die("%s", wrenc_gpu_last_error(nullptr));
-    if (extra && wrenc_gpu_config_extra_params(&cfg, extra)) die("%s", wrenc_gpu_last_error(nullptr));
+    if (wrenc_gpu_default_config(&cfg, w, h, qp, depth)) fatal("%s", wrenc_gpu_last_error(nullptr));
+    if (extra && wrenc_gpu_config_extra_params(&cfg, extra)) fatal(  // a value that is not a number: parse().unwrap() panics in the reference
+       "%s", wrenc_gpu_last_error(nullptr));
     cfg.n_slots = per_dev * batch;
     std::vector<wrenc_gpu_ctx*> ctxs;
     for (int d : devices) {
         cfg.device = d;
         wrenc_gpu_ctx* ctx = nullptr;
-        if (wrenc_gpu_create(&cfg, &ctx)) die("%s", wrenc_gpu_last_error(nullptr)); // no CPU path: fails without an MI355X
+        if (wrenc_gpu_create(&cfg, &ctx)) fatal("%s", wrenc_gpu_last_error(nullptr)); // no CPU path: fails without an MI355X
         ctxs.push_back(ctx);
     }
 
@@ -222,19 +239,19 @@ int main(int argc, char** argv) {
         s.lev = (int16_t*)wrenc_gpu_alloc_host(s.ctx, pic * batch * sizeof(int16_t));
         s.maps = (uint8_t*)wrenc_gpu_alloc_host(s.ctx, maps * batch);
         if (frec) s.rec = (uint8_t*)wrenc_gpu_alloc_host(s.ctx, pic * batch);
-        if (!s.in || !s.lev || !s.maps || (frec && !s.rec)) die("%s", wrenc_gpu_last_error(s.ctx));
+        if (!s.in || !s.lev || !s.maps || (frec && !s.rec)) fatal("%s", wrenc_gpu_last_error(s.ctx));
         s.nal.resize((size_t)batch);
         s.status.assign((size_t)batch, 0);
         s.len.assign((size_t)batch, 0);
     }
     const auto gpu_check = [](HostSet& s, int rc) {
-        if (rc) die("%s", wrenc_gpu_last_error(s.ctx));
+        if (rc) fatal("%s", wrenc_gpu_last_error(s.ctx));
     };
 
     {
         uint8_t hdr[512];
         size_t n = 0;
-        if (wrenc_bs_write_parameter_sets(w, h, qp, hdr, sizeof(hdr), &n)) die("parameter sets do not fit");
+        if (wrenc_bs_write_parameter_sets(w, h, qp, hdr, sizeof(hdr), &n)) fatal("parameter sets do not fit");
         fwrite(hdr, 1, n, fout);
     }
 
@@ -281,7 +298,7 @@ int main(int argc, char** argv) {
     const auto flush = [&](HostSet& s) {
         pool.wait();
         for (int k = 0; k < s.bs_count; ++k) {
-            if (s.status[(size_t)k]) die("wrenc_bs_write_picture failed with %d on picture %d", s.status[(size_t)k], s.bs_first_poc + k);
+            if (s.status[(size_t)k]) fatal("wrenc_bs_write_picture failed with %d on picture %d", s.status[(size_t)k], s.bs_first_poc + k);
             fwrite(s.nal[(size_t)k].data(), 1, s.len[(size_t)k], fout);
             bytes += s.len[(size_t)k];
             if (frec) fwrite(s.rec + pic * k, 1, pic, frec); // main.rs:387-399

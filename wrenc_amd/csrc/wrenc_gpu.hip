@@ -6,7 +6,9 @@
 // above-right neighbours (encoder_context.rs:934-948), so CTU (r, c) can run once
 // every CTU on anti-diagonal c + 2r - 1 is done.  One launch processes one
 // anti-diagonal of every picture of the batch (one wave per CTU); stream order
-// between launches is the only synchronisation, no in-kernel spinning.
+// between launches is the only synchronisation between CTUs.  (The one in-kernel
+// wait is a workgroup's acquire of a scratch region from a bitmap that always has
+// more regions than workgroups can be resident, see ctu_search_kernel.)
 #include "../../include/wrenc_gpu.h"
 #include "wrenc_dev.h"
 
@@ -135,6 +137,56 @@ __global__ __launch_bounds__(64) void test_dequantize_kernel(const DevConst* __r
         out[(size_t)blockIdx.x * nn + i] = ((const int16_t*)SH.r2)[(i & (n - 1)) * n + (i >> lg)];
 }
 
+// Prediction of single blocks in the environment of given reconstruction planes (one wave per item):
+// the CTU's reconstruction tile and border are loaded from the planes, then reference samples +
+// prediction run exactly as in a full evaluation of the final pass (prediction bytes to scratch).
+// item = {x, y (luma, picture), log2 luma size, comp (0 luma block, 1 Cb+Cr pair), mode, output offset}
+__global__ __launch_bounds__(64) void test_predict_kernel(const DevConst* __restrict__ k, const uint8_t* planes,
+                                                          const int* items, uint8_t* scratch, uint8_t* out) {
+    const int* it = items + 6 * blockIdx.x;
+    const int x = it[0], y = it[1], tlg = it[2], comp = it[3], mode = it[4];
+    Ctx c = {};
+    c.k = (const CONST_AS DevConst*)k;
+    c.org = (const GLOBAL_AS uint8_t*)planes; // residuals are computed against these and ignored
+    c.W = k->W;
+    c.WH = k->W * k->H;
+    c.pred_scratch = scratch + (size_t)blockIdx.x * 1024;
+    c.ctu_x = x & ~31;
+    c.ctu_y = y & ~31;
+    c.write = 1;
+    load_tables(c);
+    const int W = c.W, Wc = W >> 1;
+    const GLOBAL_AS uint8_t* rec = (const GLOBAL_AS uint8_t*)planes;
+    for (int i = LANE; i < 72; i += 64) {
+        const int gx = c.ctu_x - 4 + i, gy = c.ctu_y - 1;
+        SH.recYtop[i] = (gx >= 0 && gx < W && gy >= 0) ? rec[(size_t)gy * W + gx] : 0;
+    }
+    for (int i = LANE; i < 32 * 36; i += 64) {
+        const int yy = i / 36, xx = i % 36 - 4;
+        const int gx = c.ctu_x + xx, gy = c.ctu_y + yy;
+        SH.recY[yy * 36 + xx + 4] = gx >= 0 ? rec[(size_t)gy * W + gx] : 0;
+    }
+    for (int pc = 1; pc < 3; ++pc) {
+        for (int i = LANE; i < 40; i += 64) {
+            const int gx = (c.ctu_x >> 1) - 4 + i, gy = (c.ctu_y >> 1) - 1;
+            SH.recCtop[pc - 1][i] = (gx >= 0 && gx < Wc && gy >= 0) ? rec[plane_off(c, pc) + (size_t)gy * Wc + gx] : 0;
+        }
+        for (int i = LANE; i < 16 * 20; i += 64) {
+            const int yy = i / 20, xx = i % 20 - 4;
+            const int gx = (c.ctu_x >> 1) + xx, gy = (c.ctu_y >> 1) + yy;
+            SH.recC[pc - 1][yy * 20 + xx + 4] = gx >= 0 ? rec[plane_off(c, pc) + (size_t)gy * Wc + gx] : 0;
+        }
+    }
+    WSYNC();
+    const int tx = x & 31, ty = y & 31;
+    if (mode < LT_CCLM) build_refs(c, comp, tx, ty, tlg);
+    predict<true>(c, comp, tx, ty, tlg, mode, 0, false);
+    const int n = 1 << (tlg - (comp ? 1 : 0));
+    const int total = (comp ? 2 : 1) * n * n;
+    __threadfence_block();
+    for (int i = LANE; i < total; i += 64) out[it[5] + i] = c.pred_scratch[i];
+}
+
 // ---------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------
@@ -208,6 +260,7 @@ struct wrenc_gpu_ctx {
     std::vector<hipStream_t> lanes;            // extra encode lanes (pictures are independent)
     std::vector<hipEvent_t> lane_done;
     hipEvent_t ev_fork = nullptr;
+    hipEvent_t last_done = nullptr;            // completion event of the most recent encode call
     DevConst* d_const = nullptr;
     PicBufs* d_slots = nullptr;
     std::vector<PicBufs> slots;
@@ -219,6 +272,7 @@ struct wrenc_gpu_ctx {
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;
     std::vector<hipEvent_t> ev_pool;
     int last_launches = 0;
+    bool stats_enabled = false; // per-launch timing events: bench / profiling only (wrenc_gpu_stats_enable)
     bool stats_valid = false;
     std::string err;
     int ctu_cols = 0, ctu_rows = 0;
@@ -631,17 +685,27 @@ int wrenc_gpu_encode(wrenc_gpu_ctx* ctx, int first_slot, int n_pictures) {
         HIP_TRY(ctx, hipMalloc((void**)&ctx->d_slot_map, kScratchSlots / 8));
         HIP_TRY(ctx, hipMemset(ctx->d_slot_map, 0, kScratchSlots / 8));
     }
-    while ((int)ctx->ev_pool.size() < 2 * ndiag * n_lanes) {
-        hipEvent_t e;
-        HIP_TRY(ctx, hipEventCreate(&e));
-        ctx->ev_pool.push_back(e);
+    const bool timed = ctx->stats_enabled;
+    if (timed) {
+        // the timing events are re-recorded by every call: the previous call's must have been reached first
+        if (ctx->stats_valid) HIP_TRY(ctx, hipEventSynchronize(ctx->ev_end));
+        while ((int)ctx->ev_pool.size() < 2 * ndiag * n_lanes) {
+            hipEvent_t e;
+            HIP_TRY(ctx, hipEventCreate(&e));
+            ctx->ev_pool.push_back(e);
+        }
     }
+    // The scratch-region bitmap is only ever changed by running workgroups (acquire at start, release at
+    // end).  A kernel that was aborted would leave its bits set for good, so the map is cleared whenever no
+    // encode call is in flight (the last call's completion event has been reached).
+    if (ctx->last_done == nullptr || hipEventQuery(ctx->last_done) == hipSuccess)
+        HIP_TRY(ctx, hipMemsetAsync(ctx->d_slot_map, 0, kScratchSlots / 8, ctx->stream));
     if (ctx->uploads_pending) {
         HIP_TRY(ctx, hipEventRecord(ctx->ev_uploaded, ctx->copy_stream));
         HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_uploaded, 0));
         ctx->uploads_pending = false;
     }
-    HIP_TRY(ctx, hipEventRecord(ctx->ev_begin, ctx->stream));
+    if (timed) HIP_TRY(ctx, hipEventRecord(ctx->ev_begin, ctx->stream));
     HIP_TRY(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
     for (int l = 1; l < n_lanes; ++l) HIP_TRY(ctx, hipStreamWaitEvent(ctx->lanes[l - 1], ctx->ev_fork, 0));
     int launches = 0;
@@ -660,13 +724,13 @@ int wrenc_gpu_encode(wrenc_gpu_ctx* ctx, int first_slot, int n_pictures) {
             if (g0 * WPB + lane_pics > n_pictures) lane_pics = n_pictures - g0 * WPB;
             if (lane_pics <= 0) continue;
             hipStream_t st = l == 0 ? ctx->stream : ctx->lanes[l - 1];
-            HIP_TRY(ctx, hipEventRecord(ctx->ev_pool[2 * launches], st));
+            if (timed) HIP_TRY(ctx, hipEventRecord(ctx->ev_pool[2 * launches], st));
             hipLaunchKernelGGL(ctu_search_kernel, dim3(count * (g1 - g0)), dim3(64 * WPB), 0, st, ctx->d_const,
                                ctx->d_slots, lane_first, lane_pics, d, r_min, count, ctx->d_pred_scratch, ctx->d_slot_map,
                                ctx->d_mismatch,
                                ctx->d_overflow);
             HIP_TRY(ctx, hipGetLastError());
-            HIP_TRY(ctx, hipEventRecord(ctx->ev_pool[2 * launches + 1], st));
+            if (timed) HIP_TRY(ctx, hipEventRecord(ctx->ev_pool[2 * launches + 1], st));
             ++launches;
         }
     }
@@ -674,12 +738,13 @@ int wrenc_gpu_encode(wrenc_gpu_ctx* ctx, int first_slot, int n_pictures) {
         HIP_TRY(ctx, hipEventRecord(ctx->lane_done[l - 1], ctx->lanes[l - 1]));
         HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->lane_done[l - 1], 0));
     }
-    HIP_TRY(ctx, hipEventRecord(ctx->ev_end, ctx->stream));
+    if (timed) HIP_TRY(ctx, hipEventRecord(ctx->ev_end, ctx->stream));
     // downloads of these slots wait for this call only, not for searches queued after it
     hipEvent_t done = ctx->enc_events[ctx->enc_event_next++ % ctx->enc_events.size()];
     HIP_TRY(ctx, hipEventRecord(done, ctx->stream));
+    ctx->last_done = done;
     ctx->last_launches = launches;
-    ctx->stats_valid = true;
+    ctx->stats_valid = timed;
     for (int s = first_slot; s < first_slot + n_pictures; ++s) {
         ctx->state[s] = 2;
         ctx->slot_event[s] = done;
@@ -755,7 +820,8 @@ int wrenc_gpu_encode_picture(wrenc_gpu_ctx* ctx, const uint8_t* y, const uint8_t
 
 int wrenc_gpu_last_encode_stats(wrenc_gpu_ctx* ctx, float* total_ms, float* kernel_ms_sum, int* n_launches) {
     if (!ctx) return WRENC_GPU_EINVAL;
-    if (!ctx->stats_valid) return fail(ctx, WRENC_GPU_ESTATE, "no encode has been queued");
+    if (!ctx->stats_enabled) return fail(ctx, WRENC_GPU_ESTATE, "per-launch timing is off (wrenc_gpu_stats_enable)");
+    if (!ctx->stats_valid) return fail(ctx, WRENC_GPU_ESTATE, "no encode has been queued since timing was switched on");
     HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
     HIP_TRY(ctx, hipEventSynchronize(ctx->ev_end));
     float t = 0.f;
@@ -769,6 +835,13 @@ int wrenc_gpu_last_encode_stats(wrenc_gpu_ctx* ctx, float* total_ms, float* kern
     if (total_ms) *total_ms = t;
     if (kernel_ms_sum) *kernel_ms_sum = sum;
     if (n_launches) *n_launches = ctx->last_launches;
+    return WRENC_GPU_OK;
+}
+
+int wrenc_gpu_stats_enable(wrenc_gpu_ctx* ctx, int on) {
+    if (!ctx) return WRENC_GPU_EINVAL;
+    ctx->stats_enabled = on != 0;
+    ctx->stats_valid = false;
     return WRENC_GPU_OK;
 }
 
@@ -847,6 +920,53 @@ int wrenc_gpu_test_quantize(wrenc_gpu_ctx* ctx, const int16_t* coef, int log2n, 
     }
     (void)hipFree(d_cost);
     return rc;
+}
+
+int wrenc_gpu_test_predict(wrenc_gpu_ctx* ctx, const uint8_t* rec_y, const uint8_t* rec_cb, const uint8_t* rec_cr,
+                           int n_items, const int32_t* items, uint8_t* out, size_t out_bytes) {
+    if (!ctx || !rec_y || !rec_cb || !rec_cr || !items || !out || n_items < 1) return WRENC_GPU_EINVAL;
+    const int W = ctx->cfg.width, H = ctx->cfg.height;
+    // operand shapes are checked on the host: a bad item must never reach the kernel
+    std::vector<int> dev_items((size_t)n_items * 6);
+    size_t total = 0;
+    for (int i = 0; i < n_items; ++i) {
+        const int32_t* q = items + 5 * i;
+        const int x = q[0], y = q[1], lg = q[2], comp = q[3], mode = q[4];
+        const int n = 1 << lg;
+        const bool ok = lg >= 2 && lg <= 5 && x >= 0 && y >= 0 && x + n <= W && y + n <= H && !(x & (n - 1)) && !(y & (n - 1)) &&
+                        (comp == 0 || (comp == 1 && lg >= 3)) &&
+                        ((mode >= 0 && mode <= 66) || (comp == 1 && mode >= LT_CCLM && mode <= T_CCLM));
+        if (!ok) return fail(ctx, WRENC_GPU_EINVAL, "wrenc_gpu_test_predict: bad item");
+        int* d = &dev_items[(size_t)i * 6];
+        d[0] = x; d[1] = y; d[2] = lg; d[3] = comp; d[4] = mode; d[5] = (int)total;
+        total += comp ? (size_t)n * n / 2 : (size_t)n * n;
+    }
+    if (total != out_bytes) return fail(ctx, WRENC_GPU_EINVAL, "wrenc_gpu_test_predict: output size does not match the items");
+    HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
+    const size_t wh = (size_t)W * H;
+    uint8_t *d_planes = nullptr, *d_scratch = nullptr, *d_out = nullptr;
+    int* d_items = nullptr;
+    hipError_t e = hipMalloc((void**)&d_planes, wh + wh / 2);
+    if (e == hipSuccess) e = hipMalloc((void**)&d_scratch, (size_t)n_items * 1024);
+    if (e == hipSuccess) e = hipMalloc((void**)&d_out, total);
+    if (e == hipSuccess) e = hipMalloc((void**)&d_items, dev_items.size() * sizeof(int));
+    if (e == hipSuccess) e = hipMemcpy(d_planes, rec_y, wh, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d_planes + wh, rec_cb, wh / 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d_planes + wh + wh / 4, rec_cr, wh / 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d_items, dev_items.data(), dev_items.size() * sizeof(int), hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(test_predict_kernel, dim3(n_items), dim3(64), 0, ctx->stream, ctx->d_const, d_planes, d_items,
+                           d_scratch, d_out);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e == hipSuccess) e = hipMemcpy(out, d_out, total, hipMemcpyDeviceToHost);
+    if (d_planes) (void)hipFree(d_planes);
+    if (d_scratch) (void)hipFree(d_scratch);
+    if (d_out) (void)hipFree(d_out);
+    if (d_items) (void)hipFree(d_items);
+    if (e != hipSuccess) return fail(ctx, WRENC_GPU_EHIP, hipGetErrorString(e));
+    return WRENC_GPU_OK;
 }
 
 } // extern "C"

@@ -20,9 +20,9 @@ LIB_PATH = os.environ.get("WRENC_GPU_LIB", os.path.join(_HERE, "csrc", "libwrenc
 EXPORTED_SYMBOLS = [
     "wrenc_gpu_default_config", "wrenc_gpu_config_extra_params", "wrenc_gpu_create", "wrenc_gpu_destroy", "wrenc_gpu_last_error",
     "wrenc_gpu_upload", "wrenc_gpu_encode", "wrenc_gpu_sync", "wrenc_gpu_download",
-    "wrenc_gpu_alloc_host", "wrenc_gpu_free_host", "wrenc_gpu_encode_picture", "wrenc_gpu_last_encode_stats", "wrenc_gpu_final_pass_mismatches",
+    "wrenc_gpu_alloc_host", "wrenc_gpu_free_host", "wrenc_gpu_encode_picture", "wrenc_gpu_stats_enable", "wrenc_gpu_last_encode_stats", "wrenc_gpu_final_pass_mismatches",
     "wrenc_gpu_test_fwd_dct", "wrenc_gpu_test_inv_dct", "wrenc_gpu_test_quantize",
-    "wrenc_gpu_test_dequantize",
+    "wrenc_gpu_test_dequantize", "wrenc_gpu_test_predict",
 ]
 
 
@@ -218,6 +218,11 @@ class Encoder:
         self.encode(0, 1)
         return self.download(0)
 
+    def stats_enable(self, on=True):
+        """Per-launch timing events (measurement mode, see include/wrenc_gpu.h)."""
+        self.lib.wrenc_gpu_stats_enable.argtypes = [C.c_void_p, C.c_int]
+        self._check(self.lib.wrenc_gpu_stats_enable(self.ctx, 1 if on else 0))
+
     def last_encode_stats(self):
         t, k, n = C.c_float(), C.c_float(), C.c_int()
         self._check(self.lib.wrenc_gpu_last_encode_stats(self.ctx, C.byref(t), C.byref(k), C.byref(n)))
@@ -244,6 +249,26 @@ class Encoder:
 
     def dequantize(self, blocks):
         return self._blocks(self.lib.wrenc_gpu_test_dequantize, blocks)
+
+    def predict_blocks(self, rec_y, rec_cb, rec_cr, items):
+        """items: (n, 5) int32 {x, y, log2 luma size, comp (0 luma, 1 Cb+Cr pair), mode}; returns the list of
+        predicted blocks (luma: (n, n); pair: (2, n/2, n/2))."""
+        items = np.ascontiguousarray(items, np.int32).reshape(-1, 5)
+        sizes = [((1 << int(q[2])) ** 2) // (2 if q[3] else 1) for q in items]
+        out = np.zeros(int(sum(sizes)), np.uint8)
+        planes = [np.ascontiguousarray(a, np.uint8) for a in (rec_y, rec_cb, rec_cr)]
+        assert planes[0].shape == (self.height, self.width)
+        self.lib.wrenc_gpu_test_predict.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
+                                                    C.c_void_p, C.c_size_t]
+        self._check(self.lib.wrenc_gpu_test_predict(self.ctx, _p(planes[0]), _p(planes[1]), _p(planes[2]), len(items),
+                                                    _p(items), _p(out), out.size))
+        res, at = [], 0
+        for q, sz in zip(items, sizes):
+            n = 1 << int(q[2])
+            blk = out[at:at + sz]
+            res.append(blk.reshape(2, n // 2, n // 2) if q[3] else blk.reshape(n, n))
+            at += sz
+        return res
 
     def quantize(self, blocks):
         arr = np.ascontiguousarray(blocks, np.int16)
