@@ -133,6 +133,16 @@ void wrenc_gpu_free_host(wrenc_gpu_ctx* ctx, void* p);
 int wrenc_gpu_encode_picture(wrenc_gpu_ctx* ctx, const uint8_t* y, const uint8_t* cb,
                              const uint8_t* cr, wrenc_gpu_picture* out);
 
+/* How an encode call maps CTUs to wavefronts.  Results are identical (bit-exact) either way.
+ *   WAVE: one wavefront per CTU, a workgroup = the same CTU of 8 pictures.  Highest throughput, but it needs
+ *         hundreds of pictures in flight to fill the GPU (a picture offers only one anti-diagonal of CTUs at a time).
+ *   TEAM: four wavefronts per CTU: the candidates of a leaf search that do not depend on each other
+ *         (block_splitter.rs:887-898, 905-974) run side by side.  Shorter CTU latency, for calls with few pictures.
+ *   AUTO (default): TEAM when the call cannot fill the GPU with one wave per CTU. */
+enum wrenc_gpu_schedule { WRENC_GPU_SCHEDULE_AUTO = 0, WRENC_GPU_SCHEDULE_WAVE = 1, WRENC_GPU_SCHEDULE_TEAM = 2 };
+int wrenc_gpu_set_schedule(wrenc_gpu_ctx* ctx, int schedule);
+int wrenc_gpu_last_schedule(const wrenc_gpu_ctx* ctx); /* what the most recent encode call used */
+
 /* Per-launch timing (two HIP events around every kernel launch) is OFF by default: the product path
  * (CLI, native program) never reads it.  bench.py / profiling switch it on.  While it is on, an encode
  * call first waits for the previous call's end event (the events are re-recorded), so consecutive calls

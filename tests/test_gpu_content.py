@@ -32,12 +32,13 @@ CASES = [
 ]
 
 
+@pytest.mark.parametrize("schedule", [1, 2])    # one wave per CTU / a team of four waves per CTU
 @pytest.mark.parametrize("kind,w,h,qp,depth", CASES)
-def test_content_matches_oracle(built, kind, w, h, qp, depth):
+def test_content_matches_oracle(built, kind, w, h, qp, depth, schedule):
     from wrenc_amd import gpu
     from oracle import pyoracle as po
     y, cb, cr = _content(kind, w, h, 1234 + w + h + qp)
-    enc = gpu.Encoder(w, h, qp=qp, max_split_depth=depth)
+    enc = gpu.Encoder(w, h, qp=qp, max_split_depth=depth, schedule=schedule)
     got = enc.encode_picture(y, cb, cr)
     assert enc.final_pass_mismatches() == 0
     enc.close()

@@ -49,7 +49,7 @@ def test_random_case_matches_oracle(built, seed):
         ref = po.encode_picture(y, cb, cr, qp, depth)
     except ValueError:
         ref = None  # a level reached 1024: the reference panics there, the GPU must report it too
-    enc = gpu.Encoder(w, h, qp=qp, max_split_depth=depth)
+    enc = gpu.Encoder(w, h, qp=qp, max_split_depth=depth, schedule=1 + seed % 2)   # wave / team schedule in turn
     if ref is None:
         with pytest.raises(gpu.WrencGpuError) as ei:
             enc.encode_picture(y, cb, cr)

@@ -24,12 +24,13 @@ def _frame(i, w, h):
     return content(KINDS[i % len(KINDS)], w, h, 1000 + i)
 
 
+@pytest.mark.parametrize("schedule", [1, 2])    # wave: groups of 8 pictures; team: groups of 2 pictures x 4 waves
 @pytest.mark.parametrize("n_pictures,w,h,qp,depth,first_slot", [(19, 96, 64, 32, 2, 0), (33, 64, 64, 27, 3, 2), (9, 64, 96, 37, 1, 1)])
-def test_every_slot_of_a_multi_group_call_equals_the_oracle(built, n_pictures, w, h, qp, depth, first_slot):
+def test_every_slot_of_a_multi_group_call_equals_the_oracle(built, n_pictures, w, h, qp, depth, first_slot, schedule):
     from wrenc_amd import bitstream as bs, gpu
     from oracle import pyoracle as po
     frames = [_frame(i, w, h) for i in range(n_pictures)]
-    enc = gpu.Encoder(w, h, qp=qp, max_split_depth=depth, n_slots=first_slot + n_pictures)
+    enc = gpu.Encoder(w, h, qp=qp, max_split_depth=depth, n_slots=first_slot + n_pictures, schedule=schedule)
     for s, f in enumerate(frames):
         enc.upload(first_slot + s, *f)
     enc.encode(first_slot, n_pictures)

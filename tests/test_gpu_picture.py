@@ -25,24 +25,26 @@ def _compare(got, ref, tag):
     (128, 96, 22, 2, 0),
     (128, 96, 37, 3, 1),
 ])
-def test_picture_matches_oracle(built, w, h, qp, depth, tex):
+@pytest.mark.parametrize("schedule", [1, 2])    # one wave per CTU / a team of four waves per CTU
+def test_picture_matches_oracle(built, w, h, qp, depth, tex, schedule):
     from wrenc_amd import gpu, synth
     from oracle import pyoracle as po
     y, cb, cr = (synth.synth_textured_frame if tex else synth.synth_frame)(w, h, 3)
-    enc = gpu.Encoder(w, h, qp=qp, max_split_depth=depth)
+    enc = gpu.Encoder(w, h, qp=qp, max_split_depth=depth, schedule=schedule)
     got = enc.encode_picture(y, cb, cr)
-    assert enc.final_pass_mismatches() == 0
+    assert enc.final_pass_mismatches() == 0 and enc.last_schedule() == schedule
     enc.close()
     ref = po.encode_picture(y, cb, cr, qp, depth)
     _compare(got, ref, "%dx%d qp%d d%d" % (w, h, qp, depth))
 
 
-def test_batch_of_pictures(built):
+@pytest.mark.parametrize("schedule", [1, 2])
+def test_batch_of_pictures(built, schedule):
     """Several pictures in flight in one encode call give the same result as one by one."""
     from wrenc_amd import gpu, synth
     from oracle import pyoracle as po
     w, h, qp, depth = 96, 64, 32, 2
-    enc = gpu.Encoder(w, h, qp=qp, max_split_depth=depth, n_slots=3)
+    enc = gpu.Encoder(w, h, qp=qp, max_split_depth=depth, n_slots=3, schedule=schedule)
     frames = [synth.synth_textured_frame(w, h, f) for f in range(3)]
     for s, (y, cb, cr) in enumerate(frames):
         enc.upload(s, y, cb, cr)

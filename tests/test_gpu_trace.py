@@ -27,9 +27,9 @@ def trace_gpu(built):
         gpu._lib, gpu.LIB_PATH = saved
 
 
-def _gpu_trace(gpu, y, cb, cr, qp, depth):
+def _gpu_trace(gpu, y, cb, cr, qp, depth, schedule):
     h, w = y.shape
-    enc = gpu.Encoder(w, h, qp=qp, max_split_depth=depth)
+    enc = gpu.Encoder(w, h, qp=qp, max_split_depth=depth, schedule=schedule)
     fn = enc.lib.wrenc_gpu_trace_read
     fn.restype = C.c_long
     fn.argtypes = [C.c_void_p, C.c_void_p, C.c_long]
@@ -49,7 +49,8 @@ def _gpu_trace(gpu, y, cb, cr, qp, depth):
     ("tex", 64, 64, 32, 2), ("tex", 96, 64, 27, 3), ("cclm", 128, 64, 32, 2), ("stripes45", 64, 64, 27, 2),
     ("noise", 64, 64, 37, 3), ("tex", 64, 32, 22, 1),
 ])
-def test_every_candidate_cost_matches_oracle(trace_gpu, kind, w, h, qp, depth):
+@pytest.mark.parametrize("schedule", [1, 2])    # one wave per CTU / a team of four waves per CTU
+def test_every_candidate_cost_matches_oracle(trace_gpu, kind, w, h, qp, depth, schedule):
     from oracle import pyoracle as po
     from wrenc_amd import synth
     if kind == "tex":
@@ -57,7 +58,7 @@ def test_every_candidate_cost_matches_oracle(trace_gpu, kind, w, h, qp, depth):
     else:
         from test_gpu_content import _content
         y, cb, cr = _content(kind, w, h, 77)
-    got, gtrace = _gpu_trace(trace_gpu, y, cb, cr, qp, depth)
+    got, gtrace = _gpu_trace(trace_gpu, y, cb, cr, qp, depth, schedule)
     ref, otrace = po.encode_picture_traced(y, cb, cr, qp, depth)
     assert np.array_equal(got["ctu_cost"], ref["ctu_cost"])
     kinds = set()

@@ -130,8 +130,10 @@ struct LeafSt {
     UF<uint8_t> op_ml, op_mc, op_act;   // modes / activity of the pending full evaluation
     UF<uint8_t> tree, bx, by, lg;
     UF<uint8_t> need_refs0, need_refs1; // reference samples of the block not built yet (luma / chroma pair)
+    UF<uint8_t> need_org;               // originals of the block not staged in LDS yet (blocks <= 16x16)
     UF<uint8_t> step;
-    UF<uint8_t> cur_mode, best_mode, mode, cclm_mode, dm_mode, dm_wins;
+    UF<uint8_t> cur_mode, mode, cclm_mode, dm_mode;
+    UF<uint8_t> holder, evalr;          // team schedule: the member whose slot 0 holds the best candidate / the CCLM evaluator
     UF<uint8_t> luma_mode, chroma_mode; // result
     UF<uint8_t> best_cls;               // header-bit class (mpm_class) of the best luma mode
     UF<uint8_t> need_save, tile_best;   // best candidate's reconstruction: not saved yet / still in the tile
@@ -143,7 +145,7 @@ struct LeafSt {
 
 // CTU search + final pass state (see ctu_step)
 struct CtuSt {
-    UF<uint8_t> cont, in_leaf;
+    UF<uint8_t> cont, in_leaf, xpar; // xpar: parity of the team's next exchange
     UF<uint8_t> level, bx, by, lg, max_depth;
     UF<uint8_t> i8, z, rl, rc;       // 4x4 child index, final-pass z-order index, regen modes
     UF<uint8_t> rbx, rby, rlg;       // regen block
@@ -151,6 +153,13 @@ struct CtuSt {
     UF<uint8_t> pend, pbx, pby, plg, pslot; // reconstruction save to attach to the next request
     UF<float> ret, ns_cost_cur, split8, ctu_cost;
     LeafSt leaf;
+};
+
+// Team schedule (ctu_search_team_kernel): what a member publishes to its team after a stage (dev_search.h,
+// leaf_step_team).  A full evaluation publishes its parts, a SAD list its first minimum and its first entry.
+struct XRes {
+    uint32_t ssd_y, ssd_c;
+    long long lvl_y, lvl_c;
 };
 
 // element offsets into Lds::refs: left (index 0 = corner) / above references of luma unfiltered,
@@ -184,6 +193,7 @@ struct __attribute__((aligned(16))) Lds {
     float split_cost[4];
     uint8_t ns_luma[4], ns_chroma[4], child[4];
     CtuSt st;                  // state of the search (dev_search.h)
+    XRes xr[2];                // team schedule: this member's published result, double-buffered by stage parity
 };
 
 // Per-wave uniform context.
@@ -199,6 +209,8 @@ struct Ctx {
     int ctu_x, ctu_y; // luma, picture coordinates
     int cu32_mode;    // in-CTU neighbour lookups during search resolve to the root CU
     int write;        // 0 for a padding wave (batch not a multiple of WPB): compute, never store
+    int member;       // team schedule: this wave's place in its team of kTeam waves (0 otherwise)
+    int trace;        // diagnostic trace: this wave's evaluations are of a real picture
 };
 
 // LDS: one working set per wave (= per CTU), WPB waves per workgroup, plus tables shared
@@ -210,6 +222,9 @@ struct Ctx {
 #define WRENC_WPB 8
 #endif
 constexpr int WPB = WRENC_WPB;
+// Team schedule: kTeam waves share ONE CTU (independent candidates of a leaf search run side by side), a
+// workgroup holds WPB / kTeam teams = the same CTU of that many pictures.
+constexpr int kTeam = 4;
 struct LdsTab {
     int32_t ldq[256];
     int32_t lv[256];
@@ -230,6 +245,8 @@ __device__ __forceinline__ Ctx uni(Ctx c) {
     c.ctu_y = uni(c.ctu_y);
     c.cu32_mode = uni(c.cu32_mode);
     c.write = uni(c.write);
+    c.member = uni(c.member);
+    c.trace = uni(c.trace);
     return c;
 }
 
@@ -365,6 +382,9 @@ __device__ __forceinline__ unsigned plane_off(const Ctx& c, int pc) {
     return pc == 0 ? 0u : (pc == 1 ? (unsigned)c.WH : (unsigned)(c.WH + (c.WH >> 2)));
 }
 __device__ __forceinline__ int org_get(const Ctx& c, int pc, int x, int y) {
+#ifdef WRENC_EXP_NO_ORG // timing experiment only (wrong results): what the global loads of originals cost
+    return (x * 7 + y * 13 + pc * 31) & 255;
+#endif
     const int cs = pc ? 1 : 0;
     const int stride = c.W >> cs;
     return c.org[plane_off(c, pc) + (unsigned)(((c.ctu_y >> cs) + y) * stride + (c.ctu_x >> cs) + x)];

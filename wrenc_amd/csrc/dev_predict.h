@@ -276,13 +276,31 @@ __device__ __forceinline__ CclmParams cclm_params(Ctx c, int comp, int tx, int t
 // byte offset in r2 of the staged originals (luma at +0, Cb | Cr at +1024): the last 1.5 KB, so that
 // r1 and the first 2688 bytes of r2 are one free region during SAD lists
 constexpr int kOrgStage = 2688;
-template <bool full>
-__device__ __forceinline__ int pred_org(const Ctx& c, int pc, int x, int y, int obase, int i) {
-    if (full) return org_get(c, pc, x, y);
-    return ((const uint8_t*)SH.r2)[kOrgStage + obase + i];
+// Blocks of at most 16x16 luma samples keep their originals in LDS for the WHOLE leaf search (SAD lists and
+// full evaluations alike): 256 B luma + 2 x 64 B chroma in the last 384 bytes of r2, which no stage of a
+// block that small touches (forward DCT <= 1088 B, quantize3 ends at byte 3840, dequantise / inverse DCT
+// <= 2560, the angular tables <= 2256).  Staged once per leaf (stage_org_leaf); a 32x32 block has no such
+// room: its SAD lists stage per list (stage_org), its full evaluations read the picture.
+constexpr int kOrgLeaf = 3840;
+// byte offset in r2 of the originals of component `comp` (0 luma, 1 chroma pair) of a block of log2 size tlg
+__device__ __forceinline__ int org_byte(int comp, int tlg) {
+    return tlg <= 4 ? kOrgLeaf + (comp ? 256 : 0) : kOrgStage + (comp ? 1024 : 0);
 }
-__device__ __forceinline__ void stage_org(const Ctx& c, int comps, int tx, int ty, int tlg) {
-    uint32_t* dst = (uint32_t*)((char*)SH.r2 + kOrgStage);
+// original of sample i of the block (plane pc, component coordinates x, y); lds: the block's originals are
+// staged at byte obyte of r2
+template <bool full>
+__device__ __forceinline__ int pred_org(const Ctx& c, int pc, int x, int y, int obyte, int i, bool lds) {
+    if (full && !lds) return org_get(c, pc, x, y);
+    return ((const uint8_t*)SH.r2)[obyte + i];
+}
+__device__ __forceinline__ void stage_org(const Ctx& c, int comps, int tx, int ty, int tlg, int lbyte = kOrgStage,
+                                          int cword = 256) {
+    uint32_t* dst = (uint32_t*)((char*)SH.r2 + lbyte);
+#ifdef WRENC_EXP_NO_ORG // timing experiment only
+    for (int w = LANE; w < 384; w += 64) dst[w] = 0x50607080u + (uint32_t)w;
+    WSYNC();
+    return;
+#endif
     if (comps & 1) {
         const int words = 1 << (2 * tlg - 2);
         for (int w = LANE; w < words; w += 64) {
@@ -297,12 +315,17 @@ __device__ __forceinline__ void stage_org(const Ctx& c, int comps, int tx, int t
             const int pl = w >= words ? 1 : 0;
             const int ww = w - pl * words;
             const int row = (4 * ww) >> lg, col = (4 * ww) & ((1 << lg) - 1);
-            dst[256 + w] = *(const GLOBAL_AS uint32_t*)&c.org[plane_off(c, 1 + pl) +
+            dst[cword + w] = *(const GLOBAL_AS uint32_t*)&c.org[plane_off(c, 1 + pl) +
                                                              (unsigned)((((c.ctu_y + ty) >> 1) + row) * (c.W >> 1) +
                                                                         ((c.ctu_x + tx) >> 1) + col)];
         }
     }
     WSYNC();
+}
+
+// originals of a block of at most 16x16 luma samples, once per leaf (see kOrgLeaf)
+__device__ __forceinline__ void stage_org_leaf(const Ctx& c, int comps, int tx, int ty, int tlg) {
+    stage_org(c, comps, tx, ty, tlg, kOrgLeaf, 64);
 }
 
 // one predicted sample: accumulate |org - pred|; `full` also stores residual and prediction
@@ -345,7 +368,8 @@ __device__ __forceinline__ int predict(Ctx c, int comp, int tx, int ty, int tlg,
     const int n = 1 << lg;
     const int cx = tx >> cs, cy = ty >> cs;
     const int nn = n * n;
-    const int obase = comp ? 1024 : 0;
+    const int obyte = org_byte(comp, tlg);
+    const bool olds = tlg <= 4;
     int sad = 0;
     if (mode >= LT_CCLM) {
         // model parameters of both planes in one pass: odd lanes derive Cr, even lanes Cb
@@ -359,7 +383,7 @@ __device__ __forceinline__ int predict(Ctx c, int comp, int tx, int ty, int tlg,
             const int blk = i >> (2 * lg);
             const int ii = i & (nn - 1);
             const int x = ii & (n - 1), y = ii >> lg;
-            const int o = pred_org<full>(c, comp + blk, cx + x, cy + y, obase, i); // issued early
+            const int o = pred_org<full>(c, comp + blk, cx + x, cy + y, obyte, i, olds); // issued early
             int v;
             if (flat128) {
                 v = 128;
@@ -395,7 +419,7 @@ __device__ __forceinline__ int predict(Ctx c, int comp, int tx, int ty, int tlg,
             const int blk = i >> (2 * lg);
             const int ii = i & (nn - 1);
             const int x = ii & (n - 1), y = ii >> lg;
-            const int o = pred_org<full>(c, comp + blk, cx + x, cy + y, obase, i); // issued early
+            const int o = pred_org<full>(c, comp + blk, cx + x, cy + y, obyte, i, olds); // issued early
             const int16_t* L = SH.refs + (blk ? R_LC1 : oL0);
             const int16_t* A = SH.refs + (blk ? R_AC1 : oA0);
             int v;
@@ -458,7 +482,7 @@ __device__ __forceinline__ int predict(Ctx c, int comp, int tx, int ty, int tlg,
         const int blk = i >> (2 * lg);
         const int ii = i & (nn - 1);
         const int x = ii & (n - 1), y = ii >> lg;
-        const int o = pred_org<full>(c, comp + blk, cx + x, cy + y, obase, i); // issued early
+        const int o = pred_org<full>(c, comp + blk, cx + x, cy + y, obyte, i, olds); // issued early
         const int16_t* L = SH.refs + (blk ? R_LC1 : oL0);
         const int16_t* A = SH.refs + (blk ? R_AC1 : oA0);
         int v;
@@ -534,7 +558,7 @@ __device__ __forceinline__ unsigned sad_list_cclm(const Ctx& c, int tx, int ty, 
         const int blk = i >> (2 * lg);
         const int ii = i & (nn - 1);
         const int x = ii & (n - 1), y = ii >> lg;
-        const int o = ((const uint8_t*)SH.r2)[kOrgStage + 1024 + i];
+        const int o = ((const uint8_t*)SH.r2)[org_byte(1, tlg) + i];
         const int ds = cclm_ds6(c, tx, ty, 2 * y, 2 * x, avail_l);
 #pragma unroll
         for (int m = 0; m < 3; ++m) {
@@ -585,7 +609,7 @@ __device__ __forceinline__ unsigned sad_list_angular(const Ctx& c, int comps, in
         const int n = 1 << lg;
         const int nn = n * n;
         const int cx = tx >> cs, cy = ty >> cs;
-        const int obase = comp ? 1024 : 0;
+        const int obyte = org_byte(comp, tlg);
         const int lgs = lg + 2; // table stride 4n >= 3n + 4 per block
         // ---- parameters of my entry (intra_predictor.rs:1287-1310, 355-372) ----
         const bool valid = my_mode != kNoMode;
@@ -655,7 +679,7 @@ __device__ __forceinline__ unsigned sad_list_angular(const Ctx& c, int comps, in
             const int blk = i >> (2 * lg);
             const int ii = i & (nn - 1);
             const int x = ii & (n - 1), y = ii >> lg;
-            const int o = ((const uint8_t*)SH.r2)[kOrgStage + obase + i];
+            const int o = ((const uint8_t*)SH.r2)[obyte + i];
             const int16_t* L = SH.refs + (blk ? R_LC1 : (comp == 0 ? R_L0 : R_LC0));
             const int16_t* A = SH.refs + (blk ? R_AC1 : (comp == 0 ? R_A0 : R_AC0));
 #pragma unroll 1
@@ -738,7 +762,7 @@ __device__ __forceinline__ unsigned sad_list_angular(const Ctx& c, int comps, in
                 const int blk = i >> (2 * lg);
                 const int ii = i & (nn - 1);
                 const int x = ii & (n - 1), y = ii >> lg;
-                const int o = ((const uint8_t*)SH.r2)[kOrgStage + obase + i];
+                const int o = ((const uint8_t*)SH.r2)[obyte + i];
                 const int16_t* L = SH.refs + (blk ? R_LC1 : oL0);
                 const int16_t* A = SH.refs + (blk ? R_AC1 : oA0);
                 const int along = vertical ? y : x, across = vertical ? x : y;

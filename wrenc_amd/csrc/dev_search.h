@@ -22,6 +22,13 @@ struct Req {
     bool active;    // false: walk the schedule only (keeps the workgroup's barriers aligned)
     bool refs0, refs1; // (re)build the luma / chroma reference samples of the block first
     bool final;     // final pass: store the levels, count reconstruction changes
+    int stage;      // before anything else: stage the block's originals in LDS (component bits; blocks <= 16x16 only)
+    // team schedule only (leaf_step_team): after an active K_FULL, save its reconstruction to this member's
+    // slot 0; copy_from: whose slot a COPY_RESTORE reads (member index, default this member); xchg: the team
+    // exchanges results after this request
+    bool post_save;
+    int copy_from;
+    bool xchg;
     int n;          // K_SADLIST: number of entries
     int tree;       // tree type of the leaf that asks (diagnostic trace only)
     // before the evaluation: save the block's reconstruction to a slot / restore it from there
@@ -69,6 +76,8 @@ __device__ __forceinline__ uint32_t full_back(const Ctx& c, const PicBufs& pb, c
     const int n = 1 << lg;
     const int nn = n * n;
     const int cx = q.tx >> cs, cy = q.ty >> cs;
+    const int obyte = org_byte(comp, q.tlg);
+    const bool olds = q.tlg <= 4;
     PROF_MARK(t3_);
     if (q.final && c.write) {
         const int stride = c.W >> cs;
@@ -97,7 +106,7 @@ __device__ __forceinline__ uint32_t full_back(const Ctx& c, const PicBufs& pb, c
         v = min(max(v, 0), 255);
         if (q.final && v != rec_get(pc, cx + x, cy + y)) ++diff;
         rec_put(pc, cx + x, cy + y, v);
-        const int d = v - org_get(c, pc, cx + x, cy + y);
+        const int d = v - (olds ? (int)((const uint8_t*)SH.r2)[obyte + i] : org_get(c, pc, cx + x, cy + y));
         part += (unsigned)M24(d, d);
     }
     const uint32_t ssd = (uint32_t)wave_sum_i32((int)part); // <= 1024 * 255^2: fits 32 bits
@@ -114,8 +123,11 @@ __device__ __forceinline__ uint32_t full_back(const Ctx& c, const PicBufs& pb, c
 // Save the reconstruction of a block (comps bit 0: luma n x n, bit 1: Cb and Cr (n/2) x (n/2)) from
 // the LDS tile to a slot in global scratch, or restore it from there.  Dwords: block corners are
 // multiples of 4 samples in every plane that takes part.
-__device__ __forceinline__ void copy_block(const Ctx& c, int mode, int comps, int slot, int tx, int ty, int tlg) {
-    GLOBAL_AS uint32_t* g = (GLOBAL_AS uint32_t*)(c.slots + slot * kSlotBytes);
+__device__ __forceinline__ void copy_block(const Ctx& c, int mode, int comps, int slot, int tx, int ty, int tlg,
+                                           int from_member = -1) {
+    // a team member may restore from another member's slots: the waves' scratch parts lie back to back
+    const int rel = from_member < 0 ? 0 : (from_member - c.member) * kWaveScratch;
+    GLOBAL_AS uint32_t* g = (GLOBAL_AS uint32_t*)(c.slots + rel + slot * kSlotBytes);
     if (comps & 1) {
         const int words = 1 << (2 * tlg - 2);
         for (int w = LANE; w < words; w += 64) {
@@ -155,8 +167,10 @@ __device__ __forceinline__ Res evaluate(const Ctx& c, const PicBufs& pb, const R
     r.lvl_c = 0;
     r.v0 = r.v1 = r.v2 = r.vmin = 3.40282347e+38f;
     r.imin = 0;
-    if (q.pre_copy != COPY_NONE) copy_block(c, q.pre_copy, q.copy_comps, q.copy_slot, q.copy_tx, q.copy_ty, q.copy_tlg);
+    if (q.pre_copy != COPY_NONE)
+        copy_block(c, q.pre_copy, q.copy_comps, q.copy_slot, q.copy_tx, q.copy_ty, q.copy_tlg, q.copy_from);
     if (q.kind == K_NOP) return r;
+    if (q.stage) stage_org_leaf(c, q.stage, q.tx, q.ty, q.tlg);
     if (q.kind == K_FULL) {
         // A candidate of the search with an 8x8 or 16x16 luma block quantises its three transform
         // blocks in one pooled pass (quantize3): both components go through the first half, then
@@ -199,13 +213,14 @@ __device__ __forceinline__ Res evaluate(const Ctx& c, const PicBufs& pb, const R
                     r.ssd_y = ssd;
             }
         }
+        if (q.post_save && q.active) copy_block(c, COPY_SAVE, q.comps, 0, q.tx, q.ty, q.tlg);
         return r;
     }
     // K_SADLIST: get_intra_pred_aux_cost / get_chroma_intra_pred_aux_cost of each listed mode
     PROF_MARK(tr0_);
     if (q.refs0 && (q.comps & 1)) build_refs(c, 0, q.tx, q.ty, q.tlg);
     if (q.refs1 && (q.comps & 2)) build_refs(c, 1, q.tx, q.ty, q.tlg);
-    stage_org(c, q.comps, q.tx, q.ty, q.tlg);
+    if (q.tlg > 4) stage_org(c, q.comps, q.tx, q.ty, q.tlg); // smaller blocks: staged once per leaf
     PROF_MARK(t0_);
     PROF_ADD2(PH_REFS, tr0_, t0_);
     // SADs stay integers (< 2^20, so the f32 the reference compares is exact and ordered the same
@@ -218,7 +233,7 @@ __device__ __forceinline__ Res evaluate(const Ctx& c, const PicBufs& pb, const R
         // a list of angular modes (the 13 directional candidates, a step-search pair)
         const unsigned acc = sad_list_angular(c, q.comps, q.tx, q.ty, q.tlg, q.n, q.modes_lo, q.modes_hi);
         const int my_mode = LANE < q.n ? (int)(((LANE < 8 ? q.modes_lo : q.modes_hi) >> (8 * (LANE & 7))) & 255u) : kNoMode;
-        if (c.write && my_mode != kNoMode)
+        if (c.trace && my_mode != kNoMode)
             TRACE_REC(c.ctu_x + q.tx, c.ctu_y + q.ty, q.tlg, q.tree, (q.comps & 1) ? 0 : 2, (q.comps & 1) ? my_mode : 0, my_mode,
                       __float_as_int((float)acc));
         // first minimum = smallest (sad, index) pair
@@ -239,7 +254,7 @@ __device__ __forceinline__ Res evaluate(const Ctx& c, const PicBufs& pb, const R
         s0 = (unsigned)__builtin_amdgcn_readlane((int)acc, 0);
         s1 = (unsigned)__builtin_amdgcn_readlane((int)acc, 1);
         s2 = (unsigned)__builtin_amdgcn_readlane((int)acc, 2);
-        if (c.write && LANE < 3)
+        if (c.trace && LANE < 3)
             TRACE_REC(c.ctu_x + q.tx, c.ctu_y + q.ty, q.tlg, q.tree, 2, 0, LANE == 0 ? LT_CCLM : (LANE == 1 ? T_CCLM : L_CCLM),
                       __float_as_int((float)acc));
         smin = s0;
@@ -269,7 +284,7 @@ __device__ __forceinline__ Res evaluate(const Ctx& c, const PicBufs& pb, const R
                     PROF_ADD2(PH_PCNT + ((q.tlg - 2) * 2 + comp), 0, 1);
                 }
             }
-            if (c.write && LANE == 0 && m != kNoMode)
+            if (c.trace && LANE == 0 && m != kNoMode)
                 TRACE_REC(c.ctu_x + q.tx, c.ctu_y + q.ty, q.tlg, q.tree, (q.comps & 1) ? 0 : 2, (q.comps & 1) ? m : 0, m,
                           __float_as_int((float)sad));
             if (i == 0) s0 = sad;
@@ -455,7 +470,10 @@ __device__ __forceinline__ void req_full(Req& q, int comps, int tx, int ty, int 
     q.refs0 = refs0;
     q.refs1 = refs1;
     q.final = final;
+    q.stage = (final && tlg <= 4) ? comps : 0; // a final-pass block is evaluated once: stage its originals now
     q.pre_copy = COPY_NONE;
+    q.post_save = false;
+    q.xchg = false;
 }
 
 __device__ __forceinline__ void req_copy(Req& q, int mode, int comps, int slot, int tx, int ty, int tlg) {
@@ -465,6 +483,7 @@ __device__ __forceinline__ void req_copy(Req& q, int mode, int comps, int slot, 
     q.copy_tx = tx;
     q.copy_ty = ty;
     q.copy_tlg = tlg;
+    q.copy_from = -1;
 }
 
 enum {
@@ -481,6 +500,7 @@ __device__ __forceinline__ void leaf_init(LeafSt& s, int tree, int bx, int by, i
     s.dm_mode = (uint8_t)dm_mode;
     s.need_refs0 = 1;
     s.need_refs1 = 1;
+    s.need_org = lg <= 4 ? 1 : 0;
     s.need_save = 0;
     s.tile_best = 0;
 }
@@ -494,9 +514,19 @@ __device__ __forceinline__ void leaf_attach_save(LeafSt& s, Req& q) {
         s.need_save = 0;
     }
 }
+// the first evaluation of a leaf stages the originals of all the leaf's components (blocks <= 16x16)
+__device__ __forceinline__ void leaf_attach_org(LeafSt& s, Req& q) {
+    q.stage = 0;
+    if (s.need_org) {
+        q.stage = s.tree == TREE_SINGLE ? 3 : (s.tree == TREE_DUAL_LUMA ? 1 : 2);
+        s.need_org = 0;
+    }
+}
 // a request that only saves / restores a reconstruction
 __device__ __forceinline__ void leaf_copy_only(LeafSt& s, Req& q, int mode, int comps, int cont) {
     q.kind = K_NOP;
+    q.post_save = false;
+    q.xchg = false;
     req_copy(q, mode, comps, 0, s.bx, s.by, s.lg);
     s.cont = (uint8_t)cont;
 }
@@ -509,6 +539,7 @@ __device__ __forceinline__ void leaf_full(LeafSt& s, Req& q, int comps, int ml, 
     const bool r1 = (comps & 2) && mc < LT_CCLM && s.need_refs1 != 0;
     req_full(q, comps, s.bx, s.by, s.lg, ml, mc, !solo, act, r0, r1, false);
     q.tree = s.tree;
+    leaf_attach_org(s, q);
     leaf_attach_save(s, q);
     if (act) {
         if (r0) s.need_refs0 = 0;
@@ -524,6 +555,8 @@ __device__ __forceinline__ void leaf_full(LeafSt& s, Req& q, int comps, int ml, 
 __device__ __forceinline__ void leaf_sadlist(LeafSt& s, Req& q, int comps, int n, uint32_t m0, uint32_t m1, uint32_t m2,
                                              uint32_t m3, bool chroma_refs, int cont) {
     q.kind = K_SADLIST;
+    q.post_save = false;
+    q.xchg = false;
     q.tree = s.tree;
     q.comps = comps;
     q.tx = s.bx;
@@ -536,6 +569,7 @@ __device__ __forceinline__ void leaf_sadlist(LeafSt& s, Req& q, int comps, int n
     q.refs1 = (comps & 2) && chroma_refs && s.need_refs1 != 0;
     if (q.refs0) s.need_refs0 = 0;
     if (q.refs1) s.need_refs1 = 0;
+    leaf_attach_org(s, q);
     leaf_attach_save(s, q);
     s.cont = (uint8_t)cont;
 }
@@ -770,6 +804,310 @@ __device__ __forceinline__ bool leaf_step(const Ctx& c, LeafSt& s, const Res& r,
     }
 }
 
+
+// ---------------------------------------------------------------------------
+// Team schedule: kTeam = 4 waves search ONE CTU.  Every member runs the same control flow on its own copy
+// of the state and of the reconstruction tile; where the reference's leaf search evaluates candidates that
+// do not depend on each other (block_splitter.rs:887-898: the 15 first-round candidates read only
+// neighbours outside the block; :905-973 the two probes of a step-search round; :974 the three full
+// evaluations of the last round; the three CCLM probes), each member evaluates ONE of them, the members
+// publish their results in LDS (XRes) and meet at a workgroup barrier, and every member then makes the
+// reference's decisions from all results in the reference's order.  A full candidate's reconstruction is
+// saved to its evaluator's slot 0 in global scratch; once the leaf is decided every member restores the
+// winner from the slot of the member that holds it, so all tiles agree again before the next block.
+// Quantisation is solo (every member walks its own trellis): between exchanges the members run freely.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ const Lds& team_lds(const Ctx& c, int m) { return SHW[(WAVE & ~(kTeam - 1)) + m]; }
+
+// published result of member m in the exchange that just completed (parity par)
+__device__ __forceinline__ EvalParts xparts(const Ctx& c, int par, int m) {
+    const XRes& x = team_lds(c, m).xr[par];
+    EvalParts e;
+    e.ssd_y = (uint32_t)uni((int)x.ssd_y);
+    e.ssd_c = (uint32_t)uni((int)x.ssd_c);
+    const unsigned long long a = (unsigned long long)x.lvl_y, b = (unsigned long long)x.lvl_c;
+    e.lvl_y = (long long)(((unsigned long long)(unsigned)uni((int)(a >> 32)) << 32) | (unsigned)uni((int)a));
+    e.lvl_c = (long long)(((unsigned long long)(unsigned)uni((int)(b >> 32)) << 32) | (unsigned)uni((int)b));
+    return e;
+}
+// SAD list results: first minimum (f32 bits in ssd_y), its index (ssd_c), the first entry's cost (lvl_y)
+__device__ __forceinline__ float xvmin(const Ctx& c, int par, int m) { return __int_as_float(uni((int)team_lds(c, m).xr[par].ssd_y)); }
+__device__ __forceinline__ int ximin(const Ctx& c, int par, int m) { return uni((int)team_lds(c, m).xr[par].ssd_c); }
+__device__ __forceinline__ float xv0(const Ctx& c, int par, int m) { return __int_as_float(uni((int)team_lds(c, m).xr[par].lvl_y)); }
+
+__device__ __forceinline__ void team_publish(const Req& q, const Res& r, int par) {
+    XRes x;
+    if (q.kind == K_FULL) {
+        x.ssd_y = r.ssd_y;
+        x.ssd_c = r.ssd_c;
+        x.lvl_y = r.lvl_y;
+        x.lvl_c = r.lvl_c;
+    } else {
+        x.ssd_y = (uint32_t)__float_as_int(r.vmin);
+        x.ssd_c = (uint32_t)r.imin;
+        x.lvl_y = (long long)(unsigned)__float_as_int(r.v0);
+        x.lvl_c = 0;
+    }
+    if (LANE == 0) SH.xr[par] = x;
+}
+
+enum { TC_START = 0, TC_A, TC_PAIR_EMIT, TC_PAIR, TC_D, TC_E, TC_F, TC_DONE, TC_DC_START, TC_DC_A, TC_DC_B };
+
+// a member with nothing to evaluate in a stage
+__device__ __forceinline__ void team_idle(Req& q) {
+    q.kind = K_NOP;
+    q.pre_copy = COPY_NONE;
+    q.post_save = false;
+}
+// every member but `holder` restores comps of the leaf's block from holder's slot 0, attached to q
+__device__ __forceinline__ void team_restore(const Ctx& c, const LeafSt& s, Req& q, int comps, int holder) {
+    if (c.member != holder) {
+        req_copy(q, COPY_RESTORE, comps, 0, s.bx, s.by, s.lg);
+        q.copy_from = holder;
+    }
+}
+
+// One step of a leaf search in the team schedule; par = parity of the exchange that delivered the results
+// of the previous step's requests.  Same decisions, in the same order, as leaf_step.
+__device__ __forceinline__ bool leaf_step_team(const Ctx& c, LeafSt& s, Req& q, int par) {
+    const int tree = s.tree;
+    const int both = tree == TREE_SINGLE ? 3 : 1;
+    const int me = c.member;
+    int cont = s.cont;
+    for (;;) {
+        switch (cont) {
+        case TC_START: // stage A: planar | DC | the 13 directional SADs in two halves (:887-904)
+            if (me == 0) {
+                leaf_full(s, q, both, PLANAR, PLANAR, true, TC_A, true);
+                q.post_save = true;
+            } else if (me == 1) {
+                leaf_full(s, q, both, DC, DC, true, TC_A, true);
+                q.post_save = true;
+            } else if (me == 2) {
+                leaf_sadlist(s, q, both, 7, 2u | (7u << 8) | (13u << 16) | (18u << 24), 23u | (29u << 8) | (34u << 16), 0, 0, true, TC_A);
+            } else {
+                leaf_sadlist(s, q, both, 6, 39u | (45u << 8) | (50u << 16) | (55u << 24), 60u | (66u << 8), 0, 0, true, TC_A);
+            }
+            q.xchg = true;
+            return true;
+        case TC_A: {
+            const EvalParts e0 = xparts(c, par, 0), e1 = xparts(c, par, 1);
+            const float v0 = uni_f(assemble_cost(c, tree, 0, PLANAR, e0));
+            const int cls1 = mpm_class(c, s.bx, s.by, s.lg, DC);
+            const float v1 = uni_f(assemble_cost(c, tree, cls1, DC, e1));
+            if (c.write && LANE == 0) {
+                TRACE_REC(c.ctu_x + s.bx, c.ctu_y + s.by, s.lg, tree, 1, PLANAR, PLANAR, __float_as_int(v0));
+                TRACE_REC(c.ctu_x + s.bx, c.ctu_y + s.by, s.lg, tree, 1, DC, DC, __float_as_int(v1));
+            }
+            if (v1 < v0) { // first minimum of [planar, DC, ...] as a running strict-less update
+                s.best_cost = v1;
+                put_parts(s.e_best, e1);
+                s.mode = DC;
+                s.best_cls = (uint8_t)cls1;
+                s.holder = 1;
+            } else {
+                s.best_cost = v0;
+                put_parts(s.e_best, e0);
+                s.mode = PLANAR;
+                s.best_cls = 0;
+                s.holder = 0;
+            }
+            // first minimum over the 13 SADs: member 3's half wins only when strictly smaller
+            const float a = xvmin(c, par, 2), b = xvmin(c, par, 3);
+            const int j = (b < a ? 7 + ximin(c, par, 3) : ximin(c, par, 2)) + 2;
+            const int m = j < 8 ? (int)((0x3A5C90D0E08080ULL >> (7 * j)) & 127)
+                                : (int)((0x109E3764B53A2ULL >> (7 * (j - 8))) & 127);
+            s.cur_mode = (uint8_t)m;
+            s.cur_cost = b < a ? b : a;
+            s.step = 2;
+            cont = TC_PAIR_EMIT;
+            break;
+        }
+        case TC_PAIR_EMIT: { // a step-search round: the two probes side by side (:905-973)
+            const int cm = s.cur_mode, st = s.step;
+            const int lo = !(cm < 2 + st) ? cm - st : kNoMode;
+            const int hi = !(cm + st > 66) ? cm + st : kNoMode;
+            if (me == 2)
+                leaf_sadlist(s, q, both, 1, (uint32_t)lo, 0, 0, 0, true, TC_PAIR);
+            else if (me == 3)
+                leaf_sadlist(s, q, both, 1, (uint32_t)hi, 0, 0, 0, true, TC_PAIR);
+            else
+                team_idle(q);
+            s.cont = TC_PAIR;
+            q.xchg = true;
+            return true;
+        }
+        case TC_PAIR: {
+            const float cur = s.cur_cost, c0 = xv0(c, par, 2), c1 = xv0(c, par, 3);
+            const int st = s.step;
+            const float mn = fminf(fminf(cur, c0), c1);
+            if (cur == mn) {
+            } else if (c0 == mn) {
+                s.cur_mode -= st;
+                s.cur_cost = c0;
+            } else {
+                s.cur_mode += st;
+                s.cur_cost = c1;
+            }
+            if ((st >> 1) > 0) {
+                s.step = (uint8_t)(st >> 1);
+                cont = TC_PAIR_EMIT;
+                break;
+            }
+            // stage D: cm, cm - 1, cm + 1 side by side (:974) on the three members that do not hold the
+            // best of {planar, DC}; candidate k goes to the k-th of them in ascending order
+            const int cm = s.cur_mode, holder = s.holder;
+            const int k = me - (me > holder ? 1 : 0); // my candidate, if I am not the holder
+            const int mode = k == 0 ? cm : (k == 1 ? cm - 1 : cm + 1);
+            const bool act = k == 0 || (k == 1 ? !(cm < 3) : !(cm + 1 > 66));
+            if (me != holder && act) {
+                leaf_full(s, q, both, mode, mode, true, TC_D, true);
+                q.post_save = true;
+            } else {
+                team_idle(q);
+            }
+            s.cont = TC_D;
+            q.xchg = true;
+            return true;
+        }
+        case TC_D: {
+            const int cm = s.cur_mode, holder0 = s.holder;
+#pragma unroll 1
+            for (int k = 0; k < 3; ++k) {
+                const int mode = k == 0 ? cm : (k == 1 ? cm - 1 : cm + 1);
+                const bool act = k == 0 || (k == 1 ? !(cm < 3) : !(cm + 1 > 66));
+                if (!act) continue; // a skipped evaluation costs f32::MAX in the reference: never a new minimum
+                const int mem = k + (k >= holder0 ? 1 : 0);
+                const EvalParts e = xparts(c, par, mem);
+                const int cls = mpm_class(c, s.bx, s.by, s.lg, mode);
+                const float val = uni_f(assemble_cost(c, tree, cls, mode, e));
+                if (c.write && LANE == 0)
+                    TRACE_REC(c.ctu_x + s.bx, c.ctu_y + s.by, s.lg, tree, 1, mode, mode, __float_as_int(val));
+                if (val < s.best_cost) {
+                    s.best_cost = val;
+                    put_parts(s.e_best, e);
+                    s.mode = (uint8_t)mode;
+                    s.best_cls = (uint8_t)cls;
+                    s.holder = (uint8_t)mem;
+                }
+            }
+            s.cost = s.best_cost;
+            const int m = s.mode, holder = s.holder;
+            s.luma_mode = (uint8_t)m;
+            s.chroma_mode = (uint8_t)m;
+            if (tree == TREE_DUAL_LUMA) { // every tile gets the winner's luma; nothing else to decide
+                team_idle(q);
+                team_restore(c, s, q, 1, holder);
+                s.cont = TC_DONE;
+                q.xchg = false;
+                return true;
+            }
+            // :1040 the winner's chroma cost, then the three CCLM probes side by side on the winner's luma
+            s.cur_cost = uni_f(assemble_chroma_cost(c, m, s.e_best.get()));
+            if (c.write && LANE == 0)
+                TRACE_REC(c.ctu_x + s.bx, c.ctu_y + s.by, s.lg, tree, 3, 0, m, __float_as_int((float)s.cur_cost));
+            if (me < 3)
+                leaf_sadlist(s, q, 2, 1, (uint32_t)(me == 0 ? LT_CCLM : (me == 1 ? T_CCLM : L_CCLM)), 0, 0, 0, false, TC_E);
+            else
+                team_idle(q);
+            team_restore(c, s, q, 3, holder);
+            s.cont = TC_E;
+            q.xchg = true;
+            return true;
+        }
+        case TC_E: {
+            const int cm = pick_cclm(xv0(c, par, 0), xv0(c, par, 1), xv0(c, par, 2));
+            s.cclm_mode = (uint8_t)cm;
+            const int ev = (s.holder + 1) & (kTeam - 1); // never the holder: its slot keeps the DM chroma
+            s.evalr = (uint8_t)ev;
+            if (me == ev) {
+                leaf_full(s, q, 2, 0, cm, true, TC_F, true);
+                q.post_save = true;
+            } else {
+                team_idle(q);
+            }
+            s.cont = TC_F;
+            q.xchg = true;
+            return true;
+        }
+        case TC_F: {
+            const int ev = s.evalr, holder = s.holder;
+            const EvalParts rp = xparts(c, par, ev);
+            EvalParts e = s.e_best.get();
+            e.ssd_c = rp.ssd_c;
+            e.lvl_c = rp.lvl_c;
+            const float cclm_cost = uni_f(assemble_chroma_cost(c, s.cclm_mode, e));
+            if (c.write && LANE == 0)
+                TRACE_REC(c.ctu_x + s.bx, c.ctu_y + s.by, s.lg, tree, 3, 0, s.cclm_mode, __float_as_int(cclm_cost));
+            const float cur = s.cur_cost;
+            const bool dm_wins = cur == fminf(cclm_cost, fminf(cur, 3.40282347e+38f));
+            const int m = s.mode, bcls = s.best_cls;
+            team_idle(q);
+            q.xchg = false;
+            s.cont = TC_DONE;
+            if (dm_wins) { // only the evaluator's tile holds the CCLM chroma
+                s.cost = uni_f(assemble_cost(c, tree, bcls, m, s.e_best.get()));
+                if (me == ev) {
+                    req_copy(q, COPY_RESTORE, 2, 0, s.bx, s.by, s.lg);
+                    q.copy_from = holder;
+                }
+                return true;
+            }
+            s.chroma_mode = s.cclm_mode;
+            s.cost = uni_f(assemble_cost(c, tree, bcls, s.cclm_mode, e));
+            team_restore(c, s, q, 2, ev);
+            return true;
+        }
+        case TC_DONE:
+            return false;
+        // ---- DUAL_TREE_CHROMA leaf (:794-885): the three CCLM probes and the DM evaluation side by side ----
+        case TC_DC_START:
+            if (me < 3) {
+                leaf_sadlist(s, q, 2, 1, (uint32_t)(me == 0 ? LT_CCLM : (me == 1 ? T_CCLM : L_CCLM)), 0, 0, 0, false, TC_DC_A);
+            } else {
+                leaf_full(s, q, 2, 0, s.dm_mode, true, TC_DC_A, true);
+                q.post_save = true;
+            }
+            s.cont = TC_DC_A;
+            q.xchg = true;
+            return true;
+        case TC_DC_A: {
+            const int cm = pick_cclm(xv0(c, par, 0), xv0(c, par, 1), xv0(c, par, 2));
+            s.cclm_mode = (uint8_t)cm;
+            const float dm_cost = uni_f(assemble_chroma_cost(c, s.dm_mode, xparts(c, par, 3)));
+            s.cur_cost = dm_cost;
+            if (me == 0) {
+                leaf_full(s, q, 2, 0, cm, true, TC_DC_B, true);
+                q.post_save = true;
+            } else {
+                team_idle(q);
+            }
+            s.cont = TC_DC_B;
+            q.xchg = true;
+            return true;
+        }
+        default: { // TC_DC_B
+            const float c0 = uni_f(assemble_chroma_cost(c, s.cclm_mode, xparts(c, par, 0)));
+            const float dm_cost = s.cur_cost;
+            if (c.write && LANE == 0) {
+                TRACE_REC(c.ctu_x + s.bx, c.ctu_y + s.by, s.lg, tree, 3, 0, s.cclm_mode, __float_as_int(c0));
+                TRACE_REC(c.ctu_x + s.bx, c.ctu_y + s.by, s.lg, tree, 3, 0, s.dm_mode, __float_as_int(dm_cost));
+            }
+            const float cost = fminf(c0, fminf(dm_cost, 3.40282347e+38f));
+            s.luma_mode = 0;
+            s.cost = cost;
+            const bool dm = dm_cost == cost;
+            s.chroma_mode = dm ? s.dm_mode : s.cclm_mode;
+            team_idle(q);
+            q.xchg = false;
+            team_restore(c, s, q, 2, dm ? 3 : 0); // member 3 evaluated DM, member 0 the CCLM mode
+            s.cont = TC_DONE;
+            return true;
+        }
+        }
+    }
+}
+
 // split_ct (block_splitter.rs:782-1154) for one CTU + the final pass (ctu_encoder.rs:1421-1461):
 // exhaustive quad-tree search as an explicit depth-first walk (level 0 = 32x32 ... level 2 = 8x8;
 // an 8x8 node's split is four DUAL_TREE_LUMA 4x4 leaves + one DUAL_TREE_CHROMA 4x4 leaf,
@@ -781,13 +1119,15 @@ __device__ __forceinline__ bool leaf_step(const Ctx& c, LeafSt& s, const Res& r,
 // instead of LDS.
 enum { T_START = 0, T_ENTER, T_NODE_LEAF, T_LEAF4_EMIT, T_LEAF4, T_LEAFC, T_REGEN_DONE, T_RETURN, T_FINAL_Z, T_FZ_TAIL, T_FZ_NEXT };
 
+template <bool TEAM>
 __device__ __forceinline__ bool ctu_step(Ctx& c, const Res& r, Req& q) {
     CtuSt& t = SH.st;
     bool in_leaf = t.in_leaf != 0;
     int cont = t.cont;
     for (;;) {
         if (in_leaf) {
-            if (leaf_step(c, t.leaf, r, q)) {
+            // team schedule: the results of the previous requests are in the members' XRes of parity xpar ^ 1
+            if (TEAM ? leaf_step_team(c, t.leaf, q, t.xpar ^ 1) : leaf_step(c, t.leaf, r, q)) {
                 if (t.pend) { // the first request of a node's first child saves the unsplit candidate
                     req_copy(q, COPY_SAVE, 3, t.pslot, t.pbx, t.pby, t.plg);
                     t.pend = 0;
@@ -810,6 +1150,7 @@ __device__ __forceinline__ bool ctu_step(Ctx& c, const Res& r, Req& q) {
             const int lg = 5 - t.level;
             t.lg = (uint8_t)lg;
             leaf_init(t.leaf, TREE_SINGLE, t.bx, t.by, lg, 0);
+            if (TEAM) t.leaf.cont = TC_START;
             in_leaf = true;
             cont = T_NODE_LEAF;
             break;
@@ -856,6 +1197,7 @@ __device__ __forceinline__ bool ctu_step(Ctx& c, const Res& r, Req& q) {
         case T_LEAF4_EMIT: {
             const int i8 = t.i8;
             leaf_init(t.leaf, TREE_DUAL_LUMA, t.bx + (i8 & 1) * 4, t.by + (i8 >> 1) * 4, 2, 0);
+            if (TEAM) t.leaf.cont = TC_START;
             in_leaf = true;
             cont = T_LEAF4;
             break;
@@ -872,6 +1214,7 @@ __device__ __forceinline__ bool ctu_step(Ctx& c, const Res& r, Req& q) {
             // DM = luma mode of the CU covering the parent's centre (block_splitter.rs:795-805)
             const int bx = t.bx, by = t.by;
             leaf_init(t.leaf, TREE_DUAL_CHROMA, bx, by, 3, uni((int)SH.luma_mode[((by + 4) >> 2) * 8 + ((bx + 4) >> 2)]));
+            if (TEAM) t.leaf.cont = TC_DC_START;
             in_leaf = true;
             cont = T_LEAFC;
             break;
@@ -886,6 +1229,8 @@ __device__ __forceinline__ bool ctu_step(Ctx& c, const Res& r, Req& q) {
                 t.rl = t.ns_luma_cur;
                 t.rc = t.ns_chroma_cur;
                 q.kind = K_NOP;
+                q.post_save = false;
+                q.xchg = false;
                 req_copy(q, COPY_RESTORE, 3, 1 + t.level, t.rbx, t.rby, t.rlg);
                 t.cont = T_REGEN_DONE;
                 return true;
@@ -904,6 +1249,10 @@ __device__ __forceinline__ bool ctu_step(Ctx& c, const Res& r, Req& q) {
             if (level == 0) {
                 t.ctu_cost = t.ret;
                 t.z = 0;
+                if (TEAM && c.member != 0) { // the final pass is one chain of dependent blocks: member 0 alone
+                    t.cont = T_START;
+                    return false;
+                }
                 cont = T_FINAL_Z;
                 break;
             }
@@ -936,6 +1285,8 @@ __device__ __forceinline__ bool ctu_step(Ctx& c, const Res& r, Req& q) {
                 t.rl = (uint8_t)uni((int)SH.ns_luma[pl]);
                 t.rc = (uint8_t)uni((int)SH.ns_chroma[pl]);
                 q.kind = K_NOP;
+                q.post_save = false;
+                q.xchg = false;
                 req_copy(q, COPY_RESTORE, 3, 1 + pl, t.rbx, t.rby, t.rlg);
                 t.cont = T_REGEN_DONE;
                 return true;
@@ -999,6 +1350,7 @@ __device__ __forceinline__ void load_tables(Ctx c) {
 }
 
 
+template <bool TEAM>
 __device__ __forceinline__ void encode_ctu(Ctx& c, const PicBufs& pb, int ctu_col, int ctu_row, int* overflow) {
     const CONST_AS DevConst* k = c.k;
     const int W = k->W;
@@ -1047,18 +1399,27 @@ __device__ __forceinline__ void encode_ctu(Ctx& c, const PicBufs& pb, int ctu_co
     SH.st.cont = T_START;
     SH.st.in_leaf = 0;
     SH.st.pend = 0;
+    SH.st.xpar = 0;
     SH.st.max_depth = (uint8_t)k->max_depth;
     Res r = {};
     Req q = {};
     for (;;) {
         PROF_MARK(tc0_);
-        const bool more = ctu_step(c, r, q);
+        const bool more = ctu_step<TEAM>(c, r, q);
         PROF_MARK(tc1_);
         PROF_ADD2(PH_CTRL, tc0_, tc1_);
         PROF_ADD2(PH_NSTEP, 0, 1);
         PROF_ADD2(PH_NFULL, 0, (q.kind == K_FULL ? 1 : 0));
         if (!more) break;
         r = evaluate(c, pb, q, overflow);
+        if (TEAM && q.xchg) {
+            // publish, meet the team (the workgroup's teams walk the same schedule: the same barriers), flip the
+            // parity: a fast member's next result goes to the other buffer while slow members still read this one
+            const int par = SH.st.xpar;
+            team_publish(q, r, par);
+            SH.st.xpar = (uint8_t)(par ^ 1);
+            __syncthreads();
+        }
     }
     const float cost = SH.st.ctu_cost;
     // store recon + decisions

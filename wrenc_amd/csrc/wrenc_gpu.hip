@@ -29,17 +29,14 @@ using namespace wrenc;
 // scratch regions for resident workgroups (>= 2 per CU x 256 CUs; 32 bitmap words of 64)
 constexpr int kScratchSlots = 2048;
 
-__global__ __launch_bounds__(64 * WPB, 4) void ctu_search_kernel(const DevConst* __restrict__ k,
-                                                              const PicBufs* __restrict__ slots, int first_slot,
-                                                              int n_pictures, int diag, int r_min, int count,
-                                                              uint8_t* pred_scratch, unsigned long long* slot_map,
-                                                              unsigned long long* mismatch, int* overflow) {
-    // Per-workgroup global scratch comes from a pool of kScratchSlots regions handed out through a
-    // bitmap: the pool covers the workgroups that can be resident at once (2 per CU), not the ones
-    // of a launch, so the scratch that is live stays small enough to live in L2 / Infinity Cache
-    // whatever the batch size.  A slot is only ever used by one workgroup at a time and nothing is
-    // read that the same workgroup did not write, so its contents need no hand-over.
-    __shared__ int s_scratch_slot;
+// Per-workgroup global scratch comes from a pool of kScratchSlots regions handed out through a
+// bitmap: the pool covers the workgroups that can be resident at once (2 per CU), not the ones
+// of a launch, so the scratch that is live stays small enough to live in L2 / Infinity Cache
+// whatever the batch size.  A slot is only ever used by one workgroup at a time and nothing is
+// read that the same workgroup did not write, so its contents need no hand-over.
+// (The slot number travels through a cell of wave 0's LDS that the search only uses later: the
+// two workgroups of a CU fill its 160 KB of LDS to the byte.)
+__device__ __forceinline__ int acquire_scratch(unsigned long long* slot_map) {
     if (threadIdx.x == 0) {
         unsigned w = (blockIdx.x * 2654435761u) >> (32 - 5); // start word, 0 .. kScratchSlots / 64 - 1
         int slot = -1;
@@ -53,11 +50,27 @@ __global__ __launch_bounds__(64 * WPB, 4) void ctu_search_kernel(const DevConst*
                 w = (w + 1) & (kScratchSlots / 64 - 1);
             }
         }
-        s_scratch_slot = slot;
+        SHW[0].q_istar[0] = slot;
     }
     __syncthreads();
-    const int scratch_slot = s_scratch_slot;
-    // one workgroup = the same CTU of WPB consecutive pictures, one wave each
+    const int scratch_slot = uni(SHW[0].q_istar[0]);
+    __syncthreads(); // everybody has read the cell before the search may overwrite it
+    return scratch_slot;
+}
+// give the scratch slot back once every wave's stores to it are out
+__device__ __forceinline__ void release_scratch(unsigned long long* slot_map, int scratch_slot) {
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAnd(&slot_map[scratch_slot >> 6], ~(1ULL << (scratch_slot & 63)));
+}
+
+// Wave schedule: one workgroup = the same CTU of WPB consecutive pictures, one wave each.
+__global__ __launch_bounds__(64 * WPB, 4) void ctu_search_kernel(const DevConst* __restrict__ k,
+                                                              const PicBufs* __restrict__ slots, int first_slot,
+                                                              int n_pictures, int diag, int r_min, int count,
+                                                              uint8_t* pred_scratch, unsigned long long* slot_map,
+                                                              unsigned long long* mismatch, int* overflow) {
+    const int scratch_slot = acquire_scratch(slot_map);
     const int group = blockIdx.x / count;
     const int j = blockIdx.x - group * count;
     const int row = r_min + j;
@@ -67,6 +80,8 @@ __global__ __launch_bounds__(64 * WPB, 4) void ctu_search_kernel(const DevConst*
     c.k = (const CONST_AS DevConst*)k;
     c.mismatch = mismatch;
     c.write = pic < n_pictures ? 1 : 0;
+    c.trace = c.write;
+    c.member = 0;
     if (pic >= n_pictures) pic = n_pictures - 1; // padding wave: same work, no stores
     const PicBufs pb = slots[first_slot + pic];
     c.org = (const GLOBAL_AS uint8_t*)pb.org[0]; // Y | Cb | Cr are one slab (see wrenc_gpu_create)
@@ -75,12 +90,42 @@ __global__ __launch_bounds__(64 * WPB, 4) void ctu_search_kernel(const DevConst*
     c.pred_scratch = pred_scratch + ((size_t)scratch_slot * WPB + WAVE) * kWaveScratch;
     c.slots = (GLOBAL_AS uint8_t*)(c.pred_scratch + 1024);
     int ovf = 0;
-    encode_ctu(c, pb, col, row, &ovf);
+    encode_ctu<false>(c, pb, col, row, &ovf);
     if (ovf && LANE == 0) atomicOr(overflow, 1);
-    // give the scratch slot back once every wave's stores to it are out
-    __threadfence();
-    __syncthreads();
-    if (threadIdx.x == 0) atomicAnd(&slot_map[scratch_slot >> 6], ~(1ULL << (scratch_slot & 63)));
+    release_scratch(slot_map, scratch_slot);
+}
+
+// Team schedule: one workgroup = the same CTU of WPB / kTeam consecutive pictures, kTeam waves each
+// (dev_search.h, leaf_step_team).  For encode calls with too few pictures to fill the GPU one wave per CTU.
+__global__ __launch_bounds__(64 * WPB, 4) void ctu_search_team_kernel(const DevConst* __restrict__ k,
+                                                                   const PicBufs* __restrict__ slots, int first_slot,
+                                                                   int n_pictures, int diag, int r_min, int count,
+                                                                   uint8_t* pred_scratch, unsigned long long* slot_map,
+                                                                   unsigned long long* mismatch, int* overflow) {
+    const int scratch_slot = acquire_scratch(slot_map);
+    constexpr int kTeams = WPB / kTeam;
+    const int group = blockIdx.x / count;
+    const int j = blockIdx.x - group * count;
+    const int row = r_min + j;
+    const int col = diag - 2 * row;
+    int pic = group * kTeams + WAVE / kTeam;
+    Ctx c = {};
+    c.k = (const CONST_AS DevConst*)k;
+    c.mismatch = mismatch;
+    c.member = WAVE & (kTeam - 1);
+    c.trace = pic < n_pictures ? 1 : 0;
+    c.write = (c.trace && c.member == 0) ? 1 : 0; // one member stores the picture's results
+    if (pic >= n_pictures) pic = n_pictures - 1;  // padding team: same work, no stores
+    const PicBufs pb = slots[first_slot + pic];
+    c.org = (const GLOBAL_AS uint8_t*)pb.org[0];
+    c.W = k->W;
+    c.WH = k->W * k->H;
+    c.pred_scratch = pred_scratch + ((size_t)scratch_slot * WPB + WAVE) * kWaveScratch;
+    c.slots = (GLOBAL_AS uint8_t*)(c.pred_scratch + 1024);
+    int ovf = 0;
+    encode_ctu<true>(c, pb, col, row, &ovf);
+    if (ovf && LANE == 0) atomicOr(overflow, 1);
+    release_scratch(slot_map, scratch_slot);
 }
 
 // building-block kernels: one wave per block of side 1 << lg
@@ -199,6 +244,9 @@ thread_local std::string g_create_error;
 // the other lanes' work.
 constexpr int kEncodeLanes = 4;
 
+// AUTO picks the team schedule while (CTUs runnable side by side) x kTeam stays below this many waves
+constexpr long long kTeamBelowWaves = 7680;
+
 // DCT-2 integer cosines c[j] ~ 64*sqrt(2)*cos(j*pi/128), H.266 8.7.4.5
 // (the reference's 64-point matrix, transformer.rs:934-1191, is row k = c[(2n+1)k])
 const int kCos[65] = {64, 91, 90, 90, 90, 90, 90, 90, 89, 88, 88, 87, 87, 86, 85, 84, 83, 83, 82, 81, 80, 79,
@@ -273,6 +321,8 @@ struct wrenc_gpu_ctx {
     std::vector<hipEvent_t> ev_pool;
     int last_launches = 0;
     bool stats_enabled = false; // per-launch timing events: bench / profiling only (wrenc_gpu_stats_enable)
+    int schedule = WRENC_GPU_SCHEDULE_AUTO;
+    int last_schedule = WRENC_GPU_SCHEDULE_WAVE; // what the most recent encode call ran
     bool stats_valid = false;
     std::string err;
     int ctu_cols = 0, ctu_rows = 0;
@@ -677,8 +727,16 @@ int wrenc_gpu_encode(wrenc_gpu_ctx* ctx, int first_slot, int n_pictures) {
     HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
     const int cols = ctx->ctu_cols, rows = ctx->ctu_rows;
     const int ndiag = cols + 2 * (rows - 1);
-    // split the pictures into lanes of whole workgroups (WPB pictures each)
-    const int total_groups = (n_pictures + WPB - 1) / WPB;
+    // Which schedule: one wave per CTU fills the GPU only with hundreds of CTUs in flight per anti-diagonal
+    // step (pictures x CTUs of a diagonal); below that a team of kTeam waves per CTU shortens the CTU's
+    // chain of dependent evaluations instead.  kTeamBelowWaves: measured crossover.
+    const long long parallel_ctus = (long long)n_pictures * ((cols * rows + ndiag - 1) / ndiag);
+    const bool team = ctx->schedule == WRENC_GPU_SCHEDULE_TEAM ||
+                      (ctx->schedule == WRENC_GPU_SCHEDULE_AUTO && parallel_ctus * kTeam <= kTeamBelowWaves);
+    ctx->last_schedule = team ? WRENC_GPU_SCHEDULE_TEAM : WRENC_GPU_SCHEDULE_WAVE;
+    // split the pictures into lanes of whole workgroups (per_group pictures each)
+    const int per_group = team ? WPB / kTeam : WPB;
+    const int total_groups = (n_pictures + per_group - 1) / per_group;
     const int n_lanes = total_groups < kEncodeLanes ? total_groups : kEncodeLanes;
     if (!ctx->d_pred_scratch) {
         HIP_TRY(ctx, hipMalloc((void**)&ctx->d_pred_scratch, (size_t)kScratchSlots * WPB * kWaveScratch));
@@ -719,16 +777,20 @@ int wrenc_gpu_encode(wrenc_gpu_ctx* ctx, int first_slot, int n_pictures) {
         if (count <= 0) continue;
         for (int l = 0; l < n_lanes; ++l) {
             const int g0 = (int)((long long)total_groups * l / n_lanes), g1 = (int)((long long)total_groups * (l + 1) / n_lanes);
-            const int lane_first = first_slot + g0 * WPB;
-            int lane_pics = (g1 - g0) * WPB;
-            if (g0 * WPB + lane_pics > n_pictures) lane_pics = n_pictures - g0 * WPB;
+            const int lane_first = first_slot + g0 * per_group;
+            int lane_pics = (g1 - g0) * per_group;
+            if (g0 * per_group + lane_pics > n_pictures) lane_pics = n_pictures - g0 * per_group;
             if (lane_pics <= 0) continue;
             hipStream_t st = l == 0 ? ctx->stream : ctx->lanes[l - 1];
             if (timed) HIP_TRY(ctx, hipEventRecord(ctx->ev_pool[2 * launches], st));
-            hipLaunchKernelGGL(ctu_search_kernel, dim3(count * (g1 - g0)), dim3(64 * WPB), 0, st, ctx->d_const,
-                               ctx->d_slots, lane_first, lane_pics, d, r_min, count, ctx->d_pred_scratch, ctx->d_slot_map,
-                               ctx->d_mismatch,
-                               ctx->d_overflow);
+            if (team)
+                hipLaunchKernelGGL(ctu_search_team_kernel, dim3(count * (g1 - g0)), dim3(64 * WPB), 0, st, ctx->d_const,
+                                   ctx->d_slots, lane_first, lane_pics, d, r_min, count, ctx->d_pred_scratch,
+                                   ctx->d_slot_map, ctx->d_mismatch, ctx->d_overflow);
+            else
+                hipLaunchKernelGGL(ctu_search_kernel, dim3(count * (g1 - g0)), dim3(64 * WPB), 0, st, ctx->d_const,
+                                   ctx->d_slots, lane_first, lane_pics, d, r_min, count, ctx->d_pred_scratch,
+                                   ctx->d_slot_map, ctx->d_mismatch, ctx->d_overflow);
             HIP_TRY(ctx, hipGetLastError());
             if (timed) HIP_TRY(ctx, hipEventRecord(ctx->ev_pool[2 * launches + 1], st));
             ++launches;
@@ -837,6 +899,16 @@ int wrenc_gpu_last_encode_stats(wrenc_gpu_ctx* ctx, float* total_ms, float* kern
     if (n_launches) *n_launches = ctx->last_launches;
     return WRENC_GPU_OK;
 }
+
+int wrenc_gpu_set_schedule(wrenc_gpu_ctx* ctx, int schedule) {
+    if (!ctx) return WRENC_GPU_EINVAL;
+    if (schedule != WRENC_GPU_SCHEDULE_AUTO && schedule != WRENC_GPU_SCHEDULE_WAVE && schedule != WRENC_GPU_SCHEDULE_TEAM)
+        return fail(ctx, WRENC_GPU_EINVAL, "schedule must be WRENC_GPU_SCHEDULE_AUTO, _WAVE or _TEAM");
+    ctx->schedule = schedule;
+    return WRENC_GPU_OK;
+}
+
+int wrenc_gpu_last_schedule(const wrenc_gpu_ctx* ctx) { return ctx ? ctx->last_schedule : WRENC_GPU_EINVAL; }
 
 int wrenc_gpu_stats_enable(wrenc_gpu_ctx* ctx, int on) {
     if (!ctx) return WRENC_GPU_EINVAL;

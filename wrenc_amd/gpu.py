@@ -20,7 +20,7 @@ LIB_PATH = os.environ.get("WRENC_GPU_LIB", os.path.join(_HERE, "csrc", "libwrenc
 EXPORTED_SYMBOLS = [
     "wrenc_gpu_default_config", "wrenc_gpu_config_extra_params", "wrenc_gpu_create", "wrenc_gpu_destroy", "wrenc_gpu_last_error",
     "wrenc_gpu_upload", "wrenc_gpu_encode", "wrenc_gpu_sync", "wrenc_gpu_download",
-    "wrenc_gpu_alloc_host", "wrenc_gpu_free_host", "wrenc_gpu_encode_picture", "wrenc_gpu_stats_enable", "wrenc_gpu_last_encode_stats", "wrenc_gpu_final_pass_mismatches",
+    "wrenc_gpu_alloc_host", "wrenc_gpu_free_host", "wrenc_gpu_encode_picture", "wrenc_gpu_set_schedule", "wrenc_gpu_last_schedule", "wrenc_gpu_stats_enable", "wrenc_gpu_last_encode_stats", "wrenc_gpu_final_pass_mismatches",
     "wrenc_gpu_test_fwd_dct", "wrenc_gpu_test_inv_dct", "wrenc_gpu_test_quantize",
     "wrenc_gpu_test_dequantize", "wrenc_gpu_test_predict",
 ]
@@ -129,7 +129,8 @@ class Encoder:
     """One context = one GPU.  Mirrors the picture-granular call surface a C++
     SliceEncoder::encode uses in place of the per-CTU split_ct loop."""
 
-    def __init__(self, width, height, qp=26, max_split_depth=3, device=0, n_slots=1, config=None, extra_params=None):
+    def __init__(self, width, height, qp=26, max_split_depth=3, device=0, n_slots=1, config=None, extra_params=None,
+                 schedule=None):
         self.lib = load_library()
         self.cfg = config if config is not None else default_config(width, height, qp, max_split_depth,
                                                                      device, n_slots, extra_params)
@@ -140,6 +141,8 @@ class Encoder:
             raise WrencGpuError(rc, self.lib.wrenc_gpu_last_error(None).decode())
         self._keep = {}
         self._pinned = []
+        if schedule is not None:
+            self.set_schedule(schedule)
 
     def _check(self, rc):
         if rc:
@@ -217,6 +220,17 @@ class Encoder:
         self.upload(0, y, cb, cr)
         self.encode(0, 1)
         return self.download(0)
+
+    SCHEDULE_AUTO, SCHEDULE_WAVE, SCHEDULE_TEAM = 0, 1, 2
+
+    def set_schedule(self, schedule):
+        """How CTUs map to wavefronts (include/wrenc_gpu.h: wrenc_gpu_schedule); results are the same either way."""
+        self.lib.wrenc_gpu_set_schedule.argtypes = [C.c_void_p, C.c_int]
+        self._check(self.lib.wrenc_gpu_set_schedule(self.ctx, int(schedule)))
+
+    def last_schedule(self):
+        self.lib.wrenc_gpu_last_schedule.argtypes = [C.c_void_p]
+        return self.lib.wrenc_gpu_last_schedule(self.ctx)
 
     def stats_enable(self, on=True):
         """Per-launch timing events (measurement mode, see include/wrenc_gpu.h)."""
