@@ -168,7 +168,8 @@ def config3(grp, rank, world, local_rank, total=240, steps=1, warmup=1):
 
 
 def fill_curve(grp, local_rank, quick=False):
-    """frames/s against pictures in flight (one encode call of B resident pictures, best of 2)."""
+    """frames/s against pictures in flight (one encode call of B resident pictures, best of 2), with the schedule the
+    library picked for that call (include/wrenc_gpu.h: wave = one wavefront per CTU, team = four per CTU)."""
     from wrenc_amd import gpu, synth
     out = {}
     for name, w, h, qp, depth, points in (("1920x1088_d2", 1920, 1088, 32, 2, (8, 32, 128, 512, 1024)),
@@ -180,15 +181,17 @@ def fill_curve(grp, local_rank, quick=False):
         for s in range(max(points)):
             enc.upload(s, *frames[s % 4])
         enc.sync()
-        curve = {}
+        curve, sched = {}, {}
         for b in points:
             best = None
             for _ in range(2):
                 dt, _, _ = run_resident(enc, grp, 0, b, 1, 0)
                 best = dt if best is None else min(best, dt)
             curve[str(b)] = b / best
+            sched[str(b)] = {1: "wave", 2: "team"}.get(enc.last_schedule(), "?")
         enc.close()
         out[name] = curve
+        out[name + "_schedule"] = sched
     return out
 
 

@@ -1,25 +1,66 @@
-import os, sys, time, ctypes as C
-os.environ["WRENC_GPU_LIB"]=os.path.abspath("scratch/libwrenc_gpu_prof.so")
-sys.path.insert(0,'.')
-from wrenc_amd import gpu, synth
-w,h,qp,depth=1920,1088,32,int(sys.argv[1]) if len(sys.argv)>1 else 2
-B=int(sys.argv[2]) if len(sys.argv)>2 else 16
-frames=[synth.synth_frame(w,h,f) for f in range(4)]
-enc=gpu.Encoder(w,h,qp=qp,max_split_depth=depth,n_slots=B)
+"""Phase shares of a CTU-wave from the diagnostic build (never the product library):
+  hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -shared -DWRENC_PROFILE \
+        -o build/exp/libwrenc_gpu_prof.so wrenc_amd/csrc/wrenc_gpu.hip
+  python tools/phase_profile.py WxH DEPTH B SCHEDULE
+The counters are s_memtime differences of thread 0 of each workgroup (wave 0 = member 0 of its team in the team
+schedule), summed over all CTUs."""
+import ctypes as C
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+os.environ["WRENC_GPU_LIB"] = os.path.join(ROOT, "build", "exp", "libwrenc_gpu_prof.so")
+sys.path.insert(0, ROOT)
+from wrenc_amd import gpu, synth  # noqa: E402
+
+w, h = [int(v) for v in (sys.argv[1] if len(sys.argv) > 1 else "1920x1088").split("x")]
+depth = int(sys.argv[2]) if len(sys.argv) > 2 else 2
+B = int(sys.argv[3]) if len(sys.argv) > 3 else 16
+schedule = int(sys.argv[4]) if len(sys.argv) > 4 else 1
+frames = [synth.synth_frame(w, h, f) for f in range(4)]
+enc = gpu.Encoder(w, h, qp=32, max_split_depth=depth, n_slots=B, schedule=schedule)
 for s in range(B):
-    enc.upload(s,*frames[s%4])
+    enc.upload(s, *frames[s % 4])
 enc.sync()
-names=["predict","fdct","q_pre","q_back","q_trace","deq","idct","recon","total","ctrl","refs","skip","nstep","nfull"]+["sad_t%d_c%d"%(4<<(i//2),i%2) for i in range(8)]+["x"]+["sad_n%d_c%d"%(4<<(i//2),i%2) for i in range(8)]+["x2","qb_pre","qb_wait1","qb_walk","qb_wait2"]
-out=(C.c_ulonglong*36)()
-enc.lib.wrenc_gpu_prof_read.argtypes=[C.c_void_p, C.c_void_p, C.c_int]
-enc.lib.wrenc_gpu_prof_read(enc.ctx, out, 36)
-t0=time.time(); enc.encode(0,B); enc.sync(); dt=time.time()-t0
-enc.lib.wrenc_gpu_prof_read(enc.ctx, out, 36)
-tot=out[8]
-nctu=B*2040
-print("wall %.3f s, fps %.2f, cycles/CTU total %.0f (100MHz ticks?)"%(dt,B/dt,tot/nctu))
-acc=0
-for i,n in enumerate(names):
-    if i==8: continue
-    print("%-8s %6.2f%%  %.0f per CTU"%(n,100.0*out[i]/tot,out[i]/nctu)); acc+=out[i]
-print("other    %6.2f%%"%(100.0*(tot-acc)/tot))
+names = (["predict", "fdct", "q_pre", "q_back", "q_trace", "deq", "idct", "recon", "total", "ctrl", "refs", "skip", "nstep", "nfull"]
+         + ["sad_t%d_c%d" % (4 << (i // 2), i % 2) for i in range(8)] + ["x"] + ["sad_n%d_c%d" % (4 << (i // 2), i % 2) for i in range(8)]
+         + ["x2", "qb_pre", "qb_wait1", "qb_walk", "qb_wait2", "t_xchg", "copy"] + ["cb%d" % i for i in range(32)] + ["y"]
+         + ["cbn%d" % i for i in range(32)] + ["y2"] + ["mem_%s_m%d" % (k, m) for k in ("ctrl", "eval", "xchg", "nop") for m in range(4)] + ["y3"]
+         + ["st%d_m%d" % (k, m) for k in range(12) for m in range(4)] + ["y4"] + ["stn%d" % k for k in range(12)])
+N = len(names)
+out = (C.c_ulonglong * N)()
+enc.lib.wrenc_gpu_prof_read.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+enc.lib.wrenc_gpu_prof_read(enc.ctx, out, N)
+t0 = time.time()
+enc.encode(0, B)
+enc.sync()
+dt = time.time() - t0
+enc.lib.wrenc_gpu_prof_read(enc.ctx, out, N)
+tot = out[8]
+groups = (B + 7) // 8 if schedule == 1 else (B + 1) // 2
+nctu = groups * (w // 32) * (h // 32)       # one profiled wave per workgroup
+print("%dx%d depth %d B %d schedule %d: wall %.3f s, fps %.2f, ticks per profiled CTU-wave %.0f" % (w, h, depth, B, schedule, dt, B / dt, tot / nctu))
+for i, n in enumerate(names):
+    if i == 8 or n.startswith("x") or n.startswith("y") or n.startswith("cbn") or out[i] == 0:
+        continue
+    if n.startswith("stn"):
+        continue
+    if n.startswith("st") and "_m" in n:
+        k = int(n[2:n.index("_")])
+        cnt = max(out[names.index("stn%d" % k)], 1)
+        print("eval after step from %-2d member %s: %8.0f ticks per request (%.1f requests per CTU)" % (k, n[-1], out[i] / cnt, cnt / nctu))
+        continue
+    if n.startswith("mem_"):
+        print("%-14s %10.0f ticks per CTU" % (n, out[i] / nctu))
+        continue
+    if n.startswith("cb"):
+        k = int(n[2:])
+        cnt = out[names.index("cbn%d" % k)]
+        print("ctrl from %-3d %6.2f%%  %8.1f steps per CTU, %7.0f ticks per step" % (k, 100.0 * out[i] / tot, cnt / nctu, out[i] / max(cnt, 1)))
+        continue
+    if n in ("nstep", "nfull") or n.startswith("sad_n"):
+        print("%-10s %10.1f per CTU (count)" % (n, out[i] / nctu))
+    else:
+        print("%-10s %6.2f%%  %10.0f ticks per CTU" % (n, 100.0 * out[i] / tot, out[i] / nctu))
+enc.close()

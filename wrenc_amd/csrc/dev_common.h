@@ -1,6 +1,7 @@
 // dev_common.h -- constants, per-launch / per-picture structures, the per-wave LDS working set, search state, wave helpers, tile access, availability
 // Part of the gfx950 device code of the RD-search path; see wrenc_dev.h for the overall model.
 #pragma once
+#include <cstddef>
 
 namespace wrenc {
 
@@ -143,6 +144,81 @@ struct LeafSt {
     EvalPartsU e_best;
 };
 
+// A step of the leaf search works on a REGISTER copy of LeafSt: one LDS read fetches the whole struct
+// (lane i reads dword i), every field then comes out of that vector register with v_readlane instead of an LDS
+// round trip of its own (a step used to make ~20 dependent LDS reads: profiles/r02_issue_model.md).  Writes go
+// to the register copy and through to LDS, so the next step's snapshot and the tree-level code see them.
+template <class T>
+struct SF {
+    T v;
+    UF<T>* p;
+    __device__ __forceinline__ T get() const { return v; }
+    __device__ __forceinline__ operator T() const { return v; }
+    __device__ __forceinline__ SF& operator=(T x) {
+        v = x;
+        p->set(x);
+        return *this;
+    }
+    __device__ __forceinline__ SF& operator=(const SF& o) { return *this = o.v; }
+    __device__ __forceinline__ SF& operator+=(int x) { return *this = (T)(v + x); }
+    __device__ __forceinline__ SF& operator-=(int x) { return *this = (T)(v - x); }
+};
+struct EvalPartsSF {
+    SF<uint32_t> ssd_y, ssd_c;
+    SF<long long> lvl_y, lvl_c;
+    __device__ __forceinline__ EvalParts get() const {
+        EvalParts e;
+        e.ssd_y = ssd_y;
+        e.ssd_c = ssd_c;
+        e.lvl_y = lvl_y;
+        e.lvl_c = lvl_c;
+        return e;
+    }
+};
+struct LeafSF {
+    SF<uint8_t> cont, op_ml, op_mc, op_act, tree, bx, by, lg, need_refs0, need_refs1, need_org, step, cur_mode, mode,
+        cclm_mode, dm_mode, holder, evalr, luma_mode, chroma_mode, best_cls, need_save, tile_best;
+    SF<float> best_cost, cur_cost, c0, cost;
+    EvalPartsSF e_best;
+};
+static_assert(sizeof(LeafSt) == 64, "snap_leaf reads the struct as 16 dwords");
+__device__ __forceinline__ LeafSF snap_leaf(LeafSt& l) {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); // after this step's own stores to the struct (leaf_init)
+    const int w = ((const volatile int*)&l)[LANE & 15];
+    LeafSF s;
+#define SNAP_U8(f)                                                                                          \
+    s.f.v = (uint8_t)((unsigned)__builtin_amdgcn_readlane(w, (int)(offsetof(LeafSt, f) >> 2)) >> (8 * (offsetof(LeafSt, f) & 3))); \
+    s.f.p = &l.f
+#define SNAP_F32(f)                                                                       \
+    s.f.v = __int_as_float(__builtin_amdgcn_readlane(w, (int)(offsetof(LeafSt, f) >> 2))); \
+    s.f.p = &l.f
+    SNAP_U8(cont); SNAP_U8(op_ml); SNAP_U8(op_mc); SNAP_U8(op_act); SNAP_U8(tree); SNAP_U8(bx); SNAP_U8(by); SNAP_U8(lg);
+    SNAP_U8(need_refs0); SNAP_U8(need_refs1); SNAP_U8(need_org); SNAP_U8(step); SNAP_U8(cur_mode); SNAP_U8(mode);
+    SNAP_U8(cclm_mode); SNAP_U8(dm_mode); SNAP_U8(holder); SNAP_U8(evalr); SNAP_U8(luma_mode); SNAP_U8(chroma_mode);
+    SNAP_U8(best_cls); SNAP_U8(need_save); SNAP_U8(tile_best);
+    SNAP_F32(best_cost); SNAP_F32(cur_cost); SNAP_F32(c0); SNAP_F32(cost);
+#undef SNAP_U8
+#undef SNAP_F32
+    constexpr int eb = (int)(offsetof(LeafSt, e_best) >> 2);
+    s.e_best.ssd_y.v = (uint32_t)__builtin_amdgcn_readlane(w, eb + (int)(offsetof(EvalPartsU, ssd_y) >> 2));
+    s.e_best.ssd_y.p = &l.e_best.ssd_y;
+    s.e_best.ssd_c.v = (uint32_t)__builtin_amdgcn_readlane(w, eb + (int)(offsetof(EvalPartsU, ssd_c) >> 2));
+    s.e_best.ssd_c.p = &l.e_best.ssd_c;
+    {
+        constexpr int o = eb + (int)(offsetof(EvalPartsU, lvl_y) >> 2);
+        s.e_best.lvl_y.v = (long long)(((unsigned long long)(unsigned)__builtin_amdgcn_readlane(w, o + 1) << 32) |
+                                       (unsigned)__builtin_amdgcn_readlane(w, o));
+        s.e_best.lvl_y.p = &l.e_best.lvl_y;
+    }
+    {
+        constexpr int o = eb + (int)(offsetof(EvalPartsU, lvl_c) >> 2);
+        s.e_best.lvl_c.v = (long long)(((unsigned long long)(unsigned)__builtin_amdgcn_readlane(w, o + 1) << 32) |
+                                       (unsigned)__builtin_amdgcn_readlane(w, o));
+        s.e_best.lvl_c.p = &l.e_best.lvl_c;
+    }
+    return s;
+}
+
 // CTU search + final pass state (see ctu_step)
 struct CtuSt {
     UF<uint8_t> cont, in_leaf, xpar; // xpar: parity of the team's next exchange
@@ -261,14 +337,17 @@ __device__ __forceinline__ Ctx uni(Ctx c) {
 // Diagnostic build only (-DWRENC_PROFILE): per-phase cycle counters, summed per wave and
 // added to a global table at CTU end.  Never compiled into the product library.
 #ifdef WRENC_PROFILE
-enum { PH_PREDICT, PH_FDCT, PH_QPRE, PH_QBACK, PH_QTRACE, PH_DEQ, PH_IDCT, PH_RECON, PH_TOTAL, PH_CTRL, PH_REFS, PH_SKIP, PH_NSTEP, PH_NFULL, PH_PSZ, PH_PSZ_END = PH_PSZ + 8, PH_PCNT, PH_PCNT_END = PH_PCNT + 8, PH_QB_PRE, PH_QB_WAIT1, PH_QB_WALK, PH_QB_WAIT2, PH_COUNT };
+enum { PH_PREDICT, PH_FDCT, PH_QPRE, PH_QBACK, PH_QTRACE, PH_DEQ, PH_IDCT, PH_RECON, PH_TOTAL, PH_CTRL, PH_REFS, PH_SKIP, PH_NSTEP, PH_NFULL, PH_PSZ, PH_PSZ_END = PH_PSZ + 8, PH_PCNT, PH_PCNT_END = PH_PCNT + 8, PH_QB_PRE, PH_QB_WAIT1, PH_QB_WALK, PH_QB_WAIT2, PH_XCHG, PH_COPY, PH_CB, PH_CB_END = PH_CB + 32, PH_CBN, PH_CBN_END = PH_CBN + 32, PH_MEM, PH_MEM_END = PH_MEM + 16, PH_ST, PH_ST_END = PH_ST + 48, PH_STN, PH_STN_END = PH_STN + 12, PH_COUNT };
 __device__ unsigned long long g_prof[PH_COUNT];
 __shared__ unsigned long long s_prof[PH_COUNT];
 #define PROF_T0() const unsigned long long prof_t0_ = __builtin_readcyclecounter()
 #define PROF_ADD(ph) do { if (threadIdx.x == 0) s_prof[ph] += __builtin_readcyclecounter() - prof_t0_; } while (0)
 #define PROF_MARK(var) const unsigned long long var = __builtin_readcyclecounter()
 #define PROF_ADD2(ph, a, b) do { if (threadIdx.x == 0) s_prof[ph] += (b) - (a); } while (0)
+// per member of team 0 (waves 0..3): bucket k of PH_MEM + 4 * k + member
+#define PROF_ADDM(k, a, b) do { if (LANE == 0 && WAVE < 4) s_prof[PH_MEM + 4 * (k) + WAVE] += (b) - (a); } while (0)
 #else
+#define PROF_ADDM(k, a, b)
 #define PROF_T0()
 #define PROF_ADD(ph)
 #define PROF_MARK(var)

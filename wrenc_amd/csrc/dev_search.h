@@ -167,8 +167,11 @@ __device__ __forceinline__ Res evaluate(const Ctx& c, const PicBufs& pb, const R
     r.lvl_c = 0;
     r.v0 = r.v1 = r.v2 = r.vmin = 3.40282347e+38f;
     r.imin = 0;
+    PROF_MARK(tcp0_);
     if (q.pre_copy != COPY_NONE)
         copy_block(c, q.pre_copy, q.copy_comps, q.copy_slot, q.copy_tx, q.copy_ty, q.copy_tlg, q.copy_from);
+    PROF_MARK(tcp1_);
+    PROF_ADD2(PH_COPY, tcp0_, tcp1_);
     if (q.kind == K_NOP) return r;
     if (q.stage) stage_org_leaf(c, q.stage, q.tx, q.ty, q.tlg);
     if (q.kind == K_FULL) {
@@ -507,7 +510,7 @@ __device__ __forceinline__ void leaf_init(LeafSt& s, int tree, int bx, int by, i
 
 // a new best candidate's reconstruction is saved to slot 0 by the request that follows it (before
 // anything overwrites the tile)
-__device__ __forceinline__ void leaf_attach_save(LeafSt& s, Req& q) {
+__device__ __forceinline__ void leaf_attach_save(LeafSF& s, Req& q) {
     q.pre_copy = COPY_NONE;
     if (s.need_save) {
         req_copy(q, COPY_SAVE, s.tree == TREE_SINGLE ? 3 : 1, 0, s.bx, s.by, s.lg);
@@ -515,7 +518,7 @@ __device__ __forceinline__ void leaf_attach_save(LeafSt& s, Req& q) {
     }
 }
 // the first evaluation of a leaf stages the originals of all the leaf's components (blocks <= 16x16)
-__device__ __forceinline__ void leaf_attach_org(LeafSt& s, Req& q) {
+__device__ __forceinline__ void leaf_attach_org(LeafSF& s, Req& q) {
     q.stage = 0;
     if (s.need_org) {
         q.stage = s.tree == TREE_SINGLE ? 3 : (s.tree == TREE_DUAL_LUMA ? 1 : 2);
@@ -523,7 +526,7 @@ __device__ __forceinline__ void leaf_attach_org(LeafSt& s, Req& q) {
     }
 }
 // a request that only saves / restores a reconstruction
-__device__ __forceinline__ void leaf_copy_only(LeafSt& s, Req& q, int mode, int comps, int cont) {
+__device__ __forceinline__ void leaf_copy_only(LeafSF& s, Req& q, int mode, int comps, int cont) {
     q.kind = K_NOP;
     q.post_save = false;
     q.xchg = false;
@@ -533,7 +536,7 @@ __device__ __forceinline__ void leaf_copy_only(LeafSt& s, Req& q, int mode, int 
 
 // full evaluation (get_intra_pred_cost, block_splitter.rs:110-474) of comps with modes [ml, mc, mc];
 // the first request of a leaf for a component also (re)builds its reference samples
-__device__ __forceinline__ void leaf_full(LeafSt& s, Req& q, int comps, int ml, int mc, bool act, int cont,
+__device__ __forceinline__ void leaf_full(LeafSF& s, Req& q, int comps, int ml, int mc, bool act, int cont,
                                           bool solo = false) {
     const bool r0 = (comps & 1) && s.need_refs0 != 0;
     const bool r1 = (comps & 2) && mc < LT_CCLM && s.need_refs1 != 0;
@@ -552,7 +555,7 @@ __device__ __forceinline__ void leaf_full(LeafSt& s, Req& q, int comps, int ml, 
 }
 
 // SAD list (get_intra_pred_aux_cost / get_chroma_intra_pred_aux_cost) of n modes, one byte each
-__device__ __forceinline__ void leaf_sadlist(LeafSt& s, Req& q, int comps, int n, uint32_t m0, uint32_t m1, uint32_t m2,
+__device__ __forceinline__ void leaf_sadlist(LeafSF& s, Req& q, int comps, int n, uint32_t m0, uint32_t m1, uint32_t m2,
                                              uint32_t m3, bool chroma_refs, int cont) {
     q.kind = K_SADLIST;
     q.post_save = false;
@@ -582,7 +585,7 @@ __device__ __forceinline__ EvalParts res_parts(const Res& r) {
     e.lvl_c = r.lvl_c;
     return e;
 }
-__device__ __forceinline__ void put_parts(EvalPartsU& d, const EvalParts& e) {
+__device__ __forceinline__ void put_parts(EvalPartsSF& d, const EvalParts& e) {
     d.ssd_y = e.ssd_y;
     d.ssd_c = e.ssd_c;
     d.lvl_y = e.lvl_y;
@@ -612,7 +615,7 @@ __device__ __forceinline__ void put_parts(EvalPartsU& d, const EvalParts& e) {
 // (s.cost, s.luma_mode, s.chroma_mode).  The reference's "first minimum wins" selections are kept
 // as strict-less running updates in the reference's candidate order; a candidate = one request
 // (luma block and chroma pair together, SAD candidates as one list).
-__device__ __forceinline__ bool leaf_step(const Ctx& c, LeafSt& s, const Res& r, Req& q) {
+__device__ __forceinline__ bool leaf_step(const Ctx& c, LeafSF& s, const Res& r, Req& q) {
     const int tree = s.tree;
     const int both = tree == TREE_SINGLE ? 3 : 1;
     int cont = s.cont;
@@ -860,7 +863,7 @@ __device__ __forceinline__ void team_idle(Req& q) {
     q.post_save = false;
 }
 // every member but `holder` restores comps of the leaf's block from holder's slot 0, attached to q
-__device__ __forceinline__ void team_restore(const Ctx& c, const LeafSt& s, Req& q, int comps, int holder) {
+__device__ __forceinline__ void team_restore(const Ctx& c, const LeafSF& s, Req& q, int comps, int holder) {
     if (c.member != holder) {
         req_copy(q, COPY_RESTORE, comps, 0, s.bx, s.by, s.lg);
         q.copy_from = holder;
@@ -869,7 +872,7 @@ __device__ __forceinline__ void team_restore(const Ctx& c, const LeafSt& s, Req&
 
 // One step of a leaf search in the team schedule; par = parity of the exchange that delivered the results
 // of the previous step's requests.  Same decisions, in the same order, as leaf_step.
-__device__ __forceinline__ bool leaf_step_team(const Ctx& c, LeafSt& s, Req& q, int par) {
+__device__ __forceinline__ bool leaf_step_team(const Ctx& c, LeafSF& s, Req& q, int par) {
     const int tree = s.tree;
     const int both = tree == TREE_SINGLE ? 3 : 1;
     const int me = c.member;
@@ -1127,7 +1130,8 @@ __device__ __forceinline__ bool ctu_step(Ctx& c, const Res& r, Req& q) {
     for (;;) {
         if (in_leaf) {
             // team schedule: the results of the previous requests are in the members' XRes of parity xpar ^ 1
-            if (TEAM ? leaf_step_team(c, t.leaf, q, t.xpar ^ 1) : leaf_step(c, t.leaf, r, q)) {
+            LeafSF ls = snap_leaf(t.leaf);
+            if (TEAM ? leaf_step_team(c, ls, q, t.xpar ^ 1) : leaf_step(c, ls, r, q)) {
                 if (t.pend) { // the first request of a node's first child saves the unsplit candidate
                     req_copy(q, COPY_SAVE, 3, t.pslot, t.pbx, t.pby, t.plg);
                     t.pend = 0;
@@ -1404,21 +1408,41 @@ __device__ __forceinline__ void encode_ctu(Ctx& c, const PicBufs& pb, int ctu_co
     Res r = {};
     Req q = {};
     for (;;) {
+#ifdef WRENC_PROFILE
+        // control time by where the step starts: leaf continuation (0..19) or 20 + tree continuation
+        const int cb_ = SH.st.in_leaf ? (int)SH.st.leaf.cont : 20 + (int)SH.st.cont;
+#endif
         PROF_MARK(tc0_);
         const bool more = ctu_step<TEAM>(c, r, q);
         PROF_MARK(tc1_);
         PROF_ADD2(PH_CTRL, tc0_, tc1_);
+        PROF_ADDM(0, tc0_, tc1_);
+        PROF_ADD2(PH_CB + (cb_ & 31), tc0_, tc1_);
+        PROF_ADD2(PH_CBN + (cb_ & 31), 0, 1);
         PROF_ADD2(PH_NSTEP, 0, 1);
         PROF_ADD2(PH_NFULL, 0, (q.kind == K_FULL ? 1 : 0));
         if (!more) break;
+#ifdef WRENC_EXP_CTRL_ONLY // timing / counting experiment only (wrong results): the control flow without evaluations
+        r = Res{};
+#else
+        PROF_MARK(te0_);
         r = evaluate(c, pb, q, overflow);
+        PROF_MARK(te1_);
+        PROF_ADDM(q.kind == K_NOP ? 3 : 1, te0_, te1_);
+        if (LANE == 0 && WAVE < 4 && cb_ < 12) s_prof[PH_ST + 4 * cb_ + WAVE] += te1_ - te0_; // eval time by step origin, member
+        if (threadIdx.x == 0 && cb_ < 12) s_prof[PH_STN + cb_] += 1;
+#endif
         if (TEAM && q.xchg) {
             // publish, meet the team (the workgroup's teams walk the same schedule: the same barriers), flip the
             // parity: a fast member's next result goes to the other buffer while slow members still read this one
+            PROF_MARK(tx0_);
             const int par = SH.st.xpar;
             team_publish(q, r, par);
             SH.st.xpar = (uint8_t)(par ^ 1);
             __syncthreads();
+            PROF_MARK(tx1_);
+            PROF_ADD2(PH_XCHG, tx0_, tx1_);
+            PROF_ADDM(2, tx0_, tx1_);
         }
     }
     const float cost = SH.st.ctu_cost;
