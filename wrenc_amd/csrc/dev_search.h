@@ -1429,8 +1429,10 @@ __device__ __forceinline__ void encode_ctu(Ctx& c, const PicBufs& pb, int ctu_co
         r = evaluate(c, pb, q, overflow);
         PROF_MARK(te1_);
         PROF_ADDM(q.kind == K_NOP ? 3 : 1, te0_, te1_);
+#ifdef WRENC_PROFILE
         if (LANE == 0 && WAVE < 4 && cb_ < 12) s_prof[PH_ST + 4 * cb_ + WAVE] += te1_ - te0_; // eval time by step origin, member
         if (threadIdx.x == 0 && cb_ < 12) s_prof[PH_STN + cb_] += 1;
+#endif
 #endif
         if (TEAM && q.xchg) {
             // publish, meet the team (the workgroup's teams walk the same schedule: the same barriers), flip the
