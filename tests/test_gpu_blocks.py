@@ -75,3 +75,22 @@ def test_quantize_trellis(enc, n):
         ref = po.quantize(blocks[i], 32)
         assert np.array_equal(got[i], ref), (n, i)
         assert int(cost[i]) == po.level_cost(ref), (n, i)
+
+
+@pytest.mark.parametrize("use_mfma", [0, 1])
+def test_fwd_dct32_mfma_experiment(enc, use_mfma):
+    """north_star's MFMA question: the 32x32 forward transform as i8 MFMAs over balanced base-256 digits is exact
+    (equal to the oracle's transformer.rs:2040-2378 restatement), as is the v_dot2 version the search uses."""
+    from oracle import pyoracle as po
+    rng = np.random.default_rng(77)
+    blocks = rng.integers(-255, 256, (40, 32, 32)).astype(np.int16)
+    blocks[0] = 255
+    blocks[1] = -255
+    blocks[2] = ((np.indices((32, 32)).sum(0) & 1) * 510 - 255).astype(np.int16)
+    blocks[3] = 0
+    blocks[4] = rng.integers(-3, 4, (32, 32))
+    blocks[5] = np.where(np.indices((32, 32))[1] < 16, 255, -255)
+    got, ms = enc.fwd_dct32(blocks, use_mfma)
+    assert ms > 0
+    for i in range(blocks.shape[0]):
+        assert np.array_equal(got[i], po.fwd_dct(blocks[i])), (use_mfma, i)

@@ -28,6 +28,11 @@ struct DevConst {
     int16_t intra_angle[95];  // common.rs:145
     int32_t ang_tab[67];      // per mode: intraPredAngle (low half) | invAngle (high half), read with one scalar load
     int8_t fc[32][4];         // common.rs:153
+    // MFMA experiment (dev_transform.h, fwd_dct32_mfma): the 32-point basis as signed bytes (|T| <= 90),
+    // [u][x] for the stage that contracts over x, and with the k order of an MFMA accumulator
+    // ([v][h][j] = T[v][8 (j / 4) + 4 h + j % 4]) for the stage that contracts over the first stage's output
+    int8_t dct32_a[32][32];
+    int8_t dct32_p[32][2][16];
 };
 
 // Pointers that are loaded from memory (PicBufs) lose their address space; these casts tell the

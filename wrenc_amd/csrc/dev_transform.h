@@ -107,6 +107,84 @@ __device__ void inv_dct(Ctx c, int nb, int o1) {
     WSYNC();
 }
 
+// ---------------------------------------------------------------------------
+// MFMA EXPERIMENT (north_star: "MFMA tried only for the 32x32 separable int16 transform and kept only if
+// rocprof shows a real win"): the forward 32x32 DCT-2 (transformer.rs:2040-2378) as five
+// v_mfma_i32_32x32x32_i8.  Exact integer arithmetic: the basis fits signed bytes, the other operand is split
+// into balanced base-256 digits (v = d0 + 256 d1 + 65536 d2, d0, d1 in [-128, 127]), one MFMA per digit,
+// i32 accumulators recombined with shifts.
+//   stage 1: Ht[y][u] = sum_x R[y][x] T[u][x]      A = digits of R (9 bits: 2 digits), B = T
+//   stage 2: C[v][u]  = sum_y T[v][y] H[u][y]      A = T in accumulator k order, B = digits of Ht (17 bits: 3)
+// The first stage's accumulators ARE the second stage's B operand (same lane, same k set), so the intermediate
+// never goes through LDS.  wrenc_gpu_test_fwd_dct32 is its parity gate and micro-benchmark (tools/dct_bench.py)
+// against the v_dot2 version (fwd_dct<5>); measurements and the decision to keep it in DESIGN.md.
+// ---------------------------------------------------------------------------
+typedef int v4i_t __attribute__((ext_vector_type(4)));
+typedef int v16i_t __attribute__((ext_vector_type(16)));
+typedef short s2_t __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ uint32_t pk_digit1(uint32_t p) { // per i16 half: (v + 128) >> 8, arithmetic
+    s2_t v;
+    v.x = (short)(p & 0xFFFF);
+    v.y = (short)(p >> 16);
+    v = (v + (short)128) >> 8;
+    return (uint32_t)(unsigned short)v.x | ((uint32_t)(unsigned short)v.y << 16);
+}
+// bytes b of four dwords -> one dword (byte k from dword k)
+__device__ __forceinline__ uint32_t gather_byte(uint32_t a, uint32_t b, uint32_t c, uint32_t d, int byte) {
+    const uint32_t sel = 0x0C0C0400u + 0x0101u * (uint32_t)byte; // [b(lo src), b(hi src), 0, 0]
+    const uint32_t ab = __builtin_amdgcn_perm(b, a, sel);
+    const uint32_t cd = __builtin_amdgcn_perm(d, c, sel);
+    return __builtin_amdgcn_perm(cd, ab, 0x05040100u);           // [ab.b0, ab.b1, cd.b0, cd.b1]
+}
+
+__device__ __forceinline__ void fwd_dct32_mfma(Ctx c, int o1) {
+    const int r = LANE & 31, h = LANE >> 5;
+    const v4i_t tA = *(const CONST_AS v4i_t*)&c.k->dct32_a[r][16 * h];
+    const v4i_t tP = *(const CONST_AS v4i_t*)&c.k->dct32_p[r][h][0];
+    // ---- stage 1 ----
+    const uint4 q0 = *(const uint4*)&SH.r1[o1 + r * 32 + 16 * h];
+    const uint4 q1 = *(const uint4*)&SH.r1[o1 + r * 32 + 16 * h + 8];
+    const uint32_t p[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
+    v4i_t lo, hi;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        lo[i] = (int)__builtin_amdgcn_perm(p[2 * i + 1], p[2 * i], 0x06040200u); // byte 0 of the four i16
+        hi[i] = (int)__builtin_amdgcn_perm(pk_digit1(p[2 * i + 1]), pk_digit1(p[2 * i]), 0x06040200u);
+    }
+    v16i_t z = {};
+    v16i_t init1;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) init1[w] = 1 << 3; // (h + (1 << (LG - 2))) >> (LG - 1), LG = 5 (:2201-2209)
+    const v16i_t a_hi = __builtin_amdgcn_mfma_i32_32x32x32_i8(hi, tA, z, 0, 0, 0);
+    const v16i_t a_lo = __builtin_amdgcn_mfma_i32_32x32x32_i8(lo, tA, init1, 0, 0, 0);
+    int H[16]; // Ht[y(w, h)][u = r], y(w, h) = 8 (w / 4) + 4 h + w % 4
+#pragma unroll
+    for (int w = 0; w < 16; ++w) H[w] = (a_lo[w] + (a_hi[w] << 8)) >> 4;
+    // ---- stage 2: digits of H straight from the registers ----
+    v4i_t d0, d1, d2;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const uint32_t a = (uint32_t)H[4 * i], b = (uint32_t)H[4 * i + 1], cc = (uint32_t)H[4 * i + 2], d = (uint32_t)H[4 * i + 3];
+        d0[i] = (int)gather_byte(a, b, cc, d, 0);                                     // sext8(v)
+        d1[i] = (int)gather_byte(a + 128u, b + 128u, cc + 128u, d + 128u, 1);         // byte 1 of v + 128
+        d2[i] = (int)gather_byte(a + 32896u, b + 32896u, cc + 32896u, d + 32896u, 2); // byte 2 of v + 128 + 32768
+    }
+    v16i_t init2;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) init2[w] = 1 << 10; // (+ (1 << (LG + 5))) >> (LG + 6) (:2309-2316)
+    const v16i_t c0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(tP, d0, init2, 0, 0, 0);
+    const v16i_t c1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(tP, d1, z, 0, 0, 0);
+    const v16i_t c2 = __builtin_amdgcn_mfma_i32_32x32x32_i8(tP, d2, z, 0, 0, 0);
+    WSYNC(); // every lane has read its residuals before the coefficients overwrite them
+#pragma unroll
+    for (int w = 0; w < 16; ++w) {
+        const int v = 8 * (w >> 2) + 4 * h + (w & 3);
+        SH.r1[o1 + v * 32 + r] = (int16_t)((c0[w] + (c1[w] << 8) + (c2[w] << 16)) >> 11);
+    }
+    WSYNC();
+}
+
 // o1: where the blocks start in r1 (i16 units, a multiple of 2)
 __device__ __forceinline__ void fwd_dct_lg(Ctx c, int lg, int nb, int o1 = 0) {
     c = uni(c);
@@ -117,7 +195,16 @@ __device__ __forceinline__ void fwd_dct_lg(Ctx c, int lg, int nb, int o1 = 0) {
     case 2: fwd_dct<2>(c, nb, o1); break;
     case 3: fwd_dct<3>(c, nb, o1); break;
     case 4: fwd_dct<4>(c, nb, o1); break;
-    default: fwd_dct<5>(c, nb, o1); break;
+    default:
+        // 32x32 (always a single luma block): the i8-MFMA version, kept on measurement (3.6x in the
+        // micro-benchmark, +5.6 % frames/s at max-split-depth 0, +0.9 % at depth 2).  -DWRENC_DCT32_VDOT2 builds
+        // the v_dot2 / v_mad_i24 version instead (the comparison arm).
+#ifdef WRENC_DCT32_VDOT2
+        fwd_dct<5>(c, nb, o1);
+#else
+        fwd_dct32_mfma(c, o1);
+#endif
+        break;
     }
 }
 __device__ __forceinline__ void inv_dct_lg(Ctx c, int lg, int nb, int o1 = 0) {

@@ -140,6 +140,23 @@ __global__ __launch_bounds__(64) void test_fwd_dct_kernel(const DevConst* __rest
     for (int i = threadIdx.x; i < nn; i += 64) out[(size_t)blockIdx.x * nn + i] = SH.r1[i];
 }
 
+// MFMA experiment: the 32x32 forward transform as i8 MFMAs (dev_transform.h); `reps` repeats the transform
+// of the same block in place for the micro-benchmark (the result of the last repetition is stored)
+__global__ __launch_bounds__(64) void test_fwd_dct32_kernel(const DevConst* __restrict__ k, const int16_t* in, int16_t* out,
+                                                           int mfma, int reps) {
+    Ctx c = {};
+    c.k = (const CONST_AS DevConst*)k;
+    for (int rep = 0; rep < reps; ++rep) {
+        for (int i = threadIdx.x; i < 1024; i += 64) SH.r1[i] = in[(size_t)blockIdx.x * 1024 + i];
+        WSYNC();
+        if (mfma)
+            fwd_dct32_mfma(c, 0);
+        else
+            fwd_dct<5>(c, 1, 0);
+    }
+    for (int i = threadIdx.x; i < 1024; i += 64) out[(size_t)blockIdx.x * 1024 + i] = SH.r1[i];
+}
+
 __global__ __launch_bounds__(64) void test_inv_dct_kernel(const DevConst* __restrict__ k,
                                                           const int16_t* in, int lg, int16_t* out) {
     Ctx c = {};
@@ -401,6 +418,11 @@ void fill_dev_const(const wrenc_gpu_config& cfg, DevConst& k) {
         k.ang_tab[mode] = (int32_t)(((uint32_t)(uint16_t)(int16_t)angle) | ((uint32_t)(uint16_t)(int16_t)inv << 16));
     }
     memcpy(k.fc, kFC, sizeof(kFC));
+    for (int u = 0; u < 32; ++u) // MFMA experiment: the 32-point basis as signed bytes
+        for (int x = 0; x < 32; ++x) k.dct32_a[u][x] = (int8_t)dct64(u * 2, x);
+    for (int v = 0; v < 32; ++v)
+        for (int h = 0; h < 2; ++h)
+            for (int j = 0; j < 16; ++j) k.dct32_p[v][h][j] = (int8_t)dct64(v * 2, 8 * (j / 4) + 4 * h + j % 4);
 }
 
 } // namespace
@@ -964,6 +986,37 @@ int wrenc_gpu_test_fwd_dct(wrenc_gpu_ctx* ctx, const int16_t* res, int log2n, in
     return run_block_test(ctx, res, log2n, count, coef, [&](int16_t* i, int16_t* o) {
         hipLaunchKernelGGL(test_fwd_dct_kernel, dim3(count), dim3(64), 0, ctx->stream, ctx->d_const, i, log2n, o);
     });
+}
+int wrenc_gpu_test_fwd_dct32(wrenc_gpu_ctx* ctx, const int16_t* res, int count, int16_t* coef, int use_mfma, int reps,
+                             float* kernel_ms) {
+    if (!ctx || !res || !coef || count < 1 || reps < 1) return WRENC_GPU_EINVAL;
+    HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
+    const size_t bytes = (size_t)count * 1024 * sizeof(int16_t);
+    int16_t *d_in = nullptr, *d_out = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    HIP_TRY(ctx, hipMalloc((void**)&d_in, bytes));
+    hipError_t e = hipMalloc((void**)&d_out, bytes);
+    if (e == hipSuccess) e = hipEventCreate(&e0);
+    if (e == hipSuccess) e = hipEventCreate(&e1);
+    if (e == hipSuccess) e = hipMemcpy(d_in, res, bytes, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipEventRecord(e0, ctx->stream);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(test_fwd_dct32_kernel, dim3(count), dim3(64), 0, ctx->stream, ctx->d_const, d_in, d_out,
+                           use_mfma, reps);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipEventRecord(e1, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    float ms = 0.f;
+    if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+    if (e == hipSuccess) e = hipMemcpy(coef, d_out, bytes, hipMemcpyDeviceToHost);
+    if (kernel_ms) *kernel_ms = ms;
+    (void)hipFree(d_in);
+    if (d_out) (void)hipFree(d_out);
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    if (e != hipSuccess) return fail(ctx, WRENC_GPU_EHIP, hipGetErrorString(e));
+    return WRENC_GPU_OK;
 }
 int wrenc_gpu_test_inv_dct(wrenc_gpu_ctx* ctx, const int16_t* deq, int log2n, int count, int16_t* res) {
     return run_block_test(ctx, deq, log2n, count, res, [&](int16_t* i, int16_t* o) {
