@@ -188,7 +188,7 @@ def fill_curve(grp, local_rank, quick=False):
                 dt, _, _ = run_resident(enc, grp, 0, b, 1, 0)
                 best = dt if best is None else min(best, dt)
             curve[str(b)] = b / best
-            sched[str(b)] = {1: "wave", 2: "team"}.get(enc.last_schedule(), "?")
+            sched[str(b)] = {0: "team on thin diagonals, wave on wide ones", 1: "wave", 2: "team"}.get(enc.last_schedule(), "?")
         enc.close()
         out[name] = curve
         out[name + "_schedule"] = sched

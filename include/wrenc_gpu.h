@@ -138,10 +138,11 @@ int wrenc_gpu_encode_picture(wrenc_gpu_ctx* ctx, const uint8_t* y, const uint8_t
  *         hundreds of pictures in flight to fill the GPU (a picture offers only one anti-diagonal of CTUs at a time).
  *   TEAM: four wavefronts per CTU: the candidates of a leaf search that do not depend on each other
  *         (block_splitter.rs:887-898, 905-974) run side by side.  Shorter CTU latency, for calls with few pictures.
- *   AUTO (default): TEAM when the call cannot fill the GPU with one wave per CTU. */
+ *   AUTO (default): decided per anti-diagonal of CTUs: TEAM while pictures x CTUs of the diagonal cannot fill the GPU
+ *         with one wave each, WAVE beyond. */
 enum wrenc_gpu_schedule { WRENC_GPU_SCHEDULE_AUTO = 0, WRENC_GPU_SCHEDULE_WAVE = 1, WRENC_GPU_SCHEDULE_TEAM = 2 };
 int wrenc_gpu_set_schedule(wrenc_gpu_ctx* ctx, int schedule);
-int wrenc_gpu_last_schedule(const wrenc_gpu_ctx* ctx); /* what the most recent encode call used */
+int wrenc_gpu_last_schedule(const wrenc_gpu_ctx* ctx); /* what the most recent encode call used (AUTO = both) */
 
 /* Per-launch timing (two HIP events around every kernel launch) is OFF by default: the product path
  * (CLI, native program) never reads it.  bench.py / profiling switch it on.  While it is on, an encode

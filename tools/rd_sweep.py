@@ -36,26 +36,19 @@ def ssim(a, b):
     return float(np.mean(((2 * mu_a * mu_b + c1) * (2 * cov + c2)) / ((mu_a ** 2 + mu_b ** 2 + c1) * (va + vb + c2))))
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--width", type=int, default=3840)
-    ap.add_argument("--height", type=int, default=2176)
-    ap.add_argument("--frames", type=int, default=8)
-    ap.add_argument("--depth", type=int, default=3)
-    ap.add_argument("--qps", default="22,27,32,37")
-    ap.add_argument("--threads", type=int, default=8)
-    ap.add_argument("--extra-params", help="the reference's RD-model knobs, K1=V1,K2=V2")
-    ap.add_argument("--out")
-    a = ap.parse_args()
+def run_sweep(width=3840, height=2176, frames=8, depth=3, qps=(22, 27, 32, 37), threads=8, extra_params=None,
+              keep_streams=False, verbose=True):
+    """The sweep as a function (tests/test_gpu_rd_sweep.py runs it too).  keep_streams: each result also carries
+    "_stream" (parameter sets + pictures), "_recs" and the doc "_frames", for a decoder-side check by the caller."""
     from wrenc_amd import bitstream, gpu, synth
-    w, h, n = a.width, a.height, a.frames
-    frames = [synth.synth_textured_frame(w, h, f) for f in range(n)]
+    w, h, n = width, height, frames
+    pics = [synth.synth_textured_frame(w, h, f) for f in range(n)]
     results = []
-    pool = ThreadPoolExecutor(max_workers=a.threads)
-    for qp in [int(q) for q in a.qps.split(",")]:
-        enc = gpu.Encoder(w, h, qp=qp, max_split_depth=a.depth, n_slots=n, extra_params=a.extra_params)
+    pool = ThreadPoolExecutor(max_workers=threads)
+    for qp in [int(q) for q in qps]:
+        enc = gpu.Encoder(w, h, qp=qp, max_split_depth=depth, n_slots=n, extra_params=extra_params)
         for s in range(n):
-            enc.upload(s, *frames[s])
+            enc.upload(s, *pics[s])
         enc.sync()
         t0 = time.perf_counter()
         enc.encode(0, n)
@@ -67,27 +60,49 @@ def main():
         t0 = time.perf_counter()
         nals = list(pool.map(lambda t: bitstream.write_picture(w, h, qp, t[0], t[1]), enumerate(recs)))
         t_write = time.perf_counter() - t0
-        total = len(bitstream.write_parameter_sets(w, h, qp)) + sum(len(x) for x in nals)
+        head = bitstream.write_parameter_sets(w, h, qp)
+        total = len(head) + sum(len(x) for x in nals)
         per_frame = []
         for f in range(n):
-            py, pu, pv = (psnr(frames[f][c], recs[f][k]) for c, k in enumerate(("rec_y", "rec_cb", "rec_cr")))
+            py, pu, pv = (psnr(pics[f][c], recs[f][k]) for c, k in enumerate(("rec_y", "rec_cb", "rec_cr")))
             per_frame.append({"n": f + 1, "psnr_y": py, "psnr_u": pu, "psnr_v": pv, "psnr_avg": (4 * py + pu + pv) / 6,
-                              "ssim_y": ssim(frames[f][0], recs[f]["rec_y"]), "bytes": len(nals[f])})
+                              "ssim_y": ssim(pics[f][0], recs[f]["rec_y"]), "bytes": len(nals[f])})
         summ = {k: float(np.mean([p[k] for p in per_frame])) for k in ("psnr_y", "psnr_u", "psnr_v", "psnr_avg", "ssim_y")}
         results.append({
-            "title": "synth_textured_%dx%d[wrenc_amd@max_split_depth=%d,qp=%d]" % (w, h, a.depth, qp), "qp": qp,
+            "title": "synth_textured_%dx%d[wrenc_amd@max_split_depth=%d,qp=%d]" % (w, h, depth, qp), "qp": qp,
             "bytes": total, "duration": t_search + t_write, "frames": n,
             "bits_per_pixel": 8.0 * total / (n * w * h),
-            "search_fps": n / t_search, "bitstream_fps_%d_threads" % a.threads: n / t_write,
+            "search_fps": n / t_search, "bitstream_fps_%d_threads" % threads: n / t_write,
             "final_pass_mismatches": mism,
             "metrics": {"psnr": {"summary": {k: summ[k] for k in ("psnr_y", "psnr_u", "psnr_v", "psnr_avg")}},
                         "ssim": {"summary": {"ssim_y": summ["ssim_y"]}}, "per_frame": per_frame}})
-        print("qp %2d  %9d bytes  %.4f bpp  PSNR-Y %.2f dB  SSIM-Y %.4f  search %.1f fps  writer %.1f fps" % (
-            qp, total, results[-1]["bits_per_pixel"], summ["psnr_y"], summ["ssim_y"], n / t_search, n / t_write), flush=True)
+        if keep_streams:
+            results[-1]["_stream"] = head + b"".join(nals)
+            results[-1]["_recs"] = recs
+        if verbose:
+            print("qp %2d  %9d bytes  %.4f bpp  PSNR-Y %.2f dB  SSIM-Y %.4f  search %.1f fps  writer %.1f fps" % (
+                qp, total, results[-1]["bits_per_pixel"], summ["psnr_y"], summ["ssim_y"], n / t_search, n / t_write), flush=True)
     pool.shutdown()
-    doc = {"config": {"width": w, "height": h, "frames": n, "max_split_depth": a.depth, "content": "synth_textured_frame",
-                      "extra_params": a.extra_params},
+    doc = {"config": {"width": w, "height": h, "frames": n, "max_split_depth": depth, "content": "synth_textured_frame",
+                      "extra_params": extra_params},
            "results": results}
+    if keep_streams:
+        doc["_frames"] = pics
+    return doc
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--width", type=int, default=3840)
+    ap.add_argument("--height", type=int, default=2176)
+    ap.add_argument("--frames", type=int, default=8)
+    ap.add_argument("--depth", type=int, default=3)
+    ap.add_argument("--qps", default="22,27,32,37")
+    ap.add_argument("--threads", type=int, default=8)
+    ap.add_argument("--extra-params", help="the reference's RD-model knobs, K1=V1,K2=V2")
+    ap.add_argument("--out")
+    a = ap.parse_args()
+    doc = run_sweep(a.width, a.height, a.frames, a.depth, [int(q) for q in a.qps.split(",")], a.threads, a.extra_params)
     if a.out:
         json.dump(doc, open(a.out, "w"), indent=1)
     return 0

@@ -749,16 +749,15 @@ int wrenc_gpu_encode(wrenc_gpu_ctx* ctx, int first_slot, int n_pictures) {
     HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
     const int cols = ctx->ctu_cols, rows = ctx->ctu_rows;
     const int ndiag = cols + 2 * (rows - 1);
-    // Which schedule: one wave per CTU fills the GPU only with hundreds of CTUs in flight per anti-diagonal
-    // step (pictures x CTUs of a diagonal); below that a team of kTeam waves per CTU shortens the CTU's
-    // chain of dependent evaluations instead.  kTeamBelowWaves: measured crossover.
-    const long long parallel_ctus = (long long)n_pictures * ((cols * rows + ndiag - 1) / ndiag);
-    const bool team = ctx->schedule == WRENC_GPU_SCHEDULE_TEAM ||
-                      (ctx->schedule == WRENC_GPU_SCHEDULE_AUTO && parallel_ctus * kTeam <= kTeamBelowWaves);
-    ctx->last_schedule = team ? WRENC_GPU_SCHEDULE_TEAM : WRENC_GPU_SCHEDULE_WAVE;
-    // split the pictures into lanes of whole workgroups (per_group pictures each)
-    const int per_group = team ? WPB / kTeam : WPB;
+    // Which schedule, decided PER ANTI-DIAGONAL: one wave per CTU fills the GPU only with thousands of CTUs
+    // runnable side by side (pictures x CTUs of the diagonal); below that a team of kTeam waves per CTU
+    // shortens the CTU's chain of dependent evaluations instead.  kTeamBelowWaves: measured crossover
+    // (DESIGN.md).  The thin first and last diagonals of a big batch run as teams, its wide ones as waves.
+    // Pictures are dealt to lanes in units of WPB (the wave schedule's workgroup) whatever the schedule, so a
+    // picture stays on one stream; a team launch covers its lane's pictures in groups of WPB / kTeam.
+    const int per_group = WPB;
     const int total_groups = (n_pictures + per_group - 1) / per_group;
+    int n_team_diags = 0, n_wave_diags = 0;
     const int n_lanes = total_groups < kEncodeLanes ? total_groups : kEncodeLanes;
     if (!ctx->d_pred_scratch) {
         HIP_TRY(ctx, hipMalloc((void**)&ctx->d_pred_scratch, (size_t)kScratchSlots * WPB * kWaveScratch));
@@ -797,6 +796,9 @@ int wrenc_gpu_encode(wrenc_gpu_ctx* ctx, int first_slot, int n_pictures) {
         if (r_max > rows - 1) r_max = rows - 1;
         const int count = r_max - r_min + 1;
         if (count <= 0) continue;
+        const bool team = ctx->schedule == WRENC_GPU_SCHEDULE_TEAM ||
+                          (ctx->schedule == WRENC_GPU_SCHEDULE_AUTO && (long long)n_pictures * count * kTeam <= kTeamBelowWaves);
+        ++(team ? n_team_diags : n_wave_diags);
         for (int l = 0; l < n_lanes; ++l) {
             const int g0 = (int)((long long)total_groups * l / n_lanes), g1 = (int)((long long)total_groups * (l + 1) / n_lanes);
             const int lane_first = first_slot + g0 * per_group;
@@ -806,7 +808,8 @@ int wrenc_gpu_encode(wrenc_gpu_ctx* ctx, int first_slot, int n_pictures) {
             hipStream_t st = l == 0 ? ctx->stream : ctx->lanes[l - 1];
             if (timed) HIP_TRY(ctx, hipEventRecord(ctx->ev_pool[2 * launches], st));
             if (team)
-                hipLaunchKernelGGL(ctu_search_team_kernel, dim3(count * (g1 - g0)), dim3(64 * WPB), 0, st, ctx->d_const,
+                hipLaunchKernelGGL(ctu_search_team_kernel, dim3(count * ((lane_pics + WPB / kTeam - 1) / (WPB / kTeam))),
+                                   dim3(64 * WPB), 0, st, ctx->d_const,
                                    ctx->d_slots, lane_first, lane_pics, d, r_min, count, ctx->d_pred_scratch,
                                    ctx->d_slot_map, ctx->d_mismatch, ctx->d_overflow);
             else
@@ -827,6 +830,7 @@ int wrenc_gpu_encode(wrenc_gpu_ctx* ctx, int first_slot, int n_pictures) {
     hipEvent_t done = ctx->enc_events[ctx->enc_event_next++ % ctx->enc_events.size()];
     HIP_TRY(ctx, hipEventRecord(done, ctx->stream));
     ctx->last_done = done;
+    ctx->last_schedule = n_wave_diags == 0 ? WRENC_GPU_SCHEDULE_TEAM : (n_team_diags == 0 ? WRENC_GPU_SCHEDULE_WAVE : WRENC_GPU_SCHEDULE_AUTO);
     ctx->last_launches = launches;
     ctx->stats_valid = timed;
     for (int s = first_slot; s < first_slot + n_pictures; ++s) {
