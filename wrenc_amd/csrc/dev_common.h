@@ -50,8 +50,17 @@ constexpr int kSlotBytes = 1536;
 constexpr int kWaveScratch = 1024 + kReconSlots * kSlotBytes;
 
 // One picture's device buffers.
+// Layout of the two CTU-granular buffers of a picture (what one CTU needs sits in whole cache lines of its own;
+// rows of the planar picture are shared by four CTUs of four different anti-diagonals):
+//   org_t:  per CTU kOrgTile bytes: Y 32x32 row-major | Cb 16x16 | Cr 16x16     (written by retile_kernel at upload)
+//   border: per CTU kBorderBytes: the CTU's four rightmost reconstructed columns, Y 32 rows x 4 | Cb 16 x 4 |
+//           Cr 16 x 4, then the luma modes of its rightmost 4x4 column (8): what the CTU to its right loads
+constexpr int kOrgTile = 1536;
+constexpr int kBorderBytes = 272;
 struct PicBufs {
     const uint8_t* org[3];
+    const uint8_t* org_t;
+    uint8_t* border;
     uint8_t* rec[3];
     int16_t* lev[3];
     uint8_t* cu_log2;
@@ -189,7 +198,8 @@ struct LeafSF {
 static_assert(sizeof(LeafSt) == 64, "snap_leaf reads the struct as 16 dwords");
 __device__ __forceinline__ LeafSF snap_leaf(LeafSt& l) {
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); // after this step's own stores to the struct (leaf_init)
-    const int w = ((const volatile int*)&l)[LANE & 15];
+    // (a plain load: the fence above orders it after the stores; `volatile` would turn it into a FLAT access)
+    const int w = ((const int*)&l)[LANE & 15];
     LeafSF s;
 #define SNAP_U8(f)                                                                                          \
     s.f.v = (uint8_t)((unsigned)__builtin_amdgcn_readlane(w, (int)(offsetof(LeafSt, f) >> 2)) >> (8 * (offsetof(LeafSt, f) & 3))); \
@@ -282,7 +292,7 @@ struct __attribute__((aligned(16))) Lds {
 // stage functions never reload it from memory.
 struct Ctx {
     const CONST_AS DevConst* k;         // constant address space: uniform reads become scalar loads
-    const GLOBAL_AS uint8_t* org;       // original planes of this wave's picture: Y, Cb, Cr back to back (read-only)
+    const GLOBAL_AS uint8_t* org;       // originals of THIS CTU: the kOrgTile bytes of its tile in PicBufs::org_t (read-only)
     int W, WH;                          // luma width, luma plane size
     uint8_t* pred_scratch;              // 1 KB per wave in HBM: prediction bytes between predict and recon
     GLOBAL_AS uint8_t* slots;           // kReconSlots saved reconstructions of this wave (see copy_block)
@@ -469,9 +479,7 @@ __device__ __forceinline__ int org_get(const Ctx& c, int pc, int x, int y) {
 #ifdef WRENC_EXP_NO_ORG // timing experiment only (wrong results): what the global loads of originals cost
     return (x * 7 + y * 13 + pc * 31) & 255;
 #endif
-    const int cs = pc ? 1 : 0;
-    const int stride = c.W >> cs;
-    return c.org[plane_off(c, pc) + (unsigned)(((c.ctu_y >> cs) + y) * stride + (c.ctu_x >> cs) + x)];
+    return pc == 0 ? c.org[y * 32 + x] : c.org[768 + pc * 256 + y * 16 + x];
 }
 
 // ---------------------------------------------------------------------------

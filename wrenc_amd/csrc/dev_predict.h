@@ -305,7 +305,7 @@ __device__ __forceinline__ void stage_org(const Ctx& c, int comps, int tx, int t
         const int words = 1 << (2 * tlg - 2);
         for (int w = LANE; w < words; w += 64) {
             const int row = (4 * w) >> tlg, col = (4 * w) & ((1 << tlg) - 1);
-            dst[w] = *(const GLOBAL_AS uint32_t*)&c.org[(unsigned)((c.ctu_y + ty + row) * c.W + c.ctu_x + tx + col)];
+            dst[w] = *(const GLOBAL_AS uint32_t*)&c.org[(ty + row) * 32 + tx + col];
         }
     }
     if (comps & 2) {
@@ -315,9 +315,7 @@ __device__ __forceinline__ void stage_org(const Ctx& c, int comps, int tx, int t
             const int pl = w >= words ? 1 : 0;
             const int ww = w - pl * words;
             const int row = (4 * ww) >> lg, col = (4 * ww) & ((1 << lg) - 1);
-            dst[cword + w] = *(const GLOBAL_AS uint32_t*)&c.org[plane_off(c, 1 + pl) +
-                                                             (unsigned)((((c.ctu_y + ty) >> 1) + row) * (c.W >> 1) +
-                                                                        ((c.ctu_x + tx) >> 1) + col)];
+            dst[cword + w] = *(const GLOBAL_AS uint32_t*)&c.org[1024 + pl * 256 + ((ty >> 1) + row) * 16 + (tx >> 1) + col];
         }
     }
     WSYNC();

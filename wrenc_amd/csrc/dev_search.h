@@ -1374,29 +1374,30 @@ __device__ __forceinline__ void encode_ctu(Ctx& c, const PicBufs& pb, int ctu_co
         const int gx = c.ctu_x - 4 + i, gy = c.ctu_y - 1;
         SH.recYtop[i] = (gx >= 0 && gx < W && gy >= 0) ? rec[(size_t)gy * W + gx] : 0;
     }
-    for (int i = LANE; i < 32 * 4; i += 64) {
-        const int y = i >> 2, x = (i & 3) - 4;
-        const int gx = c.ctu_x + x, gy = c.ctu_y + y;
-        SH.recY[y * 36 + x + 4] = gx >= 0 ? rec[(size_t)gy * W + gx] : 0;
+    // columns -4..-1 and the left CTU's modes: two cache lines of the left CTU's border record instead of 64
+    // row pieces of the planes (lane = dword: 32 luma rows, 16 + 16 chroma rows, 2 dwords of modes)
+    GLOBAL_AS uint8_t* const my_border =
+        AS_GLOBAL(uint8_t, pb.border) + (size_t)(ctu_row * k->ctu_cols + ctu_col) * kBorderBytes;
+    {
+        const uint32_t v = (c.ctu_x > 0 && LANE < 66) ? ((const GLOBAL_AS uint32_t*)(my_border - kBorderBytes))[LANE] : 0u;
+        const uint32_t v2 = (c.ctu_x > 0 && LANE < 2) ? ((const GLOBAL_AS uint32_t*)(my_border - kBorderBytes))[64 + LANE] : 0u;
+        if (LANE < 32)
+            *(uint32_t*)&SH.recY[LANE * 36] = v;
+        else if (LANE < 48)
+            *(uint32_t*)&SH.recC[0][(LANE - 32) * 20] = v;
+        else
+            *(uint32_t*)&SH.recC[1][(LANE - 48) * 20] = v;
+        if (LANE < 2) *(uint32_t*)&SH.left_mode[4 * LANE] = v2;
     }
-    for (int comp = 1; comp < 3; ++comp) {
+    for (int comp = 1; comp < 3; ++comp)
         for (int i = LANE; i < 40; i += 64) {
             const int gx = (c.ctu_x >> 1) - 4 + i, gy = (c.ctu_y >> 1) - 1;
             SH.recCtop[comp - 1][i] = (gx >= 0 && gx < Wc && gy >= 0) ? rec[plane_off(c, comp) + (size_t)gy * Wc + gx] : 0;
         }
-        for (int i = LANE; i < 16 * 4; i += 64) {
-            const int y = i >> 2, x = (i & 3) - 4;
-            const int gx = (c.ctu_x >> 1) + x, gy = (c.ctu_y >> 1) + y;
-            SH.recC[comp - 1][y * 20 + x + 4] = gx >= 0 ? rec[plane_off(c, comp) + (size_t)gy * Wc + gx] : 0;
-        }
-    }
     // tile.rs:49-58: planes start at zero
     for (int i = LANE; i < 32 * 32; i += 64) SH.recY[(i >> 5) * 36 + (i & 31) + 4] = 0;
     for (int comp = 1; comp < 3; ++comp)
         for (int i = LANE; i < 256; i += 64) SH.recC[comp - 1][(i >> 4) * 20 + (i & 15) + 4] = 0;
-    if (LANE < 8)
-        SH.left_mode[LANE] =
-            c.ctu_x > 0 ? AS_GLOBAL(uint8_t, pb.luma_mode)[(size_t)((c.ctu_y >> 2) + LANE) * (W >> 2) + (c.ctu_x >> 2) - 1] : 0;
     WSYNC();
     // ---- the search + final pass: one evaluator, driven by the state machine ----
     static_assert(sizeof(Lds) * WPB + sizeof(LdsTab) <= 81920, "two workgroups per CU need <= 80 KB each");
@@ -1469,6 +1470,23 @@ __device__ __forceinline__ void encode_ctu(Ctx& c, const PicBufs& pb, int ctu_co
             AS_GLOBAL(uint8_t, pb.chroma_mode)[oc] = SH.chroma_mode[i];
         }
         if (i == 0) AS_GLOBAL(float, pb.ctu_cost)[ctu_row * k->ctu_cols + ctu_col] = cost;
+        // the border record for the CTU to the right (see kBorderBytes)
+        {
+            uint32_t v;
+            if (LANE < 32)
+                v = *(const uint32_t*)&SH.recY[LANE * 36 + 32];
+            else if (LANE < 48)
+                v = *(const uint32_t*)&SH.recC[0][(LANE - 32) * 20 + 16];
+            else
+                v = *(const uint32_t*)&SH.recC[1][(LANE - 48) * 20 + 16];
+            ((GLOBAL_AS uint32_t*)my_border)[LANE] = v;
+            if (LANE < 2) {
+                const int r0 = 4 * LANE; // modes of the 4x4 units (7, r0 .. r0 + 3)
+                ((GLOBAL_AS uint32_t*)my_border)[64 + LANE] =
+                    (uint32_t)SH.luma_mode[r0 * 8 + 7] | ((uint32_t)SH.luma_mode[(r0 + 1) * 8 + 7] << 8) |
+                    ((uint32_t)SH.luma_mode[(r0 + 2) * 8 + 7] << 16) | ((uint32_t)SH.luma_mode[(r0 + 3) * 8 + 7] << 24);
+            }
+        }
     }
 #ifdef WRENC_PROFILE
     PROF_MARK(tt1_);

@@ -152,15 +152,16 @@ __device__ __forceinline__ void fwd_dct32_mfma(Ctx c, int o1) {
         lo[i] = (int)__builtin_amdgcn_perm(p[2 * i + 1], p[2 * i], 0x06040200u); // byte 0 of the four i16
         hi[i] = (int)__builtin_amdgcn_perm(pk_digit1(p[2 * i + 1]), pk_digit1(p[2 * i]), 0x06040200u);
     }
+    // one accumulator set, digit after digit from the top: acc = (acc << 8) + digit product (16 live registers
+    // instead of one set per digit: the search kernel has no registers to spare)
     v16i_t z = {};
-    v16i_t init1;
+    v16i_t acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(hi, tA, z, 0, 0, 0);
 #pragma unroll
-    for (int w = 0; w < 16; ++w) init1[w] = 1 << 3; // (h + (1 << (LG - 2))) >> (LG - 1), LG = 5 (:2201-2209)
-    const v16i_t a_hi = __builtin_amdgcn_mfma_i32_32x32x32_i8(hi, tA, z, 0, 0, 0);
-    const v16i_t a_lo = __builtin_amdgcn_mfma_i32_32x32x32_i8(lo, tA, init1, 0, 0, 0);
+    for (int w = 0; w < 16; ++w) acc[w] = (acc[w] << 8) + (1 << 3); // (h + (1 << (LG - 2))) >> (LG - 1), LG = 5 (:2201-2209)
+    acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(lo, tA, acc, 0, 0, 0);
     int H[16]; // Ht[y(w, h)][u = r], y(w, h) = 8 (w / 4) + 4 h + w % 4
 #pragma unroll
-    for (int w = 0; w < 16; ++w) H[w] = (a_lo[w] + (a_hi[w] << 8)) >> 4;
+    for (int w = 0; w < 16; ++w) H[w] = acc[w] >> 4;
     // ---- stage 2: digits of H straight from the registers ----
     v4i_t d0, d1, d2;
 #pragma unroll
@@ -170,17 +171,18 @@ __device__ __forceinline__ void fwd_dct32_mfma(Ctx c, int o1) {
         d1[i] = (int)gather_byte(a + 128u, b + 128u, cc + 128u, d + 128u, 1);         // byte 1 of v + 128
         d2[i] = (int)gather_byte(a + 32896u, b + 32896u, cc + 32896u, d + 32896u, 2); // byte 2 of v + 128 + 32768
     }
-    v16i_t init2;
+    acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(tP, d2, z, 0, 0, 0);
 #pragma unroll
-    for (int w = 0; w < 16; ++w) init2[w] = 1 << 10; // (+ (1 << (LG + 5))) >> (LG + 6) (:2309-2316)
-    const v16i_t c0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(tP, d0, init2, 0, 0, 0);
-    const v16i_t c1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(tP, d1, z, 0, 0, 0);
-    const v16i_t c2 = __builtin_amdgcn_mfma_i32_32x32x32_i8(tP, d2, z, 0, 0, 0);
+    for (int w = 0; w < 16; ++w) acc[w] <<= 8;
+    acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(tP, d1, acc, 0, 0, 0);
+#pragma unroll
+    for (int w = 0; w < 16; ++w) acc[w] = (acc[w] << 8) + (1 << 10); // (+ (1 << (LG + 5))) >> (LG + 6) (:2309-2316)
+    acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(tP, d0, acc, 0, 0, 0);
     WSYNC(); // every lane has read its residuals before the coefficients overwrite them
 #pragma unroll
     for (int w = 0; w < 16; ++w) {
         const int v = 8 * (w >> 2) + 4 * h + (w & 3);
-        SH.r1[o1 + v * 32 + r] = (int16_t)((c0[w] + (c1[w] << 8) + (c2[w] << 16)) >> 11);
+        SH.r1[o1 + v * 32 + r] = (int16_t)(acc[w] >> 11);
     }
     WSYNC();
 }

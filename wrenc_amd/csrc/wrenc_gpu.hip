@@ -64,6 +64,26 @@ __device__ __forceinline__ void release_scratch(unsigned long long* slot_map, in
     if (threadIdx.x == 0) atomicAnd(&slot_map[scratch_slot >> 6], ~(1ULL << (scratch_slot & 63)));
 }
 
+// Originals of a freshly uploaded picture, planar -> one contiguous tile per CTU (PicBufs::org_t): the search then
+// fetches a CTU's 1.5 KB as 12 whole cache lines instead of 64 row pieces of lines it shares with three other CTUs.
+// One wave per CTU, lane = dword.
+__global__ __launch_bounds__(64) void retile_kernel(const uint8_t* __restrict__ planar, uint8_t* __restrict__ tiled, int W, int H,
+                                                   int ctu_cols) {
+    const int ctu = blockIdx.x, col = ctu % ctu_cols, row = ctu / ctu_cols;
+    const size_t wh = (size_t)W * H;
+    uint32_t* dst = (uint32_t*)(tiled + (size_t)ctu * kOrgTile);
+    for (int w = threadIdx.x; w < kOrgTile / 4; w += 64) {
+        size_t src;
+        if (w < 256) { // luma: 8 dwords per row
+            src = (size_t)(row * 32 + (w >> 3)) * W + col * 32 + (w & 7) * 4;
+        } else {       // chroma: 4 dwords per row, Cb then Cr
+            const int pl = (w - 256) >> 6, ww = (w - 256) & 63;
+            src = wh + (size_t)pl * (wh >> 2) + (size_t)(row * 16 + (ww >> 2)) * (W >> 1) + col * 16 + (ww & 3) * 4;
+        }
+        dst[w] = *(const uint32_t*)(planar + src);
+    }
+}
+
 // Wave schedule: one workgroup = the same CTU of WPB consecutive pictures, one wave each.
 __global__ __launch_bounds__(64 * WPB, 4) void ctu_search_kernel(const DevConst* __restrict__ k,
                                                               const PicBufs* __restrict__ slots, int first_slot,
@@ -84,7 +104,7 @@ __global__ __launch_bounds__(64 * WPB, 4) void ctu_search_kernel(const DevConst*
     c.member = 0;
     if (pic >= n_pictures) pic = n_pictures - 1; // padding wave: same work, no stores
     const PicBufs pb = slots[first_slot + pic];
-    c.org = (const GLOBAL_AS uint8_t*)pb.org[0]; // Y | Cb | Cr are one slab (see wrenc_gpu_create)
+    c.org = (const GLOBAL_AS uint8_t*)pb.org_t + (size_t)(row * k->ctu_cols + col) * kOrgTile;
     c.W = k->W;
     c.WH = k->W * k->H;
     c.pred_scratch = pred_scratch + ((size_t)scratch_slot * WPB + WAVE) * kWaveScratch;
@@ -117,7 +137,7 @@ __global__ __launch_bounds__(64 * WPB, 4) void ctu_search_team_kernel(const DevC
     c.write = (c.trace && c.member == 0) ? 1 : 0; // one member stores the picture's results
     if (pic >= n_pictures) pic = n_pictures - 1;  // padding team: same work, no stores
     const PicBufs pb = slots[first_slot + pic];
-    c.org = (const GLOBAL_AS uint8_t*)pb.org[0];
+    c.org = (const GLOBAL_AS uint8_t*)pb.org_t + (size_t)(row * k->ctu_cols + col) * kOrgTile;
     c.W = k->W;
     c.WH = k->W * k->H;
     c.pred_scratch = pred_scratch + ((size_t)scratch_slot * WPB + WAVE) * kWaveScratch;
@@ -593,6 +613,8 @@ void wrenc_gpu_destroy(wrenc_gpu_ctx* ctx) {
     for (PicBufs& b : ctx->slots) {
         // planes 1 and 2 point into plane 0's slab
         if (b.org[0]) (void)hipFree((void*)b.org[0]);
+        if (b.org_t) (void)hipFree((void*)b.org_t);
+        if (b.border) (void)hipFree(b.border);
         if (b.rec[0]) (void)hipFree(b.rec[0]);
         if (b.lev[0]) (void)hipFree(b.lev[0]);
         if (b.cu_log2) (void)hipFree(b.cu_log2);
@@ -703,6 +725,9 @@ int wrenc_gpu_create(const wrenc_gpu_config* cfg, wrenc_gpu_ctx** out) {
         b.org[0] = org_slab;
         b.org[1] = org_slab + wh;
         b.org[2] = org_slab + wh + wh / 4;
+        const size_t n_ctus = (size_t)ctx->ctu_cols * ctx->ctu_rows;
+        CREATE_TRY(hipMalloc((void**)&b.org_t, n_ctus * kOrgTile));
+        CREATE_TRY(hipMalloc((void**)&b.border, n_ctus * kBorderBytes));
         CREATE_TRY(hipMalloc((void**)&b.rec[0], wh + wh / 2));
         b.rec[1] = b.rec[0] + wh;
         b.rec[2] = b.rec[0] + wh + wh / 4;
@@ -735,6 +760,10 @@ int wrenc_gpu_upload(wrenc_gpu_ctx* ctx, int slot, const uint8_t* y, const uint8
     HIP_TRY(ctx, hipMemcpy2DAsync((void*)b.org[0], w, y, stride_y, w, h, hipMemcpyHostToDevice, cs));
     HIP_TRY(ctx, hipMemcpy2DAsync((void*)b.org[1], w / 2, cb, stride_c, w / 2, h / 2, hipMemcpyHostToDevice, cs));
     HIP_TRY(ctx, hipMemcpy2DAsync((void*)b.org[2], w / 2, cr, stride_c, w / 2, h / 2, hipMemcpyHostToDevice, cs));
+    // planar staging -> CTU tiles (what the search reads), behind the copies on the same stream
+    hipLaunchKernelGGL(retile_kernel, dim3(ctx->ctu_cols * ctx->ctu_rows), dim3(64), 0, cs, b.org[0], (uint8_t*)b.org_t, (int)w,
+                       (int)h, ctx->ctu_cols);
+    HIP_TRY(ctx, hipGetLastError());
     ctx->uploads_pending = true;
     ctx->state[slot] = 1;
     return WRENC_GPU_OK;
