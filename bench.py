@@ -347,8 +347,9 @@ def main():
         if world == 1:
             result["fill_curve"] = fill_curve(grp, local_rank)
             threads = max(1, min(16, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else 8))
-            result["e2e"] = {"smooth": e2e_native(w, h, args.qp, args.depth, 512, 256, threads, False),
-                             "textured": e2e_native(w, h, args.qp, args.depth, 512, 256, threads, True)}
+            # 4 batches of 512: the first batch's search and the last batch's entropy coding have nothing to overlap with
+            result["e2e"] = {"smooth": e2e_native(w, h, args.qp, args.depth, 2048, 512, threads, False),
+                             "textured": e2e_native(w, h, args.qp, args.depth, 2048, 512, threads, True)}
     grp.close()
     if rank == 0:
         print(json.dumps(result))
