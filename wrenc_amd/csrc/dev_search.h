@@ -10,7 +10,7 @@ namespace wrenc {
 // Evaluation requests and the evaluator
 // ---------------------------------------------------------------------------
 enum { K_SADLIST = 0, K_FULL = 1, K_NOP = 2 };
-enum { COPY_NONE = 0, COPY_SAVE = 1, COPY_RESTORE = 2 };
+enum { COPY_NONE = 0, COPY_SAVE = 1, COPY_RESTORE = 2, COPY_PULL = 3 };
 
 struct Req {
     int kind;       // K_SADLIST: predict + SAD of a list of modes (block_splitter.rs:64-108, 476-522);
@@ -23,10 +23,10 @@ struct Req {
     bool refs0, refs1; // (re)build the luma / chroma reference samples of the block first
     bool final;     // final pass: store the levels, count reconstruction changes
     int stage;      // before anything else: stage the block's originals in LDS (component bits; blocks <= 16x16 only)
-    // team schedule only (leaf_step_team): after an active K_FULL, save its reconstruction to this member's
-    // slot 0; copy_from: whose slot a COPY_RESTORE reads (member index, default this member); xchg: the team
-    // exchanges results after this request
-    bool post_save;
+    // team schedule only (leaf_step_team): COPY_PULL copies the block from the LDS tile of member copy_from into
+    // this member's tile (every member issues it, the source included, and all meet at a barrier behind it);
+    // xchg: the team exchanges results after this request
+    bool post_save; // unused
     int copy_from;
     bool xchg;
     int n;          // K_SADLIST: number of entries
@@ -125,9 +125,33 @@ __device__ __forceinline__ uint32_t full_back(const Ctx& c, const PicBufs& pb, c
 // multiples of 4 samples in every plane that takes part.
 __device__ __forceinline__ void copy_block(const Ctx& c, int mode, int comps, int slot, int tx, int ty, int tlg,
                                            int from_member = -1) {
-    // a team member may restore from another member's slots: the waves' scratch parts lie back to back
-    const int rel = from_member < 0 ? 0 : (from_member - c.member) * kWaveScratch;
-    GLOBAL_AS uint32_t* g = (GLOBAL_AS uint32_t*)(c.slots + rel + slot * kSlotBytes);
+    if (mode == COPY_PULL) { // tile to tile inside the workgroup's LDS (team schedule)
+        if (from_member != c.member) {
+            const Lds& src = SHW[(WAVE & ~(kTeam - 1)) + from_member];
+            if (comps & 1) {
+                const int words = 1 << (2 * tlg - 2);
+                for (int w = LANE; w < words; w += 64) {
+                    const int row = (4 * w) >> tlg, col = (4 * w) & ((1 << tlg) - 1);
+                    const int at = (ty + row) * 36 + tx + col + 4;
+                    *(uint32_t*)&SH.recY[at] = *(const uint32_t*)&src.recY[at];
+                }
+            }
+            if (comps & 2) {
+                const int lg = tlg - 1;
+                const int words = 1 << (2 * lg - 2); // per plane
+                for (int w = LANE; w < 2 * words; w += 64) {
+                    const int pl = w >= words ? 1 : 0;
+                    const int ww = w - pl * words;
+                    const int row = (4 * ww) >> lg, col = (4 * ww) & ((1 << lg) - 1);
+                    const int at = ((ty >> 1) + row) * 20 + (tx >> 1) + col + 4;
+                    *(uint32_t*)&SH.recC[pl][at] = *(const uint32_t*)&src.recC[pl][at];
+                }
+            }
+        }
+        __syncthreads(); // nobody writes its tile again before every member has pulled
+        return;
+    }
+    GLOBAL_AS uint32_t* g = (GLOBAL_AS uint32_t*)(c.slots + slot * kSlotBytes);
     if (comps & 1) {
         const int words = 1 << (2 * tlg - 2);
         for (int w = LANE; w < words; w += 64) {
@@ -216,7 +240,6 @@ __device__ __forceinline__ Res evaluate(const Ctx& c, const PicBufs& pb, const R
                     r.ssd_y = ssd;
             }
         }
-        if (q.post_save && q.active) copy_block(c, COPY_SAVE, q.comps, 0, q.tx, q.ty, q.tlg);
         return r;
     }
     // K_SADLIST: get_intra_pred_aux_cost / get_chroma_intra_pred_aux_cost of each listed mode
@@ -862,12 +885,11 @@ __device__ __forceinline__ void team_idle(Req& q) {
     q.pre_copy = COPY_NONE;
     q.post_save = false;
 }
-// every member but `holder` restores comps of the leaf's block from holder's slot 0, attached to q
+// every member copies comps of the leaf's block from the tile of member `holder` (who holds the winner's
+// reconstruction) into its own tile: attached to q as a COPY_PULL, which every member must issue
 __device__ __forceinline__ void team_restore(const Ctx& c, const LeafSF& s, Req& q, int comps, int holder) {
-    if (c.member != holder) {
-        req_copy(q, COPY_RESTORE, comps, 0, s.bx, s.by, s.lg);
-        q.copy_from = holder;
-    }
+    req_copy(q, COPY_PULL, comps, 0, s.bx, s.by, s.lg);
+    q.copy_from = holder;
 }
 
 // One step of a leaf search in the team schedule; par = parity of the exchange that delivered the results
@@ -882,10 +904,8 @@ __device__ __forceinline__ bool leaf_step_team(const Ctx& c, LeafSF& s, Req& q, 
         case TC_START: // stage A: planar | DC | the 13 directional SADs in two halves (:887-904)
             if (me == 0) {
                 leaf_full(s, q, both, PLANAR, PLANAR, true, TC_A, true);
-                q.post_save = true;
             } else if (me == 1) {
                 leaf_full(s, q, both, DC, DC, true, TC_A, true);
-                q.post_save = true;
             } else if (me == 2) {
                 leaf_sadlist(s, q, both, 7, 2u | (7u << 8) | (13u << 16) | (18u << 24), 23u | (29u << 8) | (34u << 16), 0, 0, true, TC_A);
             } else {
@@ -965,7 +985,6 @@ __device__ __forceinline__ bool leaf_step_team(const Ctx& c, LeafSF& s, Req& q, 
             const bool act = k == 0 || (k == 1 ? !(cm < 3) : !(cm + 1 > 66));
             if (me != holder && act) {
                 leaf_full(s, q, both, mode, mode, true, TC_D, true);
-                q.post_save = true;
             } else {
                 team_idle(q);
             }
@@ -1025,7 +1044,6 @@ __device__ __forceinline__ bool leaf_step_team(const Ctx& c, LeafSF& s, Req& q, 
             s.evalr = (uint8_t)ev;
             if (me == ev) {
                 leaf_full(s, q, 2, 0, cm, true, TC_F, true);
-                q.post_save = true;
             } else {
                 team_idle(q);
             }
@@ -1048,12 +1066,9 @@ __device__ __forceinline__ bool leaf_step_team(const Ctx& c, LeafSF& s, Req& q, 
             team_idle(q);
             q.xchg = false;
             s.cont = TC_DONE;
-            if (dm_wins) { // only the evaluator's tile holds the CCLM chroma
+            if (dm_wins) { // only the evaluator's tile holds the CCLM chroma: it takes the DM chroma back
                 s.cost = uni_f(assemble_cost(c, tree, bcls, m, s.e_best.get()));
-                if (me == ev) {
-                    req_copy(q, COPY_RESTORE, 2, 0, s.bx, s.by, s.lg);
-                    q.copy_from = holder;
-                }
+                team_restore(c, s, q, 2, holder);
                 return true;
             }
             s.chroma_mode = s.cclm_mode;
@@ -1069,7 +1084,6 @@ __device__ __forceinline__ bool leaf_step_team(const Ctx& c, LeafSF& s, Req& q, 
                 leaf_sadlist(s, q, 2, 1, (uint32_t)(me == 0 ? LT_CCLM : (me == 1 ? T_CCLM : L_CCLM)), 0, 0, 0, false, TC_DC_A);
             } else {
                 leaf_full(s, q, 2, 0, s.dm_mode, true, TC_DC_A, true);
-                q.post_save = true;
             }
             s.cont = TC_DC_A;
             q.xchg = true;
@@ -1081,7 +1095,6 @@ __device__ __forceinline__ bool leaf_step_team(const Ctx& c, LeafSF& s, Req& q, 
             s.cur_cost = dm_cost;
             if (me == 0) {
                 leaf_full(s, q, 2, 0, cm, true, TC_DC_B, true);
-                q.post_save = true;
             } else {
                 team_idle(q);
             }
