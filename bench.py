@@ -21,6 +21,7 @@ Objects next to it on the same JSON line (rank 0 prints ONE line):
   config3       BASELINE.json configs[3]: 3840x2176, 240 pictures in total, QP32,
                 max-split-depth 3, picture p on rank p mod N (strong scaling); frames/s of the
                 whole job at this N
+  textured      the same workload on textured content (`value` is on smooth content: N = 1)
   fill_curve    frames/s against pictures in flight (N = 1)
   e2e           file to stream with the native program: upload + search + read-back + host CABAC
                 (N = 1)
@@ -195,6 +196,22 @@ def fill_curve(grp, local_rank, quick=False):
     return out
 
 
+def textured_rate(grp, local_rank, w, h, qp, depth, batch):
+    """The timed workload again on synth_textured_frame content (206 KB instead of 31 KB of stream per picture: few
+    all-zero transform blocks, which the quantiser's zero-block exits favour): one warm-up call, one timed call."""
+    from wrenc_amd import gpu, synth
+    enc = gpu.Encoder(w, h, qp=qp, max_split_depth=depth, device=local_rank, n_slots=batch)
+    frames = [synth.synth_textured_frame(w, h, f) for f in range(8)]
+    for s in range(batch):
+        enc.upload(s, *frames[s % 8])
+    enc.sync()
+    dt, _, _ = run_resident(enc, grp, 0, batch, 1, 1)
+    mism = enc.final_pass_mismatches()
+    enc.close()
+    return {"value": batch / dt, "unit": "frames/s", "content": "synth_textured_frame", "pictures": batch,
+            "final_pass_mismatches": mism}
+
+
 def e2e_native(w, h, qp, depth, n_pictures, batch, threads, textured):
     """File to stream with the native program (wrenc_amd/csrc/host/wrenc): raw YUV file in (tmpfs), .vvc out;
     read + upload + search + read-back + host CABAC on `threads` threads.  The program's own clock, which starts
@@ -345,6 +362,7 @@ def main():
         if rank == 0:
             result["config3"] = c3
         if world == 1:
+            result["textured"] = textured_rate(grp, local_rank, w, h, args.qp, args.depth, B)
             result["fill_curve"] = fill_curve(grp, local_rank)
             threads = max(1, min(16, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else 8))
             # 4 batches of 512: the first batch's search and the last batch's entropy coding have nothing to overlap with

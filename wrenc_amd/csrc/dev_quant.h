@@ -189,7 +189,19 @@ __device__ __forceinline__ unsigned shift_in_less(unsigned bits, int kb, int ka)
 //   shared == false: the wave walks its own blocks in quads 0..nb-1 (final pass, tests).
 // Forward trace = composition of per-position state maps (prefix scan over lanes), then every
 // lane emits its own positions and their level costs.
-__device__ __forceinline__ long long quantize(Ctx c, int lg, int nb, bool shared, bool active, int* overflow) {
+// parity of this wave's pooled quantisation calls, kept in an unused cell of q_pm (reset in encode_ctu)
+__device__ __forceinline__ int zero_flag_cell() {
+    const int par = uni((int)SH.q_pm[0][0][3]) & 1;
+    if (LANE == 0) SH.q_pm[0][0][3] = (uint16_t)(par ^ 1);
+    return par;
+}
+
+// Zero blocks: when every coefficient of the call is zero the levels are zero and cost nothing (zeros behind the
+// last non-zero level are free, block_splitter.rs:436-458), and r1 already holds them.  A wave in that case skips
+// the trace; when NO wave of the workgroup has a non-zero coefficient (the usual case in flat areas) the pooled
+// walk ends after the first barrier of its first chunk, where the waves see each other's flags.  *any_level tells
+// the caller whether any level is non-zero (else dequantisation and the inverse transform are skipped too).
+__device__ __forceinline__ long long quantize(Ctx c, int lg, int nb, bool shared, bool active, int* overflow, bool* any_level) {
     c = uni(c);
     lg = uni(lg);
     nb = uni(nb);
@@ -207,11 +219,13 @@ __device__ __forceinline__ long long quantize(Ctx c, int lg, int nb, bool shared
     const uint16_t* dec16 = (const uint16_t*)SH.decw; // decisions: [blk][sub-block][state] 16-bit masks
     PROF_MARK(q0_);
     int istar0 = P, istar1 = P;
+    bool any_nz = false;
     if (active) {
-        int first0 = P, first1 = P;
+        int first0 = P, first1 = P, nzl = 0;
         for (int idx = LANE; idx < nb * P; idx += 64) {
             const int blk = idx >> lgP, p = idx & (P - 1);
             const int tc = SH.r1[blk * P + scan[p]];
+            nzl |= tc;
             int S = (int)((unsigned)tc << sh) - off;
             if (tc < 0) S = -S;
             const int qd = tc == 0 ? 0 : (int)(((unsigned long long)(unsigned)S * k->div_magic) >> 47);
@@ -226,11 +240,17 @@ __device__ __forceinline__ long long quantize(Ctx c, int lg, int nb, bool shared
         }
         istar0 = wave_min_i32(first0);
         if (nb == 2) istar1 = wave_min_i32(first1);
+        any_nz = __ballot(nzl != 0) != 0ULL;
     }
+    *any_level = false;
+    if (!shared && !any_nz) return 0; // solo call on a zero block (or an inactive one): nothing to walk
+    // "this wave has a non-zero coefficient", read by the whole workgroup below; two cells in turn (every wave makes
+    // the same sequence of pooled calls), so that a wave already in its next call cannot overwrite a flag that a
+    // slow wave has yet to read
+    const int fcell = shared ? zero_flag_cell() : 0;
     if (LANE == 0) {
-        SH.q_istar[0] = istar0;
-        SH.q_istar[1] = istar1;
-        SH.q_active = active ? 1 : 0;
+        SH.q_istar[fcell] = any_nz ? 1 : 0;
+        SH.q_active = (active && any_nz) ? 1 : 0;
     }
     PROF_MARK(q1_);
     PROF_ADD2(PH_QPRE, q0_, q1_);
@@ -250,7 +270,7 @@ __device__ __forceinline__ long long quantize(Ctx c, int lg, int nb, bool shared
     for (int base = P - CH; base >= 0; base -= CH) {
         PROF_MARK(qb0_);
         WSYNC();
-        if (active) {
+        if (active && any_nz) { // (a zero block writes no entries: r1 stays its all-zero levels)
             // per position and state class (0: state 0, 1: state 1, 2: states 2 and 3): (u, w) doubled,
             // see above; per sub-block: parity masks of the two delta classes and, for state 0, whether
             // its first position in coding order (kk == 15) keeps a zero inside the trailing run
@@ -276,6 +296,11 @@ __device__ __forceinline__ long long quantize(Ctx c, int lg, int nb, bool shared
         else
             WSYNC();
         PROF_MARK(qb2_);
+        if (shared && base == P - CH) {
+            // first chunk: does ANY wave of the workgroup have a non-zero coefficient?  (lane w reads wave w's flag)
+            const bool wg_nz = __ballot(LANE < WPB && SHW[LANE < WPB ? LANE : 0].q_istar[fcell] != 0) != 0ULL;
+            if (!wg_nz) break; // every wave takes this exit: no barrier is left behind
+        }
         if (walker && (!shared || tb->q_active)) {
             const int cls = st == 0 ? 0 : (st == 1 ? 1 : 2);
             uint16_t* wdec = (uint16_t*)const_cast<uint32_t*>(tb->decw) + wblk * (P >> 2);
@@ -321,7 +346,7 @@ __device__ __forceinline__ long long quantize(Ctx c, int lg, int nb, bool shared
     WSYNC();
     PROF_MARK(q2_);
     PROF_ADD2(PH_QBACK, q1_, q2_);
-    if (!active) return 0;
+    if (!active || !any_nz) return 0;
     // ---- forward trace from state 0 (quantizer.rs:686-721) + level-cost walk ----
     // lanes are split evenly between the blocks; each lane owns `per` consecutive positions
     const int half = nb == 2 ? 32 : 64;
@@ -369,6 +394,7 @@ __device__ __forceinline__ long long quantize(Ctx c, int lg, int nb, bool shared
     const int pf = group_min_i32(fnz, half); // zeros before a block's first non-zero level cost nothing
     if (act) // zeros after the first non-zero position: positions j > pf - p0 of this lane
         sum_nz += (long long)__popc(zmask >> min(max(pf - p0 + 1, 0), 16)) * SHT.lv[0];
+    *any_level = __ballot(pf < P) != 0ULL;
     const long long sum = wave_sum_i64(sum_nz);
     if (__ballot(ovf != 0) != 0ULL) *overflow = 1;
     WSYNC();
@@ -385,7 +411,7 @@ __device__ __forceinline__ long long quantize(Ctx c, int lg, int nb, bool shared
 // 8 luma blocks (lanes 0..31) and the 8 Cb blocks (lanes 32..63), wave 1 the 8 Cr blocks.
 // Scratch: r2 = [scan-order coefficients | quotients | chunk entries], decw.
 __device__ __forceinline__ void quantize3(Ctx c, int lg0, bool active, int* overflow, long long* lvl_y,
-                                          long long* lvl_c) {
+                                          long long* lvl_c, bool* any_y, bool* any_c) {
     static_assert(WPB == 8, "the merged pass maps 8 waves x 3 blocks onto two walker waves");
     c = uni(c);
     lg0 = uni(lg0);
@@ -404,8 +430,11 @@ __device__ __forceinline__ void quantize3(Ctx c, int lg0, bool active, int* over
     *lvl_c = 0;
     PROF_MARK(q0_);
     int istar0 = P0, istar1 = Pc, istar2 = Pc;
+    bool any_nz = false;
+    *any_y = false;
+    *any_c = false;
     if (active) {
-        int first0 = P0, first1 = Pc, first2 = Pc;
+        int first0 = P0, first1 = Pc, first2 = Pc, nzl = 0;
         for (int idx = LANE; idx < T; idx += 64) {
             const int b = idx < P0 ? 0 : (idx < P0 + Pc ? 1 : 2);
             const int boff = b == 0 ? 0 : (b == 1 ? P0 : P0 + Pc);
@@ -413,6 +442,7 @@ __device__ __forceinline__ void quantize3(Ctx c, int lg0, bool active, int* over
             const int sh = b == 0 ? sh0 : shc;
             const int off = (1 << sh) >> 1;
             const int tc = SH.r1[boff + (b == 0 ? scan0[p] : scanc[p])];
+            nzl |= tc;
             int S = (int)((unsigned)tc << sh) - off;
             if (tc < 0) S = -S;
             const int qd = tc == 0 ? 0 : (int)(((unsigned long long)(unsigned)S * k->div_magic) >> 47);
@@ -430,8 +460,13 @@ __device__ __forceinline__ void quantize3(Ctx c, int lg0, bool active, int* over
         istar0 = wave_min_i32(first0);
         istar1 = wave_min_i32(first1);
         istar2 = wave_min_i32(first2);
+        any_nz = __ballot(nzl != 0) != 0ULL;
     }
-    if (LANE == 0) SH.q_active = active ? 1 : 0;
+    const int fcell = zero_flag_cell();
+    if (LANE == 0) {
+        SH.q_istar[fcell] = any_nz ? 1 : 0;
+        SH.q_active = (active && any_nz) ? 1 : 0;
+    }
     PROF_MARK(q1_);
     PROF_ADD2(PH_QPRE, q0_, q1_);
     const int ldq1 = (int)ldq_at(c, 1);
@@ -452,7 +487,7 @@ __device__ __forceinline__ void quantize3(Ctx c, int lg0, bool active, int* over
         const int base0 = P0 - 64 * (ch + 1), basec = Pc - 16 * (ch + 1);
         PROF_MARK(qb0_);
         WSYNC();
-        if (active) {
+        if (active && any_nz) {
 #pragma unroll 1
             for (int pass = 0; pass < 2; ++pass) {
                 const int e = LANE + 64 * pass;
@@ -483,6 +518,10 @@ __device__ __forceinline__ void quantize3(Ctx c, int lg0, bool active, int* over
         PROF_MARK(qb1_);
         __syncthreads();
         PROF_MARK(qb2_);
+        if (ch == 0) { // zero blocks in every wave of the workgroup: see quantize()
+            const bool wg_nz = __ballot(LANE < WPB && SHW[LANE < WPB ? LANE : 0].q_istar[fcell] != 0) != 0ULL;
+            if (!wg_nz) break;
+        }
         if (walker && tb->q_active) {
             for (int sbi = wnsb - 1; sbi >= 0; --sbi) { // one 4x4 sub-block per iteration
                 const int g16 = sbi * 16;
@@ -524,7 +563,7 @@ __device__ __forceinline__ void quantize3(Ctx c, int lg0, bool active, int* over
     WSYNC();
     PROF_MARK(q2_);
     PROF_ADD2(PH_QBACK, q1_, q2_);
-    if (!active) return;
+    if (!active || !any_nz) return;
     // ---- forward trace + level cost: lanes 0..31 luma, 32..47 Cb, 48..63 Cr ----
     const int b = LANE < 32 ? 0 : (LANE < 48 ? 1 : 2);
     const int lane_in = b == 0 ? LANE : (LANE & 15);
@@ -567,6 +606,8 @@ __device__ __forceinline__ void quantize3(Ctx c, int lg0, bool active, int* over
         const int m1 = __builtin_amdgcn_readlane(rm, 32), m2 = __builtin_amdgcn_readlane(rm, 48);
         const int pf = b == 0 ? m0 : (b == 1 ? m1 : m2);
         sum_nz += (long long)__popc(zmask >> min(max(pf - p0 + 1, 0), 16)) * SHT.lv[0];
+        *any_y = m0 < P0;
+        *any_c = m1 < Pc || m2 < Pc;
     }
     // level cost of the luma block (rows 0-1) and of the chroma pair (rows 2-3), three limbs each
     {

@@ -69,7 +69,8 @@ __device__ __forceinline__ void full_front(const Ctx& c, const Req& q, int comp,
 
 // Second half: levels at r1[rbase ..] -> (final pass: store them) -> dequantise, inverse transform,
 // reconstruct into the tile; returns the SSD against the originals (block_splitter.rs:146-185)
-__device__ __forceinline__ uint32_t full_back(const Ctx& c, const PicBufs& pb, const Req& q, int comp, int rbase) {
+__device__ __forceinline__ uint32_t full_back(const Ctx& c, const PicBufs& pb, const Req& q, int comp, int rbase,
+                                              bool any_level) {
     const int cs = comp ? 1 : 0;
     const int nb = comp ? 2 : 1;
     const int lg = q.tlg - cs;
@@ -89,9 +90,10 @@ __device__ __forceinline__ uint32_t full_back(const Ctx& c, const PicBufs& pb, c
             (blk ? lev1 : lev0)[(size_t)(ii >> lg) * stride + (ii & (n - 1))] = SH.r1[rbase + i];
         }
     }
-    dequantize_t(c, lg, nb, rbase);
+    // all levels zero: the residual is zero too, and r1 (the levels) already says so
+    if (any_level) dequantize_t(c, lg, nb, rbase);
     PROF_MARK(t4_);
-    inv_dct_lg(c, lg, nb, rbase);
+    if (any_level) inv_dct_lg(c, lg, nb, rbase);
     PROF_MARK(t5_);
     PROF_ADD2(PH_DEQ, t3_, t4_);
     PROF_ADD2(PH_IDCT, t4_, t5_);
@@ -216,14 +218,19 @@ __device__ __forceinline__ Res evaluate(const Ctx& c, const PicBufs& pb, const R
                     if ((cset >> comp) & 1) full_front(c, q, comp, comp ? q.mc : q.ml, (merged && comp) ? p0 : 0);
             }
             PROF_MARK(ts0_);
+            bool any_y = false, any_c = false;
             if (merged) {
-                quantize3(c, q.tlg, q.active, overflow, &r.lvl_y, &r.lvl_c);
+                quantize3(c, q.tlg, q.active, overflow, &r.lvl_y, &r.lvl_c, &any_y, &any_c);
             } else {
-                const long long lvl = quantize(c, q.tlg - round, round ? 2 : 1, q.shared, q.active, overflow);
-                if (round)
+                bool any = false;
+                const long long lvl = quantize(c, q.tlg - round, round ? 2 : 1, q.shared, q.active, overflow, &any);
+                if (round) {
                     r.lvl_c = lvl;
-                else
+                    any_c = any;
+                } else {
                     r.lvl_y = lvl;
+                    any_y = any;
+                }
             }
             PROF_MARK(ts1_);
             if (!q.active) { // only kept the shared-Viterbi barriers company
@@ -233,7 +240,7 @@ __device__ __forceinline__ Res evaluate(const Ctx& c, const PicBufs& pb, const R
 #pragma unroll 1
             for (int comp = 0; comp < 2; ++comp) {
                 if (!((cset >> comp) & 1)) continue;
-                const uint32_t ssd = full_back(c, pb, q, comp, (merged && comp) ? p0 : 0);
+                const uint32_t ssd = full_back(c, pb, q, comp, (merged && comp) ? p0 : 0, comp ? any_c : any_y);
                 if (comp)
                     r.ssd_c = ssd;
                 else
@@ -1418,6 +1425,7 @@ __device__ __forceinline__ void encode_ctu(Ctx& c, const PicBufs& pb, int ctu_co
     SH.st.in_leaf = 0;
     SH.st.pend = 0;
     SH.st.xpar = 0;
+    if (LANE == 0) SH.q_pm[0][0][3] = 0; // parity of the pooled quantisation calls (dev_quant.h, zero_flag_cell)
     SH.st.max_depth = (uint8_t)k->max_depth;
     Res r = {};
     Req q = {};

@@ -54,23 +54,20 @@ const int kQStateTrans[4][2] = {{0, 2}, {2, 0}, {1, 3}, {3, 1}}; // encoder_cont
 const int kRiceParams[32] = {0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 1, 1, 1, 2, 2,
                              2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 3, 3, 3, 3}; // cabac_contexts.rs:919
 
+} // namespace
+
 class PictureCoder {
 public:
     PictureCoder(int width, int height, int qp, const wrenc_bs_record& rec, BitWriter& bw)
         : W_(width), H_(height), qp_(qp), r_(rec), cabac_(bw) {}
 
-    // slice_encoder.rs:343-404: CTUs in raster order, CABAC initialised at the first one
-    // (ctu_encoder.rs:38-47), end_of_slice_one_bit after the last
-    int run() {
-        cabac_.start(qp_);
-        for (int y = 0; y < H_; y += 32)
-            for (int x = 0; x < W_; x += 32) {
-                const int rc = coding_tree(x, y, 5);
-                if (rc) return rc;
-            }
-        cabac_.finish();
-        return WRENC_BS_OK;
+    // ctu_encoder.rs:38-47 (CABAC initialised at the picture's first CTU) + :172-201 (the CTU's coding tree)
+    int encode_ctu(int x, int y) {
+        if (x == 0 && y == 0) cabac_.start(qp_);
+        return coding_tree(x, y, 5);
     }
+    // slice_encoder.rs:388-394: end_of_slice_one_bit behind the last CTU
+    void end_of_slice() { cabac_.finish(); }
 
 private:
     int leaf_lg(int x, int y) const { return r_.cu_log2_size[(size_t)(y >> 2) * (W_ >> 2) + (x >> 2)]; }
@@ -511,11 +508,41 @@ private:
     int tpl_[34 * kS]; // AbsLevelPass1 | significant << 8
 };
 
-} // namespace
+int CtuEncoder::encode(Bins& bins, const Ctu& ctu, const SliceHeader& sh) {
+    (void)bins; // the coder was constructed on these bins
+    (void)sh;   // and with this slice QP
+    return coder_.encode_ctu(ctu.x, ctu.y);
+}
+
+// slice_encoder.rs:343-427 with one tile and one slice per picture: CTUs in raster order
+static int encode_ctus(const Slice& slice, const SliceHeader& sh, Bins& bins) {
+    PictureCoder coder(slice.width, slice.height, sh.slice_qp, *slice.record, bins);
+    for (int y = 0; y < slice.height; y += 32)
+        for (int x = 0; x < slice.width; x += 32) {
+            CtuEncoder ctu_encoder(coder); // slice_encoder.rs:378: one CtuEncoder per CTU
+            const Ctu ctu = {x, y};
+            const int rc = ctu_encoder.encode(bins, ctu, sh);
+            if (rc) return rc;
+        }
+    coder.end_of_slice();
+    return WRENC_BS_OK;
+}
+
+Bins SliceEncoder::encode(const Slice& slice, const SliceHeader& sh, int* status) {
+    Bins bins;
+    write_slice_header(bins, sh.slice_qp); // encode_sh, slice_encoder.rs:32-341 (ends byte aligned)
+    const size_t header_bits = bins.bit_count();
+    const int rc = encode_ctus(slice, sh, bins);
+    slice_data_bits_ = (long long)(bins.bit_count() - header_bits);
+    if (status) *status = rc;
+    bins.align(); // slice_encoder.rs:418
+    return bins;
+}
 
 int write_slice_data(int width, int height, int qp, const wrenc_bs_record& rec, BitWriter& bw) {
-    PictureCoder coder(width, height, qp, rec, bw);
-    return coder.run();
+    const Slice slice = {width, height, &rec};
+    const SliceHeader sh = {qp};
+    return encode_ctus(slice, sh, bw);
 }
 
 } // namespace wrenc_host

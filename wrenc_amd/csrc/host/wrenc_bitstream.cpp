@@ -65,14 +65,15 @@ int wrenc_bs_write_picture(int width, int height, int qp, int poc, const wrenc_b
         append_nal(stream, 9, NAL_PH, 0, bw.bytes()); // main.rs:307-313
     }
     {
-        BitWriter bw;
-        write_slice_header(bw, qp);
-        const size_t header_bits = bw.bit_count();
-        const int rc = write_slice_data(width, height, qp, *rec, bw);
+        // main.rs:380-382: let bins = slice_encoder.encode(&slice, &sh)
+        const Slice slice = {width, height, rec};
+        const SliceHeader sh = {qp};
+        SliceEncoder slice_encoder;
+        int rc = WRENC_BS_OK;
+        const Bins bins = slice_encoder.encode(slice, sh, &rc);
         if (rc) return rc;
-        g_last_slice_data_bits = (long long)(bw.bit_count() - header_bits);
-        bw.align(); // slice_encoder.rs:418
-        append_nal(stream, 9, NAL_IDR_W_RADL, 0, bw.bytes()); // main.rs:377-383
+        g_last_slice_data_bits = slice_encoder.slice_data_bits();
+        append_nal(stream, 9, NAL_IDR_W_RADL, 0, bins.bytes()); // main.rs:377-383
     }
     return hand_over(stream, out, cap, len);
 }

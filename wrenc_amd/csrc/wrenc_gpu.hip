@@ -199,7 +199,8 @@ __global__ __launch_bounds__(64) void test_quantize_kernel(const DevConst* __res
     for (int i = threadIdx.x; i < nn; i += 64) SH.r1[i] = in[(size_t)blockIdx.x * nn + i];
     WSYNC();
     int ovf = 0;
-    const long long lc = quantize(c, lg, 1, false, true, &ovf);
+    bool any = false;
+    const long long lc = quantize(c, lg, 1, false, true, &ovf, &any);
     for (int i = threadIdx.x; i < nn; i += 64) out[(size_t)blockIdx.x * nn + i] = SH.r1[i];
     if (threadIdx.x == 0) {
         cost[blockIdx.x] = lc;
