@@ -9,12 +9,16 @@ namespace wrenc {
 // ---------------------------------------------------------------------------
 // Evaluation requests and the evaluator
 // ---------------------------------------------------------------------------
-enum { K_SADLIST = 0, K_FULL = 1, K_NOP = 2 };
+enum { K_SADLIST = 0, K_FULL = 1, K_NOP = 2, K_SADSEARCH = 3, K_CCLMSEARCH = 4 };
 enum { COPY_NONE = 0, COPY_SAVE = 1, COPY_RESTORE = 2, COPY_PULL = 3 };
 
 struct Req {
     int kind;       // K_SADLIST: predict + SAD of a list of modes (block_splitter.rs:64-108, 476-522);
-                    // K_FULL: predict .. reconstruct (:146-185)
+                    // K_FULL: predict .. reconstruct (:146-185); K_SADSEARCH: the whole SAD part of a leaf search in
+                    // one request -- the 13 directional candidates, their first minimum and the two step-search
+                    // rounds around it (:899-973): returns the mode (Res::imin) and its SAD (Res::vmin);
+                    // K_CCLMSEARCH: the CCLM part of a leaf search in one request -- the SADs of LT / T / L_CCLM, the
+                    // pick (:847-854) and the full evaluation of the chroma pair with it: Res::imin = the mode, + parts
     int comps;      // bit 0: luma block, bit 1: Cb+Cr pair
     int tx, ty, tlg;
     int ml, mc;     // K_FULL: luma / chroma mode
@@ -182,6 +186,37 @@ __device__ __forceinline__ void copy_block(const Ctx& c, int mode, int comps, in
     WSYNC();
 }
 
+// SADs of a list of n angular modes (one byte each in lo | hi; kNoMode = not evaluated, f32::MAX in the reference):
+// SADs of the first two entries, the first minimum (smallest (sad, index) pair) and its index; kNoSad where none
+struct ListOut {
+    unsigned s0, s1, s2, smin;
+    int imin;
+};
+__device__ __forceinline__ ListOut angular_list(const Ctx& c, const Req& q, int n, unsigned long long lo, unsigned long long hi) {
+    constexpr unsigned kNoSad = 0xFFFFFFFFu;
+    ListOut o;
+    o.s0 = o.s1 = o.s2 = o.smin = kNoSad;
+    o.imin = 0;
+    const unsigned acc = sad_list_angular(c, q.comps, q.tx, q.ty, q.tlg, n, lo, hi);
+    const int my_mode = LANE < n ? (int)(((LANE < 8 ? lo : hi) >> (8 * (LANE & 7))) & 255u) : kNoMode;
+    if (c.trace && my_mode != kNoMode)
+        TRACE_REC(c.ctu_x + q.tx, c.ctu_y + q.ty, q.tlg, q.tree, (q.comps & 1) ? 0 : 2, (q.comps & 1) ? my_mode : 0, my_mode,
+                  __float_as_int((float)acc));
+    // first minimum = smallest (sad, index) pair
+    const int key = my_mode != kNoMode ? (int)((acc << 4) | (unsigned)LANE) : 0x7FFFFFFF;
+    const int kmin = wave_min_i32(key);
+    if (kmin != 0x7FFFFFFF) {
+        o.smin = (unsigned)kmin >> 4;
+        o.imin = kmin & 15;
+    }
+    const unsigned a0 = (unsigned)__builtin_amdgcn_readlane((int)acc, 0), a1 = (unsigned)__builtin_amdgcn_readlane((int)acc, 1),
+                   a2 = (unsigned)__builtin_amdgcn_readlane((int)acc, 2);
+    if ((int)(lo & 255u) != kNoMode) o.s0 = a0;
+    if (n > 1 && (int)((lo >> 8) & 255u) != kNoMode) o.s1 = a1;
+    if (n > 2 && (int)((lo >> 16) & 255u) != kNoMode) o.s2 = a2;
+    return o;
+}
+
 // The evaluator: every block evaluation of the search, of the regeneration and of the final pass
 // goes through this one inlined copy (the search logic below is a state machine that hands out
 // evaluation requests; no function calls in the hot path).
@@ -200,7 +235,21 @@ __device__ __forceinline__ Res evaluate(const Ctx& c, const PicBufs& pb, const R
     PROF_ADD2(PH_COPY, tcp0_, tcp1_);
     if (q.kind == K_NOP) return r;
     if (q.stage) stage_org_leaf(c, q.stage, q.tx, q.ty, q.tlg);
-    if (q.kind == K_FULL) {
+    int mc = q.mc;
+    if (q.kind == K_CCLMSEARCH) {
+        // get_chroma_intra_pred_aux_cost of LT, T, L_CCLM in one sample pass, then the pick of :847-854 (SADs are
+        // integers < 2^20: comparing them is comparing the reference's f32 values); the evaluation follows below
+        if (q.tlg > 4) stage_org(c, 2, q.tx, q.ty, q.tlg);
+        const unsigned acc = sad_list_cclm(c, q.tx, q.ty, q.tlg);
+        const unsigned lt = (unsigned)__builtin_amdgcn_readlane((int)acc, 0), t = (unsigned)__builtin_amdgcn_readlane((int)acc, 1),
+                       l = (unsigned)__builtin_amdgcn_readlane((int)acc, 2);
+        if (c.trace && LANE < 3)
+            TRACE_REC(c.ctu_x + q.tx, c.ctu_y + q.ty, q.tlg, q.tree, 2, 0, LANE == 0 ? LT_CCLM : (LANE == 1 ? T_CCLM : L_CCLM),
+                      __float_as_int((float)acc));
+        mc = (lt <= t && lt <= l) ? LT_CCLM : (t <= l ? T_CCLM : L_CCLM);
+        r.imin = mc;
+    }
+    if (q.kind == K_FULL || q.kind == K_CCLMSEARCH) {
         // A candidate of the search with an 8x8 or 16x16 luma block quantises its three transform
         // blocks in one pooled pass (quantize3): both components go through the first half, then
         // the pass, then both through the second half.  Everything else runs component by component
@@ -215,7 +264,7 @@ __device__ __forceinline__ Res evaluate(const Ctx& c, const PicBufs& pb, const R
             if (q.active) {
 #pragma unroll 1
                 for (int comp = 0; comp < 2; ++comp)
-                    if ((cset >> comp) & 1) full_front(c, q, comp, comp ? q.mc : q.ml, (merged && comp) ? p0 : 0);
+                    if ((cset >> comp) & 1) full_front(c, q, comp, comp ? mc : q.ml, (merged && comp) ? p0 : 0);
             }
             PROF_MARK(ts0_);
             bool any_y = false, any_c = false;
@@ -262,25 +311,43 @@ __device__ __forceinline__ Res evaluate(const Ctx& c, const PicBufs& pb, const R
     unsigned s0 = kNoSad, s1 = kNoSad, s2 = kNoSad, smin = kNoSad;
     const int m_first = (int)(q.modes_lo & 255u);
     const int m_second = (int)((q.modes_lo >> 8) & 255u);
-    if ((m_first >= 2 && m_first <= 66) || (m_first == kNoMode && m_second <= 66)) {
-        // a list of angular modes (the 13 directional candidates, a step-search pair)
-        const unsigned acc = sad_list_angular(c, q.comps, q.tx, q.ty, q.tlg, q.n, q.modes_lo, q.modes_hi);
-        const int my_mode = LANE < q.n ? (int)(((LANE < 8 ? q.modes_lo : q.modes_hi) >> (8 * (LANE & 7))) & 255u) : kNoMode;
-        if (c.trace && my_mode != kNoMode)
-            TRACE_REC(c.ctu_x + q.tx, c.ctu_y + q.ty, q.tlg, q.tree, (q.comps & 1) ? 0 : 2, (q.comps & 1) ? my_mode : 0, my_mode,
-                      __float_as_int((float)acc));
-        // first minimum = smallest (sad, index) pair
-        const int key = my_mode != kNoMode ? (int)((acc << 4) | (unsigned)LANE) : 0x7FFFFFFF;
-        const int kmin = wave_min_i32(key);
-        if (kmin != 0x7FFFFFFF) {
-            smin = (unsigned)kmin >> 4;
-            r.imin = kmin & 15;
+    if (q.kind == K_SADSEARCH) {
+        // the 13 directional candidates {2,7,13,18,23,29,34,39,45,50,55,60,66}: SAD, first minimum (:899-904)
+        const ListOut l = angular_list(c, q, 13, 2ULL | (7ULL << 8) | (13ULL << 16) | (18ULL << 24) | (23ULL << 32) | (29ULL << 40) |
+                                                    (34ULL << 48) | (39ULL << 56),
+                                       45ULL | (50ULL << 8) | (55ULL << 16) | (60ULL << 24) | (66ULL << 32));
+        const int j = l.imin + 2; // entry i = candidate i + 2 of the 15, 7 bits each
+        int cm = j < 8 ? (int)((0x3A5C90D0E08080ULL >> (7 * j)) & 127) : (int)((0x109E3764B53A2ULL >> (7 * (j - 8))) & 127);
+        unsigned cur = l.smin;
+        // step_search(mode, 2, cost, aux = true) (:905-973): rounds with step 2 and 1; keep the current mode on ties,
+        // then the lower probe (Q12).  The SADs are integers < 2^20, so comparing them as integers is comparing the
+        // reference's f32 values; a probe outside 2..66 is kNoSad = f32::MAX.
+#pragma unroll 1
+        for (int st = 2; st > 0; st >>= 1) {
+            const int lo = !(cm < 2 + st) ? cm - st : kNoMode;
+            const int hi = !(cm + st > 66) ? cm + st : kNoMode;
+            const ListOut p = angular_list(c, q, 2, (unsigned long long)lo | ((unsigned long long)hi << 8), 0);
+            const unsigned c0 = p.s0, c1 = p.s1;
+            const unsigned mn = min(min(cur, c0), c1);
+            if (cur == mn) {
+            } else if (c0 == mn) {
+                cm -= st;
+                cur = c0;
+            } else {
+                cm += st;
+                cur = c1;
+            }
         }
-        const unsigned a0 = (unsigned)__builtin_amdgcn_readlane((int)acc, 0), a1 = (unsigned)__builtin_amdgcn_readlane((int)acc, 1),
-                       a2 = (unsigned)__builtin_amdgcn_readlane((int)acc, 2);
-        if (m_first != kNoMode) s0 = a0;
-        if (q.n > 1 && m_second != kNoMode) s1 = a1;
-        if (q.n > 2 && (int)((q.modes_lo >> 16) & 255u) != kNoMode) s2 = a2;
+        smin = cur;
+        r.imin = uni(cm);
+    } else if ((m_first >= 2 && m_first <= 66) || (m_first == kNoMode && m_second <= 66)) {
+        // a list of angular modes (a step-search pair)
+        const ListOut l = angular_list(c, q, q.n, q.modes_lo, q.modes_hi);
+        s0 = l.s0;
+        s1 = l.s1;
+        s2 = l.s2;
+        smin = l.smin;
+        r.imin = l.imin;
     } else if (q.comps == 2 && q.n == 3 && (unsigned)q.modes_lo == ((unsigned)LT_CCLM | ((unsigned)T_CCLM << 8) | ((unsigned)L_CCLM << 16))) {
         // the three CCLM modes of a chroma pair, one sample pass
         const unsigned acc = sad_list_cclm(c, q.tx, q.ty, q.tlg);
@@ -607,6 +674,18 @@ __device__ __forceinline__ void leaf_sadlist(LeafSF& s, Req& q, int comps, int n
     s.cont = (uint8_t)cont;
 }
 
+// the whole CCLM part of a leaf search as one request (K_CCLMSEARCH): chroma pair only
+__device__ __forceinline__ void leaf_cclmsearch(LeafSF& s, Req& q, int cont, bool solo = false) {
+    leaf_full(s, q, 2, 0, LT_CCLM, true, cont, solo); // (the mode is a placeholder >= LT_CCLM: no reference samples needed)
+    q.kind = K_CCLMSEARCH;
+}
+
+// the whole SAD part of a luma / single-tree leaf search as one request (K_SADSEARCH)
+__device__ __forceinline__ void leaf_sadsearch(LeafSF& s, Req& q, int comps, int cont) {
+    leaf_sadlist(s, q, comps, 13, 0, 0, 0, 0, true, cont);
+    q.kind = K_SADSEARCH;
+}
+
 __device__ __forceinline__ EvalParts res_parts(const Res& r) {
     EvalParts e;
     e.ssd_y = r.ssd_y;
@@ -679,52 +758,18 @@ __device__ __forceinline__ bool leaf_step(const Ctx& c, LeafSF& s, const Res& r,
             return true;
         case C_DCM:
             LEAF_CANDIDATE(DC);
-            // the 13 directional candidates: SAD, first minimum (:899-904)
-            leaf_sadlist(s, q, both, 13, 2u | (7u << 8) | (13u << 16) | (18u << 24),
-                         23u | (29u << 8) | (34u << 16) | (39u << 24), 45u | (50u << 8) | (55u << 16) | (60u << 24), 66u,
-                         true, C_LIST);
+            // the 13 directional candidates, their first minimum (:899-904) and step_search(mode, 2, cost, aux = true)
+            // (:905-973) in ONE request: the evaluator runs the three lists back to back
+            leaf_sadsearch(s, q, both, C_LIST);
             return true;
         case C_LIST: {
-            // entry i of the list = candidate i + 2 of {0,1,2,7,13,18,23,29,34,39,45,50,55,60,66}, 7 bits each
-            const int j = r.imin + 2;
-            const int m = j < 8 ? (int)((0x3A5C90D0E08080ULL >> (7 * j)) & 127)
-                                : (int)((0x109E3764B53A2ULL >> (7 * (j - 8))) & 127);
-            // step_search(mode, 2, cost, aux=true) (:905-973)
-            s.cur_mode = (uint8_t)m;
-            s.cur_cost = r.vmin;
-            s.step = 2;
-            cont = C_PAIR_EMIT;
-            break;
-        }
-        case C_PAIR_EMIT: {
-            const int cm = s.cur_mode, st = s.step;
-            const int lo = !(cm < 2 + st) ? cm - st : kNoMode;
-            const int hi = !(cm + st > 66) ? cm + st : kNoMode;
-            leaf_sadlist(s, q, both, 2, (uint32_t)lo | ((uint32_t)hi << 8), 0, 0, 0, true, C_PAIR);
-            return true;
-        }
-        case C_PAIR: {
-            const float cur = s.cur_cost, c0 = r.v0, c1 = r.v1;
-            const int st = s.step;
-            const float mn = fminf(fminf(cur, c0), c1);
-            if (cur == mn) {
-            } else if (c0 == mn) {
-                s.cur_mode -= st;
-                s.cur_cost = c0;
-            } else {
-                s.cur_mode += st;
-                s.cur_cost = c1;
-            }
-            if ((st >> 1) > 0) {
-                s.step = (uint8_t)(st >> 1);
-                cont = C_PAIR_EMIT;
-                break;
-            }
             // step_search(mode, 1, _, aux=false) (:974) on {cur, cur - 1, cur + 1}, then the minimum of
             // {planar, DC, dir} (:975-978): first minimum of [planar, DC, cur, cur - 1, cur + 1], kept as
             // one running best.  Out-of-range neighbours are "evaluated" inactive: the wave still
             // walks the schedule so that the workgroup's shared Viterbi barriers stay aligned
-            const int cm = s.cur_mode;
+            const int cm = r.imin;
+            s.cur_mode = (uint8_t)cm;
+            s.cur_cost = r.vmin;
             leaf_full(s, q, both, cm, cm, true, C_F0);
             return true;
         }
@@ -760,21 +805,16 @@ __device__ __forceinline__ bool leaf_step(const Ctx& c, LeafSF& s, const Res& r,
             s.cur_cost = uni_f(assemble_chroma_cost(c, m, s.e_best.get()));
             if (c.write && LANE == 0)
                 TRACE_REC(c.ctu_x + s.bx, c.ctu_y + s.by, s.lg, tree, 3, 0, m, __float_as_int((float)s.cur_cost));
-            leaf_sadlist(s, q, 2, 3, (uint32_t)LT_CCLM | ((uint32_t)T_CCLM << 8) | ((uint32_t)L_CCLM << 16), 0, 0, 0, false,
-                         C_CX);
+            // the three CCLM probes, the pick and the evaluation of the picked mode in one request (K_CCLMSEARCH)
+            leaf_cclmsearch(s, q, C_CCLM);
             if (!in_tile) req_copy(q, COPY_RESTORE, 1, 0, s.bx, s.by, s.lg); // (its save went out earlier)
             return true;
         }
         case C_WIN:
             return false;
-        case C_CX: {
-            const int cm = pick_cclm(r.v0, r.v1, r.v2);
-            s.cclm_mode = (uint8_t)cm;
-            leaf_full(s, q, 2, 0, cm, true, C_CCLM);
-            return true;
-        }
         case C_CCLM: {
             // the CCLM candidate = the winner's luma parts + the chroma parts just evaluated
+            s.cclm_mode = (uint8_t)r.imin;
             EvalParts e = s.e_best.get();
             e.ssd_c = rp.ssd_c;
             e.lvl_c = rp.lvl_c;
@@ -799,17 +839,11 @@ __device__ __forceinline__ bool leaf_step(const Ctx& c, LeafSF& s, const Res& r,
         case C_DM:
             return false;
         // ---- DUAL_TREE_CHROMA leaf (:794-885) ----
-        case C_DC_START:
-            leaf_sadlist(s, q, 2, 3, (uint32_t)LT_CCLM | ((uint32_t)T_CCLM << 8) | ((uint32_t)L_CCLM << 16), 0, 0, 0, false,
-                         C_DC2);
+        case C_DC_START: // the three CCLM probes, the pick and the evaluation of the picked mode (K_CCLMSEARCH)
+            leaf_cclmsearch(s, q, C_DC3);
             return true;
-        case C_DC2: {
-            const int cm = pick_cclm(r.v0, r.v1, r.v2);
-            s.cclm_mode = (uint8_t)cm;
-            leaf_full(s, q, 2, 0, cm, true, C_DC3);
-            return true;
-        }
         case C_DC3:
+            s.cclm_mode = (uint8_t)r.imin;
             s.c0 = uni_f(assemble_chroma_cost(c, s.cclm_mode, rp));
             if (c.write && LANE == 0)
                 TRACE_REC(c.ctu_x + s.bx, c.ctu_y + s.by, s.lg, tree, 3, 0, s.cclm_mode, __float_as_int((float)s.c0));
@@ -870,8 +904,8 @@ __device__ __forceinline__ float xv0(const Ctx& c, int par, int m) { return __in
 
 __device__ __forceinline__ void team_publish(const Req& q, const Res& r, int par) {
     XRes x;
-    if (q.kind == K_FULL) {
-        x.ssd_y = r.ssd_y;
+    if (q.kind == K_FULL || q.kind == K_CCLMSEARCH) {
+        x.ssd_y = q.kind == K_CCLMSEARCH ? (uint32_t)r.imin : r.ssd_y; // a chroma-only request: the picked mode rides here
         x.ssd_c = r.ssd_c;
         x.lvl_y = r.lvl_y;
         x.lvl_c = r.lvl_c;
@@ -884,7 +918,7 @@ __device__ __forceinline__ void team_publish(const Req& q, const Res& r, int par
     if (LANE == 0) SH.xr[par] = x;
 }
 
-enum { TC_START = 0, TC_A, TC_PAIR_EMIT, TC_PAIR, TC_D, TC_E, TC_F, TC_DONE, TC_DC_START, TC_DC_A, TC_DC_B };
+enum { TC_START = 0, TC_A, TC_D, TC_E, TC_F, TC_DONE, TC_DC_START, TC_DC_A, TC_DC_B };
 
 // a member with nothing to evaluate in a stage
 __device__ __forceinline__ void team_idle(Req& q) {
@@ -908,16 +942,17 @@ __device__ __forceinline__ bool leaf_step_team(const Ctx& c, LeafSF& s, Req& q, 
     int cont = s.cont;
     for (;;) {
         switch (cont) {
-        case TC_START: // stage A: planar | DC | the 13 directional SADs in two halves (:887-904)
+        case TC_START: // stage A: planar | DC | the directional SAD search (:887-973)
             if (me == 0) {
                 leaf_full(s, q, both, PLANAR, PLANAR, true, TC_A, true);
             } else if (me == 1) {
                 leaf_full(s, q, both, DC, DC, true, TC_A, true);
             } else if (me == 2) {
-                leaf_sadlist(s, q, both, 7, 2u | (7u << 8) | (13u << 16) | (18u << 24), 23u | (29u << 8) | (34u << 16), 0, 0, true, TC_A);
+                leaf_sadsearch(s, q, both, TC_A); // the 13 directional SADs + both step-search rounds (K_SADSEARCH)
             } else {
-                leaf_sadlist(s, q, both, 6, 39u | (45u << 8) | (50u << 16) | (55u << 24), 60u | (66u << 8), 0, 0, true, TC_A);
+                team_idle(q);
             }
+            s.cont = TC_A;
             q.xchg = true;
             return true;
         case TC_A: {
@@ -942,48 +977,9 @@ __device__ __forceinline__ bool leaf_step_team(const Ctx& c, LeafSF& s, Req& q, 
                 s.best_cls = 0;
                 s.holder = 0;
             }
-            // first minimum over the 13 SADs: member 3's half wins only when strictly smaller
-            const float a = xvmin(c, par, 2), b = xvmin(c, par, 3);
-            const int j = (b < a ? 7 + ximin(c, par, 3) : ximin(c, par, 2)) + 2;
-            const int m = j < 8 ? (int)((0x3A5C90D0E08080ULL >> (7 * j)) & 127)
-                                : (int)((0x109E3764B53A2ULL >> (7 * (j - 8))) & 127);
-            s.cur_mode = (uint8_t)m;
-            s.cur_cost = b < a ? b : a;
-            s.step = 2;
-            cont = TC_PAIR_EMIT;
-            break;
-        }
-        case TC_PAIR_EMIT: { // a step-search round: the two probes side by side (:905-973)
-            const int cm = s.cur_mode, st = s.step;
-            const int lo = !(cm < 2 + st) ? cm - st : kNoMode;
-            const int hi = !(cm + st > 66) ? cm + st : kNoMode;
-            if (me == 2)
-                leaf_sadlist(s, q, both, 1, (uint32_t)lo, 0, 0, 0, true, TC_PAIR);
-            else if (me == 3)
-                leaf_sadlist(s, q, both, 1, (uint32_t)hi, 0, 0, 0, true, TC_PAIR);
-            else
-                team_idle(q);
-            s.cont = TC_PAIR;
-            q.xchg = true;
-            return true;
-        }
-        case TC_PAIR: {
-            const float cur = s.cur_cost, c0 = xv0(c, par, 2), c1 = xv0(c, par, 3);
-            const int st = s.step;
-            const float mn = fminf(fminf(cur, c0), c1);
-            if (cur == mn) {
-            } else if (c0 == mn) {
-                s.cur_mode -= st;
-                s.cur_cost = c0;
-            } else {
-                s.cur_mode += st;
-                s.cur_cost = c1;
-            }
-            if ((st >> 1) > 0) {
-                s.step = (uint8_t)(st >> 1);
-                cont = TC_PAIR_EMIT;
-                break;
-            }
+            // member 2 searched the directional modes (K_SADSEARCH): its winner and its SAD
+            s.cur_mode = (uint8_t)ximin(c, par, 2);
+            s.cur_cost = xvmin(c, par, 2);
             // stage D: cm, cm - 1, cm + 1 side by side (:974) on the three members that do not hold the
             // best of {planar, DC}; candidate k goes to the k-th of them in ascending order
             const int cm = s.cur_mode, holder = s.holder;
@@ -1035,6 +1031,8 @@ __device__ __forceinline__ bool leaf_step_team(const Ctx& c, LeafSF& s, Req& q, 
             s.cur_cost = uni_f(assemble_chroma_cost(c, m, s.e_best.get()));
             if (c.write && LANE == 0)
                 TRACE_REC(c.ctu_x + s.bx, c.ctu_y + s.by, s.lg, tree, 3, 0, m, __float_as_int((float)s.cur_cost));
+            // the three CCLM probes side by side on the winner's luma, which everybody pulls first (one member doing
+            // the three-mode pass and the evaluation in one request, as the wave schedule does, measured 3 % slower here)
             if (me < 3)
                 leaf_sadlist(s, q, 2, 1, (uint32_t)(me == 0 ? LT_CCLM : (me == 1 ? T_CCLM : L_CCLM)), 0, 0, 0, false, TC_E);
             else
@@ -1047,7 +1045,7 @@ __device__ __forceinline__ bool leaf_step_team(const Ctx& c, LeafSF& s, Req& q, 
         case TC_E: {
             const int cm = pick_cclm(xv0(c, par, 0), xv0(c, par, 1), xv0(c, par, 2));
             s.cclm_mode = (uint8_t)cm;
-            const int ev = (s.holder + 1) & (kTeam - 1); // never the holder: its slot keeps the DM chroma
+            const int ev = (s.holder + 1) & (kTeam - 1); // never the holder: its tile keeps the DM chroma
             s.evalr = (uint8_t)ev;
             if (me == ev) {
                 leaf_full(s, q, 2, 0, cm, true, TC_F, true);
@@ -1086,7 +1084,7 @@ __device__ __forceinline__ bool leaf_step_team(const Ctx& c, LeafSF& s, Req& q, 
         case TC_DONE:
             return false;
         // ---- DUAL_TREE_CHROMA leaf (:794-885): the three CCLM probes and the DM evaluation side by side ----
-        case TC_DC_START:
+        case TC_DC_START: // the three CCLM probes and the DM evaluation side by side
             if (me < 3) {
                 leaf_sadlist(s, q, 2, 1, (uint32_t)(me == 0 ? LT_CCLM : (me == 1 ? T_CCLM : L_CCLM)), 0, 0, 0, false, TC_DC_A);
             } else {
