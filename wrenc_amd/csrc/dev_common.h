@@ -242,6 +242,9 @@ struct CtuSt {
     UF<uint8_t> rbx, rby, rlg;       // regen block
     UF<uint8_t> ns_luma_cur, ns_chroma_cur;
     UF<uint8_t> pend, pbx, pby, plg, pslot; // reconstruction save to attach to the next request
+    // team schedule: a decided leaf's winner still to be pulled into every member's tile, done by the driver loop
+    // before the next evaluation.  dp0 = on | comps << 1 | from << 3 | (lg - 2) << 5, dp1 = bx / 4 | (by / 4) << 3
+    UF<uint8_t> dp0, dp1;
     UF<float> ret, ns_cost_cur, split8, ctu_cost;
     LeafSt leaf;
 };

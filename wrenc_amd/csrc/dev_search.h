@@ -933,9 +933,16 @@ __device__ __forceinline__ void team_restore(const Ctx& c, const LeafSF& s, Req&
     q.copy_from = holder;
 }
 
+// the leaf is decided: the winner's comps come from member `holder`'s tile -- deferred to the driver loop, which
+// pulls before the next evaluation (one control step and one empty request less per leaf)
+__device__ __forceinline__ void team_defer_pull(CtuSt& t, const LeafSF& s, int comps, int holder) {
+    t.dp1 = (uint8_t)((s.bx >> 2) | ((s.by >> 2) << 3));
+    t.dp0 = (uint8_t)(1 | (comps << 1) | (holder << 3) | ((s.lg - 2) << 5));
+}
+
 // One step of a leaf search in the team schedule; par = parity of the exchange that delivered the results
 // of the previous step's requests.  Same decisions, in the same order, as leaf_step.
-__device__ __forceinline__ bool leaf_step_team(const Ctx& c, LeafSF& s, Req& q, int par) {
+__device__ __forceinline__ bool leaf_step_team(const Ctx& c, CtuSt& t, LeafSF& s, Req& q, int par) {
     const int tree = s.tree;
     const int both = tree == TREE_SINGLE ? 3 : 1;
     const int me = c.member;
@@ -1021,11 +1028,8 @@ __device__ __forceinline__ bool leaf_step_team(const Ctx& c, LeafSF& s, Req& q, 
             s.luma_mode = (uint8_t)m;
             s.chroma_mode = (uint8_t)m;
             if (tree == TREE_DUAL_LUMA) { // every tile gets the winner's luma; nothing else to decide
-                team_idle(q);
-                team_restore(c, s, q, 1, holder);
-                s.cont = TC_DONE;
-                q.xchg = false;
-                return true;
+                team_defer_pull(t, s, 1, holder);
+                return false;
             }
             // :1040 the winner's chroma cost, then the three CCLM probes side by side on the winner's luma
             s.cur_cost = uni_f(assemble_chroma_cost(c, m, s.e_best.get()));
@@ -1068,18 +1072,15 @@ __device__ __forceinline__ bool leaf_step_team(const Ctx& c, LeafSF& s, Req& q, 
             const float cur = s.cur_cost;
             const bool dm_wins = cur == fminf(cclm_cost, fminf(cur, 3.40282347e+38f));
             const int m = s.mode, bcls = s.best_cls;
-            team_idle(q);
-            q.xchg = false;
-            s.cont = TC_DONE;
             if (dm_wins) { // only the evaluator's tile holds the CCLM chroma: it takes the DM chroma back
                 s.cost = uni_f(assemble_cost(c, tree, bcls, m, s.e_best.get()));
-                team_restore(c, s, q, 2, holder);
-                return true;
+                team_defer_pull(t, s, 2, holder);
+                return false;
             }
             s.chroma_mode = s.cclm_mode;
             s.cost = uni_f(assemble_cost(c, tree, bcls, s.cclm_mode, e));
-            team_restore(c, s, q, 2, ev);
-            return true;
+            team_defer_pull(t, s, 2, ev);
+            return false;
         }
         case TC_DONE:
             return false;
@@ -1119,11 +1120,8 @@ __device__ __forceinline__ bool leaf_step_team(const Ctx& c, LeafSF& s, Req& q, 
             s.cost = cost;
             const bool dm = dm_cost == cost;
             s.chroma_mode = dm ? s.dm_mode : s.cclm_mode;
-            team_idle(q);
-            q.xchg = false;
-            team_restore(c, s, q, 2, dm ? 3 : 0); // member 3 evaluated DM, member 0 the CCLM mode
-            s.cont = TC_DONE;
-            return true;
+            team_defer_pull(t, s, 2, dm ? 3 : 0); // member 3 evaluated DM, member 0 the CCLM mode
+            return false;
         }
         }
     }
@@ -1149,7 +1147,7 @@ __device__ __forceinline__ bool ctu_step(Ctx& c, const Res& r, Req& q) {
         if (in_leaf) {
             // team schedule: the results of the previous requests are in the members' XRes of parity xpar ^ 1
             LeafSF ls = snap_leaf(t.leaf);
-            if (TEAM ? leaf_step_team(c, ls, q, t.xpar ^ 1) : leaf_step(c, ls, r, q)) {
+            if (TEAM ? leaf_step_team(c, t, ls, q, t.xpar ^ 1) : leaf_step(c, ls, r, q)) {
                 if (t.pend) { // the first request of a node's first child saves the unsplit candidate
                     req_copy(q, COPY_SAVE, 3, t.pslot, t.pbx, t.pby, t.plg);
                     t.pend = 0;
@@ -1271,6 +1269,13 @@ __device__ __forceinline__ bool ctu_step(Ctx& c, const Res& r, Req& q) {
             if (level == 0) {
                 t.ctu_cost = t.ret;
                 t.z = 0;
+                if (TEAM && t.dp0) { // the last leaf's winner is still to be pulled: one empty request for every member
+                    q.kind = K_NOP;
+                    q.pre_copy = COPY_NONE;
+                    q.xchg = false;
+                    t.cont = T_RETURN;
+                    return true;
+                }
                 if (TEAM && c.member != 0) { // the final pass is one chain of dependent blocks: member 0 alone
                     t.cont = T_START;
                     return false;
@@ -1422,6 +1427,7 @@ __device__ __forceinline__ void encode_ctu(Ctx& c, const PicBufs& pb, int ctu_co
     SH.st.cont = T_START;
     SH.st.in_leaf = 0;
     SH.st.pend = 0;
+    SH.st.dp0 = 0;
     SH.st.xpar = 0;
     if (LANE == 0) SH.q_pm[0][0][3] = 0; // parity of the pooled quantisation calls (dev_quant.h, zero_flag_cell)
     SH.st.max_depth = (uint8_t)k->max_depth;
@@ -1442,6 +1448,14 @@ __device__ __forceinline__ void encode_ctu(Ctx& c, const PicBufs& pb, int ctu_co
         PROF_ADD2(PH_NSTEP, 0, 1);
         PROF_ADD2(PH_NFULL, 0, (q.kind == K_FULL ? 1 : 0));
         if (!more) break;
+        if (TEAM) { // a decided leaf's winner into every member's tile (team_defer_pull), before anything else
+            const int dp = SH.st.dp0;
+            if (dp) {
+                const int dq = SH.st.dp1;
+                SH.st.dp0 = 0;
+                copy_block(c, COPY_PULL, (dp >> 1) & 3, 0, (dq & 7) << 2, (dq >> 3) << 2, (dp >> 5) + 2, (dp >> 3) & 3);
+            }
+        }
 #ifdef WRENC_EXP_CTRL_ONLY // timing / counting experiment only (wrong results): the control flow without evaluations
         r = Res{};
 #else
