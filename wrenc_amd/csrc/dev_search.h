@@ -10,6 +10,9 @@ namespace wrenc {
 // Evaluation requests and the evaluator
 // ---------------------------------------------------------------------------
 enum { K_SADLIST = 0, K_FULL = 1, K_NOP = 2, K_SADSEARCH = 3, K_CCLMSEARCH = 4 };
+#ifndef WRENC_POOL_MIN_TLG
+#define WRENC_POOL_MIN_TLG 3
+#endif
 enum { COPY_NONE = 0, COPY_SAVE = 1, COPY_RESTORE = 2, COPY_PULL = 3 };
 
 struct Req {
@@ -254,7 +257,11 @@ __device__ __forceinline__ Res evaluate(const Ctx& c, const PicBufs& pb, const R
         // blocks in one pooled pass (quantize3): both components go through the first half, then
         // the pass, then both through the second half.  Everything else runs component by component
         // (the two share r1 / r2).  One copy of each stage either way.
-        const bool merged = WPB == 8 && q.shared && q.comps == 3 && q.tlg <= 4;
+        // Pooling the Viterbi walk of the workgroup's 8 blocks pays for long walks; a block of few positions walks
+        // faster alone than the two workgroup barriers per chunk cost (WRENC_POOL_MIN_TLG: smallest CU size, log2,
+        // whose transform blocks are pooled; every wave of the workgroup evaluates the same size, so they agree)
+        const bool pooled = q.shared && q.tlg >= WRENC_POOL_MIN_TLG;
+        const bool merged = WPB == 8 && pooled && q.comps == 3 && q.tlg <= 4;
         const int p0 = 1 << (2 * q.tlg);
         const int rounds = merged ? 1 : 2;
 #pragma unroll 1
@@ -272,7 +279,7 @@ __device__ __forceinline__ Res evaluate(const Ctx& c, const PicBufs& pb, const R
                 quantize3(c, q.tlg, q.active, overflow, &r.lvl_y, &r.lvl_c, &any_y, &any_c);
             } else {
                 bool any = false;
-                const long long lvl = quantize(c, q.tlg - round, round ? 2 : 1, q.shared, q.active, overflow, &any);
+                const long long lvl = quantize(c, q.tlg - round, round ? 2 : 1, pooled, q.active, overflow, &any);
                 if (round) {
                     r.lvl_c = lvl;
                     any_c = any;
