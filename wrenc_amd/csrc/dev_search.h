@@ -534,24 +534,19 @@ __device__ __forceinline__ int pick_cclm(float lt, float t, float l) {
     return L_CCLM;
 }
 
-__device__ __noinline__ void fill_maps(int bx, int by, int lg, int luma_mode, int chroma_mode, bool luma,
-                                       bool chroma) {
-    bx = uni(bx);
-    by = uni(by);
-    lg = uni(lg);
-    luma_mode = uni(luma_mode);
-    chroma_mode = uni(chroma_mode);
-    const int n4 = (1 << lg) >> 2;
-    if (luma)
-        for (int i = LANE; i < n4 * n4; i += 64) {
-            const int idx = ((by >> 2) + i / n4) * 8 + (bx >> 2) + i % n4;
-            SH.cu_log2[idx] = (uint8_t)lg;
-            SH.luma_mode[idx] = (uint8_t)luma_mode;
-        }
+// the decision maps of a block: at most 8 x 8 units of 4x4 (one lane each), sizes are powers of two
+__device__ __forceinline__ void fill_maps(int bx, int by, int lg, int luma_mode, int chroma_mode, bool luma,
+                                          bool chroma) {
+    const int l4 = lg - 2; // log2 of the block's side in 4x4 units
+    if (luma && LANE < (1 << (2 * l4))) {
+        const int idx = ((by >> 2) + (LANE >> l4)) * 8 + (bx >> 2) + (LANE & ((1 << l4) - 1));
+        SH.cu_log2[idx] = (uint8_t)lg;
+        SH.luma_mode[idx] = (uint8_t)luma_mode;
+    }
     if (chroma) {
-        const int n8 = max(n4 >> 1, 1);
-        for (int i = LANE; i < n8 * n8; i += 64)
-            SH.chroma_mode[((by >> 3) + i / n8) * 4 + (bx >> 3) + i % n8] = (uint8_t)chroma_mode;
+        const int l8 = max(l4 - 1, 0);
+        if (LANE < (1 << (2 * l8)))
+            SH.chroma_mode[((by >> 3) + (LANE >> l8)) * 4 + (bx >> 3) + (LANE & ((1 << l8) - 1))] = (uint8_t)chroma_mode;
     }
     WSYNC();
 }
