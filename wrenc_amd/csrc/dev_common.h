@@ -41,6 +41,7 @@ struct DevConst {
 // The constant block is written by the host before the launch and never during it.
 #define CONST_AS __attribute__((address_space(4)))
 #define AS_GLOBAL(T, p) ((GLOBAL_AS T*)(p))
+#define LDS_AS __attribute__((address_space(3)))
 
 // Per-wave global scratch: 1 KB of prediction bytes, then kReconSlots saved reconstructions
 // (slot 0: best candidate of the running leaf; 1 + level: unsplit candidate of the open node at
@@ -260,17 +261,23 @@ struct XRes {
 // luma filtered, Cb, Cr
 constexpr int R_L0 = 0, R_A0 = 66, R_LF = 130, R_AF = 196, R_LC0 = 260, R_LC1 = 294, R_AC0 = 328, R_AC1 = 360;
 
+typedef uint8_t ref_t; // a reference sample (reconstructed or [1 2 1]-filtered: 0..255)
 struct __attribute__((aligned(16))) Lds {
     // Transform working set, time-multiplexed through a full evaluation (dev_search.h):
-    //   r1: residual -> coefficients -> Viterbi chunk costs / levels -> reconstructed residual
-    //   r2: stage-1 DCT output (i32) -> scan-order coefficients + quotients -> dequantised^T + V
+    //   r1: residual -> coefficients -> Viterbi chunk costs / levels -> inverse-transform intermediate -> residual
+    //   r2: stage-1 DCT output (i32, blocks up to 16x16; the 32x32 transform keeps it in MFMA accumulators) ->
+    //       scan-order coefficients (+ chroma chunk costs of the merged pass) -> dequantised^T
+    // Bytes [kOrgLeaf, 2048) of r2 hold the originals of a block of at most 16x16 for its whole leaf search
+    // (dev_predict.h); no stage of a block that small reaches them.
+    // 2 KB each: five workgroups of four waves per CU (LDS is what caps the waves in flight, and the kernel's
+    // throughput is proportional to them: profiles/r02_issue_model.md).
     int16_t r1[1024];
-    int32_t r2[33 * 32];
+    int32_t r2[512];
     // reference samples of the current block, built once per (block, component) and reused by
     // every candidate mode: luma unfiltered + [1 2 1]-filtered, chroma unfiltered
     // one array addressed by element offsets (R_*), so that choosing among the sets is integer
     // arithmetic on a DS address, never a pointer select
-    int16_t refs[392];
+    ref_t refs[392];
     uint8_t recYtop[72];       // y = -1, x = -4..67 (index x+4)
     uint8_t recY[32 * 36];     // x = -4..31 (index x+4), stride 36
     uint8_t recCtop[2][40];    // y = -1, x = -4..35
@@ -313,9 +320,11 @@ struct Ctx {
 // they execute the same schedule; the 4-lane Viterbi of all WPB transform blocks is run by
 // wave 0 in WPB quads at once (see quantize()).
 #ifndef WRENC_WPB
-#define WRENC_WPB 8
+#define WRENC_WPB 4
 #endif
 constexpr int WPB = WRENC_WPB;
+// Workgroups resident per CU, which LDS decides: 5 x 4 waves = 5 waves per SIMD (96 VGPRs each).
+constexpr int kWorkgroupsPerCU = 20 / WPB;
 // Team schedule: kTeam waves share ONE CTU (independent candidates of a leaf search run side by side), a
 // workgroup holds WPB / kTeam teams = the same CTU of that many pictures.
 constexpr int kTeam = 4;
@@ -323,6 +332,9 @@ struct LdsTab {
     int32_t ldq[256];
     int32_t lv[256];
     int8_t fc[32][4]; // common.rs:153 (copied from the constant block)
+#ifdef WRENC_EXP_LDS_PAD
+    char pad[WRENC_EXP_LDS_PAD]; // occupancy experiments only (profiles/r02_issue_model.md)
+#endif
 };
 __shared__ Lds SHW[WPB];
 __shared__ LdsTab SHT;

@@ -48,8 +48,8 @@ __device__ __forceinline__ void build_refs(Ctx c, int comp, int tx, int ty, int 
         const int blk = tt >= total ? 1 : 0;
         const int t = tt - blk * total;
         const int pc = comp + blk;
-        int16_t* refL = SH.refs + (pc == 0 ? R_L0 : (pc == 1 ? R_LC0 : R_LC1));
-        int16_t* refA = SH.refs + (pc == 0 ? R_A0 : (pc == 1 ? R_AC0 : R_AC1));
+        ref_t* refL = SH.refs + (pc == 0 ? R_L0 : (pc == 1 ? R_LC0 : R_LC1));
+        ref_t* refA = SH.refs + (pc == 0 ? R_A0 : (pc == 1 ? R_AC0 : R_AC1));
         // unified item: t <= 2n -> left index li = t (li 0 = corner, li k -> y = k-1); else above
         int seg;
         const bool is_left = t <= 2 * n;
@@ -85,15 +85,15 @@ __device__ __forceinline__ void build_refs(Ctx c, int comp, int tx, int ty, int 
             v = src_left ? rec_get(pc, cx - 1, cy + sli - 1) : rec_get(pc, cx + sai, cy - 1);
         }
         if (is_left)
-            refL[li] = (int16_t)v;
+            refL[li] = (ref_t)v;
         else
-            refA[ai] = (int16_t)v;
+            refA[ai] = (ref_t)v;
     }
     WSYNC();
     // [1 2 1] filter, intra_predictor.rs:304-352 (used by modes 0, 2, 34, 66 only)
     if (comp == 0 && n * n > 32) {
-        const int16_t* refL = SH.refs + R_L0;
-        const int16_t* refA = SH.refs + R_A0;
+        const ref_t* refL = SH.refs + R_L0;
+        const ref_t* refA = SH.refs + R_A0;
         for (int t = LANE; t < total; t += 64) {
             if (t <= 2 * n) {
                 const int li = t;
@@ -104,7 +104,7 @@ __device__ __forceinline__ void build_refs(Ctx c, int comp, int tx, int ty, int 
                     v = (refL[1] + 2 * refL[0] + refA[0] + 2) >> 2;
                 else
                     v = (refL[li + 1] + 2 * refL[li] + refL[li - 1] + 2) >> 2;
-                SH.refs[R_LF + li] = (int16_t)v;
+                SH.refs[R_LF + li] = (ref_t)v;
             } else {
                 const int ai = t - (2 * n + 1);
                 int v;
@@ -114,7 +114,7 @@ __device__ __forceinline__ void build_refs(Ctx c, int comp, int tx, int ty, int 
                     v = (refL[0] + 2 * refA[0] + refA[1] + 2) >> 2;
                 else
                     v = (refA[ai - 1] + 2 * refA[ai] + refA[ai + 1] + 2) >> 2;
-                SH.refs[R_AF + ai] = (int16_t)v;
+                SH.refs[R_AF + ai] = (ref_t)v;
             }
         }
         WSYNC();
@@ -273,15 +273,15 @@ __device__ __forceinline__ CclmParams cclm_params(Ctx c, int comp, int tx, int t
 // Original sample for prediction index i (plane pc, component coordinates x, y).  A full
 // evaluation reads the picture; SAD lists read the copy of the block's originals that
 // stage_org() put into r2 (free while no transform runs), index obase + i.
-// byte offset in r2 of the staged originals (luma at +0, Cb | Cr at +1024): the last 1.5 KB, so that
-// r1 and the first 2688 bytes of r2 are one free region during SAD lists
-constexpr int kOrgStage = 2688;
+// byte offset in r2 of the staged originals (luma at +0, Cb | Cr at +1024): the last 1.5 KB of its 2 KB (the
+// tables of a SAD list fill r1, nothing else runs meanwhile)
+constexpr int kOrgStage = 512;
 // Blocks of at most 16x16 luma samples keep their originals in LDS for the WHOLE leaf search (SAD lists and
 // full evaluations alike): 256 B luma + 2 x 64 B chroma in the last 384 bytes of r2, which no stage of a
-// block that small touches (forward DCT <= 1088 B, quantize3 ends at byte 3840, dequantise / inverse DCT
-// <= 2560, the angular tables <= 2256).  Staged once per leaf (stage_org_leaf); a 32x32 block has no such
-// room: its SAD lists stage per list (stage_org), its full evaluations read the picture.
-constexpr int kOrgLeaf = 3840;
+// block that small touches (forward DCT <= 1088 B, quantize3 ends at byte 1536, dequantise <= 512, the angular
+// table of a prediction at 1280..1488; SAD-list tables are in r1).  Staged once per leaf (stage_org_leaf); a
+// 32x32 block has no such room: its SAD lists stage per list (stage_org), its full evaluations read the picture.
+constexpr int kOrgLeaf = 1664;
 // byte offset in r2 of the originals of component `comp` (0 luma, 1 chroma pair) of a block of log2 size tlg
 __device__ __forceinline__ int org_byte(int comp, int tlg) {
     return tlg <= 4 ? kOrgLeaf + (comp ? 256 : 0) : kOrgStage + (comp ? 1024 : 0);
@@ -399,8 +399,8 @@ __device__ __forceinline__ int predict(Ctx c, int comp, int tx, int ty, int tlg,
     const bool filt = comp == 0 && nn > 32 && (mode == 0 || mode == 2 || mode == 34 || mode == 66);
     const int oL0 = comp == 0 ? (filt ? R_LF : R_L0) : R_LC0; // index 0 = corner
     const int oA0 = comp == 0 ? (filt ? R_AF : R_A0) : R_AC0;
-    const int16_t* L0 = SH.refs + oL0;
-    const int16_t* A0 = SH.refs + oA0;
+    const ref_t* L0 = SH.refs + oL0;
+    const ref_t* A0 = SH.refs + oA0;
     if (mode == PLANAR || mode == DC) {
         int dcv0 = 0, dcv1 = 0;
         if (mode == DC) {
@@ -418,8 +418,8 @@ __device__ __forceinline__ int predict(Ctx c, int comp, int tx, int ty, int tlg,
             const int ii = i & (nn - 1);
             const int x = ii & (n - 1), y = ii >> lg;
             const int o = pred_org<full>(c, comp + blk, cx + x, cy + y, obyte, i, olds); // issued early
-            const int16_t* L = SH.refs + (blk ? R_LC1 : oL0);
-            const int16_t* A = SH.refs + (blk ? R_AC1 : oA0);
+            const ref_t* L = SH.refs + (blk ? R_LC1 : oL0);
+            const ref_t* A = SH.refs + (blk ? R_AC1 : oA0);
             int v;
             if (mode == PLANAR) {
                 const int pv = M24(n - 1 - y, A[x]) + M24(y + 1, L[n + 1]);
@@ -455,12 +455,12 @@ __device__ __forceinline__ int predict(Ctx c, int comp, int tx, int ty, int tlg,
     // The main reference of the mode, projected once (intra_predictor.rs:1311-1420): entry idx in
     // [-n, 2n + 3] = ref[idx] of the reference's refx / refy arrays: idx >= 0 reads the main side
     // (0 = corner, k = sample k - 1, clamped to 2n), idx < 0 the side array at the inverse-angle
-    // projection.  It lives in the upper half of r2 (no transform runs during a prediction), so
+    // projection.  It lives in r2 (no transform runs during a prediction), so
     // a sample's taps are consecutive LDS reads with no selects.
     const bool vertical = mode >= 34;
     // Bytes, each XOR 0x80 (ref - 128 as a signed byte): the filters run as one v_dot4_i32_i8 over four
     // packed taps, see sad_list_angular.
-    constexpr int RM0 = 2048, RMS = 104; // byte offset of the table in r2, stride per block
+    constexpr int RM0 = 1280, RMS = 104; // byte offset of the table in r2 (below kOrgLeaf), stride per block
     uint8_t* rm = (uint8_t*)SH.r2 + RM0;
     {
         const int ne = 3 * n + 4;
@@ -481,8 +481,8 @@ __device__ __forceinline__ int predict(Ctx c, int comp, int tx, int ty, int tlg,
         const int ii = i & (nn - 1);
         const int x = ii & (n - 1), y = ii >> lg;
         const int o = pred_org<full>(c, comp + blk, cx + x, cy + y, obyte, i, olds); // issued early
-        const int16_t* L = SH.refs + (blk ? R_LC1 : oL0);
-        const int16_t* A = SH.refs + (blk ? R_AC1 : oA0);
+        const ref_t* L = SH.refs + (blk ? R_LC1 : oL0);
+        const ref_t* A = SH.refs + (blk ? R_AC1 : oA0);
         int v;
         {
             const int along = vertical ? y : x, across = vertical ? x : y;
@@ -678,8 +678,8 @@ __device__ __forceinline__ unsigned sad_list_angular(const Ctx& c, int comps, in
             const int ii = i & (nn - 1);
             const int x = ii & (n - 1), y = ii >> lg;
             const int o = ((const uint8_t*)SH.r2)[obyte + i];
-            const int16_t* L = SH.refs + (blk ? R_LC1 : (comp == 0 ? R_L0 : R_LC0));
-            const int16_t* A = SH.refs + (blk ? R_AC1 : (comp == 0 ? R_A0 : R_AC0));
+            const ref_t* L = SH.refs + (blk ? R_LC1 : (comp == 0 ? R_L0 : R_LC0));
+            const ref_t* A = SH.refs + (blk ? R_AC1 : (comp == 0 ? R_A0 : R_AC0));
 #pragma unroll 1
             for (int base = 0; base < nmodes; base += 64 >> lgS) {
                 const int mi = base + slot;
@@ -761,8 +761,8 @@ __device__ __forceinline__ unsigned sad_list_angular(const Ctx& c, int comps, in
                 const int ii = i & (nn - 1);
                 const int x = ii & (n - 1), y = ii >> lg;
                 const int o = ((const uint8_t*)SH.r2)[obyte + i];
-                const int16_t* L = SH.refs + (blk ? R_LC1 : oL0);
-                const int16_t* A = SH.refs + (blk ? R_AC1 : oA0);
+                const ref_t* L = SH.refs + (blk ? R_LC1 : oL0);
+                const ref_t* A = SH.refs + (blk ? R_AC1 : oA0);
                 const int along = vertical ? y : x, across = vertical ? x : y;
                 const int i_idx = M24(along + 1, angle) >> 5;
                 const int i_fact = M24(along + 1, angle) & 31;

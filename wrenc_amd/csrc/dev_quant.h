@@ -59,7 +59,7 @@ __device__ __forceinline__ int position_map(int tc, int qd, bool dcn, int nib) {
 // Which wave of the workgroup walks the pooled Viterbi.  Waves w and w + 4 share a SIMD with the same
 // two waves of the CU's other workgroup; if every workgroup walked in wave 0, one SIMD of each CU would
 // carry all the serial walks and its waves would reach every barrier last.  Spread by workgroup index.
-__device__ __forceinline__ int walker_wave() { return (int)((blockIdx.x * 2654435761u) >> 30); }
+__device__ __forceinline__ int walker_wave() { return (int)((blockIdx.x * 2654435761u) >> 30) & (WPB < 4 ? WPB - 1 : 3); }
 
 // Path costs are kept in 32 bits, DOUBLED, with the tie-break of quantizer.rs:505 in the low bit.
 // Only cost DIFFERENCES between the four states decide the path, and they are bounded: any
@@ -85,6 +85,15 @@ __device__ __forceinline__ int ldq_fast(const Ctx& c, int idx) {
         if (idx > 255) v = (int)c.k->ldq[idx];
     }
     return v;
+}
+
+// |(tc << sh) - off| / lsc, the quotient every decision of a position starts from (quantizer.rs:378, :441); 0 for a
+// zero coefficient.  Recomputed where it is needed (a shift, a 32 x 32 -> 64 multiply by the reciprocal) rather
+// than kept per position: the 2 KB that array took are what lets a fifth workgroup fit the CU's LDS.
+__device__ __forceinline__ int quotient(const CONST_AS DevConst* k, int tc, int sh, int off) {
+    int S = (int)((unsigned)tc << sh) - off;
+    if (tc < 0) S = -S;
+    return tc == 0 ? 0 : (int)(((unsigned long long)(unsigned)S * k->div_magic) >> 47);
 }
 
 // Chunk entry of one position (see the comment above kNoBranch): writes (u, w) of the three state
@@ -213,8 +222,7 @@ __device__ __forceinline__ long long quantize(Ctx c, int lg, int nb, bool shared
     const int off = (1 << sh) >> 1;
     const int lsc = k->lsc;
     const CONST_AS uint16_t* scan = k->scan_idx[lg - 2];
-    int16_t* tcs = (int16_t*)SH.r2;          // [blk][p]: coefficient in reverse-scan order
-    int16_t* qds = (int16_t*)SH.r2 + 1024;   // [blk][p]: |(tc << sh) - off| / lsc
+    int16_t* tcs = (int16_t*)SH.r2;          // [blk][p]: coefficient in reverse-scan order (all of r2 for a 32x32 block)
     int32_t* cc = (int32_t*)SH.r1;           // chunk: [blk][CH][6] ints (coefficients are dead after the gather)
     const uint16_t* dec16 = (const uint16_t*)SH.decw; // decisions: [blk][sub-block][state] 16-bit masks
     PROF_MARK(q0_);
@@ -226,11 +234,8 @@ __device__ __forceinline__ long long quantize(Ctx c, int lg, int nb, bool shared
             const int blk = idx >> lgP, p = idx & (P - 1);
             const int tc = SH.r1[blk * P + scan[p]];
             nzl |= tc;
-            int S = (int)((unsigned)tc << sh) - off;
-            if (tc < 0) S = -S;
-            const int qd = tc == 0 ? 0 : (int)(((unsigned long long)(unsigned)S * k->div_magic) >> 47);
+            const int qd = quotient(k, tc, sh, off);
             tcs[idx] = (int16_t)tc;
-            qds[idx] = (int16_t)qd;
             if (tc != 0 && (qd >> 1) > 0) {
                 if (blk)
                     first1 = min(first1, p);
@@ -279,9 +284,11 @@ __device__ __forceinline__ long long quantize(Ctx c, int lg, int nb, bool shared
             const int i = LANE - blk * CH;
             const int p = base + i;
             int par0 = 0, par1 = 0, adj = 0;
-            if (mine)
-                chunk_entry(c, cc + LANE * 6, tcs[blk * P + p], qds[blk * P + p], p == P - 1, p <= (blk ? istar1 : istar0),
+            if (mine) {
+                const int tc = tcs[blk * P + p];
+                chunk_entry(c, cc + LANE * 6, tc, quotient(k, tc, sh, off), p == P - 1, p <= (blk ? istar1 : istar0),
                             sh, off, lsc, ldq1, &par0, &par1, &adj, &ovf);
+            }
             const unsigned long long b0 = __ballot(mine && par0), b1 = __ballot(mine && par1), ba = __ballot(mine && adj);
             if (mine && (LANE & 15) == 0) {
                 uint16_t* pm = SH.q_pm[blk][i >> 4];
@@ -356,14 +363,14 @@ __device__ __forceinline__ long long quantize(Ctx c, int lg, int nb, bool shared
     const int p0 = lane_in * per;
     const bool act = p0 < P;
     const int16_t* btcs = tcs + blk * P;
-    const int16_t* bqds = qds + blk * P;
     const uint16_t* bdec = dec16 + blk * (P >> 2);
     int fmap = kMapId;
     const DecMasks dm = dec_masks(bdec, act ? p0 : 0); // a lane's positions lie in one sub-block (per divides 16)
     if (act) {
         for (int j = 0; j < per; ++j) {
             const int p = p0 + j;
-            fmap = compose_map(position_map(btcs[p], bqds[p], p == P - 1, dec_nib(dm, p)), fmap);
+            const int tc = btcs[p];
+            fmap = compose_map(position_map(tc, quotient(k, tc, sh, off), p == P - 1, dec_nib(dm, p)), fmap);
         }
     }
     // inclusive prefix composition across the lanes of a block: Hillis-Steele inside the 16-lane rows
@@ -387,8 +394,9 @@ __device__ __forceinline__ long long quantize(Ctx c, int lg, int nb, bool shared
         int state = entry;
         for (int j = 0; j < per; ++j) {
             const int p = p0 + j;
-            SH.r1[blk * P + scan[p]] =
-                (int16_t)emit_level(c, btcs[p], bqds[p], p == P - 1, dec_nib(dm, p), p, j, state, zmask, sum_nz, fnz, ovf);
+            const int tc = btcs[p];
+            SH.r1[blk * P + scan[p]] = (int16_t)emit_level(c, tc, quotient(k, tc, sh, off), p == P - 1, dec_nib(dm, p), p, j,
+                                                           state, zmask, sum_nz, fnz, ovf);
         }
     }
     const int pf = group_min_i32(fnz, half); // zeros before a block's first non-zero level cost nothing
@@ -407,12 +415,14 @@ __device__ __forceinline__ long long quantize(Ctx c, int lg, int nb, bool shared
 // n0 x n0 at r1[0, P0), Cb and Cr (n0/2)^2 at r1[P0, P0 + Pc) and r1[P0 + Pc, P0 + 2 Pc), n0 = 8 or
 // 16 (search only: every wave of the workgroup is in this call with the same block size).  Same
 // algorithm as quantize(); the chroma chains are a quarter as long as the luma chain, so a chunk is
-// 64 luma + 16 + 16 chroma positions and the chroma blocks ride along for free: wave 0 walks the
-// 8 luma blocks (lanes 0..31) and the 8 Cb blocks (lanes 32..63), wave 1 the 8 Cr blocks.
-// Scratch: r2 = [scan-order coefficients | quotients | chunk entries], decw.
+// 64 luma + 16 + 16 chroma positions and the chroma blocks ride along for free.  The 3 * WPB walks take one quad
+// of lanes each, all luma blocks first, then Cb, then Cr, over as many walker waves as that needs (WPB = 4: twelve
+// quads of one wave).
+// Scratch: r2 = [scan-order coefficients | chroma chunk entries], r1 = luma chunk entries (the coefficients are
+// dead after the gather and every level is written at the end, as in quantize()), decw.
 __device__ __forceinline__ void quantize3(Ctx c, int lg0, bool active, int* overflow, long long* lvl_y,
                                           long long* lvl_c, bool* any_y, bool* any_c) {
-    static_assert(WPB == 8, "the merged pass maps 8 waves x 3 blocks onto two walker waves");
+    static_assert(WPB <= 8, "a walker wave has 16 quads; walker_wave() + 1 must stay below WPB");
     c = uni(c);
     lg0 = uni(lg0);
     const CONST_AS DevConst* k = c.k;
@@ -423,9 +433,9 @@ __device__ __forceinline__ void quantize3(Ctx c, int lg0, bool active, int* over
     const CONST_AS uint16_t* scan0 = k->scan_idx[lg0 - 2];
     const CONST_AS uint16_t* scanc = k->scan_idx[lgc - 2];
     int16_t* tcs = (int16_t*)SH.r2;               // [T]: coefficient in reverse-scan order, block after block
-    int16_t* qds = (int16_t*)SH.r2 + T;           // [T]: |(tc << sh) - off| / lsc
-    constexpr int kCcByte = 1536;                 // 2 * 2 * T <= 1536 for T <= 384
-    int32_t* cc = (int32_t*)((char*)SH.r2 + kCcByte); // chunk: [96][6] ints
+    constexpr int kCcByte = 768;                  // 2 * T <= 768 for T <= 384
+    int32_t* cc0 = (int32_t*)SH.r1;                     // chunk, luma: [64][6] ints
+    int32_t* cc1 = (int32_t*)((char*)SH.r2 + kCcByte);  // chunk, Cb | Cr: [32][6] ints (ends at byte 1536 < kOrgLeaf)
     *lvl_y = 0;
     *lvl_c = 0;
     PROF_MARK(q0_);
@@ -443,11 +453,8 @@ __device__ __forceinline__ void quantize3(Ctx c, int lg0, bool active, int* over
             const int off = (1 << sh) >> 1;
             const int tc = SH.r1[boff + (b == 0 ? scan0[p] : scanc[p])];
             nzl |= tc;
-            int S = (int)((unsigned)tc << sh) - off;
-            if (tc < 0) S = -S;
-            const int qd = tc == 0 ? 0 : (int)(((unsigned long long)(unsigned)S * k->div_magic) >> 47);
+            const int qd = quotient(k, tc, sh, off);
             tcs[idx] = (int16_t)tc;
-            qds[idx] = (int16_t)qd;
             if (tc != 0 && (qd >> 1) > 0) {
                 if (b == 0)
                     first0 = min(first0, p);
@@ -472,12 +479,15 @@ __device__ __forceinline__ void quantize3(Ctx c, int lg0, bool active, int* over
     const int ldq1 = (int)ldq_at(c, 1);
     const int st = LANE & 3;
     const int cls = st == 0 ? 0 : (st == 1 ? 1 : 2);
-    // walker lanes: wave 0 lanes 0..31 luma of wave LANE/4, lanes 32..63 Cb; wave 1 lanes 0..31 Cr
-    const int wv = (WAVE - walker_wave()) & (WPB - 1); // 0 and 1: the two walker waves
-    const int wb = wv == 0 ? (LANE < 32 ? 0 : 1) : 2;
-    const bool walker = wv == 0 || (wv == 1 && LANE < 32);
-    const Lds* tb = &SHW[(LANE & 31) >> 2];
-    const int32_t* wcc = (const int32_t*)((const char*)tb->r2 + kCcByte) + (wb == 0 ? 0 : (wb == 1 ? 64 : 80)) * 6;
+    // walker quads: global quad gq = 16 * (walker wave) + LANE / 4 walks block kind gq / WPB of wave gq % WPB
+    constexpr int kWalkers = (3 * WPB + 15) / 16;
+    const int wv = (WAVE - walker_wave()) & (WPB - 1); // 0 .. kWalkers - 1: the walker waves
+    const int gq = 16 * wv + (LANE >> 2);
+    const int wb = min(gq / WPB, 2);
+    const bool walker = wv < kWalkers && gq < 3 * WPB;
+    const Lds* tb = &SHW[gq % WPB];
+    const int32_t* wcc = wb == 0 ? (const int32_t*)tb->r1
+                                 : (const int32_t*)((const char*)tb->r2 + kCcByte) + (wb == 1 ? 0 : 16) * 6;
     uint16_t* wdec = (uint16_t*)const_cast<uint32_t*>(tb->decw) + (wb == 0 ? 0 : (wb == 1 ? (P0 >> 2) : (P0 >> 2) + (Pc >> 2)));
     const int wnsb = wb == 0 ? 4 : 1; // sub-blocks of the walker's block per chunk
     int C = 0;
@@ -500,7 +510,8 @@ __device__ __forceinline__ void quantize3(Ctx c, int lg0, bool active, int* over
                 int par0 = 0, par1 = 0, adj = 0;
                 if (mine) {
                     const int sh = b == 0 ? sh0 : shc;
-                    chunk_entry(c, cc + e * 6, tcs[gidx], qds[gidx], p == Pb - 1,
+                    const int tc = tcs[gidx];
+                    chunk_entry(c, b == 0 ? cc0 + e * 6 : cc1 + (e - 64) * 6, tc, quotient(k, tc, sh, (1 << sh) >> 1), p == Pb - 1,
                                 p <= (b == 0 ? istar0 : (b == 1 ? istar1 : istar2)), sh, (1 << sh) >> 1, lsc, ldq1, &par0,
                                 &par1, &adj, &ovf);
                 }
@@ -572,13 +583,14 @@ __device__ __forceinline__ void quantize3(Ctx c, int lg0, bool active, int* over
     const int boff = b == 0 ? 0 : (b == 1 ? P0 : P0 + Pc);
     const int p0 = lane_in * per;
     const int16_t* btcs = tcs + boff;
-    const int16_t* bqds = qds + boff;
+    const int shb = b == 0 ? sh0 : shc, offb = (1 << shb) >> 1;
     const uint16_t* bdec = (const uint16_t*)SH.decw + (b == 0 ? 0 : (b == 1 ? (P0 >> 2) : (P0 >> 2) + (Pc >> 2)));
     int fmap = kMapId;
     const DecMasks dm = dec_masks(bdec, p0); // a lane's positions lie in one sub-block (per divides 16)
     for (int j = 0; j < per; ++j) {
         const int p = p0 + j;
-        fmap = compose_map(position_map(btcs[p], bqds[p], p == Pb - 1, dec_nib(dm, p)), fmap);
+        const int tc = btcs[p];
+        fmap = compose_map(position_map(tc, quotient(k, tc, shb, offb), p == Pb - 1, dec_nib(dm, p)), fmap);
     }
     int pre = fmap;
     pre = compose_map(pre, __builtin_amdgcn_update_dpp(kMapId, pre, 0x111, 0xF, 0xF, false)); // row_shr:1
@@ -595,8 +607,9 @@ __device__ __forceinline__ void quantize3(Ctx c, int lg0, bool active, int* over
         int state = entry;
         for (int j = 0; j < per; ++j) {
             const int p = p0 + j;
-            SH.r1[boff + (b == 0 ? scan0[p] : scanc[p])] =
-                (int16_t)emit_level(c, btcs[p], bqds[p], p == Pb - 1, dec_nib(dm, p), p, j, state, zmask, sum_nz, fnz, ovf);
+            const int tc = btcs[p];
+            SH.r1[boff + (b == 0 ? scan0[p] : scanc[p])] = (int16_t)emit_level(
+                c, tc, quotient(k, tc, shb, offb), p == Pb - 1, dec_nib(dm, p), p, j, state, zmask, sum_nz, fnz, ovf);
         }
     }
     // zeros before a block's first non-zero level cost nothing: minimum per block (rows 0-1 | 2 | 3)

@@ -261,7 +261,11 @@ __device__ __forceinline__ Res evaluate(const Ctx& c, const PicBufs& pb, const R
         // faster alone than the two workgroup barriers per chunk cost (WRENC_POOL_MIN_TLG: smallest CU size, log2,
         // whose transform blocks are pooled; every wave of the workgroup evaluates the same size, so they agree)
         const bool pooled = q.shared && q.tlg >= WRENC_POOL_MIN_TLG;
-        const bool merged = WPB == 8 && pooled && q.comps == 3 && q.tlg <= 4;
+        #ifdef WRENC_EXP_NO_MERGED
+        const bool merged = false;
+#else
+        const bool merged = pooled && q.comps == 3 && q.tlg <= 4;
+#endif
         const int p0 = 1 << (2 * q.tlg);
         const int rounds = merged ? 1 : 2;
 #pragma unroll 1
@@ -1425,7 +1429,10 @@ __device__ __forceinline__ void encode_ctu(Ctx& c, const PicBufs& pb, int ctu_co
         for (int i = LANE; i < 256; i += 64) SH.recC[comp - 1][(i >> 4) * 20 + (i & 15) + 4] = 0;
     WSYNC();
     // ---- the search + final pass: one evaluator, driven by the state machine ----
-    static_assert(sizeof(Lds) * WPB + sizeof(LdsTab) <= 81920, "two workgroups per CU need <= 80 KB each");
+    #ifndef WRENC_EXP_LDS_PAD
+    static_assert(sizeof(Lds) * WPB + sizeof(LdsTab) <= (160 * 1024) / kWorkgroupsPerCU,
+                  "kWorkgroupsPerCU workgroups must fit the CU's 160 KB of LDS");
+#endif
     SH.st.cont = T_START;
     SH.st.in_leaf = 0;
     SH.st.pend = 0;

@@ -24,12 +24,15 @@ __device__ __forceinline__ int dot2(uint32_t a, uint32_t b, int acc) {
 }
 
 // forward: nb residual blocks in r1 ([blk][y][x] i16) -> coefficients in place, via r2;
-// transformer.rs:2040-2378
-template <int LG>
-__device__ void fwd_dct(Ctx c, int nb, int o1) {
+// transformer.rs:2040-2378.  The i32 intermediate of all nb blocks goes through r2 at once when it fits its
+// 2 KB, block after block otherwise (the two 16x16 blocks of a 32x32 CU's chroma pair).
+// h: the intermediate's buffer of HBYTES bytes in LDS (r2 in the search; the micro-benchmark of the 32x32 v_dot2
+// version brings its own, wrenc_gpu.hip).
+template <int LG, int HBYTES>
+__device__ void fwd_dct(Ctx c, int nb, int o1, LDS_AS int32_t* h) {
     constexpr int N = 1 << LG;
     constexpr int G = 64 / N;
-    constexpr int HS = N + 1; // r2 row stride
+    constexpr int HS = N + 1; // row stride of the intermediate
     const int u = LANE & (N - 1);
     const int g = LANE >> LG;
     uint32_t t[N / 2];
@@ -38,36 +41,44 @@ __device__ void fwd_dct(Ctx c, int nb, int o1) {
 #pragma unroll
         for (int k = 0; k < N / 2; ++k) t[k] = src[k];
     }
-    // stage 1: H[u][y] = (sum_x T[u][x] r[y][x] + d) >> (LG-1)   (:2139-2209); rows of all blocks
+    constexpr int kFit = HBYTES / (N * HS * (int)sizeof(int32_t)); // blocks whose intermediate fits the buffer
+    static_assert(kFit >= 1, "one block's stage-1 output must fit the buffer");
+    const int per = nb <= kFit ? nb : 1; // blocks per round
 #pragma unroll 1
-    for (int yy = g; yy < nb * N; yy += G) {
-        const uint32_t* row = (const uint32_t*)&SH.r1[o1 + yy * N];
-        int acc = 0;
-#pragma unroll
-        for (int k = 0; k < N / 2; ++k) acc = dot2(row[k], t[k], acc);
-        const int blk = yy >> LG, y = yy & (N - 1);
-        SH.r2[blk * (N * HS) + u * HS + y] = (acc + (1 << (LG - 2))) >> (LG - 1);
-    }
-    WSYNC();
-    // stage 2: C[v][x] = (sum_y T[v][y] H[x][y] + d) >> (LG+6)  (:2246-2316); lane v = u
+    for (int b0 = 0; b0 < nb; b0 += per) {
+        // stage 1: H[u][y] = (sum_x T[u][x] r[y][x] + d) >> (LG-1)   (:2139-2209); rows of the round's blocks
 #pragma unroll 1
-    for (int xx = g; xx < nb * N; xx += G) {
-        const int blk = xx >> LG, x = xx & (N - 1);
-        const int32_t* col = &SH.r2[blk * (N * HS) + x * HS];
-        int acc = 0;
+        for (int yy = g; yy < per * N; yy += G) {
+            const uint32_t* row = (const uint32_t*)&SH.r1[o1 + (b0 * N + yy) * N];
+            int acc = 0;
 #pragma unroll
-        for (int k = 0; k < N / 2; ++k) {
-            // |T| <= 90 and |H| <= 46410: 24-bit multiplies are exact (v_mad_i32_i24)
-            acc += __mul24((int)(short)(t[k] & 0xFFFF), col[2 * k]);
-            acc += __mul24((int)t[k] >> 16, col[2 * k + 1]);
+            for (int k = 0; k < N / 2; ++k) acc = dot2(row[k], t[k], acc);
+            const int blk = yy >> LG, y = yy & (N - 1);
+            h[blk * (N * HS) + u * HS + y] = (acc + (1 << (LG - 2))) >> (LG - 1);
         }
-        SH.r1[o1 + blk * (N * N) + u * N + x] = (int16_t)((acc + (1 << (LG + 5))) >> (LG + 6));
+        WSYNC();
+        // stage 2: C[v][x] = (sum_y T[v][y] H[x][y] + d) >> (LG+6)  (:2246-2316); lane v = u
+#pragma unroll 1
+        for (int xx = g; xx < per * N; xx += G) {
+            const int blk = xx >> LG, x = xx & (N - 1);
+            const LDS_AS int32_t* col = &h[blk * (N * HS) + x * HS];
+            int acc = 0;
+#pragma unroll
+            for (int k = 0; k < N / 2; ++k) {
+                // |T| <= 90 and |H| <= 46410: 24-bit multiplies are exact (v_mad_i32_i24)
+                acc += __mul24((int)(short)(t[k] & 0xFFFF), col[2 * k]);
+                acc += __mul24((int)t[k] >> 16, col[2 * k + 1]);
+            }
+            SH.r1[o1 + (b0 + blk) * (N * N) + u * N + x] = (int16_t)((acc + (1 << (LG + 5))) >> (LG + 6));
+        }
+        WSYNC();
     }
-    WSYNC();
 }
 
-// inverse: nb transposed dequantised blocks in the lower half of r2 ([blk][x][i], i16) ->
-// residuals r1 ([blk][y][x]); the intermediate lives in the upper half of r2.  transformer.rs:2380-2737
+// inverse: nb transposed dequantised blocks in r2 ([blk][x][i], i16) -> residuals r1 ([blk][y][x]).  The
+// intermediate V takes the place of the levels in r1 (dead once dequantised) and the second stage runs in
+// place: a row of V is read whole by the 2^LG lanes that then write that row, and no other lane touches it.
+// transformer.rs:2380-2737
 template <int LG>
 __device__ void inv_dct(Ctx c, int nb, int o1) {
     constexpr int N = 1 << LG;
@@ -75,7 +86,7 @@ __device__ void inv_dct(Ctx c, int nb, int o1) {
     const int u = LANE & (N - 1);
     const int g = LANE >> LG;
     const int16_t* dqt = (const int16_t*)SH.r2;
-    int16_t* vbuf = (int16_t*)SH.r2 + 1024;
+    int16_t* vbuf = SH.r1 + o1;
     uint32_t t[N / 2]; // Tt[u][i] = T_N[i][u]
     {
         const CONST_AS uint32_t* src = (const CONST_AS uint32_t*)&c.k->dct_t[LG - 2][u][0];
@@ -99,10 +110,14 @@ __device__ void inv_dct(Ctx c, int nb, int o1) {
 #pragma unroll 1
     for (int yy = g; yy < nb * N; yy += G) {
         const uint32_t* row = (const uint32_t*)&vbuf[yy * N];
+        uint32_t rv[N / 2];
+#pragma unroll
+        for (int k = 0; k < N / 2; ++k) rv[k] = row[k];
+        WSYNC(); // the whole row is in registers before any lane overwrites an element of it
         int acc = 0;
 #pragma unroll
-        for (int k = 0; k < N / 2; ++k) acc = dot2(row[k], t[k], acc);
-        SH.r1[o1 + yy * N + u] = (int16_t)((acc + 2048) >> 12);
+        for (int k = 0; k < N / 2; ++k) acc = dot2(rv[k], t[k], acc);
+        vbuf[yy * N + u] = (int16_t)((acc + 2048) >> 12);
     }
     WSYNC();
 }
@@ -193,19 +208,17 @@ __device__ __forceinline__ void fwd_dct_lg(Ctx c, int lg, int nb, int o1 = 0) {
     lg = uni(lg);
     nb = uni(nb);
     o1 = uni(o1);
+    LDS_AS int32_t* h = (LDS_AS int32_t*)SH.r2;
+    constexpr int HB = (int)sizeof(SH.r2);
     switch (lg) {
-    case 2: fwd_dct<2>(c, nb, o1); break;
-    case 3: fwd_dct<3>(c, nb, o1); break;
-    case 4: fwd_dct<4>(c, nb, o1); break;
+    case 2: fwd_dct<2, HB>(c, nb, o1, h); break;
+    case 3: fwd_dct<3, HB>(c, nb, o1, h); break;
+    case 4: fwd_dct<4, HB>(c, nb, o1, h); break;
     default:
         // 32x32 (always a single luma block): the i8-MFMA version, kept on measurement (3.6x in the
-        // micro-benchmark, +5.6 % frames/s at max-split-depth 0, +0.9 % at depth 2).  -DWRENC_DCT32_VDOT2 builds
-        // the v_dot2 / v_mad_i24 version instead (the comparison arm).
-#ifdef WRENC_DCT32_VDOT2
-        fwd_dct<5>(c, nb, o1);
-#else
+        // micro-benchmark, +5.6 % frames/s at max-split-depth 0, +0.9 % at depth 2); its intermediate stays in the
+        // accumulators, which is what lets r2 be 2 KB.
         fwd_dct32_mfma(c, o1);
-#endif
         break;
     }
 }

@@ -27,7 +27,7 @@ using namespace wrenc;
 // kernels
 // ---------------------------------------------------------------------------
 // scratch regions for resident workgroups (>= 2 per CU x 256 CUs; 32 bitmap words of 64)
-constexpr int kScratchSlots = 2048;
+constexpr int kScratchSlots = 16384 / WPB; // >= the workgroups resident at once (a power of two, >= 64)
 
 // Per-workgroup global scratch comes from a pool of kScratchSlots regions handed out through a
 // bitmap: the pool covers the workgroups that can be resident at once (2 per CU), not the ones
@@ -38,7 +38,7 @@ constexpr int kScratchSlots = 2048;
 // two workgroups of a CU fill its 160 KB of LDS to the byte.)
 __device__ __forceinline__ int acquire_scratch(unsigned long long* slot_map) {
     if (threadIdx.x == 0) {
-        unsigned w = (blockIdx.x * 2654435761u) >> (32 - 5); // start word, 0 .. kScratchSlots / 64 - 1
+        unsigned w = ((blockIdx.x * 2654435761u) >> 16) & (kScratchSlots / 64 - 1); // start word
         int slot = -1;
         while (slot < 0) {
             const unsigned long long cur = __hip_atomic_load(&slot_map[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -85,7 +85,7 @@ __global__ __launch_bounds__(64) void retile_kernel(const uint8_t* __restrict__ 
 }
 
 // Wave schedule: one workgroup = the same CTU of WPB consecutive pictures, one wave each.
-__global__ __launch_bounds__(64 * WPB, 4) void ctu_search_kernel(const DevConst* __restrict__ k,
+__global__ __launch_bounds__(64 * WPB, 5) void ctu_search_kernel(const DevConst* __restrict__ k,
                                                               const PicBufs* __restrict__ slots, int first_slot,
                                                               int n_pictures, int diag, int r_min, int count,
                                                               uint8_t* pred_scratch, unsigned long long* slot_map,
@@ -117,13 +117,13 @@ __global__ __launch_bounds__(64 * WPB, 4) void ctu_search_kernel(const DevConst*
 
 // Team schedule: one workgroup = the same CTU of WPB / kTeam consecutive pictures, kTeam waves each
 // (dev_search.h, leaf_step_team).  For encode calls with too few pictures to fill the GPU one wave per CTU.
-__global__ __launch_bounds__(64 * WPB, 4) void ctu_search_team_kernel(const DevConst* __restrict__ k,
+__global__ __launch_bounds__(64 * WPB, 5) void ctu_search_team_kernel(const DevConst* __restrict__ k,
                                                                    const PicBufs* __restrict__ slots, int first_slot,
                                                                    int n_pictures, int diag, int r_min, int count,
                                                                    uint8_t* pred_scratch, unsigned long long* slot_map,
                                                                    unsigned long long* mismatch, int* overflow) {
     const int scratch_slot = acquire_scratch(slot_map);
-    constexpr int kTeams = WPB / kTeam;
+    constexpr int kTeams = WPB >= kTeam ? WPB / kTeam : 1; // (WPB < kTeam: occupancy experiments, wave schedule only)
     const int group = blockIdx.x / count;
     const int j = blockIdx.x - group * count;
     const int row = r_min + j;
@@ -162,6 +162,7 @@ __global__ __launch_bounds__(64) void test_fwd_dct_kernel(const DevConst* __rest
 
 // MFMA experiment: the 32x32 forward transform as i8 MFMAs (dev_transform.h); `reps` repeats the transform
 // of the same block in place for the micro-benchmark (the result of the last repetition is stored)
+__shared__ int32_t s_h32[33 * 32]; // the v_dot2 arm's i32 intermediate (the search kernel has no such room)
 __global__ __launch_bounds__(64) void test_fwd_dct32_kernel(const DevConst* __restrict__ k, const int16_t* in, int16_t* out,
                                                            int mfma, int reps) {
     Ctx c = {};
@@ -172,7 +173,7 @@ __global__ __launch_bounds__(64) void test_fwd_dct32_kernel(const DevConst* __re
         if (mfma)
             fwd_dct32_mfma(c, 0);
         else
-            fwd_dct<5>(c, 1, 0);
+            fwd_dct<5, (int)sizeof(s_h32)>(c, 1, 0, (LDS_AS int32_t*)s_h32);
     }
     for (int i = threadIdx.x; i < 1024; i += 64) out[(size_t)blockIdx.x * 1024 + i] = SH.r1[i];
 }
@@ -786,6 +787,7 @@ int wrenc_gpu_encode(wrenc_gpu_ctx* ctx, int first_slot, int n_pictures) {
     // Pictures are dealt to lanes in units of WPB (the wave schedule's workgroup) whatever the schedule, so a
     // picture stays on one stream; a team launch covers its lane's pictures in groups of WPB / kTeam.
     const int per_group = WPB;
+    constexpr int kTeamsPerGroup = WPB >= kTeam ? WPB / kTeam : 1;
     const int total_groups = (n_pictures + per_group - 1) / per_group;
     int n_team_diags = 0, n_wave_diags = 0;
     const int n_lanes = total_groups < kEncodeLanes ? total_groups : kEncodeLanes;
@@ -838,7 +840,7 @@ int wrenc_gpu_encode(wrenc_gpu_ctx* ctx, int first_slot, int n_pictures) {
             hipStream_t st = l == 0 ? ctx->stream : ctx->lanes[l - 1];
             if (timed) HIP_TRY(ctx, hipEventRecord(ctx->ev_pool[2 * launches], st));
             if (team)
-                hipLaunchKernelGGL(ctu_search_team_kernel, dim3(count * ((lane_pics + WPB / kTeam - 1) / (WPB / kTeam))),
+                hipLaunchKernelGGL(ctu_search_team_kernel, dim3(count * ((lane_pics + kTeamsPerGroup - 1) / kTeamsPerGroup)),
                                    dim3(64 * WPB), 0, st, ctx->d_const,
                                    ctx->d_slots, lane_first, lane_pics, d, r_min, count, ctx->d_pred_scratch,
                                    ctx->d_slot_map, ctx->d_mismatch, ctx->d_overflow);
