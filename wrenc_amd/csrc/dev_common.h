@@ -318,7 +318,7 @@ struct Ctx {
 // by the workgroup.  File scope so that every access is a DS instruction (no FLAT ops).
 // The waves of a workgroup process the SAME CTU position of WPB different pictures, so
 // they execute the same schedule; the 4-lane Viterbi of all WPB transform blocks is run by
-// wave 0 in WPB quads at once (see quantize()).
+// one wave in WPB quads at once (see quantize()).
 #ifndef WRENC_WPB
 #define WRENC_WPB 4
 #endif

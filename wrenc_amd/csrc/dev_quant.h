@@ -420,7 +420,8 @@ __device__ __forceinline__ long long quantize(Ctx c, int lg, int nb, bool shared
 // quads of one wave).
 // Scratch: r2 = [scan-order coefficients | chroma chunk entries], r1 = luma chunk entries (the coefficients are
 // dead after the gather and every level is written at the end, as in quantize()), decw.
-__device__ __forceinline__ void quantize3(Ctx c, int lg0, bool active, int* overflow, long long* lvl_y,
+// shared == false: the wave walks its own three blocks in quads 0..2, no workgroup barrier (as in quantize()).
+__device__ __forceinline__ void quantize3(Ctx c, int lg0, bool shared, bool active, int* overflow, long long* lvl_y,
                                           long long* lvl_c, bool* any_y, bool* any_c) {
     static_assert(WPB <= 8, "a walker wave has 16 quads; walker_wave() + 1 must stay below WPB");
     c = uni(c);
@@ -469,7 +470,8 @@ __device__ __forceinline__ void quantize3(Ctx c, int lg0, bool active, int* over
         istar2 = wave_min_i32(first2);
         any_nz = __ballot(nzl != 0) != 0ULL;
     }
-    const int fcell = zero_flag_cell();
+    if (!shared && !any_nz) return; // solo call on three zero blocks (or an inactive wave): nothing to walk
+    const int fcell = shared ? zero_flag_cell() : 0;
     if (LANE == 0) {
         SH.q_istar[fcell] = any_nz ? 1 : 0;
         SH.q_active = (active && any_nz) ? 1 : 0;
@@ -480,12 +482,13 @@ __device__ __forceinline__ void quantize3(Ctx c, int lg0, bool active, int* over
     const int st = LANE & 3;
     const int cls = st == 0 ? 0 : (st == 1 ? 1 : 2);
     // walker quads: global quad gq = 16 * (walker wave) + LANE / 4 walks block kind gq / WPB of wave gq % WPB
+    // (solo: quad gq walks block kind gq of this wave)
     constexpr int kWalkers = (3 * WPB + 15) / 16;
-    const int wv = (WAVE - walker_wave()) & (WPB - 1); // 0 .. kWalkers - 1: the walker waves
+    const int wv = shared ? ((WAVE - walker_wave()) & (WPB - 1)) : 0; // 0 .. kWalkers - 1: the walker waves
     const int gq = 16 * wv + (LANE >> 2);
-    const int wb = min(gq / WPB, 2);
-    const bool walker = wv < kWalkers && gq < 3 * WPB;
-    const Lds* tb = &SHW[gq % WPB];
+    const int wb = min(shared ? gq / WPB : gq, 2);
+    const bool walker = shared ? (wv < kWalkers && gq < 3 * WPB) : (gq < 3);
+    const Lds* tb = shared ? &SHW[gq % WPB] : &SH;
     const int32_t* wcc = wb == 0 ? (const int32_t*)tb->r1
                                  : (const int32_t*)((const char*)tb->r2 + kCcByte) + (wb == 1 ? 0 : 16) * 6;
     uint16_t* wdec = (uint16_t*)const_cast<uint32_t*>(tb->decw) + (wb == 0 ? 0 : (wb == 1 ? (P0 >> 2) : (P0 >> 2) + (Pc >> 2)));
@@ -527,13 +530,16 @@ __device__ __forceinline__ void quantize3(Ctx c, int lg0, bool active, int* over
             }
         }
         PROF_MARK(qb1_);
-        __syncthreads();
+        if (shared)
+            __syncthreads();
+        else
+            WSYNC();
         PROF_MARK(qb2_);
-        if (ch == 0) { // zero blocks in every wave of the workgroup: see quantize()
+        if (shared && ch == 0) { // zero blocks in every wave of the workgroup: see quantize()
             const bool wg_nz = __ballot(LANE < WPB && SHW[LANE < WPB ? LANE : 0].q_istar[fcell] != 0) != 0ULL;
             if (!wg_nz) break;
         }
-        if (walker && tb->q_active) {
+        if (walker && (!shared || tb->q_active)) {
             for (int sbi = wnsb - 1; sbi >= 0; --sbi) { // one 4x4 sub-block per iteration
                 const int g16 = sbi * 16;
                 const uint16_t* pm = tb->q_pm[wb][sbi];
@@ -564,7 +570,7 @@ __device__ __forceinline__ void quantize3(Ctx c, int lg0, bool active, int* over
             }
         }
         PROF_MARK(qb3_);
-        __syncthreads();
+        if (shared) __syncthreads();
         PROF_MARK(qb4_);
         PROF_ADD2(PH_QB_PRE, qb0_, qb1_);
         PROF_ADD2(PH_QB_WAIT1, qb1_, qb2_);

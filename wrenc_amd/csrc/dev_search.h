@@ -254,17 +254,17 @@ __device__ __forceinline__ Res evaluate(const Ctx& c, const PicBufs& pb, const R
     }
     if (q.kind == K_FULL || q.kind == K_CCLMSEARCH) {
         // A candidate of the search with an 8x8 or 16x16 luma block quantises its three transform
-        // blocks in one pooled pass (quantize3): both components go through the first half, then
+        // blocks in one pass (quantize3, pooled or not): both components go through the first half, then
         // the pass, then both through the second half.  Everything else runs component by component
         // (the two share r1 / r2).  One copy of each stage either way.
-        // Pooling the Viterbi walk of the workgroup's 8 blocks pays for long walks; a block of few positions walks
+        // Pooling the Viterbi walk of the workgroup's WPB blocks pays for long walks; a block of few positions walks
         // faster alone than the two workgroup barriers per chunk cost (WRENC_POOL_MIN_TLG: smallest CU size, log2,
         // whose transform blocks are pooled; every wave of the workgroup evaluates the same size, so they agree)
         const bool pooled = q.shared && q.tlg >= WRENC_POOL_MIN_TLG;
         #ifdef WRENC_EXP_NO_MERGED
         const bool merged = false;
 #else
-        const bool merged = pooled && q.comps == 3 && q.tlg <= 4;
+        const bool merged = !q.final && q.comps == 3 && q.tlg >= 3 && q.tlg <= 4; // (pooled or not)
 #endif
         const int p0 = 1 << (2 * q.tlg);
         const int rounds = merged ? 1 : 2;
@@ -280,7 +280,7 @@ __device__ __forceinline__ Res evaluate(const Ctx& c, const PicBufs& pb, const R
             PROF_MARK(ts0_);
             bool any_y = false, any_c = false;
             if (merged) {
-                quantize3(c, q.tlg, q.active, overflow, &r.lvl_y, &r.lvl_c, &any_y, &any_c);
+                quantize3(c, q.tlg, pooled, q.active, overflow, &r.lvl_y, &r.lvl_c, &any_y, &any_c);
             } else {
                 bool any = false;
                 const long long lvl = quantize(c, q.tlg - round, round ? 2 : 1, pooled, q.active, overflow, &any);

@@ -1,11 +1,13 @@
 // wrenc_dev.h -- CDNA4 (gfx950) device code of the all-intra RD-search path.
 //
-// Execution model: ONE 64-lane wavefront owns one 32x32 CTU; a workgroup is WPB = 8 waves working on
-// the SAME CTU position of 8 different pictures, so the waves make the same sequence of full
+// Execution model: ONE 64-lane wavefront owns one 32x32 CTU; a workgroup is WPB = 4 waves working on
+// the SAME CTU position of 4 different pictures, so the waves make the same sequence of full
 // evaluations and pool their one serial stage (the Viterbi walk) in one wave.  A wave keeps its
 // working set in LDS (transform buffers, cached reference samples, the reconstruction tile with its
-// neighbour border, trellis decisions, decision maps, search state: 9.9 KB); originals are read from
-// the picture (L1 / L2), saved reconstructions live in a small pool of global scratch.  Search control
+// neighbour border, trellis decisions, decision maps, search state: 7.2 KB, sized so that five workgroups
+// = 20 waves fit a CU: the kernel is latency-bound per wave and its throughput follows the waves in
+// flight); originals come from the picture's CTU tile (L1 / L2) or a staged copy in LDS, saved
+// reconstructions live in a small pool of global scratch.  Search control
 // is a scalar state machine that hands evaluation requests to one inlined evaluator: no device function
 // calls, no scratch, every branch scalar.
 //

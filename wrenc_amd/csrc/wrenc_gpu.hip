@@ -30,12 +30,11 @@ using namespace wrenc;
 constexpr int kScratchSlots = 16384 / WPB; // >= the workgroups resident at once (a power of two, >= 64)
 
 // Per-workgroup global scratch comes from a pool of kScratchSlots regions handed out through a
-// bitmap: the pool covers the workgroups that can be resident at once (2 per CU), not the ones
+// bitmap: the pool covers the workgroups that can be resident at once (kWorkgroupsPerCU per CU), not the ones
 // of a launch, so the scratch that is live stays small enough to live in L2 / Infinity Cache
 // whatever the batch size.  A slot is only ever used by one workgroup at a time and nothing is
 // read that the same workgroup did not write, so its contents need no hand-over.
-// (The slot number travels through a cell of wave 0's LDS that the search only uses later: the
-// two workgroups of a CU fill its 160 KB of LDS to the byte.)
+// (The slot number travels through a cell of wave 0's LDS that the search only uses later.)
 __device__ __forceinline__ int acquire_scratch(unsigned long long* slot_map) {
     if (threadIdx.x == 0) {
         unsigned w = ((blockIdx.x * 2654435761u) >> 16) & (kScratchSlots / 64 - 1); // start word
@@ -283,8 +282,12 @@ thread_local std::string g_create_error;
 // the other lanes' work.
 constexpr int kEncodeLanes = 4;
 
-// AUTO picks the team schedule while (CTUs runnable side by side) x kTeam stays below this many waves
-constexpr long long kTeamBelowWaves = 7680;
+
+// AUTO picks the team schedule for an anti-diagonal while one wave per CTU would leave more than half of the
+// GPU's wave slots empty (slots: CUs x kWorkgroupsPerCU x WPB = 5120 on an MI355X).  Measured (DESIGN.md section 5,
+// gpurun_out/r3b): threshold at 25 / 50 / 75 / 100 % of the slots gives 282 / 306 / 270 / 269 frames/s at 1080p depth 2
+// with 128 pictures, 54.4 / 55.9 / 53.8 / 48.9 at 3840x2176 depth 3 with 128; 50 % is best at every batch size tried.
+constexpr int kTeamBelowSlotsPct = 50;
 
 // DCT-2 integer cosines c[j] ~ 64*sqrt(2)*cos(j*pi/128), H.266 8.7.4.5
 // (the reference's 64-point matrix, transformer.rs:934-1191, is row k = c[(2n+1)k])
@@ -337,6 +340,7 @@ void diag_scan(int lw, int lh, uint8_t (*out)[2]) { // ctu.rs:54-77
 
 struct wrenc_gpu_ctx {
     wrenc_gpu_config cfg;
+    long long wave_slots = 0;                  // waves of the search kernel the device holds at once
     hipStream_t stream = nullptr;              // lane 0 of the encode; timing events
     hipStream_t copy_stream = nullptr;         // uploads and downloads: they overlap the search of other slots
     hipEvent_t ev_uploaded = nullptr;          // end of the uploads an encode call has to wait for
@@ -664,6 +668,7 @@ int wrenc_gpu_create(const wrenc_gpu_config* cfg, wrenc_gpu_ctx** out) {
     wrenc_gpu_ctx* ctx = new (std::nothrow) wrenc_gpu_ctx();
     if (!ctx) return fail(nullptr, WRENC_GPU_ENOMEM, "out of host memory");
     ctx->cfg = *cfg;
+    ctx->wave_slots = (long long)prop.multiProcessorCount * kWorkgroupsPerCU * WPB;
     ctx->ctu_cols = cfg->width / 32;
     ctx->ctu_rows = cfg->height / 32;
     auto bail = [&](int code, const std::string& msg) {
@@ -782,8 +787,7 @@ int wrenc_gpu_encode(wrenc_gpu_ctx* ctx, int first_slot, int n_pictures) {
     const int ndiag = cols + 2 * (rows - 1);
     // Which schedule, decided PER ANTI-DIAGONAL: one wave per CTU fills the GPU only with thousands of CTUs
     // runnable side by side (pictures x CTUs of the diagonal); below that a team of kTeam waves per CTU
-    // shortens the CTU's chain of dependent evaluations instead.  kTeamBelowWaves: measured crossover
-    // (DESIGN.md).  The thin first and last diagonals of a big batch run as teams, its wide ones as waves.
+    // shortens the CTU's chain of dependent evaluations instead (kTeamBelowSlotsPct above).  The thin first and last diagonals of a big batch run as teams, its wide ones as waves.
     // Pictures are dealt to lanes in units of WPB (the wave schedule's workgroup) whatever the schedule, so a
     // picture stays on one stream; a team launch covers its lane's pictures in groups of WPB / kTeam.
     const int per_group = WPB;
@@ -829,7 +833,8 @@ int wrenc_gpu_encode(wrenc_gpu_ctx* ctx, int first_slot, int n_pictures) {
         const int count = r_max - r_min + 1;
         if (count <= 0) continue;
         const bool team = ctx->schedule == WRENC_GPU_SCHEDULE_TEAM ||
-                          (ctx->schedule == WRENC_GPU_SCHEDULE_AUTO && (long long)n_pictures * count * kTeam <= kTeamBelowWaves);
+                          (ctx->schedule == WRENC_GPU_SCHEDULE_AUTO &&
+                           (long long)n_pictures * count * 100 <= ctx->wave_slots * kTeamBelowSlotsPct);
         ++(team ? n_team_diags : n_wave_diags);
         for (int l = 0; l < n_lanes; ++l) {
             const int g0 = (int)((long long)total_groups * l / n_lanes), g1 = (int)((long long)total_groups * (l + 1) / n_lanes);
