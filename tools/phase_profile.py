@@ -38,7 +38,8 @@ enc.sync()
 dt = time.time() - t0
 enc.lib.wrenc_gpu_prof_read(enc.ctx, out, N)
 tot = out[8]
-groups = (B + 7) // 8 if schedule == 1 else (B + 1) // 2
+WPB, TEAM = 4, 4  # wrenc_amd/csrc/dev_common.h
+groups = (B + WPB - 1) // WPB if schedule == 1 else (B + WPB // TEAM - 1) // (WPB // TEAM)
 nctu = groups * (w // 32) * (h // 32)       # one profiled wave per workgroup
 print("%dx%d depth %d B %d schedule %d: wall %.3f s, fps %.2f, ticks per profiled CTU-wave %.0f" % (w, h, depth, B, schedule, dt, B / dt, tot / nctu))
 for i, n in enumerate(names):
