@@ -526,6 +526,92 @@ __device__ __forceinline__ int predict(Ctx c, int comp, int tx, int ty, int tlg,
     return sad;
 }
 
+// Prediction of up to four CANDIDATES of one 4x4 luma block at once (the packed 4x4 leaf search, dev_search.h
+// K_LEAF4): candidate s = lanes 16 s .. 16 s + 15, lane = (s, sample); `mode` is the lane's candidate mode
+// (PLANAR, DC or 2..66; kNoMode lanes compute nothing).  Same arithmetic as predict() for comp 0, tlg 2 (a block of
+// 16 samples never uses the filtered references); the projected main reference of an angular candidate is built
+// by the candidate's own 16 lanes into tab4 (16 bytes per candidate, in r2 below kOrgLeaf).  build_refs(c, 0, ..)
+// must have run.  Returns the predicted sample.
+constexpr int kTab4Byte = 1280; // byte offset in r2: 4 x 16 bytes + 4 of slack for the last dword pair
+__device__ __forceinline__ int predict4_lane(const Ctx& c, int mode) {
+    constexpr int n = 4, lg = 2;
+    const int s = LANE >> 4, i = LANE & 15;
+    const int x = i & 3, y = i >> 2;
+    const ref_t* L = SH.refs + R_L0; // index 0 = corner
+    const ref_t* A = SH.refs + R_A0;
+    uint8_t* tab = (uint8_t*)SH.r2 + kTab4Byte;
+    const bool ang = mode >= 2 && mode <= 66;
+    int angle = 0, inv_angle = 0;
+    bool vertical = false;
+    if (ang) {
+        const int at = c.k->ang_tab[mode];
+        angle = (int)(int16_t)(at & 0xFFFF);
+        inv_angle = at >> 16;
+        vertical = mode >= 34;
+        // entry ee of the candidate's table = ref[ee - n] (intra_predictor.rs:1311-1420), see predict()
+        const int idx = i - n;
+        const int k = idx >= 0 ? min(idx, 2 * n) : max(min((M24(idx, inv_angle) + 256) >> 9, n), 0);
+        const bool from_above = (idx >= 0) == vertical;
+        tab[16 * s + i] = (uint8_t)((k == 0 ? L[0] : (from_above ? A[k - 1] : L[k])) ^ 0x80);
+    }
+    WSYNC();
+    int v = 0;
+    if (mode == PLANAR || mode == DC) {
+        if (mode == PLANAR) {
+            const int pv = M24(n - 1 - y, A[x]) + M24(y + 1, L[n + 1]);
+            const int ph = M24(n - 1 - x, L[y + 1]) + M24(x + 1, A[n]);
+            v = ((pv + ph + n) >> (lg + 1)) & 0xFF;
+        } else {
+            v = ((A[0] + A[1] + A[2] + A[3] + L[1] + L[2] + L[3] + L[4] + n) >> (lg + 1)) & 0xFF; // `as u8`
+        }
+        const int wl = pdpc_w(0, x), wt = pdpc_w(0, y); // n_scale = (2 * lg - 2) >> 2 = 0
+        v = (int16_t)(M24(L[y + 1], wl) + M24(A[x], wt) + M24(64 - wt - wl, v) + 32) >> 6;
+        v = min(max(v, 0), 255);
+    } else if (ang) {
+        bool filter_flag = false;
+        if (!(mode == 2 || mode == 34 || mode == 66)) filter_flag = min(abs(mode - 50), abs(mode - 18)) > 24; // lg == 2
+        int n_scale;
+        if (mode > 50 || mode < 18)
+            n_scale = min(lg - ilog2i(3 * inv_angle - 2) + 8, 2);
+        else
+            n_scale = (2 * lg - 2) >> 2;
+        const int along = vertical ? y : x, across = vertical ? x : y;
+        const int i_idx = M24(along + 1, angle) >> 5;
+        const int i_fact = M24(along + 1, angle) & 31;
+        const int ta = 16 * s + n + across + i_idx; // taps = ref[across + i_idx + 0..3]
+        const uint32_t* tp = (const uint32_t*)(tab + (ta & ~3));
+        const int taps = (int)__builtin_amdgcn_alignbyte(tp[1], tp[0], ta & 3);
+        const int w = filter_flag ? 0x00102010 + (i_fact >> 1) * 0x0100FEFF : *(const int*)&SHT.fc[i_fact][0];
+        v = min(max(__builtin_amdgcn_sdot4(w, taps, 8192 + 32, false) >> 6, 0), 255);
+        if (mode <= 18 || mode >= 50) { // PDPC, intra_predictor.rs:355-757; left[] = L+1, above[] = A
+            int rl = 0, rt = 0, wl = 0, wt = 0;
+            bool on = true;
+            if (mode == 18 || mode == 50) {
+                const int alrs = L[0];
+                rl = (int16_t)(L[y + 1] - alrs + v);
+                rt = (int16_t)(A[x] - alrs + v);
+                wl = mode == 50 ? pdpc_w(n_scale, x) : 0;
+                wt = mode == 18 ? pdpc_w(n_scale, y) : 0;
+            } else if (mode < 18 && n_scale >= 0) {
+                const int dx_int = (M24(y + 1, inv_angle) + 256) >> 9;
+                rt = y < (3 << n_scale) ? A[x + dx_int] : 0;
+                wt = pdpc_w(n_scale, y);
+            } else if (mode > 50 && n_scale >= 0) {
+                const int dy_int = (M24(x + 1, inv_angle) + 256) >> 9;
+                rl = x < (3 << n_scale) ? L[1 + y + dy_int] : 0;
+                wl = pdpc_w(n_scale, x);
+            } else {
+                on = false;
+            }
+            if (on) {
+                v = (int16_t)(M24(rl, wl) + M24(rt, wt) + M24(64 - wt - wl, v) + 32) >> 6;
+                v = min(max(v, 0), 255);
+            }
+        }
+    }
+    return v;
+}
+
 // SADs of the three CCLM modes of a chroma pair (get_chroma_intra_pred_aux_cost of LT_CCLM, T_CCLM,
 // L_CCLM, block_splitter.rs:476-522, 847-854): the down-sampled luma of a sample is the same for
 // the three modes, so it is computed once and the three linear models are applied to it.

@@ -648,6 +648,125 @@ __device__ __forceinline__ void quantize3(Ctx c, int lg0, bool shared, bool acti
     PROF_ADD2(PH_QTRACE, q2_, q3_);
 }
 
+// Dependent quantisation of nb <= 4 luma blocks of 4x4 at once (the candidates of a packed 4x4 leaf search,
+// dev_search.h K_LEAF4): block b = lanes 16 b .. 16 b + 15, one lane per position, one quad walks each block's
+// 16 positions (a single chunk: no barrier of any kind).  Same algorithm and arithmetic as quantize(); block b's
+// level cost (block_splitter.rs:436-458) comes back in lvl[b], "has a non-zero level" in bit b of *any_mask.
+// Coefficients r1[16 b ..] -> levels in place (a lane keeps its coefficient in a register).  Scratch: r1 chunk
+// entries, decw.
+__device__ __forceinline__ void quantize_p16(Ctx c, int nb, int* overflow, long long lvl[4], int* any_mask) {
+    c = uni(c);
+    nb = uni(nb);
+    const CONST_AS DevConst* k = c.k;
+    constexpr int P = 16, lg = 2;
+    constexpr int sh = 8 + lg - 5 + 1; // quantizer.rs:558-569
+    constexpr int off = (1 << sh) >> 1;
+    const int lsc = k->lsc;
+    const CONST_AS uint16_t* scan = k->scan_idx[0];
+    int32_t* cc = (int32_t*)SH.r1;
+    PROF_MARK(q0_);
+    const int blk = LANE >> 4, p = LANE & 15;
+    const bool mine = blk < nb;
+    int tc = 0, qd = 0;
+    if (mine) {
+        tc = SH.r1[blk * P + scan[p]];
+        qd = quotient(k, tc, sh, off);
+    }
+    const int istar = row_min_i32((tc != 0 && (qd >> 1) > 0) ? p : P); // of this lane's block
+    const unsigned long long nzb = __ballot(tc != 0);
+    lvl[0] = lvl[1] = lvl[2] = lvl[3] = 0;
+    *any_mask = 0;
+    if (nzb == 0ULL) return; // every block is zero: the levels are the zero coefficients already in r1
+    PROF_MARK(q1_);
+    PROF_ADD2(PH_QPRE, q0_, q1_);
+    WSYNC(); // every lane has its coefficient before the chunk entries overwrite r1
+    const int ldq1 = (int)ldq_at(c, 1);
+    int ovf = 0;
+    {
+        int par0 = 0, par1 = 0, adj = 0;
+        if (mine) chunk_entry(c, cc + LANE * 6, tc, qd, p == P - 1, p <= istar, sh, off, lsc, ldq1, &par0, &par1, &adj, &ovf);
+        const unsigned long long b0 = __ballot(mine && par0), b1 = __ballot(mine && par1), ba = __ballot(mine && adj);
+        if (mine && p == 0) {
+            uint16_t* pm = SH.q_pm[0][blk];
+            pm[0] = (uint16_t)(b0 >> LANE);
+            pm[1] = (uint16_t)(b1 >> LANE);
+            pm[2] = (uint16_t)((ba >> (LANE + 15)) & 1);
+        }
+    }
+    WSYNC();
+    PROF_MARK(qb1_);
+    uint16_t* dec16 = (uint16_t*)SH.decw;
+    {
+        const int st = LANE & 3, quad = LANE >> 2;
+        if (quad < nb) {
+            const int cls = st == 0 ? 0 : (st == 1 ? 1 : 2);
+            const int32_t* wcc = cc + quad * P * 6;
+            const uint16_t* pm = SH.q_pm[0][quad];
+            const unsigned parmask = pm[st > 1 ? 1 : 0];
+            const bool adj = st == 0 && pm[2] != 0;
+            int2 cur[16];
+#pragma unroll
+            for (int kk = 0; kk < 16; ++kk) cur[kk] = *(const int2*)&wcc[kk * 6 + 2 * cls];
+            unsigned bits = 0;
+            int C = 0;
+#pragma unroll
+            for (int kk = 15; kk >= 0; --kk) {
+                const int2 e = cur[kk];
+                const int KA = e.x + dpp_quad<0xD8>(C); // C[trans[s][0]]: quad_perm [0,2,1,3]
+                const int KB = e.y + dpp_quad<0x72>(C); // C[trans[s][1]]: quad_perm [2,0,3,1]
+                C = min(KA, KB) & ~1;
+                bits = shift_in_less(bits, KB, KA);
+                if (kk == 15) { // first position of a sub-block in coding order (:512-514)
+                    const bool choseB = KB < KA;
+                    const bool pick1 = choseB != (((parmask >> 15) & 1) != 0);
+                    if (!pick1 && adj) C -= 2 * ldq1;
+                }
+            }
+            bits ^= parmask; // choseB -> pick1
+            dec16[quad * 4 + st] = (uint16_t)bits;
+        }
+    }
+    WSYNC();
+    PROF_MARK(q2_);
+    PROF_ADD2(PH_QBACK, q1_, q2_);
+    PROF_ADD2(PH_QB_WALK, qb1_, q2_);
+    // ---- forward trace from state 0 (quantizer.rs:686-721) + level cost, one position per lane ----
+    const DecMasks dm = dec_masks(dec16 + blk * 4, 0);
+    const int nib = dec_nib(dm, p);
+    int pre = mine ? position_map(tc, qd, p == P - 1, nib) : kMapId;
+    pre = compose_map(pre, __builtin_amdgcn_update_dpp(kMapId, pre, 0x111, 0xF, 0xF, false)); // row_shr:1
+    pre = compose_map(pre, __builtin_amdgcn_update_dpp(kMapId, pre, 0x112, 0xF, 0xF, false)); // row_shr:2
+    pre = compose_map(pre, __builtin_amdgcn_update_dpp(kMapId, pre, 0x114, 0xF, 0xF, false)); // row_shr:4
+    pre = compose_map(pre, __builtin_amdgcn_update_dpp(kMapId, pre, 0x118, 0xF, 0xF, false)); // row_shr:8
+    int entry = __builtin_amdgcn_update_dpp(0, pre, 0x111, 0xF, 0xF, false) & 3; // state after the previous lane of the row
+    if (p == 0) entry = 0;
+    long long sum_nz = 0;
+    unsigned zmask = 0;
+    int fnz = P;
+    if (mine) {
+        int state = entry;
+        SH.r1[blk * P + scan[p]] = (int16_t)emit_level(c, tc, qd, p == P - 1, nib, p, 0, state, zmask, sum_nz, fnz, ovf);
+    }
+    const int pf = row_min_i32(fnz); // zeros before a block's first non-zero level cost nothing
+    if (mine && (zmask & 1u) && p > pf) sum_nz += SHT.lv[0];
+    {
+        const long long hi = sum_nz >> 24;
+        const int ra = row_sum_i32((int)(sum_nz & 0xFFFFFF)), rb = row_sum_i32((int)(hi & 0xFFFFFF)), rc = row_sum_i32((int)(hi >> 24));
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const long long a0 = (long long)(unsigned)__builtin_amdgcn_readlane(ra, 16 * b);
+            const long long a1 = (long long)(unsigned)__builtin_amdgcn_readlane(rb, 16 * b);
+            const long long a2 = (long long)__builtin_amdgcn_readlane(rc, 16 * b);
+            lvl[b] = a0 + ((a1 + (a2 << 24)) << 24);
+            if (__builtin_amdgcn_readlane(pf, 16 * b) < P) *any_mask |= 1 << b;
+        }
+    }
+    if (__ballot(ovf != 0) != 0ULL) *overflow = 1;
+    WSYNC();
+    PROF_MARK(q3_);
+    PROF_ADD2(PH_QTRACE, q2_, q3_);
+}
+
 // levels r1 (row-major) -> transposed dequantised coefficients in r2 (dT[x][i] = d[i][x]);
 // quantizer.rs:761-1079
 __device__ __forceinline__ void dequantize_t(Ctx c, int lg, int nb, int o1 = 0) {
