@@ -177,6 +177,10 @@ int wrenc_gpu_test_inv_dct(wrenc_gpu_ctx* ctx, const int16_t* deq, int log2n, in
 int wrenc_gpu_test_quantize(wrenc_gpu_ctx* ctx, const int16_t* coef, int log2n, int count,
                             int16_t* levels, int64_t* level_cost);      /* quantizer.rs:519 +
                                                                            block_splitter.rs:415-460 */
+/* The same quantiser as the packed 4x4 leaf search runs it: `count` 4x4 blocks, up to four per wavefront at once
+ * (quantizer.rs:519 + block_splitter.rs:415-460; wrenc_amd/csrc/dev_quant.h quantize_p16). */
+int wrenc_gpu_test_quantize_p16(wrenc_gpu_ctx* ctx, const int16_t* coef, int count, int16_t* levels,
+                                int64_t* level_cost);
 int wrenc_gpu_test_dequantize(wrenc_gpu_ctx* ctx, const int16_t* levels, int log2n, int count,
                               int16_t* deq);                            /* quantizer.rs:761 */
 

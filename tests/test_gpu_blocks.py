@@ -77,6 +77,39 @@ def test_quantize_trellis(enc, n):
         assert int(cost[i]) == po.level_cost(ref), (n, i)
 
 
+@pytest.mark.parametrize("count", [1, 2, 3, 4, 5, 203])
+def test_quantize_packed_4x4(enc, count):
+    """quantize_p16, the quantiser of the packed 4x4 leaf search (up to four blocks per wavefront, one 16-lane row
+    each): every block equals the reference's memoised DFS and its level cost, whatever its neighbours in the pack
+    are -- zero blocks next to saturated ones, partial packs (count % 4 != 0)."""
+    from oracle import pyoracle as po
+    rng = np.random.default_rng(900 + count)
+    decay = np.exp(-np.add.outer(np.arange(4), np.arange(4)) / 1.5)
+    blocks = []
+    for it in range(count):
+        scale = [3, 30, 200, 1500, 9000][it % 5]
+        b = (rng.standard_normal((4, 4)) * scale * decay).clip(-32768, 32767).astype(np.int16)
+        if it % 7 == 3:
+            b[:] = 0
+        if it % 11 == 5:
+            b = rng.integers(-3, 4, (4, 4)).astype(np.int16)
+        if it % 13 == 6:
+            b[:] = 0
+            b[0, 0] = [1, -1, 40, -40][it % 4]
+        if it % 17 == 9:
+            b[:] = 0
+            b[3, 3] = [2, -700][it % 2]
+        blocks.append(b)
+    blocks = np.stack(blocks)
+    got, cost = enc.quantize_p16(blocks)
+    solo, solo_cost = enc.quantize(blocks)
+    for i in range(count):
+        ref = po.quantize(blocks[i], 32)
+        assert np.array_equal(got[i], ref), (count, i)
+        assert int(cost[i]) == po.level_cost(ref), (count, i)
+    assert np.array_equal(got, solo) and np.array_equal(cost, solo_cost)
+
+
 @pytest.mark.parametrize("use_mfma", [0, 1])
 def test_fwd_dct32_mfma_experiment(enc, use_mfma):
     """north_star's MFMA question: the 32x32 forward transform as i8 MFMAs over balanced base-256 digits is exact

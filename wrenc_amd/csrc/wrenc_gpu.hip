@@ -208,6 +208,26 @@ __global__ __launch_bounds__(64) void test_quantize_kernel(const DevConst* __res
     }
 }
 
+// quantize_p16 (the packed 4x4 leaf search's quantiser): each wave takes up to four consecutive 4x4 blocks
+__global__ __launch_bounds__(64) void test_quantize_p16_kernel(const DevConst* __restrict__ k, const int16_t* in, int count,
+                                                               int16_t* out, long long* cost, int* overflow) {
+    Ctx c = {};
+    c.k = (const CONST_AS DevConst*)k;
+    load_tables(c);
+    const int first = 4 * blockIdx.x;
+    const int nb = min(4, count - first);
+    if (threadIdx.x < 16 * nb) SH.r1[threadIdx.x] = in[(size_t)first * 16 + threadIdx.x];
+    WSYNC();
+    int ovf = 0, any = 0;
+    long long lvl[4];
+    quantize_p16(c, nb, &ovf, lvl, &any);
+    if (threadIdx.x < 16 * nb) out[(size_t)first * 16 + threadIdx.x] = SH.r1[threadIdx.x];
+    if (threadIdx.x == 0) {
+        for (int b = 0; b < nb; ++b) cost[first + b] = lvl[b];
+        if (ovf) atomicOr(overflow, 1);
+    }
+}
+
 __global__ __launch_bounds__(64) void test_dequantize_kernel(const DevConst* __restrict__ k,
                                                              const int16_t* in, int lg, int16_t* out) {
     Ctx c = {};
@@ -1078,6 +1098,24 @@ int wrenc_gpu_test_quantize(wrenc_gpu_ctx* ctx, const int16_t* coef, int log2n, 
     HIP_TRY(ctx, hipMalloc((void**)&d_cost, sizeof(long long) * count));
     int rc = run_block_test(ctx, coef, log2n, count, levels, [&](int16_t* i, int16_t* o) {
         hipLaunchKernelGGL(test_quantize_kernel, dim3(count), dim3(64), 0, ctx->stream, ctx->d_const, i, log2n, o,
+                           d_cost, ctx->d_overflow);
+    });
+    if (rc == WRENC_GPU_OK) {
+        hipError_t e = hipMemcpy(level_cost, d_cost, sizeof(long long) * count, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) rc = fail(ctx, WRENC_GPU_EHIP, hipGetErrorString(e));
+    }
+    (void)hipFree(d_cost);
+    return rc;
+}
+
+int wrenc_gpu_test_quantize_p16(wrenc_gpu_ctx* ctx, const int16_t* coef, int count, int16_t* levels, int64_t* level_cost) {
+    if (!ctx || !level_cost) return WRENC_GPU_EINVAL;
+    if (count < 1) return fail(ctx, WRENC_GPU_EINVAL, "count must be >= 1");
+    HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
+    long long* d_cost = nullptr;
+    HIP_TRY(ctx, hipMalloc((void**)&d_cost, sizeof(long long) * count));
+    int rc = run_block_test(ctx, coef, 2, count, levels, [&](int16_t* i, int16_t* o) {
+        hipLaunchKernelGGL(test_quantize_p16_kernel, dim3((count + 3) / 4), dim3(64), 0, ctx->stream, ctx->d_const, i, count, o,
                            d_cost, ctx->d_overflow);
     });
     if (rc == WRENC_GPU_OK) {

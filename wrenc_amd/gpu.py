@@ -22,7 +22,7 @@ EXPORTED_SYMBOLS = [
     "wrenc_gpu_upload", "wrenc_gpu_encode", "wrenc_gpu_sync", "wrenc_gpu_download",
     "wrenc_gpu_alloc_host", "wrenc_gpu_free_host", "wrenc_gpu_encode_picture", "wrenc_gpu_set_schedule", "wrenc_gpu_last_schedule", "wrenc_gpu_stats_enable", "wrenc_gpu_last_encode_stats", "wrenc_gpu_final_pass_mismatches",
     "wrenc_gpu_test_fwd_dct", "wrenc_gpu_test_inv_dct", "wrenc_gpu_test_quantize",
-    "wrenc_gpu_test_dequantize", "wrenc_gpu_test_predict", "wrenc_gpu_test_fwd_dct32",
+    "wrenc_gpu_test_dequantize", "wrenc_gpu_test_predict", "wrenc_gpu_test_fwd_dct32", "wrenc_gpu_test_quantize_p16",
 ]
 
 
@@ -295,6 +295,17 @@ class Encoder:
             res.append(blk.reshape(2, n // 2, n // 2) if q[3] else blk.reshape(n, n))
             at += sz
         return res
+
+    def quantize_p16(self, blocks):
+        """4x4 blocks through the packed quantiser of the 4x4 leaf search (four blocks per wavefront)."""
+        arr = np.ascontiguousarray(blocks, np.int16)
+        count, n, _ = arr.shape
+        assert n == 4
+        out = np.zeros_like(arr)
+        cost = np.zeros(count, np.int64)
+        self.lib.wrenc_gpu_test_quantize_p16.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        self._check(self.lib.wrenc_gpu_test_quantize_p16(self.ctx, _p(arr), count, _p(out), _p(cost)))
+        return out, cost
 
     def quantize(self, blocks):
         arr = np.ascontiguousarray(blocks, np.int16)
