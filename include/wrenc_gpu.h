@@ -188,7 +188,8 @@ int wrenc_gpu_test_dequantize(wrenc_gpu_ctx* ctx, const int16_t* levels, int log
  * :759-1146, DC :1148-1285, ANGULAR 2..66 :1287-1602, PDPC :355-757, CCLM :1604-2055) in the environment of
  * given reconstruction planes of the context's picture size.  items: n_items x 5 int32 {x, y (luma, picture
  * coordinates, multiples of the size), log2 luma size 2..5, comp (0 = luma block, 1 = Cb+Cr pair of the block,
- * log2 size >= 3), mode (0..66, or 81..83 for comp 1)}.  out: the predicted samples, item after item (luma
+ * log2 size >= 3, 2 = the 4x4 luma block through the row-parallel predictor of the packed 4x4 leaf search, log2 size 2),
+ * mode (0..66, or 81..83 for comp 1)}.  out: the predicted samples, item after item (luma
  * n x n; pair: Cb (n/2)^2 then Cr (n/2)^2); out_bytes must equal their total. */
 int wrenc_gpu_test_predict(wrenc_gpu_ctx* ctx, const uint8_t* rec_y, const uint8_t* rec_cb,
                            const uint8_t* rec_cr, int n_items, const int32_t* items, uint8_t* out,

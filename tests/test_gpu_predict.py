@@ -27,13 +27,13 @@ def _planes(kind, seed):
 def _items(lg, comp):
     """GPU items (x, y, lg, comp, mode) and the oracle's items for the same blocks."""
     n = 1 << lg
-    modes = list(range(67)) + ([81, 82, 83] if comp else [])
+    modes = list(range(67)) + ([81, 82, 83] if comp == 1 else [])
     gpu_items, ora_items = [], []
     for y in range(0, H, n):
         for x in range(0, W, n):
             for m in modes:
                 gpu_items.append((x, y, lg, comp, m))
-                if comp == 0:
+                if comp != 1:   # comp 2: the same 4x4 luma block through the packed predictor (predict4_lane)
                     ora_items.append([(x, y, lg, 1 if lg == 2 else 0, 0, m)])
                 else:   # the pair: Cb then Cr; an 8x8's 4x4 chroma exists in both tree types
                     ora_items.append([(x, y, lg, 0, 1, m), (x, y, lg, 0, 2, m)])
@@ -41,7 +41,7 @@ def _items(lg, comp):
 
 
 @pytest.mark.parametrize("kind", ["smooth", "noise", "extreme"])
-@pytest.mark.parametrize("lg,comp", [(5, 0), (4, 0), (3, 0), (2, 0), (5, 1), (4, 1), (3, 1)])
+@pytest.mark.parametrize("lg,comp", [(5, 0), (4, 0), (3, 0), (2, 0), (2, 2), (5, 1), (4, 1), (3, 1)])
 def test_predict_all_modes(built, kind, lg, comp):
     from wrenc_amd import gpu
     from oracle import pyoracle as po
@@ -56,7 +56,7 @@ def test_predict_all_modes(built, kind, lg, comp):
     for item, g, grp in zip(gi, got, oi):
         r = ref[at:at + len(grp)]
         at += len(grp)
-        want = r[0] if comp == 0 else np.stack(r)
+        want = r[0] if comp != 1 else np.stack(r)
         assert np.array_equal(g, want), (kind, item)
 
 

@@ -282,6 +282,14 @@ __global__ __launch_bounds__(64) void test_predict_kernel(const DevConst* __rest
     }
     WSYNC();
     const int tx = x & 31, ty = y & 31;
+    if (comp == 2) {
+        // the packed predictor of the 4x4 leaf search: the item's mode in row 0, other modes in the rows next to it
+        build_refs(c, 0, tx, ty, 2);
+        const int row = LANE >> 4;
+        const int v = predict4_lane(c, row == 0 ? mode : (mode + 1 + 22 * row) % 67);
+        if (LANE < 16) out[it[5] + LANE] = (uint8_t)v;
+        return;
+    }
     if (mode < LT_CCLM) build_refs(c, comp, tx, ty, tlg);
     predict<true>(c, comp, tx, ty, tlg, mode, 0, false);
     const int n = 1 << (tlg - (comp ? 1 : 0));
@@ -1138,12 +1146,12 @@ int wrenc_gpu_test_predict(wrenc_gpu_ctx* ctx, const uint8_t* rec_y, const uint8
         const int x = q[0], y = q[1], lg = q[2], comp = q[3], mode = q[4];
         const int n = 1 << lg;
         const bool ok = lg >= 2 && lg <= 5 && x >= 0 && y >= 0 && x + n <= W && y + n <= H && !(x & (n - 1)) && !(y & (n - 1)) &&
-                        (comp == 0 || (comp == 1 && lg >= 3)) &&
+                        (comp == 0 || (comp == 1 && lg >= 3) || (comp == 2 && lg == 2)) &&
                         ((mode >= 0 && mode <= 66) || (comp == 1 && mode >= LT_CCLM && mode <= T_CCLM));
         if (!ok) return fail(ctx, WRENC_GPU_EINVAL, "wrenc_gpu_test_predict: bad item");
         int* d = &dev_items[(size_t)i * 6];
         d[0] = x; d[1] = y; d[2] = lg; d[3] = comp; d[4] = mode; d[5] = (int)total;
-        total += comp ? (size_t)n * n / 2 : (size_t)n * n;
+        total += comp == 1 ? (size_t)n * n / 2 : (size_t)n * n;
     }
     if (total != out_bytes) return fail(ctx, WRENC_GPU_EINVAL, "wrenc_gpu_test_predict: output size does not match the items");
     HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));

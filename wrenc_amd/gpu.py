@@ -277,10 +277,10 @@ class Encoder:
         return self._blocks(self.lib.wrenc_gpu_test_dequantize, blocks)
 
     def predict_blocks(self, rec_y, rec_cb, rec_cr, items):
-        """items: (n, 5) int32 {x, y, log2 luma size, comp (0 luma, 1 Cb+Cr pair), mode}; returns the list of
-        predicted blocks (luma: (n, n); pair: (2, n/2, n/2))."""
+        """items: (n, 5) int32 {x, y, log2 luma size, comp (0 luma, 1 Cb+Cr pair, 2 luma 4x4 through the packed predictor
+        of the 4x4 leaf search), mode}; returns the list of predicted blocks (luma: (n, n); pair: (2, n/2, n/2))."""
         items = np.ascontiguousarray(items, np.int32).reshape(-1, 5)
-        sizes = [((1 << int(q[2])) ** 2) // (2 if q[3] else 1) for q in items]
+        sizes = [((1 << int(q[2])) ** 2) // (2 if q[3] == 1 else 1) for q in items]
         out = np.zeros(int(sum(sizes)), np.uint8)
         planes = [np.ascontiguousarray(a, np.uint8) for a in (rec_y, rec_cb, rec_cr)]
         assert planes[0].shape == (self.height, self.width)
@@ -292,7 +292,7 @@ class Encoder:
         for q, sz in zip(items, sizes):
             n = 1 << int(q[2])
             blk = out[at:at + sz]
-            res.append(blk.reshape(2, n // 2, n // 2) if q[3] else blk.reshape(n, n))
+            res.append(blk.reshape(2, n // 2, n // 2) if q[3] == 1 else blk.reshape(n, n))
             at += sz
         return res
 
