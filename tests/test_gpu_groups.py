@@ -1,9 +1,9 @@
 """The multi-group, multi-lane split of one encode call against the oracle: an encode call
-deals its pictures to workgroups of WPB = 8 pictures and the workgroups to up to 4 HIP streams ("lanes");
-the last workgroup is padded with waves that compute and never store.  19 pictures = 3 workgroups on 3 lanes
-with 5 padding waves; 33 pictures = 5 workgroups on 4 lanes with 7 padding waves.  The pictures of a
-workgroup are of DIFFERENT content kinds, so its 8 waves walk the pooled Viterbi's barriers with different
-data.  Every slot's full record (ctu_cost included) must equal the oracle's and the stream bytes the CPU path's."""
+deals its pictures to workgroups of WPB = 4 pictures and the workgroups to up to 4 HIP streams ("lanes");
+the last workgroup is padded with waves that compute and never store.  19 pictures = 5 workgroups on 4 lanes
+with 1 padding wave; 33 pictures = 9 workgroups on 4 lanes with 3 padding waves; 9 pictures = 3 workgroups with 3.
+The pictures of a workgroup are of DIFFERENT content kinds, so its waves walk the pooled Viterbi's barriers with
+different data.  Every slot's full record (ctu_cost included) must equal the oracle's and the stream bytes the CPU path's."""
 import numpy as np
 import pytest
 
@@ -24,7 +24,7 @@ def _frame(i, w, h):
     return content(KINDS[i % len(KINDS)], w, h, 1000 + i)
 
 
-@pytest.mark.parametrize("schedule", [1, 2])    # wave: groups of 8 pictures; team: groups of 2 pictures x 4 waves
+@pytest.mark.parametrize("schedule", [1, 2])    # wave: groups of 4 pictures; team: one picture x 4 waves per workgroup
 @pytest.mark.parametrize("n_pictures,w,h,qp,depth,first_slot", [(19, 96, 64, 32, 2, 0), (33, 64, 64, 27, 3, 2), (9, 64, 96, 37, 1, 1)])
 def test_every_slot_of_a_multi_group_call_equals_the_oracle(built, n_pictures, w, h, qp, depth, first_slot, schedule):
     from wrenc_amd import bitstream as bs, gpu
