@@ -533,12 +533,14 @@ __device__ __forceinline__ int predict(Ctx c, int comp, int tx, int ty, int tlg,
 // by the candidate's own 16 lanes into tab4 (16 bytes per candidate, in r2 below kOrgLeaf).  build_refs(c, 0, ..)
 // must have run.  Returns the predicted sample.
 constexpr int kTab4Byte = 1280; // byte offset in r2: 4 x 16 bytes + 4 of slack for the last dword pair
-__device__ __forceinline__ int predict4_lane(const Ctx& c, int mode) {
+// pl < 0: luma; pl = 0 / 1 (may differ per lane): the 4x4 Cb / Cr block of an 8x8 CU, predicted from that plane's
+// reference samples with the 2-tap chroma interpolation (build_refs(c, 1, ..) must have run).
+__device__ __forceinline__ int predict4_lane(const Ctx& c, int mode, int pl = -1) {
     constexpr int n = 4, lg = 2;
     const int s = LANE >> 4, i = LANE & 15;
     const int x = i & 3, y = i >> 2;
-    const ref_t* L = SH.refs + R_L0; // index 0 = corner
-    const ref_t* A = SH.refs + R_A0;
+    const ref_t* L = SH.refs + (pl < 0 ? R_L0 : (pl ? R_LC1 : R_LC0)); // index 0 = corner
+    const ref_t* A = SH.refs + (pl < 0 ? R_A0 : (pl ? R_AC1 : R_AC0));
     uint8_t* tab = (uint8_t*)SH.r2 + kTab4Byte;
     const bool ang = mode >= 2 && mode <= 66;
     int angle = 0, inv_angle = 0;
@@ -581,8 +583,12 @@ __device__ __forceinline__ int predict4_lane(const Ctx& c, int mode) {
         const int ta = 16 * s + n + across + i_idx; // taps = ref[across + i_idx + 0..3]
         const uint32_t* tp = (const uint32_t*)(tab + (ta & ~3));
         const int taps = (int)__builtin_amdgcn_alignbyte(tp[1], tp[0], ta & 3);
-        const int w = filter_flag ? 0x00102010 + (i_fact >> 1) * 0x0100FEFF : *(const int*)&SHT.fc[i_fact][0];
-        v = min(max(__builtin_amdgcn_sdot4(w, taps, 8192 + 32, false) >> 6, 0), 255);
+        if (pl < 0) {
+            const int w = filter_flag ? 0x00102010 + (i_fact >> 1) * 0x0100FEFF : *(const int*)&SHT.fc[i_fact][0];
+            v = min(max(__builtin_amdgcn_sdot4(w, taps, 8192 + 32, false) >> 6, 0), 255);
+        } else { // i_fact == 0 gives the second tap itself; a convex combination of 8-bit samples needs no clamp
+            v = __builtin_amdgcn_sdot4(((32 - i_fact) << 8) | (i_fact << 16), taps, 4096 + 16, false) >> 5;
+        }
         if (mode <= 18 || mode >= 50) { // PDPC, intra_predictor.rs:355-757; left[] = L+1, above[] = A
             int rl = 0, rt = 0, wl = 0, wt = 0;
             bool on = true;

@@ -9,7 +9,7 @@ namespace wrenc {
 // ---------------------------------------------------------------------------
 // Evaluation requests and the evaluator
 // ---------------------------------------------------------------------------
-enum { K_SADLIST = 0, K_FULL = 1, K_NOP = 2, K_SADSEARCH = 3, K_CCLMSEARCH = 4, K_LEAF4 = 5 };
+enum { K_SADLIST = 0, K_FULL = 1, K_NOP = 2, K_SADSEARCH = 3, K_CCLMSEARCH = 4, K_LEAF4 = 5, K_LEAFC4 = 6 };
 #ifndef WRENC_POOL_MIN_TLG
 #define WRENC_POOL_MIN_TLG 3
 #endif
@@ -23,7 +23,8 @@ struct Req {
                     // K_CCLMSEARCH: the CCLM part of a leaf search in one request -- the SADs of LT / T / L_CCLM, the
                     // pick (:847-854) and the full evaluation of the chroma pair with it: Res::imin = the mode, + parts;
                     // K_LEAF4: the whole search of a 4x4 DUAL_TREE_LUMA leaf (:886-1078) in one request, its full candidates
-                    // evaluated side by side in the wave's four 16-lane rows (leaf4_search): Res::imin = the mode, vmin = its cost
+                    // evaluated side by side in the wave's four 16-lane rows (leaf4_search): Res::imin = the mode, vmin = its cost;
+                    // K_LEAFC4: the same for the DUAL_TREE_CHROMA leaf of a split 8x8 CU (:794-885; leafc4_search), mc = the DM mode
     int comps;      // bit 0: luma block, bit 1: Cb+Cr pair
     int tx, ty, tlg;
     int ml, mc;     // K_FULL: luma / chroma mode
@@ -256,6 +257,7 @@ __device__ __forceinline__ void sad_search(const Ctx& c, const Req& q, int& cm_o
 }
 
 __device__ __forceinline__ Res leaf4_search(const Ctx& c, const Req& q, int* overflow); // below, after the cost functions
+__device__ __forceinline__ Res leafc4_search(const Ctx& c, const Req& q, int* overflow);
 
 // The evaluator: every block evaluation of the search, of the regeneration and of the final pass
 // goes through this one inlined copy (the search logic below is a state machine that hands out
@@ -276,6 +278,7 @@ __device__ __forceinline__ Res evaluate(const Ctx& c, const PicBufs& pb, const R
     if (q.kind == K_NOP) return r;
     if (q.stage) stage_org_leaf(c, q.stage, q.tx, q.ty, q.tlg);
     if (q.kind == K_LEAF4) return leaf4_search(c, q, overflow);
+    if (q.kind == K_LEAFC4) return leafc4_search(c, q, overflow);
     int mc = q.mc;
     if (q.kind == K_CCLMSEARCH) {
         // get_chroma_intra_pred_aux_cost of LT, T, L_CCLM in one sample pass, then the pick of :847-854 (SADs are
@@ -671,6 +674,85 @@ __device__ __forceinline__ Res leaf4_search(const Ctx& c, const Req& q, int* ove
     return r;
 }
 
+// K_LEAFC4: the DUAL_TREE_CHROMA leaf of a split 8x8 CU (block_splitter.rs:794-885) in one request.  The three CCLM
+// SADs and the pick (:847-854) as in K_CCLMSEARCH, then the picked CCLM mode and the DM mode (q.mc) are evaluated SIDE
+// BY SIDE: rows 0 / 1 = Cb / Cr of the CCLM candidate, rows 2 / 3 = Cb / Cr of the DM candidate, four 4x4 blocks
+// through the stages of pack4_eval.  The winner's rows (DM on a tie, :857-873) write their reconstruction to the tile.
+__device__ __forceinline__ Res leafc4_search(const Ctx& c, const Req& q, int* overflow) {
+    Res r;
+    r.ssd_y = 0;
+    r.ssd_c = 0;
+    r.lvl_y = 0;
+    r.lvl_c = 0;
+    r.v0 = r.v1 = r.v2 = 3.40282347e+38f;
+    const int dm = q.mc;
+    // get_chroma_intra_pred_aux_cost of LT, T, L_CCLM in one sample pass, then the pick (SADs are integers < 2^20)
+    const unsigned acc = sad_list_cclm(c, q.tx, q.ty, 3);
+    const unsigned lt = (unsigned)__builtin_amdgcn_readlane((int)acc, 0), t = (unsigned)__builtin_amdgcn_readlane((int)acc, 1),
+                   l = (unsigned)__builtin_amdgcn_readlane((int)acc, 2);
+    if (c.trace && LANE < 3)
+        TRACE_REC(c.ctu_x + q.tx, c.ctu_y + q.ty, 3, q.tree, 2, 0, LANE == 0 ? LT_CCLM : (LANE == 1 ? T_CCLM : L_CCLM),
+                  __float_as_int((float)acc));
+    const int cm = (lt <= t && lt <= l) ? LT_CCLM : (t <= l ? T_CCLM : L_CCLM);
+    if (q.refs1) build_refs(c, 1, q.tx, q.ty, 3);
+    PROF_MARK(t0_);
+    // model parameters of both planes: odd lanes derive Cr, even lanes Cb (as predict())
+    const CclmParams cpv = cclm_params(c, 1 + (LANE & 1), q.tx, q.ty, 3, cm);
+    const int a0 = __builtin_amdgcn_readlane(cpv.a, 0), a1 = __builtin_amdgcn_readlane(cpv.a, 1);
+    const int k0 = __builtin_amdgcn_readlane(cpv.k, 0), k1 = __builtin_amdgcn_readlane(cpv.k, 1);
+    const int b0 = __builtin_amdgcn_readlane(cpv.b, 0), b1 = __builtin_amdgcn_readlane(cpv.b, 1);
+    const bool flat128 = __builtin_amdgcn_readlane((int)cpv.flat128, 0) != 0;
+    const bool avail_l = __builtin_amdgcn_readlane((int)cpv.avail_l, 0) != 0;
+    const int row = LANE >> 4, i = LANE & 15, x = i & 3, y = i >> 2;
+    const int pl = row & 1;
+    int v = predict4_lane(c, row >= 2 ? dm : kNoMode, pl); // rows 2, 3: the DM candidate (every lane passes the WSYNC inside)
+    if (row < 2) {
+        v = 128;
+        if (!flat128) {
+            const int ds = cclm_ds6(c, q.tx, q.ty, 2 * y, 2 * x, avail_l);
+            v = (M24(ds, pl ? a1 : a0) >> (pl ? k1 : k0)) + (pl ? b1 : b0);
+            v = min(max(v, 0), 255);
+        }
+    }
+    const int org = ((const uint8_t*)SH.r2)[kOrgLeaf + 256 + 16 * pl + i];
+    SH.r1[LANE] = (int16_t)(org - v);
+    WSYNC();
+    PROF_MARK(t1_);
+    PROF_ADD2(PH_PREDICT, t0_, t1_);
+    fwd_dct_lg(c, 2, 4, 0);
+    long long lvl[4];
+    int any_mask = 0;
+    quantize_p16(c, 4, overflow, lvl, &any_mask);
+    if (any_mask) {
+        dequantize_t(c, 2, 4, 0);
+        inv_dct_lg(c, 2, 4, 0);
+    }
+    int rec = (int16_t)(v + (int)SH.r1[LANE]);
+    rec = min(max(rec, 0), 255);
+    const int d = rec - org;
+    const int rs = row_sum_i32(M24(d, d));
+    EvalParts ec, ed;
+    ec.ssd_y = ed.ssd_y = 0;
+    ec.lvl_y = ed.lvl_y = 0;
+    ec.ssd_c = (uint32_t)(__builtin_amdgcn_readlane(rs, 0) + __builtin_amdgcn_readlane(rs, 16));
+    ed.ssd_c = (uint32_t)(__builtin_amdgcn_readlane(rs, 32) + __builtin_amdgcn_readlane(rs, 48));
+    ec.lvl_c = lvl[0] + lvl[1];
+    ed.lvl_c = lvl[2] + lvl[3];
+    const float c0 = uni_f(assemble_chroma_cost(c, cm, ec));
+    const float dm_cost = uni_f(assemble_chroma_cost(c, dm, ed));
+    if (c.write && LANE == 0) {
+        TRACE_REC(c.ctu_x + q.tx, c.ctu_y + q.ty, 3, q.tree, 3, 0, cm, __float_as_int(c0));
+        TRACE_REC(c.ctu_x + q.tx, c.ctu_y + q.ty, 3, q.tree, 3, 0, dm, __float_as_int(dm_cost));
+    }
+    const float cost = fminf(c0, fminf(dm_cost, 3.40282347e+38f));
+    const bool dm_wins = dm_cost == cost;
+    if ((row >= 2) == dm_wins) rec_put(1 + pl, (q.tx >> 1) + x, (q.ty >> 1) + y, rec);
+    WSYNC();
+    r.vmin = cost;
+    r.imin = dm_wins ? dm : cm;
+    return r;
+}
+
 // the decision maps of a block: at most 8 x 8 units of 4x4 (one lane each), sizes are powers of two
 __device__ __forceinline__ void fill_maps(int bx, int by, int lg, int luma_mode, int chroma_mode, bool luma,
                                           bool chroma) {
@@ -727,7 +809,7 @@ __device__ __forceinline__ void req_copy(Req& q, int mode, int comps, int slot, 
 
 enum {
     C_START = 0, C_PLANAR, C_DCM, C_LIST, C_PAIR_EMIT, C_PAIR, C_F0, C_F1, C_F2, C_WIN, C_CX, C_CCLM, C_DM,
-    C_DC_START, C_DC2, C_DC3, C_DC4, C_DC5, C_L4
+    C_DC_START, C_DC2, C_DC3, C_DC4, C_DC5, C_L4, C_LC4
 };
 
 __device__ __forceinline__ void leaf_init(LeafSt& s, int tree, int bx, int by, int lg, int dm_mode) {
@@ -1003,8 +1085,18 @@ __device__ __forceinline__ bool leaf_step(const Ctx& c, LeafSF& s, const Res& r,
             return false;
         // ---- DUAL_TREE_CHROMA leaf (:794-885) ----
         case C_DC_START: // the three CCLM probes, the pick and the evaluation of the picked mode (K_CCLMSEARCH)
+            if (WRENC_LEAF4) { // the whole chroma leaf in one request, CCLM and DM candidates side by side (K_LEAFC4)
+                leaf_full(s, q, 2, 0, s.dm_mode, true, C_LC4, true);
+                q.kind = K_LEAFC4;
+                return true;
+            }
             leaf_cclmsearch(s, q, C_DC3);
             return true;
+        case C_LC4:
+            s.luma_mode = 0;
+            s.cost = r.vmin;
+            s.chroma_mode = (uint8_t)r.imin;
+            return false;
         case C_DC3:
             s.cclm_mode = (uint8_t)r.imin;
             s.c0 = uni_f(assemble_chroma_cost(c, s.cclm_mode, rp));
