@@ -634,7 +634,7 @@ __device__ __forceinline__ Res leaf4_search(const Ctx& c, const Req& q, int* ove
         e_.lvl_c = 0;                                                                                                  \
         const int cls_ = mpm_class(c, q.tx, q.ty, 2, (M));                                                             \
         const float val_ = uni_f(assemble_cost(c, TREE_DUAL_LUMA, cls_, (M), e_));                                     \
-        if (c.write && LANE == 0)                                                                                      \
+        if (c.trace && LANE == 0) /* (team schedule: each half is traced by the member that runs it) */                \
             TRACE_REC(c.ctu_x + q.tx, c.ctu_y + q.ty, 2, TREE_DUAL_LUMA, 1, (M), (M), __float_as_int(val_));           \
         if (first_ || val_ < best) {                                                                                   \
             best = val_;                                                                                               \
@@ -644,7 +644,8 @@ __device__ __forceinline__ Res leaf4_search(const Ctx& c, const Req& q, int* ove
         first_ = false;                                                                                                \
     } while (0)
     bool first_ = true;
-    {
+    // q.n: which half runs here (team schedule: member 0 takes pack A, member 1 the SAD search and pack B; 3 = both)
+    if (q.n & 1) {
         // pack A: planar and DC (:887-898)
         const Pack4Out a = pack4_eval(c, q, 2, PLANAR, DC, kNoMode, overflow);
         int win_ = -1;
@@ -653,11 +654,11 @@ __device__ __forceinline__ Res leaf4_search(const Ctx& c, const Req& q, int* ove
         if (row == win_) rec_put(0, q.tx + x, q.ty + y, a.rec);
         WSYNC();
     }
-    int cm;
-    unsigned smin;
-    sad_search(c, q, cm, smin);
-    cm = uni(cm);
-    {
+    if (q.n & 2) {
+        int cm;
+        unsigned smin;
+        sad_search(c, q, cm, smin);
+        cm = uni(cm);
         // pack B: step_search(mode, 1, _, aux = false) on {cm, cm - 1, cm + 1} (:974)
         const int lo = !(cm < 3) ? cm - 1 : kNoMode, hi = !(cm + 1 > 66) ? cm + 1 : kNoMode;
         const Pack4Out b = pack4_eval(c, q, 3, cm, lo, hi, overflow);
@@ -915,6 +916,7 @@ __device__ __forceinline__ bool leaf_is_leaf4(const LeafSF& s) { return WRENC_LE
 __device__ __forceinline__ void leaf_leaf4(LeafSF& s, Req& q, int cont) {
     req_full(q, 1, s.bx, s.by, s.lg, 0, 0, false, true, s.need_refs0 != 0, false, false);
     q.kind = K_LEAF4;
+    q.n = 3;
     q.tree = s.tree;
     leaf_attach_org(s, q);
     leaf_attach_save(s, q);
@@ -1206,9 +1208,16 @@ __device__ __forceinline__ bool leaf_step_team(const Ctx& c, CtuSt& t, LeafSF& s
         switch (cont) {
         case TC_START: // stage A: planar | DC | the directional SAD search (:887-973)
             if (leaf_is_leaf4(s)) {
-                // a 4x4 luma leaf: every member runs the whole packed search on its own tile -- same result in
-                // every tile, no exchange, no pull (cheaper than three exchanges for 16 samples)
-                leaf_leaf4(s, q, TC_L4);
+                // a 4x4 luma leaf: the packed search in two halves side by side -- member 0 planar and DC, member 1
+                // the SAD search and {cm, cm - 1, cm + 1} -- one exchange, then everybody pulls the winner
+                if (me < 2) {
+                    leaf_leaf4(s, q, TC_L4);
+                    q.n = 1 + me;
+                } else {
+                    team_idle(q);
+                }
+                s.cont = TC_L4;
+                q.xchg = true;
                 return true;
             }
             if (me == 0) {
@@ -1223,11 +1232,17 @@ __device__ __forceinline__ bool leaf_step_team(const Ctx& c, CtuSt& t, LeafSF& s
             s.cont = TC_A;
             q.xchg = true;
             return true;
-        case TC_L4:
-            s.cost = r.vmin;
-            s.luma_mode = (uint8_t)r.imin;
-            s.chroma_mode = (uint8_t)r.imin;
+        case TC_L4: {
+            // first minimum of [planar, DC | cm, cm - 1, cm + 1]: the second half wins only if strictly cheaper
+            const float va = xvmin(c, par, 0), vb = xvmin(c, par, 1);
+            const int holder = vb < va ? 1 : 0;
+            const int m = ximin(c, par, holder);
+            s.cost = holder ? vb : va;
+            s.luma_mode = (uint8_t)m;
+            s.chroma_mode = (uint8_t)m;
+            team_defer_pull(t, s, 1, holder);
             return false;
+        }
         case TC_A: {
             const EvalParts e0 = xparts(c, par, 0), e1 = xparts(c, par, 1);
             const float v0 = uni_f(assemble_cost(c, tree, 0, PLANAR, e0));
