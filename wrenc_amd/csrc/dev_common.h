@@ -71,7 +71,18 @@ struct PicBufs {
 };
 
 // LDS working set of one wave / one CTU.
-#define LANE ((int)(threadIdx.x & 63))
+// The lane index, behind an optimisation barrier.  The CTU search is one long loop; whatever the compiler can derive
+// from a plain `threadIdx.x & 63` alone (row and quad numbers, per-lane table addresses of every stage) it computes
+// once in front of that loop and keeps for the whole kernel -- which at 96 VGPRs means a dozen spilled registers,
+// written to scratch by every CTU and reloaded in front of the stages' inner loops.  Behind the barrier the index is
+// an ordinary value: what depends on it is recomputed where it is used (a v_and or two), 1 spilled VGPR instead of
+// 14, +1 % frames/s (gpurun_out/r3s/lane.log).
+__device__ __forceinline__ int lane_fresh() {
+    int l = (int)(threadIdx.x & 63);
+    asm volatile("" : "+v"(l));
+    return l;
+}
+#define LANE lane_fresh()
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
 // SSD and level cost of the luma block and of the chroma pair of one evaluated candidate

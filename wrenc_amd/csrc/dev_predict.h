@@ -537,7 +537,8 @@ constexpr int kTab4Byte = 1280; // byte offset in r2: 4 x 16 bytes + 4 of slack 
 // reference samples with the 2-tap chroma interpolation (build_refs(c, 1, ..) must have run).
 __device__ __forceinline__ int predict4_lane(const Ctx& c, int mode, int pl = -1) {
     constexpr int n = 4, lg = 2;
-    const int s = LANE >> 4, i = LANE & 15;
+    const int lane = lane_fresh();
+    const int s = lane >> 4, i = lane & 15;
     const int x = i & 3, y = i >> 2;
     const ref_t* L = SH.refs + (pl < 0 ? R_L0 : (pl ? R_LC1 : R_LC0)); // index 0 = corner
     const ref_t* A = SH.refs + (pl < 0 ? R_A0 : (pl ? R_AC1 : R_AC0));

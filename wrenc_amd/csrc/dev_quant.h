@@ -657,6 +657,7 @@ __device__ __forceinline__ void quantize3(Ctx c, int lg0, bool shared, bool acti
 __device__ __forceinline__ void quantize_p16(Ctx c, int nb, int* overflow, long long lvl[4], int* any_mask) {
     c = uni(c);
     nb = uni(nb);
+    const int lane = lane_fresh();
     const CONST_AS DevConst* k = c.k;
     constexpr int P = 16, lg = 2;
     constexpr int sh = 8 + lg - 5 + 1; // quantizer.rs:558-569
@@ -665,7 +666,7 @@ __device__ __forceinline__ void quantize_p16(Ctx c, int nb, int* overflow, long 
     const CONST_AS uint16_t* scan = k->scan_idx[0];
     int32_t* cc = (int32_t*)SH.r1;
     PROF_MARK(q0_);
-    const int blk = LANE >> 4, p = LANE & 15;
+    const int blk = lane >> 4, p = lane & 15;
     const bool mine = blk < nb;
     int tc = 0, qd = 0;
     if (mine) {
@@ -684,20 +685,20 @@ __device__ __forceinline__ void quantize_p16(Ctx c, int nb, int* overflow, long 
     int ovf = 0;
     {
         int par0 = 0, par1 = 0, adj = 0;
-        if (mine) chunk_entry(c, cc + LANE * 6, tc, qd, p == P - 1, p <= istar, sh, off, lsc, ldq1, &par0, &par1, &adj, &ovf);
+        if (mine) chunk_entry(c, cc + lane * 6, tc, qd, p == P - 1, p <= istar, sh, off, lsc, ldq1, &par0, &par1, &adj, &ovf);
         const unsigned long long b0 = __ballot(mine && par0), b1 = __ballot(mine && par1), ba = __ballot(mine && adj);
         if (mine && p == 0) {
             uint16_t* pm = SH.q_pm[0][blk];
-            pm[0] = (uint16_t)(b0 >> LANE);
-            pm[1] = (uint16_t)(b1 >> LANE);
-            pm[2] = (uint16_t)((ba >> (LANE + 15)) & 1);
+            pm[0] = (uint16_t)(b0 >> lane);
+            pm[1] = (uint16_t)(b1 >> lane);
+            pm[2] = (uint16_t)((ba >> (lane + 15)) & 1);
         }
     }
     WSYNC();
     PROF_MARK(qb1_);
     uint16_t* dec16 = (uint16_t*)SH.decw;
     {
-        const int st = LANE & 3, quad = LANE >> 2;
+        const int st = lane & 3, quad = lane >> 2;
         if (quad < nb) {
             const int cls = st == 0 ? 0 : (st == 1 ? 1 : 2);
             const int32_t* wcc = cc + quad * P * 6;

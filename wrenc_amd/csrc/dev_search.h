@@ -573,13 +573,14 @@ struct Pack4Out {
 };
 __device__ __forceinline__ Pack4Out pack4_eval(const Ctx& c, const Req& q, int nb, int m0, int m1, int m2, int* overflow) {
     Pack4Out o;
-    const int s = LANE >> 4, i = LANE & 15;
+    const int lane = lane_fresh();
+    const int s = lane >> 4, i = lane & 15;
     const int mode = s == 0 ? m0 : (s == 1 ? m1 : (s == 2 ? m2 : kNoMode));
     const bool on = s < nb && mode != kNoMode;
     PROF_MARK(t0_);
     const int v = predict4_lane(c, on ? mode : kNoMode);
     const int org = ((const uint8_t*)SH.r2)[kOrgLeaf + i];
-    if (s < nb) SH.r1[LANE] = (int16_t)(on ? org - v : 0); // (a candidate that is not evaluated rides along as a zero block)
+    if (s < nb) SH.r1[lane] = (int16_t)(on ? org - v : 0); // (a candidate that is not evaluated rides along as a zero block)
     WSYNC();
     PROF_MARK(t1_);
     PROF_ADD2(PH_PREDICT, t0_, t1_);
@@ -596,7 +597,7 @@ __device__ __forceinline__ Pack4Out pack4_eval(const Ctx& c, const Req& q, int n
     }
     PROF_MARK(t4_);
     PROF_ADD2(PH_IDCT, t3_, t4_);
-    int rec = (int16_t)(v + (int)SH.r1[s < nb ? LANE : 0]); // pred as i16 + res, clamp (:178)
+    int rec = (int16_t)(v + (int)SH.r1[s < nb ? lane : 0]); // pred as i16 + res, clamp (:178)
     rec = min(max(rec, 0), 255);
     const int d = rec - org;
     const int row = row_sum_i32(on ? M24(d, d) : 0);
@@ -619,8 +620,9 @@ __device__ __forceinline__ Res leaf4_search(const Ctx& c, const Req& q, int* ove
     r.lvl_y = 0;
     r.lvl_c = 0;
     r.v0 = r.v1 = r.v2 = 3.40282347e+38f;
+    const int lane = lane_fresh();
     if (q.refs0) build_refs(c, 0, q.tx, q.ty, 2);
-    const int x = LANE & 3, y = (LANE >> 2) & 3, row = LANE >> 4;
+    const int x = lane & 3, y = (lane >> 2) & 3, row = lane >> 4;
     float best = 3.40282347e+38f;
     int best_mode = PLANAR;
     // one candidate of a pack that has come back: its cost, the trace record, the running first minimum; returns
@@ -634,7 +636,7 @@ __device__ __forceinline__ Res leaf4_search(const Ctx& c, const Req& q, int* ove
         e_.lvl_c = 0;                                                                                                  \
         const int cls_ = mpm_class(c, q.tx, q.ty, 2, (M));                                                             \
         const float val_ = uni_f(assemble_cost(c, TREE_DUAL_LUMA, cls_, (M), e_));                                     \
-        if (c.trace && LANE == 0) /* (team schedule: each half is traced by the member that runs it) */                \
+        if (c.trace && lane == 0) /* (team schedule: each half is traced by the member that runs it) */                \
             TRACE_REC(c.ctu_x + q.tx, c.ctu_y + q.ty, 2, TREE_DUAL_LUMA, 1, (M), (M), __float_as_int(val_));           \
         if (first_ || val_ < best) {                                                                                   \
             best = val_;                                                                                               \
@@ -686,25 +688,26 @@ __device__ __forceinline__ Res leafc4_search(const Ctx& c, const Req& q, int* ov
     r.lvl_y = 0;
     r.lvl_c = 0;
     r.v0 = r.v1 = r.v2 = 3.40282347e+38f;
+    const int lane = lane_fresh();
     const int dm = q.mc;
     // get_chroma_intra_pred_aux_cost of LT, T, L_CCLM in one sample pass, then the pick (SADs are integers < 2^20)
     const unsigned acc = sad_list_cclm(c, q.tx, q.ty, 3);
     const unsigned lt = (unsigned)__builtin_amdgcn_readlane((int)acc, 0), t = (unsigned)__builtin_amdgcn_readlane((int)acc, 1),
                    l = (unsigned)__builtin_amdgcn_readlane((int)acc, 2);
-    if (c.trace && LANE < 3)
-        TRACE_REC(c.ctu_x + q.tx, c.ctu_y + q.ty, 3, q.tree, 2, 0, LANE == 0 ? LT_CCLM : (LANE == 1 ? T_CCLM : L_CCLM),
+    if (c.trace && lane < 3)
+        TRACE_REC(c.ctu_x + q.tx, c.ctu_y + q.ty, 3, q.tree, 2, 0, lane == 0 ? LT_CCLM : (lane == 1 ? T_CCLM : L_CCLM),
                   __float_as_int((float)acc));
     const int cm = (lt <= t && lt <= l) ? LT_CCLM : (t <= l ? T_CCLM : L_CCLM);
     if (q.refs1) build_refs(c, 1, q.tx, q.ty, 3);
     PROF_MARK(t0_);
     // model parameters of both planes: odd lanes derive Cr, even lanes Cb (as predict())
-    const CclmParams cpv = cclm_params(c, 1 + (LANE & 1), q.tx, q.ty, 3, cm);
+    const CclmParams cpv = cclm_params(c, 1 + (lane & 1), q.tx, q.ty, 3, cm);
     const int a0 = __builtin_amdgcn_readlane(cpv.a, 0), a1 = __builtin_amdgcn_readlane(cpv.a, 1);
     const int k0 = __builtin_amdgcn_readlane(cpv.k, 0), k1 = __builtin_amdgcn_readlane(cpv.k, 1);
     const int b0 = __builtin_amdgcn_readlane(cpv.b, 0), b1 = __builtin_amdgcn_readlane(cpv.b, 1);
     const bool flat128 = __builtin_amdgcn_readlane((int)cpv.flat128, 0) != 0;
     const bool avail_l = __builtin_amdgcn_readlane((int)cpv.avail_l, 0) != 0;
-    const int row = LANE >> 4, i = LANE & 15, x = i & 3, y = i >> 2;
+    const int row = lane >> 4, i = lane & 15, x = i & 3, y = i >> 2;
     const int pl = row & 1;
     int v = predict4_lane(c, row >= 2 ? dm : kNoMode, pl); // rows 2, 3: the DM candidate (every lane passes the WSYNC inside)
     if (row < 2) {
@@ -716,7 +719,7 @@ __device__ __forceinline__ Res leafc4_search(const Ctx& c, const Req& q, int* ov
         }
     }
     const int org = ((const uint8_t*)SH.r2)[kOrgLeaf + 256 + 16 * pl + i];
-    SH.r1[LANE] = (int16_t)(org - v);
+    SH.r1[lane] = (int16_t)(org - v);
     WSYNC();
     PROF_MARK(t1_);
     PROF_ADD2(PH_PREDICT, t0_, t1_);
@@ -728,7 +731,7 @@ __device__ __forceinline__ Res leafc4_search(const Ctx& c, const Req& q, int* ov
         dequantize_t(c, 2, 4, 0);
         inv_dct_lg(c, 2, 4, 0);
     }
-    int rec = (int16_t)(v + (int)SH.r1[LANE]);
+    int rec = (int16_t)(v + (int)SH.r1[lane]);
     rec = min(max(rec, 0), 255);
     const int d = rec - org;
     const int rs = row_sum_i32(M24(d, d));
@@ -741,7 +744,7 @@ __device__ __forceinline__ Res leafc4_search(const Ctx& c, const Req& q, int* ov
     ed.lvl_c = lvl[2] + lvl[3];
     const float c0 = uni_f(assemble_chroma_cost(c, cm, ec));
     const float dm_cost = uni_f(assemble_chroma_cost(c, dm, ed));
-    if (c.write && LANE == 0) {
+    if (c.write && lane == 0) {
         TRACE_REC(c.ctu_x + q.tx, c.ctu_y + q.ty, 3, q.tree, 3, 0, cm, __float_as_int(c0));
         TRACE_REC(c.ctu_x + q.tx, c.ctu_y + q.ty, 3, q.tree, 3, 0, dm, __float_as_int(dm_cost));
     }
