@@ -166,11 +166,15 @@ int wrenc_gpu_final_pass_mismatches(wrenc_gpu_ctx* ctx, long long* count);
  * int16, host pointers.  Same arithmetic as the picture path. */
 int wrenc_gpu_test_fwd_dct(wrenc_gpu_ctx* ctx, const int16_t* res, int log2n, int count,
                            int16_t* coef);                              /* transformer.rs:2040 */
-/* The 32x32 forward transform of `count` blocks (residuals within +-255), by the search kernel's v_dot2 code
- * (use_mfma = 0) or by the i8-MFMA experiment (use_mfma = 1; wrenc_amd/csrc/dev_transform.h); the kernel repeats the
+/* The 32x32 forward transform of `count` blocks (residuals within +-255), by the v_dot2 code the search kernel used
+ * until round 2 (use_mfma = 0) or by the i8-MFMA version it runs now (use_mfma = 1; wrenc_amd/csrc/dev_transform.h); the kernel repeats the
  * transform `reps` times per block and *kernel_ms receives its HIP-event duration: parity gate and micro-benchmark
  * of north_star's MFMA question in one entry point (transformer.rs:2040-2378). */
 int wrenc_gpu_test_fwd_dct32(wrenc_gpu_ctx* ctx, const int16_t* res, int count, int16_t* coef,
+                             int use_mfma, int reps, float* kernel_ms);
+/* The same for the inverse 32x32 transform (transformer.rs:2380-2737): `count` dequantised blocks in, residuals out;
+ * use_mfma = 1 is what the search kernel runs (four v_mfma_i32_32x32x32_i8), 0 the v_dot2 version it replaced. */
+int wrenc_gpu_test_inv_dct32(wrenc_gpu_ctx* ctx, const int16_t* deq, int count, int16_t* res,
                              int use_mfma, int reps, float* kernel_ms);
 int wrenc_gpu_test_inv_dct(wrenc_gpu_ctx* ctx, const int16_t* deq, int log2n, int count,
                            int16_t* res);                               /* transformer.rs:2380 */

@@ -127,3 +127,31 @@ def test_fwd_dct32_mfma_experiment(enc, use_mfma):
     assert ms > 0
     for i in range(blocks.shape[0]):
         assert np.array_equal(got[i], po.fwd_dct(blocks[i])), (use_mfma, i)
+
+
+@pytest.mark.parametrize("use_mfma", [0, 1])
+def test_inv_dct32_mfma(enc, use_mfma):
+    """The inverse 32x32 transform as i8 MFMAs (16-bit operands as a signed high byte and a low byte minus 128, the
+    128 * column-sum constant folded into the rounding offset) equals the oracle's transformer.rs:2380-2737
+    restatement on the whole i16 input range -- the first stage's clip to 16 bits included -- as does the v_dot2
+    version it replaced."""
+    from oracle import pyoracle as po
+    rng = np.random.default_rng(78)
+    blocks = rng.integers(-2000, 2001, (48, 32, 32)).astype(np.int16)
+    blocks[0] = 32767
+    blocks[1] = -32768
+    blocks[2] = ((np.indices((32, 32)).sum(0) & 1) * 65535 - 32768).astype(np.int16)
+    blocks[3] = 0
+    blocks[4] = rng.integers(-3, 4, (32, 32))
+    blocks[5] = np.where(np.indices((32, 32))[1] < 16, 32767, -32768)
+    blocks[6] = rng.integers(-32768, 32768, (32, 32))
+    blocks[7, 1:, :] = 0          # a single row of large coefficients: the clip of the first stage
+    blocks[7, 0, :] = 32767
+    blocks[8] = 0
+    blocks[8, 0, 0] = -32768
+    for i in range(9, 16):
+        blocks[i] = rng.integers(-32768, 32768, (32, 32)) * (rng.random((32, 32)) < 0.1)
+    got, ms = enc.inv_dct32(blocks, use_mfma)
+    assert ms > 0
+    for i in range(blocks.shape[0]):
+        assert np.array_equal(got[i], po.inv_dct(blocks[i])), (use_mfma, i)

@@ -33,6 +33,14 @@ struct DevConst {
     // ([v][h][j] = T[v][8 (j / 4) + 4 h + j % 4]) for the stage that contracts over the first stage's output
     int8_t dct32_a[32][32];
     int8_t dct32_p[32][2][16];
+    // the same for the inverse transform (inv_dct32_mfma): [y][i] = T[i][y] for its first stage, [x][h][j] =
+    // T[8 (j / 4) + 4 h + j % 4][x] for its second; both stages feed 16-bit operands as a signed high byte and a low
+    // byte minus 128, so 128 * sum_i T[i][n] comes back with the rounding constant: idct32_k1[y] = 128 S[y] + 64,
+    // idct32_k2[h][w] = 128 S[x] + 2048 for the x of accumulator w in lane half h
+    int8_t idct32_b[32][32];
+    int8_t idct32_p[32][2][16];
+    int32_t idct32_k1[32];
+    int32_t idct32_k2[2][16];
 };
 
 // Pointers that are loaded from memory (PicBufs) lose their address space; these casts tell the

@@ -202,6 +202,62 @@ __device__ __forceinline__ void fwd_dct32_mfma(Ctx c, int o1) {
     WSYNC();
 }
 
+// The inverse 32x32 transform (transformer.rs:2380-2737) the same way, four MFMAs.  16-bit operands (the dequantised
+// coefficients, the clipped intermediate) go in as two bytes each: the signed high byte and the low byte minus 128
+// (v = 256 hi + (lo - 128) + 128), so every product sum is short by 128 * sum_i T[i][n], a per-output constant that
+// comes back together with the rounding offset (DevConst::idct32_k1 / k2).
+//   stage 1: Vt[x][y] = sum_i dT[x][i] T[i][y]      A = bytes of the transposed dequantised block (r2), B = T
+//   stage 2: Rt[x][y] = sum_i T[i][x] V[y][i]       A = T in accumulator k order, B = bytes of V straight from the
+//                                                   first stage's accumulators (same lane, same k set)
+// Residuals to r1[o1 ..] ([y][x]); nothing goes through LDS in between.
+__device__ __forceinline__ void inv_dct32_mfma(Ctx c, int o1) {
+    const int r = LANE & 31, h = LANE >> 5;
+    const v4i_t tB = *(const CONST_AS v4i_t*)&c.k->idct32_b[r][16 * h];
+    const v4i_t tP = *(const CONST_AS v4i_t*)&c.k->idct32_p[r][h][0];
+    const int k1 = c.k->idct32_k1[r];
+    // ---- stage 1 ----
+    const int16_t* dqt = (const int16_t*)SH.r2;
+    const uint4 q0 = *(const uint4*)&dqt[r * 32 + 16 * h];
+    const uint4 q1 = *(const uint4*)&dqt[r * 32 + 16 * h + 8];
+    const uint32_t p[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
+    v4i_t lo, hi;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        lo[i] = (int)(__builtin_amdgcn_perm(p[2 * i + 1], p[2 * i], 0x06040200u) ^ 0x80808080u); // low bytes - 128
+        hi[i] = (int)__builtin_amdgcn_perm(p[2 * i + 1], p[2 * i], 0x07050301u);                 // high bytes, signed
+    }
+    v16i_t z = {};
+    v16i_t acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(hi, tB, z, 0, 0, 0);
+#pragma unroll
+    for (int w = 0; w < 16; ++w) acc[w] = (acc[w] << 8) + k1; // + 128 S[y] + 64 (:2499-2543)
+    acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(lo, tB, acc, 0, 0, 0);
+    int V[16]; // V[y = r][x(w, h)], x(w, h) = 8 (w / 4) + 4 h + w % 4
+#pragma unroll
+    for (int w = 0; w < 16; ++w) V[w] = min(max(acc[w] >> 7, -32768), 32767);
+    // ---- stage 2: bytes of V straight from the registers ----
+    v4i_t d0, d1;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const uint32_t a = (uint32_t)V[4 * i], b = (uint32_t)V[4 * i + 1], cc = (uint32_t)V[4 * i + 2], d = (uint32_t)V[4 * i + 3];
+        d0[i] = (int)(gather_byte(a, b, cc, d, 0) ^ 0x80808080u);
+        d1[i] = (int)gather_byte(a, b, cc, d, 1);
+    }
+    const v16i_t k2 = *(const CONST_AS v16i_t*)&c.k->idct32_k2[h][0];
+    acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(tP, d1, z, 0, 0, 0);
+#pragma unroll
+    for (int w = 0; w < 16; ++w) acc[w] = (acc[w] << 8) + k2[w]; // + 128 S[x] + 2048 (:2680-2737)
+    acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(tP, d0, acc, 0, 0, 0);
+    // lane (y = r, h): residuals at x = 8 q + 4 h + 0..3, q = 0..3
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        uint2 v;
+        v.x = ((uint32_t)(acc[4 * q] >> 12) & 0xFFFFu) | ((uint32_t)(acc[4 * q + 1] >> 12) << 16);
+        v.y = ((uint32_t)(acc[4 * q + 2] >> 12) & 0xFFFFu) | ((uint32_t)(acc[4 * q + 3] >> 12) << 16);
+        *(uint2*)&SH.r1[o1 + r * 32 + 8 * q + 4 * h] = v;
+    }
+    WSYNC();
+}
+
 // o1: where the blocks start in r1 (i16 units, a multiple of 2)
 __device__ __forceinline__ void fwd_dct_lg(Ctx c, int lg, int nb, int o1 = 0) {
     c = uni(c);
@@ -231,7 +287,13 @@ __device__ __forceinline__ void inv_dct_lg(Ctx c, int lg, int nb, int o1 = 0) {
     case 2: inv_dct<2>(c, nb, o1); break;
     case 3: inv_dct<3>(c, nb, o1); break;
     case 4: inv_dct<4>(c, nb, o1); break;
-    default: inv_dct<5>(c, nb, o1); break;
+    default:
+#ifdef WRENC_IDCT32_VDOT2
+        inv_dct<5>(c, nb, o1); // the comparison arm of the micro-benchmark (tools/dct_bench.py)
+#else
+        inv_dct32_mfma(c, o1); // 32x32 is always a single luma block
+#endif
+        break;
     }
 }
 

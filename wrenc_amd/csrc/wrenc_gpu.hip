@@ -177,6 +177,23 @@ __global__ __launch_bounds__(64) void test_fwd_dct32_kernel(const DevConst* __re
     for (int i = threadIdx.x; i < 1024; i += 64) out[(size_t)blockIdx.x * 1024 + i] = SH.r1[i];
 }
 
+// the same for the inverse 32x32 transform: dequantised blocks in (row-major), residuals out
+__global__ __launch_bounds__(64) void test_inv_dct32_kernel(const DevConst* __restrict__ k, const int16_t* in, int16_t* out,
+                                                           int mfma, int reps) {
+    Ctx c = {};
+    c.k = (const CONST_AS DevConst*)k;
+    for (int rep = 0; rep < reps; ++rep) {
+        for (int i = threadIdx.x; i < 1024; i += 64) // transposed load: dT[x][i] = d[i][x]
+            ((int16_t*)SH.r2)[(i & 31) * 32 + (i >> 5)] = in[(size_t)blockIdx.x * 1024 + i];
+        WSYNC();
+        if (mfma)
+            inv_dct32_mfma(c, 0);
+        else
+            inv_dct<5>(c, 1, 0);
+    }
+    for (int i = threadIdx.x; i < 1024; i += 64) out[(size_t)blockIdx.x * 1024 + i] = SH.r1[i];
+}
+
 __global__ __launch_bounds__(64) void test_inv_dct_kernel(const DevConst* __restrict__ k,
                                                           const int16_t* in, int lg, int16_t* out) {
     Ctx c = {};
@@ -477,6 +494,20 @@ void fill_dev_const(const wrenc_gpu_config& cfg, DevConst& k) {
     for (int v = 0; v < 32; ++v)
         for (int h = 0; h < 2; ++h)
             for (int j = 0; j < 16; ++j) k.dct32_p[v][h][j] = (int8_t)dct64(v * 2, 8 * (j / 4) + 4 * h + j % 4);
+    int colsum[32];
+    for (int n = 0; n < 32; ++n) {
+        colsum[n] = 0;
+        for (int i = 0; i < 32; ++i) colsum[n] += dct64(i * 2, n);
+    }
+    for (int y = 0; y < 32; ++y) {
+        for (int i = 0; i < 32; ++i) k.idct32_b[y][i] = (int8_t)dct64(i * 2, y);
+        k.idct32_k1[y] = 128 * colsum[y] + 64;
+    }
+    for (int x = 0; x < 32; ++x)
+        for (int h = 0; h < 2; ++h)
+            for (int j = 0; j < 16; ++j) k.idct32_p[x][h][j] = (int8_t)dct64((8 * (j / 4) + 4 * h + j % 4) * 2, x);
+    for (int h = 0; h < 2; ++h)
+        for (int w = 0; w < 16; ++w) k.idct32_k2[h][w] = 128 * colsum[8 * (w / 4) + 4 * h + w % 4] + 2048;
 }
 
 } // namespace
@@ -1056,9 +1087,10 @@ int wrenc_gpu_test_fwd_dct(wrenc_gpu_ctx* ctx, const int16_t* res, int log2n, in
         hipLaunchKernelGGL(test_fwd_dct_kernel, dim3(count), dim3(64), 0, ctx->stream, ctx->d_const, i, log2n, o);
     });
 }
-int wrenc_gpu_test_fwd_dct32(wrenc_gpu_ctx* ctx, const int16_t* res, int count, int16_t* coef, int use_mfma, int reps,
-                             float* kernel_ms) {
-    if (!ctx || !res || !coef || count < 1 || reps < 1) return WRENC_GPU_EINVAL;
+// a 32x32 transform micro-benchmark: `count` blocks, `reps` repetitions each, HIP-event duration of the one kernel
+static int run_dct32_bench(wrenc_gpu_ctx* ctx, const int16_t* in, int count, int16_t* out, int use_mfma, int reps,
+                           float* kernel_ms, bool inverse) {
+    if (!ctx || !in || !out || count < 1 || reps < 1) return WRENC_GPU_EINVAL;
     HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
     const size_t bytes = (size_t)count * 1024 * sizeof(int16_t);
     int16_t *d_in = nullptr, *d_out = nullptr;
@@ -1067,18 +1099,20 @@ int wrenc_gpu_test_fwd_dct32(wrenc_gpu_ctx* ctx, const int16_t* res, int count, 
     hipError_t e = hipMalloc((void**)&d_out, bytes);
     if (e == hipSuccess) e = hipEventCreate(&e0);
     if (e == hipSuccess) e = hipEventCreate(&e1);
-    if (e == hipSuccess) e = hipMemcpy(d_in, res, bytes, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d_in, in, bytes, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipEventRecord(e0, ctx->stream);
     if (e == hipSuccess) {
-        hipLaunchKernelGGL(test_fwd_dct32_kernel, dim3(count), dim3(64), 0, ctx->stream, ctx->d_const, d_in, d_out,
-                           use_mfma, reps);
+        if (inverse)
+            hipLaunchKernelGGL(test_inv_dct32_kernel, dim3(count), dim3(64), 0, ctx->stream, ctx->d_const, d_in, d_out, use_mfma, reps);
+        else
+            hipLaunchKernelGGL(test_fwd_dct32_kernel, dim3(count), dim3(64), 0, ctx->stream, ctx->d_const, d_in, d_out, use_mfma, reps);
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipEventRecord(e1, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     float ms = 0.f;
     if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
-    if (e == hipSuccess) e = hipMemcpy(coef, d_out, bytes, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(out, d_out, bytes, hipMemcpyDeviceToHost);
     if (kernel_ms) *kernel_ms = ms;
     (void)hipFree(d_in);
     if (d_out) (void)hipFree(d_out);
@@ -1086,6 +1120,14 @@ int wrenc_gpu_test_fwd_dct32(wrenc_gpu_ctx* ctx, const int16_t* res, int count, 
     if (e1) (void)hipEventDestroy(e1);
     if (e != hipSuccess) return fail(ctx, WRENC_GPU_EHIP, hipGetErrorString(e));
     return WRENC_GPU_OK;
+}
+int wrenc_gpu_test_fwd_dct32(wrenc_gpu_ctx* ctx, const int16_t* res, int count, int16_t* coef, int use_mfma, int reps,
+                             float* kernel_ms) {
+    return run_dct32_bench(ctx, res, count, coef, use_mfma, reps, kernel_ms, false);
+}
+int wrenc_gpu_test_inv_dct32(wrenc_gpu_ctx* ctx, const int16_t* deq, int count, int16_t* res, int use_mfma, int reps,
+                             float* kernel_ms) {
+    return run_dct32_bench(ctx, deq, count, res, use_mfma, reps, kernel_ms, true);
 }
 int wrenc_gpu_test_inv_dct(wrenc_gpu_ctx* ctx, const int16_t* deq, int log2n, int count, int16_t* res) {
     return run_block_test(ctx, deq, log2n, count, res, [&](int16_t* i, int16_t* o) {

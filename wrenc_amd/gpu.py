@@ -22,7 +22,7 @@ EXPORTED_SYMBOLS = [
     "wrenc_gpu_upload", "wrenc_gpu_encode", "wrenc_gpu_sync", "wrenc_gpu_download",
     "wrenc_gpu_alloc_host", "wrenc_gpu_free_host", "wrenc_gpu_encode_picture", "wrenc_gpu_set_schedule", "wrenc_gpu_last_schedule", "wrenc_gpu_stats_enable", "wrenc_gpu_last_encode_stats", "wrenc_gpu_final_pass_mismatches",
     "wrenc_gpu_test_fwd_dct", "wrenc_gpu_test_inv_dct", "wrenc_gpu_test_quantize",
-    "wrenc_gpu_test_dequantize", "wrenc_gpu_test_predict", "wrenc_gpu_test_fwd_dct32", "wrenc_gpu_test_quantize_p16",
+    "wrenc_gpu_test_dequantize", "wrenc_gpu_test_predict", "wrenc_gpu_test_fwd_dct32", "wrenc_gpu_test_inv_dct32", "wrenc_gpu_test_quantize_p16",
 ]
 
 
@@ -267,6 +267,18 @@ class Encoder:
         self.lib.wrenc_gpu_test_fwd_dct32.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int,
                                                       C.POINTER(C.c_float)]
         self._check(self.lib.wrenc_gpu_test_fwd_dct32(self.ctx, _p(arr), arr.shape[0], _p(out), int(use_mfma), int(reps),
+                                                      C.byref(ms)))
+        return out, ms.value
+
+    def inv_dct32(self, blocks, use_mfma, reps=1):
+        """(residuals, kernel ms) of the 32x32 inverse transform: v_dot2 code or the i8-MFMA version."""
+        arr = np.ascontiguousarray(blocks, np.int16)
+        assert arr.shape[1:] == (32, 32)
+        out = np.zeros_like(arr)
+        ms = C.c_float()
+        self.lib.wrenc_gpu_test_inv_dct32.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int,
+                                                      C.POINTER(C.c_float)]
+        self._check(self.lib.wrenc_gpu_test_inv_dct32(self.ctx, _p(arr), arr.shape[0], _p(out), int(use_mfma), int(reps),
                                                       C.byref(ms)))
         return out, ms.value
 
