@@ -1708,7 +1708,9 @@ __device__ __forceinline__ void encode_ctu(Ctx& c, const PicBufs& pb, int ctu_co
     WSYNC();
     // ---- the search + final pass: one evaluator, driven by the state machine ----
     #ifndef WRENC_EXP_LDS_PAD
-    static_assert(sizeof(Lds) * WPB + sizeof(LdsTab) <= (160 * 1024) / kWorkgroupsPerCU,
+    // LDS is handed out in granules of 1280 bytes (measured: a workgroup of 32,480 bytes -- 672 more than today, for scan
+    // tables -- fits the CU four times, not five: 520 -> 460 frames/s, gpurun_out/r3w/ab.log)
+    static_assert((sizeof(Lds) * WPB + sizeof(LdsTab) + 1279) / 1280 * 1280 * kWorkgroupsPerCU <= 160 * 1024,
                   "kWorkgroupsPerCU workgroups must fit the CU's 160 KB of LDS");
 #endif
     SH.st.cont = T_START;
