@@ -24,7 +24,7 @@ for s in range(B):
     enc.upload(s, *frames[s % 4])
 enc.sync()
 names = (["predict", "fdct", "q_pre", "q_back", "q_trace", "deq", "idct", "recon", "total", "ctrl", "refs", "skip", "nstep", "nfull"]
-         + ["sad_t%d_c%d" % (4 << (i // 2), i % 2) for i in range(8)] + ["x"] + ["sad_n%d_c%d" % (4 << (i // 2), i % 2) for i in range(8)]
+         + ["stages_t%d_c%d" % (4 << (i // 2), i % 2) for i in range(8)] + ["x"] + ["stages_n%d_c%d" % (4 << (i // 2), i % 2) for i in range(8)]
          + ["x2", "qb_pre", "qb_wait1", "qb_walk", "qb_wait2", "t_xchg", "copy"] + ["cb%d" % i for i in range(32)] + ["y"]
          + ["cbn%d" % i for i in range(32)] + ["y2"] + ["mem_%s_m%d" % (k, m) for k in ("ctrl", "eval", "xchg", "nop") for m in range(4)] + ["y3"]
          + ["st%d_m%d" % (k, m) for k in range(12) for m in range(4)] + ["y4"] + ["stn%d" % k for k in range(12)])
@@ -60,7 +60,7 @@ for i, n in enumerate(names):
         cnt = out[names.index("cbn%d" % k)]
         print("ctrl from %-3d %6.2f%%  %8.1f steps per CTU, %7.0f ticks per step" % (k, 100.0 * out[i] / tot, cnt / nctu, out[i] / max(cnt, 1)))
         continue
-    if n in ("nstep", "nfull") or n.startswith("sad_n"):
+    if n in ("nstep", "nfull") or n.startswith("stages_n"):
         print("%-10s %10.1f per CTU (count)" % (n, out[i] / nctu))
     else:
         print("%-10s %6.2f%%  %10.0f ticks per CTU" % (n, 100.0 * out[i] / tot, out[i] / nctu))

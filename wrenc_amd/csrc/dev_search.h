@@ -316,7 +316,13 @@ __device__ __forceinline__ Res evaluate(const Ctx& c, const PicBufs& pb, const R
             if (q.active) {
 #pragma unroll 1
                 for (int comp = 0; comp < 2; ++comp)
-                    if ((cset >> comp) & 1) full_front(c, q, comp, comp ? mc : q.ml, (merged && comp) ? p0 : 0);
+                    if ((cset >> comp) & 1) {
+                        PROF_MARK(tf0_);
+                        full_front(c, q, comp, comp ? mc : q.ml, (merged && comp) ? p0 : 0);
+                        PROF_MARK(tf1_);
+                        PROF_ADD2(PH_PSZ + ((q.tlg - 2) * 2 + comp), tf0_, tf1_); // stage passes by block size and component
+                        PROF_ADD2(PH_PCNT + ((q.tlg - 2) * 2 + comp), 0, 1);
+                    }
             }
             PROF_MARK(ts0_);
             bool any_y = false, any_c = false;
@@ -341,7 +347,10 @@ __device__ __forceinline__ Res evaluate(const Ctx& c, const PicBufs& pb, const R
 #pragma unroll 1
             for (int comp = 0; comp < 2; ++comp) {
                 if (!((cset >> comp) & 1)) continue;
+                PROF_MARK(tb0_);
                 const uint32_t ssd = full_back(c, pb, q, comp, (merged && comp) ? p0 : 0, comp ? any_c : any_y);
+                PROF_MARK(tb1_);
+                PROF_ADD2(PH_PSZ + ((q.tlg - 2) * 2 + comp), tb0_, tb1_);
                 if (comp)
                     r.ssd_c = ssd;
                 else
