@@ -134,7 +134,7 @@ int wrenc_gpu_encode_picture(wrenc_gpu_ctx* ctx, const uint8_t* y, const uint8_t
                              const uint8_t* cr, wrenc_gpu_picture* out);
 
 /* How an encode call maps CTUs to wavefronts.  Results are identical (bit-exact) either way.
- *   WAVE: one wavefront per CTU, a workgroup = the same CTU of 8 pictures.  Highest throughput, but it needs
+ *   WAVE: one wavefront per CTU, a workgroup = the same CTU of 4 pictures.  Highest throughput, but it needs
  *         hundreds of pictures in flight to fill the GPU (a picture offers only one anti-diagonal of CTUs at a time).
  *   TEAM: four wavefronts per CTU: the candidates of a leaf search that do not depend on each other
  *         (block_splitter.rs:887-898, 905-974) run side by side.  Shorter CTU latency, for calls with few pictures.
@@ -143,6 +143,10 @@ int wrenc_gpu_encode_picture(wrenc_gpu_ctx* ctx, const uint8_t* y, const uint8_t
 enum wrenc_gpu_schedule { WRENC_GPU_SCHEDULE_AUTO = 0, WRENC_GPU_SCHEDULE_WAVE = 1, WRENC_GPU_SCHEDULE_TEAM = 2 };
 int wrenc_gpu_set_schedule(wrenc_gpu_ctx* ctx, int schedule);
 int wrenc_gpu_last_schedule(const wrenc_gpu_ctx* ctx); /* what the most recent encode call used (AUTO = both) */
+/* Test entry: overrides the number of wave slots AUTO compares a diagonal's CTUs x pictures with (default: what the
+ * device holds, CUs x waves per CU), so that a SMALL encode call mixes TEAM and WAVE diagonals as a big one does on
+ * the real figure (tests/test_gpu_groups.py).  slots <= 0 restores the device's value.  Results do not depend on it. */
+int wrenc_gpu_test_set_wave_slots(wrenc_gpu_ctx* ctx, long long slots);
 
 /* Per-launch timing (two HIP events around every kernel launch) is OFF by default: the product path
  * (CLI, native program) never reads it.  bench.py / profiling switch it on.  While it is on, an encode
@@ -163,7 +167,10 @@ int wrenc_gpu_final_pass_mismatches(wrenc_gpu_ctx* ctx, long long* count);
 
 /* ---- kernel-level entry points (parity tests of the building blocks) ----
  * Each runs `count` independent square blocks of side 1<<log2n (2..5), row-major
- * int16, host pointers.  Same arithmetic as the picture path. */
+ * int16, host pointers.  Same arithmetic as the picture path.
+ * Precondition of the 32x32 forward transform (log2n = 5, and wrenc_gpu_test_fwd_dct32 with use_mfma = 1): every
+ * residual lies within +-255, as original minus prediction always does -- the i8-MFMA code splits it into two
+ * base-256 digits.  Inputs outside that range return WRENC_GPU_EINVAL (nothing is computed). */
 int wrenc_gpu_test_fwd_dct(wrenc_gpu_ctx* ctx, const int16_t* res, int log2n, int count,
                            int16_t* coef);                              /* transformer.rs:2040 */
 /* The 32x32 forward transform of `count` blocks (residuals within +-255), by the v_dot2 code the search kernel used

@@ -155,3 +155,21 @@ def test_inv_dct32_mfma(enc, use_mfma):
     assert ms > 0
     for i in range(blocks.shape[0]):
         assert np.array_equal(got[i], po.inv_dct(blocks[i])), (use_mfma, i)
+
+
+def test_fwd_dct32_refuses_residuals_outside_9_bits(enc):
+    """The 32x32 forward transform runs as i8 MFMAs over two base-256 digits of the residual: exact for |r| <= 255,
+    which is every residual the search can form.  The public test entries refuse anything else instead of returning
+    wrong coefficients (include/wrenc_gpu.h); smaller sizes take the whole i16 range."""
+    from wrenc_amd import gpu
+    from oracle import pyoracle as po
+    blocks = np.zeros((2, 32, 32), np.int16)
+    blocks[1, 3, 4] = 256
+    for call in (lambda: enc.fwd_dct(blocks), lambda: enc.fwd_dct32(blocks, 1)):
+        with pytest.raises(gpu.WrencGpuError) as e:
+            call()
+        assert e.value.code == -1          # WRENC_GPU_EINVAL
+    got, _ = enc.fwd_dct32(blocks, 0)          # the v_dot2 code has no such limit
+    assert np.array_equal(got[1], po.fwd_dct(blocks[1]))
+    small = np.full((1, 16, 16), -3000, np.int16)
+    assert np.array_equal(enc.fwd_dct(small)[0], po.fwd_dct(small[0]))

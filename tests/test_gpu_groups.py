@@ -64,3 +64,34 @@ def test_two_calls_in_flight_on_disjoint_slots(built):
         for k in KEYS:
             assert np.array_equal(got[k], ref[k]), (s, k)
     enc.close()
+
+
+@pytest.mark.parametrize("n_pictures,w,h,qp,depth", [(9, 160, 96, 32, 2), (6, 128, 128, 27, 3)])
+def test_auto_schedule_mixing_team_and_wave_diagonals(built, n_pictures, w, h, qp, depth):
+    """AUTO decides per anti-diagonal: with the device's real wave-slot count a test-sized call is all
+    TEAM, so the count is overridden (wrenc_gpu_test_set_wave_slots) until the thin first / last diagonals run as teams
+    and the wide ones as waves inside ONE call -- the border records, the scratch-region bitmap and the picture-to-lane
+    mapping all cross the switch.  Every slot's full record equals the oracle's; mixed content, padding waves."""
+    from wrenc_amd import bitstream as bs, gpu
+    from oracle import pyoracle as po
+    frames = [_frame(i, w, h) for i in range(n_pictures)]
+    enc = gpu.Encoder(w, h, qp=qp, max_split_depth=depth, n_slots=n_pictures, schedule=0)
+    # diagonals hold 1 .. min(cols, rows-ish) CTUs: team while pictures x count x 100 <= slots x 50
+    enc.test_set_wave_slots(2 * n_pictures * 2 - 1)          # count = 1 -> team, count >= 2 -> wave
+    for s, f in enumerate(frames):
+        enc.upload(s, *f)
+    enc.encode(0, n_pictures)
+    enc.sync()
+    assert enc.last_schedule() == 0                          # AUTO = both kernels ran in this call
+    assert enc.final_pass_mismatches() == 0
+    for s, f in enumerate(frames):
+        got = enc.download(s)
+        ref = po.encode_picture(*f, qp, depth)
+        for k in KEYS:
+            assert np.array_equal(got[k], ref[k]), (s, k)
+        assert bs.write_picture(w, h, qp, s, got) == bs.write_picture(w, h, qp, s, ref), s
+    enc.test_set_wave_slots(0)
+    enc.encode(0, n_pictures)
+    enc.sync()
+    assert enc.last_schedule() == 2                          # the device's own figure: all teams at this size
+    enc.close()

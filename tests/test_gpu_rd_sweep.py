@@ -23,6 +23,7 @@ def _tool():
 
 def test_rd_sweep_2160p(built):
     from oracle import pyoracle as po
+    from wrenc_amd import metrics
     rd = _tool()
     w, h, n, qps = 3840, 2176, 2, (22, 27, 32, 37)
     doc = rd.run_sweep(w, h, frames=n, depth=3, qps=qps, threads=8, keep_streams=True, verbose=False)
@@ -30,8 +31,10 @@ def test_rd_sweep_2160p(built):
     assert [r["qp"] for r in res] == list(qps)
     for r in res:      # the result shape of evaluate_mp.py:78-120
         assert set(("title", "qp", "bytes", "duration", "metrics")) <= set(r)
-        assert set(r["metrics"]["psnr"]["summary"]) == {"psnr_y", "psnr_u", "psnr_v", "psnr_avg"}
-        assert len(r["metrics"]["per_frame"]) == n and r["final_pass_mismatches"] == 0
+        for m in ("PSNR", "SSIM"):      # metrics.json: per-frame metrics with the attributes Avg, Y, U, V
+            assert set(r["metrics"][m]["summary"]) == {"Avg", "Y", "U", "V"}
+            assert len(r["metrics"][m]["per_frame"]) == n
+        assert r["final_pass_mismatches"] == 0
         assert r["bytes"] == len(r["_stream"])
         info = po.parse_stream_info(r["_stream"])
         assert (info["width"], info["height"], info["n_pictures"]) == (w, h, n)
@@ -41,12 +44,16 @@ def test_rd_sweep_2160p(built):
             dy, dcb, dcr = po.spec_decode_record(back, r["qp"])
             rec = r["_recs"][f]
             assert np.array_equal(dy, rec["rec_y"]) and np.array_equal(dcb, rec["rec_cb"]) and np.array_equal(dcr, rec["rec_cr"])
-            pf = r["metrics"]["per_frame"][f]
-            assert abs(rd.psnr(doc["_frames"][f][0], dy) - pf["psnr_y"]) < 1e-9
-            assert abs(rd.ssim(doc["_frames"][f][0], dy) - pf["ssim_y"]) < 1e-9
+            got = metrics.frame_metrics(doc["_frames"][f], (dy, dcb, dcr))
+            for m in ("PSNR", "SSIM"):
+                pf = r["metrics"][m]["per_frame"][f]
+                for k in ("Avg", "Y", "U", "V"):
+                    assert abs(got[m][k] - pf[k]) < 1e-9
+            p = got["PSNR"]     # Avg is ffmpeg's psnr_avg: from the plane-weighted MSE, not a mean of dB values
+            assert abs(metrics.psnr_avg_from_planes(p["Y"], p["U"], p["V"]) - p["Avg"]) < 1e-6
     # an RD curve: rate and quality both fall as QP rises
     b = [r["bytes"] for r in res]
-    p = [r["metrics"]["psnr"]["summary"]["psnr_y"] for r in res]
-    s = [r["metrics"]["ssim"]["summary"]["ssim_y"] for r in res]
+    p = [r["metrics"]["PSNR"]["summary"]["Y"] for r in res]
+    s = [r["metrics"]["SSIM"]["summary"]["Y"] for r in res]
     assert b[0] > b[1] > b[2] > b[3] and p[0] > p[1] > p[2] > p[3] and s[0] > s[1] > s[2] > s[3]
     assert 1.2 < b[0] / b[1] < 3.0 and p[0] - p[3] > 5.0 and p[3] > 29.0

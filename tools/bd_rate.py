@@ -12,9 +12,9 @@ import sys
 from scipy import interpolate
 
 
-def samples(path, metric="psnr_avg"):
+def samples(path, metric="Avg"):
     doc = json.load(open(path))
-    pts = sorted((r["metrics"]["psnr"]["summary"][metric], r["bytes"]) for r in doc["results"])
+    pts = sorted((r["metrics"]["PSNR"]["summary"][metric], r["bytes"]) for r in doc["results"])
     return [p[0] for p in pts], [p[1] for p in pts]
 
 

@@ -27,7 +27,9 @@ names = (["predict", "fdct", "q_pre", "q_back", "q_trace", "deq", "idct", "recon
          + ["stages_t%d_c%d" % (4 << (i // 2), i % 2) for i in range(8)] + ["x"] + ["stages_n%d_c%d" % (4 << (i // 2), i % 2) for i in range(8)]
          + ["x2", "qb_pre", "qb_wait1", "qb_walk", "qb_wait2", "t_xchg", "copy"] + ["cb%d" % i for i in range(32)] + ["y"]
          + ["cbn%d" % i for i in range(32)] + ["y2"] + ["mem_%s_m%d" % (k, m) for k in ("ctrl", "eval", "xchg", "nop") for m in range(4)] + ["y3"]
-         + ["st%d_m%d" % (k, m) for k in range(12) for m in range(4)] + ["y4"] + ["stn%d" % k for k in range(12)])
+         + ["st%d_m%d" % (k, m) for k in range(12) for m in range(4)] + ["y4"] + ["stn%d" % k for k in range(12)] + ["y5"]
+         + ["ev%d" % i for i in range(32)] + ["y6"] + ["evn%d" % i for i in range(32)] + ["y7"] + ["quant_t%d" % (4 << i) for i in range(4)])
+KINDS = ["sadlist", "full", "nop/copy", "sadsearch", "cclmsearch", "leaf4", "leafc4", "leaf8"]
 N = len(names)
 out = (C.c_ulonglong * N)()
 enc.lib.wrenc_gpu_prof_read.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
@@ -45,7 +47,12 @@ print("%dx%d depth %d B %d schedule %d: wall %.3f s, fps %.2f, ticks per profile
 for i, n in enumerate(names):
     if i == 8 or n.startswith("x") or n.startswith("y") or n.startswith("cbn") or out[i] == 0:
         continue
-    if n.startswith("stn"):
+    if n.startswith("stn") or n.startswith("evn"):
+        continue
+    if n.startswith("ev"):
+        k = int(n[2:])
+        cnt = max(out[names.index("evn%d" % k)], 1)
+        print("requests %-10s t%-2d %6.2f%%  %7.1f per CTU, %8.0f ticks per request" % (KINDS[k // 4], 4 << (k % 4), 100.0 * out[i] / tot, cnt / nctu, out[i] / cnt))
         continue
     if n.startswith("st") and "_m" in n:
         k = int(n[2:n.index("_")])

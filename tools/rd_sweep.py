@@ -2,9 +2,11 @@
 """RD-curve sweep (BASELINE.json configs[2]): encode the same pictures at several QPs
 with the full CT-partition search, write the real bitstream, and report bytes, PSNR / SSIM of the
 reconstruction and the rates of the two stages.  The result list follows the shape of the reference's
-tools/evaluation/evaluate_mp.py:78-120 (title, qp, bytes, duration, metrics.{psnr,ssim}.summary), without
-ffmpeg / VTM: PSNR and SSIM are computed here from the encoder's reconstruction, which the stream parser
-tests show is what a decoder rebuilds.
+tools/evaluation/evaluate_mp.py:78-120 (title, qp, bytes, duration, metrics.{PSNR,SSIM}.{summary,per_frame} with the
+attributes Avg / Y / U / V of metrics.json), without ffmpeg / VTM: PSNR and SSIM are ffmpeg's definitions restated in
+wrenc_amd/metrics.py (psnr_avg from the plane-weighted MSE, SSIM over 8x8 windows at stride 4; pinned against the
+reference's own summary.json by tests/test_metrics.py), computed from the encoder's reconstruction, which the stream
+parser tests show is what a decoder rebuilds.
 
     python tools/rd_sweep.py [--width 3840 --height 2176 --frames 8 --depth 3 --qps 22,27,32,37] [--out file.json]
 """
@@ -20,27 +22,11 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
-def psnr(a, b):
-    mse = np.mean((a.astype(np.float64) - b.astype(np.float64)) ** 2)
-    return 100.0 if mse == 0 else 10.0 * np.log10(255.0 * 255.0 / mse)   # evaluate_mp.py:108 caps inf at 100
-
-
-def ssim(a, b):
-    """Wang et al. SSIM, 11x11 Gaussian window (sigma 1.5), mean over the plane."""
-    from scipy.ndimage import gaussian_filter
-    a, b = a.astype(np.float64), b.astype(np.float64)
-    f = lambda x: gaussian_filter(x, 1.5, truncate=3.5)
-    mu_a, mu_b = f(a), f(b)
-    va, vb, cov = f(a * a) - mu_a ** 2, f(b * b) - mu_b ** 2, f(a * b) - mu_a * mu_b
-    c1, c2 = (0.01 * 255) ** 2, (0.03 * 255) ** 2
-    return float(np.mean(((2 * mu_a * mu_b + c1) * (2 * cov + c2)) / ((mu_a ** 2 + mu_b ** 2 + c1) * (va + vb + c2))))
-
-
 def run_sweep(width=3840, height=2176, frames=8, depth=3, qps=(22, 27, 32, 37), threads=8, extra_params=None,
               keep_streams=False, verbose=True):
     """The sweep as a function (tests/test_gpu_rd_sweep.py runs it too).  keep_streams: each result also carries
     "_stream" (parameter sets + pictures), "_recs" and the doc "_frames", for a decoder-side check by the caller."""
-    from wrenc_amd import bitstream, gpu, synth
+    from wrenc_amd import bitstream, gpu, metrics, synth
     w, h, n = width, height, frames
     pics = [synth.synth_textured_frame(w, h, f) for f in range(n)]
     results = []
@@ -64,24 +50,26 @@ def run_sweep(width=3840, height=2176, frames=8, depth=3, qps=(22, 27, 32, 37), 
         total = len(head) + sum(len(x) for x in nals)
         per_frame = []
         for f in range(n):
-            py, pu, pv = (psnr(pics[f][c], recs[f][k]) for c, k in enumerate(("rec_y", "rec_cb", "rec_cr")))
-            per_frame.append({"n": f + 1, "psnr_y": py, "psnr_u": pu, "psnr_v": pv, "psnr_avg": (4 * py + pu + pv) / 6,
-                              "ssim_y": ssim(pics[f][0], recs[f]["rec_y"]), "bytes": len(nals[f])})
-        summ = {k: float(np.mean([p[k] for p in per_frame])) for k in ("psnr_y", "psnr_u", "psnr_v", "psnr_avg", "ssim_y")}
+            m = metrics.frame_metrics(pics[f], (recs[f]["rec_y"], recs[f]["rec_cb"], recs[f]["rec_cr"]))
+            m["n"] = f + 1
+            m["bytes"] = len(nals[f])
+            per_frame.append(m)
+        summ = {k: metrics.summarise([p[k] for p in per_frame]) for k in ("PSNR", "SSIM")}
         results.append({
             "title": "synth_textured_%dx%d[wrenc_amd@max_split_depth=%d,qp=%d]" % (w, h, depth, qp), "qp": qp,
             "bytes": total, "duration": t_search + t_write, "frames": n,
             "bits_per_pixel": 8.0 * total / (n * w * h),
             "search_fps": n / t_search, "bitstream_fps_%d_threads" % threads: n / t_write,
             "final_pass_mismatches": mism,
-            "metrics": {"psnr": {"summary": {k: summ[k] for k in ("psnr_y", "psnr_u", "psnr_v", "psnr_avg")}},
-                        "ssim": {"summary": {"ssim_y": summ["ssim_y"]}}, "per_frame": per_frame}})
+            "metrics": {k: {"summary": summ[k], "per_frame": [dict(p[k], n=p["n"]) for p in per_frame]} for k in ("PSNR", "SSIM")},
+            "frame_bytes": [p["bytes"] for p in per_frame]})
         if keep_streams:
             results[-1]["_stream"] = head + b"".join(nals)
             results[-1]["_recs"] = recs
         if verbose:
-            print("qp %2d  %9d bytes  %.4f bpp  PSNR-Y %.2f dB  SSIM-Y %.4f  search %.1f fps  writer %.1f fps" % (
-                qp, total, results[-1]["bits_per_pixel"], summ["psnr_y"], summ["ssim_y"], n / t_search, n / t_write), flush=True)
+            print("qp %2d  %9d bytes  %.4f bpp  PSNR Avg %.2f Y %.2f U %.2f V %.2f dB  SSIM All %.4f Y %.4f  search %.1f fps  writer %.1f fps" % (
+                qp, total, results[-1]["bits_per_pixel"], summ["PSNR"]["Avg"], summ["PSNR"]["Y"], summ["PSNR"]["U"], summ["PSNR"]["V"],
+                summ["SSIM"]["Avg"], summ["SSIM"]["Y"], n / t_search, n / t_write), flush=True)
     pool.shutdown()
     doc = {"config": {"width": w, "height": h, "frames": n, "max_split_depth": depth, "content": "synth_textured_frame",
                       "extra_params": extra_params},

@@ -36,7 +36,6 @@ struct Req {
     // team schedule only (leaf_step_team): COPY_PULL copies the block from the LDS tile of member copy_from into
     // this member's tile (every member issues it, the source included, and all meet at a barrier behind it);
     // xchg: the team exchanges results after this request
-    bool post_save; // unused
     int copy_from;
     bool xchg;
     int n;          // K_SADLIST: number of entries
@@ -340,6 +339,7 @@ __device__ __forceinline__ Res evaluate(const Ctx& c, const PicBufs& pb, const R
                 }
             }
             PROF_MARK(ts1_);
+            PROF_ADD2(PH_QZ + ((q.tlg - 2) & 3), ts0_, ts1_);
             if (!q.active) { // only kept the shared-Viterbi barriers company
                 PROF_ADD2(PH_SKIP, ts0_, ts1_);
                 continue;
@@ -806,7 +806,6 @@ __device__ __forceinline__ void req_full(Req& q, int comps, int tx, int ty, int 
     q.final = final;
     q.stage = (final && tlg <= 4) ? comps : 0; // a final-pass block is evaluated once: stage its originals now
     q.pre_copy = COPY_NONE;
-    q.post_save = false;
     q.xchg = false;
 }
 
@@ -859,7 +858,6 @@ __device__ __forceinline__ void leaf_attach_org(LeafSF& s, Req& q) {
 // a request that only saves / restores a reconstruction
 __device__ __forceinline__ void leaf_copy_only(LeafSF& s, Req& q, int mode, int comps, int cont) {
     q.kind = K_NOP;
-    q.post_save = false;
     q.xchg = false;
     req_copy(q, mode, comps, 0, s.bx, s.by, s.lg);
     s.cont = (uint8_t)cont;
@@ -889,7 +887,6 @@ __device__ __forceinline__ void leaf_full(LeafSF& s, Req& q, int comps, int ml, 
 __device__ __forceinline__ void leaf_sadlist(LeafSF& s, Req& q, int comps, int n, uint32_t m0, uint32_t m1, uint32_t m2,
                                              uint32_t m3, bool chroma_refs, int cont) {
     q.kind = K_SADLIST;
-    q.post_save = false;
     q.xchg = false;
     q.tree = s.tree;
     q.comps = comps;
@@ -1193,7 +1190,6 @@ enum { TC_START = 0, TC_A, TC_D, TC_E, TC_F, TC_DONE, TC_DC_START, TC_DC_A, TC_D
 __device__ __forceinline__ void team_idle(Req& q) {
     q.kind = K_NOP;
     q.pre_copy = COPY_NONE;
-    q.post_save = false;
 }
 // every member copies comps of the leaf's block from the tile of member `holder` (who holds the winner's
 // reconstruction) into its own tile: attached to q as a COPY_PULL, which every member must issue
@@ -1542,7 +1538,6 @@ __device__ __forceinline__ bool ctu_step(Ctx& c, const Res& r, Req& q) {
                 t.rl = t.ns_luma_cur;
                 t.rc = t.ns_chroma_cur;
                 q.kind = K_NOP;
-                q.post_save = false;
                 q.xchg = false;
                 req_copy(q, COPY_RESTORE, 3, 1 + t.level, t.rbx, t.rby, t.rlg);
                 t.cont = T_REGEN_DONE;
@@ -1605,7 +1600,6 @@ __device__ __forceinline__ bool ctu_step(Ctx& c, const Res& r, Req& q) {
                 t.rl = (uint8_t)uni((int)SH.ns_luma[pl]);
                 t.rc = (uint8_t)uni((int)SH.ns_chroma[pl]);
                 q.kind = K_NOP;
-                q.post_save = false;
                 q.xchg = false;
                 req_copy(q, COPY_RESTORE, 3, 1 + pl, t.rbx, t.rby, t.rlg);
                 t.cont = T_REGEN_DONE;
@@ -1679,7 +1673,7 @@ __device__ __forceinline__ void encode_ctu(Ctx& c, const PicBufs& pb, int ctu_co
     c.ctu_y = ctu_row * 32;
     c.cu32_mode = PLANAR;
 #ifdef WRENC_PROFILE
-    if (threadIdx.x < PH_COUNT) s_prof[threadIdx.x] = 0;
+    for (int i = threadIdx.x; i < PH_COUNT; i += blockDim.x) s_prof[i] = 0;
     __syncthreads();
 #endif
     PROF_MARK(tt0_);
@@ -1761,6 +1755,8 @@ __device__ __forceinline__ void encode_ctu(Ctx& c, const PicBufs& pb, int ctu_co
         r = evaluate(c, pb, q, overflow);
         PROF_MARK(te1_);
         PROF_ADDM(q.kind == K_NOP ? 3 : 1, te0_, te1_);
+        PROF_ADD2(PH_EV + (((q.kind & 7) * 4 + ((q.kind == K_NOP ? q.copy_tlg : q.tlg) - 2)) & 31), te0_, te1_); // by request kind and block size
+        PROF_ADD2(PH_EVN + (((q.kind & 7) * 4 + ((q.kind == K_NOP ? q.copy_tlg : q.tlg) - 2)) & 31), 0, 1);
 #ifdef WRENC_PROFILE
         if (LANE == 0 && WAVE < 4 && cb_ < 12) s_prof[PH_ST + 4 * cb_ + WAVE] += te1_ - te0_; // eval time by step origin, member
         if (threadIdx.x == 0 && cb_ < 12) s_prof[PH_STN + cb_] += 1;
@@ -1823,7 +1819,7 @@ __device__ __forceinline__ void encode_ctu(Ctx& c, const PicBufs& pb, int ctu_co
     PROF_MARK(tt1_);
     PROF_ADD2(PH_TOTAL, tt0_, tt1_);
     __syncthreads();
-    if (threadIdx.x < PH_COUNT) atomicAdd(&g_prof[threadIdx.x], s_prof[threadIdx.x]);
+    for (int i = threadIdx.x; i < PH_COUNT; i += blockDim.x) atomicAdd(&g_prof[i], s_prof[i]);
 #endif
 }
 

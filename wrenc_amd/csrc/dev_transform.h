@@ -9,8 +9,7 @@ namespace wrenc {
 // registers; G = 64/N lane groups walk the rows/columns; the other operand is
 // read from LDS as a wave-broadcast.
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ int dot2(uint32_t a, uint32_t b, int acc) {
-#if __has_builtin(__builtin_amdgcn_sdot2)
+__device__ __forceinline__ int dot2(uint32_t a, uint32_t b, int acc) { // v_dot2_i32_i16
     typedef short s2 __attribute__((ext_vector_type(2)));
     s2 va, vb;
     va.x = (short)(a & 0xFFFF);
@@ -18,9 +17,6 @@ __device__ __forceinline__ int dot2(uint32_t a, uint32_t b, int acc) {
     vb.x = (short)(b & 0xFFFF);
     vb.y = (short)(b >> 16);
     return __builtin_amdgcn_sdot2(va, vb, acc, false);
-#else
-    return acc + (int)(short)(a & 0xFFFF) * (int)(short)(b & 0xFFFF) + ((int)a >> 16) * ((int)b >> 16);
-#endif
 }
 
 // forward: nb residual blocks in r1 ([blk][y][x] i16) -> coefficients in place, via r2;

@@ -26,7 +26,8 @@ using namespace wrenc;
 // ---------------------------------------------------------------------------
 // kernels
 // ---------------------------------------------------------------------------
-// scratch regions for resident workgroups (>= 2 per CU x 256 CUs; 32 bitmap words of 64)
+// scratch regions for resident workgroups: 16384 / WPB = 4096 regions of WPB x kWaveScratch bytes (64 bitmap words of
+// 64 bits), against kWorkgroupsPerCU x 256 CUs = 1280 workgroups resident at once
 constexpr int kScratchSlots = 16384 / WPB; // >= the workgroups resident at once (a power of two, >= 64)
 
 // Per-workgroup global scratch comes from a pool of kScratchSlots regions handed out through a
@@ -386,6 +387,7 @@ void diag_scan(int lw, int lh, uint8_t (*out)[2]) { // ctu.rs:54-77
 struct wrenc_gpu_ctx {
     wrenc_gpu_config cfg;
     long long wave_slots = 0;                  // waves of the search kernel the device holds at once
+    long long device_wave_slots = 0;           // (wave_slots can be overridden by a test: wrenc_gpu_test_set_wave_slots)
     hipStream_t stream = nullptr;              // lane 0 of the encode; timing events
     hipStream_t copy_stream = nullptr;         // uploads and downloads: they overlap the search of other slots
     hipEvent_t ev_uploaded = nullptr;          // end of the uploads an encode call has to wait for
@@ -727,7 +729,7 @@ int wrenc_gpu_create(const wrenc_gpu_config* cfg, wrenc_gpu_ctx** out) {
     wrenc_gpu_ctx* ctx = new (std::nothrow) wrenc_gpu_ctx();
     if (!ctx) return fail(nullptr, WRENC_GPU_ENOMEM, "out of host memory");
     ctx->cfg = *cfg;
-    ctx->wave_slots = (long long)prop.multiProcessorCount * kWorkgroupsPerCU * WPB;
+    ctx->wave_slots = ctx->device_wave_slots = (long long)prop.multiProcessorCount * kWorkgroupsPerCU * WPB;
     ctx->ctu_cols = cfg->width / 32;
     ctx->ctu_rows = cfg->height / 32;
     auto bail = [&](int code, const std::string& msg) {
@@ -1032,6 +1034,12 @@ int wrenc_gpu_set_schedule(wrenc_gpu_ctx* ctx, int schedule) {
 
 int wrenc_gpu_last_schedule(const wrenc_gpu_ctx* ctx) { return ctx ? ctx->last_schedule : WRENC_GPU_EINVAL; }
 
+int wrenc_gpu_test_set_wave_slots(wrenc_gpu_ctx* ctx, long long slots) {
+    if (!ctx) return WRENC_GPU_EINVAL;
+    ctx->wave_slots = slots > 0 ? slots : ctx->device_wave_slots;
+    return WRENC_GPU_OK;
+}
+
 int wrenc_gpu_stats_enable(wrenc_gpu_ctx* ctx, int on) {
     if (!ctx) return WRENC_GPU_EINVAL;
     ctx->stats_enabled = on != 0;
@@ -1082,7 +1090,17 @@ int wrenc_gpu_prof_read(wrenc_gpu_ctx* ctx, unsigned long long* out, int n) {
 
 // ---- building-block entry points ----
 
+// the 32x32 forward transform runs as i8 MFMAs on two base-256 digits of the residual (fwd_dct32_mfma): exact for
+// |residual| <= 255, which is all the search can produce; the test entries refuse anything else
+static bool residuals_fit_9_bits(const int16_t* res, size_t n) {
+    for (size_t i = 0; i < n; ++i)
+        if (res[i] < -255 || res[i] > 255) return false;
+    return true;
+}
+
 int wrenc_gpu_test_fwd_dct(wrenc_gpu_ctx* ctx, const int16_t* res, int log2n, int count, int16_t* coef) {
+    if (ctx && res && log2n == 5 && count >= 1 && !residuals_fit_9_bits(res, (size_t)count * 1024))
+        return fail(ctx, WRENC_GPU_EINVAL, "wrenc_gpu_test_fwd_dct: a 32x32 residual lies outside +-255");
     return run_block_test(ctx, res, log2n, count, coef, [&](int16_t* i, int16_t* o) {
         hipLaunchKernelGGL(test_fwd_dct_kernel, dim3(count), dim3(64), 0, ctx->stream, ctx->d_const, i, log2n, o);
     });
@@ -1091,6 +1109,8 @@ int wrenc_gpu_test_fwd_dct(wrenc_gpu_ctx* ctx, const int16_t* res, int log2n, in
 static int run_dct32_bench(wrenc_gpu_ctx* ctx, const int16_t* in, int count, int16_t* out, int use_mfma, int reps,
                            float* kernel_ms, bool inverse) {
     if (!ctx || !in || !out || count < 1 || reps < 1) return WRENC_GPU_EINVAL;
+    if (!inverse && use_mfma && !residuals_fit_9_bits(in, (size_t)count * 1024))
+        return fail(ctx, WRENC_GPU_EINVAL, "wrenc_gpu_test_fwd_dct32: a residual lies outside +-255 (MFMA path)");
     HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
     const size_t bytes = (size_t)count * 1024 * sizeof(int16_t);
     int16_t *d_in = nullptr, *d_out = nullptr;
