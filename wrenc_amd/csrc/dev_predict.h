@@ -331,13 +331,19 @@ __device__ __forceinline__ void stage_org_leaf(const Ctx& c, int comps, int tx, 
 // residual is added to it (nothing reads that area in between: the reference samples are cached, and
 // CCLM reads the luma plane while it writes chroma).  Only the final pass, which compares its
 // reconstruction with the search's, keeps the tile and parks the prediction in global scratch.
+// A PACK of candidates evaluated side by side (dev_search.h, K_LEAF8) parks each candidate's prediction in LDS
+// instead: PRED_PARK, byte kParkByte + i of decw (behind the pack's trellis decisions).
+enum { PRED_SCRATCH = 0, PRED_TILE = 1, PRED_PARK = 2 };
+constexpr int kParkByte = 160; // 144 bytes of decisions in front, 288 bytes of predictions (3 x (64 + 16 + 16)) behind
 template <bool full>
-__device__ __forceinline__ int emit_sample(const Ctx& c, int o, int i, int v, int pc, int x, int y, bool to_tile) {
+__device__ __forceinline__ int emit_sample(const Ctx& c, int o, int i, int v, int pc, int x, int y, int to_tile) {
     const int d = o - v;
     if (full) { // i already includes the block's base in r1 / the prediction scratch
         SH.r1[i] = (int16_t)d;
-        if (to_tile)
+        if (to_tile == PRED_TILE)
             rec_put(pc, x, y, v);
+        else if (to_tile == PRED_PARK)
+            ((uint8_t*)SH.decw)[kParkByte + i] = (uint8_t)v;
         else
             c.pred_scratch[i] = (uint8_t)v;
     }
@@ -352,9 +358,10 @@ __device__ __forceinline__ int emit_sample(const Ctx& c, int o, int i, int v, in
 // Returns the lane's partial sum of |org - pred| (the SAD of block_splitter.rs:96-104).
 template <bool full>
 __device__ __forceinline__ int predict(Ctx c, int comp, int tx, int ty, int tlg, int mode, int rbase = 0,
-                                       bool to_tile = true) {
+                                       int to_tile = PRED_TILE) {
     c = uni(c);
     rbase = uni(rbase);
+    to_tile = uni(to_tile);
     comp = uni(comp);
     tx = uni(tx);
     ty = uni(ty);

@@ -768,6 +768,243 @@ __device__ __forceinline__ void quantize_p16(Ctx c, int nb, int* overflow, long 
     PROF_ADD2(PH_QTRACE, q2_, q3_);
 }
 
+// Dependent quantisation of the transform blocks of nc <= 3 CANDIDATES of one 8x8 single-tree CU at once (the packed
+// 8x8 leaf search, dev_search.h K_LEAF8): per candidate a luma 8x8 block at r1[64 c ..] and its Cb | Cr 4x4 blocks at
+// r1[64 nc + 32 c ..].  Every block is a chain of its own and the chains do not depend on each other, so they are walked
+// SIDE BY SIDE by this wave alone -- no pooling over the workgroup, no barrier: a ROUND gives each of the wave's four
+// 16-lane rows one chain's next 16 positions (the chunk entries of 64 positions, one lane each), then one quad per row
+// walks them.  Rounds 0..3 take the luma chains' sub-blocks (DC end first) in rows 0 .. nc - 1 and chroma blocks in the
+// remaining rows; with three candidates a fifth round takes the last two chroma blocks.  The serial part of a pack is
+// 4 (5) x 16 steps for up to nine chains, where the one-candidate-per-request search walked 64 positions per candidate
+// between two workgroup barriers.  Same arithmetic as quantize(): chunk_entry, the one-compare walk, the forward trace
+// by composed state maps, emit_level.  Levels in place; per candidate the level cost of the luma block and of the
+// chroma pair (block_splitter.rs:436-458) and whether any level of the pack's luma / chroma blocks is non-zero.
+// Scratch: r2[0, 192 nc) scan-order coefficients, r1 chunk entries, decw[0, 144) decisions, q_pm.
+__device__ __forceinline__ void quantize_pk8(Ctx c, int nc, int* overflow, long long lvl_y[3], long long lvl_c[3], bool* any_y,
+                                             bool* any_c) {
+    c = uni(c);
+    nc = uni(nc);
+    const int lane = lane_fresh();
+    const CONST_AS DevConst* k = c.k;
+    constexpr int shl = 8 + 3 - 5 + 1, offl = (1 << shl) >> 1; // quantizer.rs:558-569
+    constexpr int shc = 8 + 2 - 5 + 1, offc = (1 << shc) >> 1;
+    const int lsc = k->lsc;
+    const CONST_AS uint16_t* scan8 = k->scan_idx[1];
+    const CONST_AS uint16_t* scan4 = k->scan_idx[0];
+    int16_t* tcs = (int16_t*)SH.r2;
+    int32_t* cc = (int32_t*)SH.r1;
+    uint16_t* dec16 = (uint16_t*)SH.decw;  // luma candidate c: [16 c + 4 sub-block + state]; chroma block b: [48 + 4 b + state]
+    uint16_t* ist = &SH.q_pm[1][0][0];     // first significant position: [c] luma candidate c, [4 + b] chroma block b
+    const int row = lane >> 4, i16 = lane & 15;
+    const int nL = 64 * nc;
+    PROF_MARK(q0_);
+    lvl_y[0] = lvl_y[1] = lvl_y[2] = 0;
+    lvl_c[0] = lvl_c[1] = lvl_c[2] = 0;
+    *any_y = false;
+    *any_c = false;
+    int nzl = 0;
+#pragma unroll
+    for (int cd = 0; cd < 3; ++cd) {
+        if (cd < nc) {
+            const int tc = SH.r1[cd * 64 + scan8[lane]];
+            nzl |= tc;
+            tcs[cd * 64 + lane] = (int16_t)tc;
+            const int qd = quotient(k, tc, shl, offl);
+            const int first = wave_min_i32((tc != 0 && (qd >> 1) > 0) ? lane : 64);
+            if (lane == 0) ist[cd] = (uint16_t)first;
+        }
+    }
+#pragma unroll
+    for (int ps = 0; ps < 2; ++ps) {
+        const int blk = 4 * ps + row;
+        const bool mine = blk < 2 * nc;
+        int tc = 0, qd = 0;
+        if (mine) {
+            tc = SH.r1[nL + blk * 16 + scan4[i16]];
+            nzl |= tc;
+            tcs[nL + blk * 16 + i16] = (int16_t)tc;
+            qd = quotient(k, tc, shc, offc);
+        }
+        const int first = row_min_i32((tc != 0 && (qd >> 1) > 0) ? i16 : 16);
+        if (mine && i16 == 0) ist[4 + blk] = (uint16_t)first;
+    }
+    if (__ballot(nzl != 0) == 0ULL) return; // every block of the pack is zero: the levels are the zeros already in r1
+    WSYNC();
+    PROF_MARK(q1_);
+    PROF_ADD2(PH_QPRE, q0_, q1_);
+    const int ldq1 = (int)ldq_at(c, 1);
+    const int st = lane & 3, quad = lane >> 2;
+    const int cls = st == 0 ? 0 : (st == 1 ? 1 : 2);
+    int C = 0;
+    int ovf = 0;
+    const int nrounds = nc == 3 ? 5 : 4;
+#pragma unroll 1
+    for (int r = 0; r < nrounds; ++r) {
+        const int nlum = r < 4 ? nc : 0;                // rows 0 .. nlum - 1: luma candidates
+        const int cstart = r * (4 - nc);                // first chroma block of the round
+        const int ccount = max(0, min(4 - nlum, 2 * nc - cstart));
+        const int base0 = 48 - 16 * r;                  // the luma chains' positions of the round
+        {
+            const bool is_l = row < nlum;
+            const int j = row - nlum;
+            const bool mine = is_l || j < ccount;
+            const int blk = cstart + j;
+            const int p = is_l ? base0 + i16 : i16;
+            const int sh = is_l ? shl : shc, off = is_l ? offl : offc;
+            int par0 = 0, par1 = 0, adj = 0;
+            if (mine) {
+                const int tc = tcs[is_l ? row * 64 + p : nL + blk * 16 + p];
+                const int first = ist[is_l ? row : 4 + blk];
+                chunk_entry(c, cc + lane * 6, tc, quotient(k, tc, sh, off), p == (is_l ? 63 : 15), p <= first, sh, off, lsc, ldq1,
+                            &par0, &par1, &adj, &ovf);
+            }
+            const unsigned long long b0 = __ballot(mine && par0), b1 = __ballot(mine && par1), ba = __ballot(mine && adj);
+            if (mine && i16 == 0) {
+                uint16_t* pm = SH.q_pm[0][row];
+                pm[0] = (uint16_t)(b0 >> lane);
+                pm[1] = (uint16_t)(b1 >> lane);
+                pm[2] = (uint16_t)((ba >> (lane + 15)) & 1);
+            }
+        }
+        WSYNC();
+        PROF_MARK(qb1_);
+        if (quad < 4) {
+            const bool is_l = quad < nlum;
+            const int j = quad - nlum;
+            if (is_l || j < ccount) {
+                if (!is_l) C = 0; // a chroma block is a chain of its own
+                const int32_t* wcc = cc + quad * 16 * 6;
+                const uint16_t* pm = SH.q_pm[0][quad];
+                const unsigned parmask = pm[st > 1 ? 1 : 0];
+                const bool adj = st == 0 && pm[2] != 0;
+                int2 cur[16];
+#pragma unroll
+                for (int kk = 0; kk < 16; ++kk) cur[kk] = *(const int2*)&wcc[kk * 6 + 2 * cls];
+                unsigned bits = 0;
+#pragma unroll
+                for (int kk = 15; kk >= 0; --kk) {
+                    const int2 e = cur[kk];
+                    const int KA = e.x + dpp_quad<0xD8>(C); // C[trans[s][0]]: quad_perm [0,2,1,3]
+                    const int KB = e.y + dpp_quad<0x72>(C); // C[trans[s][1]]: quad_perm [2,0,3,1]
+                    C = min(KA, KB) & ~1;
+                    bits = shift_in_less(bits, KB, KA);
+                    if (kk == 15) { // first position of a sub-block in coding order (:512-514)
+                        const bool choseB = KB < KA;
+                        const bool pick1 = choseB != (((parmask >> 15) & 1) != 0);
+                        if (!pick1 && adj) C -= 2 * ldq1;
+                    }
+                }
+                bits ^= parmask; // choseB -> pick1
+                int m = min(C, dpp_quad<0xB1>(C)); // renormalise (see quantize())
+                m = min(m, dpp_quad<0x4E>(m));
+                C -= m;
+                dec16[(is_l ? quad * 16 + (base0 >> 4) * 4 : 48 + (cstart + j) * 4) + st] = (uint16_t)bits;
+            }
+        }
+        WSYNC();
+        PROF_MARK(qb2_);
+        PROF_ADD2(PH_QB_WALK, qb1_, qb2_);
+    }
+    PROF_MARK(q2_);
+    PROF_ADD2(PH_QBACK, q1_, q2_);
+    // ---- forward trace from state 0 (quantizer.rs:686-721) + level cost ----
+    // luma: row = candidate, four consecutive positions per lane (they lie in one sub-block)
+    {
+        const bool act = row < nc;
+        const int cd = act ? row : 0;
+        const int p0 = i16 * 4;
+        const int16_t* btcs = tcs + cd * 64;
+        const DecMasks dm = dec_masks(dec16 + cd * 16, p0);
+        int fmap = kMapId;
+        if (act) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int p = p0 + j;
+                const int tc = btcs[p];
+                fmap = compose_map(position_map(tc, quotient(k, tc, shl, offl), p == 63, dec_nib(dm, p)), fmap);
+            }
+        }
+        int pre = fmap;
+        pre = compose_map(pre, __builtin_amdgcn_update_dpp(kMapId, pre, 0x111, 0xF, 0xF, false)); // row_shr:1
+        pre = compose_map(pre, __builtin_amdgcn_update_dpp(kMapId, pre, 0x112, 0xF, 0xF, false)); // row_shr:2
+        pre = compose_map(pre, __builtin_amdgcn_update_dpp(kMapId, pre, 0x114, 0xF, 0xF, false)); // row_shr:4
+        pre = compose_map(pre, __builtin_amdgcn_update_dpp(kMapId, pre, 0x118, 0xF, 0xF, false)); // row_shr:8
+        int entry = __builtin_amdgcn_update_dpp(0, pre, 0x111, 0xF, 0xF, false) & 3; // state after the previous lane of the row
+        if (i16 == 0) entry = 0;
+        long long sum_nz = 0;
+        unsigned zmask = 0;
+        int fnz = 64;
+        if (act) {
+            int state = entry;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int p = p0 + j;
+                const int tc = btcs[p];
+                SH.r1[cd * 64 + scan8[p]] = (int16_t)emit_level(c, tc, quotient(k, tc, shl, offl), p == 63, dec_nib(dm, p), p, j, state,
+                                                                zmask, sum_nz, fnz, ovf);
+            }
+        }
+        const int pf = row_min_i32(fnz); // zeros before a block's first non-zero level cost nothing
+        if (act) sum_nz += (long long)__popc(zmask >> min(max(pf - p0 + 1, 0), 16)) * SHT.lv[0];
+        const long long hi = sum_nz >> 24;
+        const int ra = row_sum_i32((int)(sum_nz & 0xFFFFFF)), rb = row_sum_i32((int)(hi & 0xFFFFFF)), rc = row_sum_i32((int)(hi >> 24));
+#pragma unroll
+        for (int b = 0; b < 3; ++b) {
+            const long long a0 = (long long)(unsigned)__builtin_amdgcn_readlane(ra, 16 * b);
+            const long long a1 = (long long)(unsigned)__builtin_amdgcn_readlane(rb, 16 * b);
+            const long long a2 = (long long)__builtin_amdgcn_readlane(rc, 16 * b);
+            if (b < nc) {
+                lvl_y[b] = a0 + ((a1 + (a2 << 24)) << 24);
+                if (__builtin_amdgcn_readlane(pf, 16 * b) < 64) *any_y = true;
+            }
+        }
+    }
+    // chroma: row = block 4 ps + row, one position per lane (as quantize_p16)
+#pragma unroll
+    for (int ps = 0; ps < 2; ++ps) {
+        if (4 * ps >= 2 * nc) continue; // (uniform)
+        const int blk = 4 * ps + row;
+        const bool mine = blk < 2 * nc;
+        const int bb = mine ? blk : 0;
+        const int tc = mine ? (int)tcs[nL + bb * 16 + i16] : 0;
+        const int qd = quotient(k, tc, shc, offc);
+        const DecMasks dm = dec_masks(dec16 + 48 + bb * 4, 0);
+        const int nib = dec_nib(dm, i16);
+        int pre = mine ? position_map(tc, qd, i16 == 15, nib) : kMapId;
+        pre = compose_map(pre, __builtin_amdgcn_update_dpp(kMapId, pre, 0x111, 0xF, 0xF, false)); // row_shr:1
+        pre = compose_map(pre, __builtin_amdgcn_update_dpp(kMapId, pre, 0x112, 0xF, 0xF, false)); // row_shr:2
+        pre = compose_map(pre, __builtin_amdgcn_update_dpp(kMapId, pre, 0x114, 0xF, 0xF, false)); // row_shr:4
+        pre = compose_map(pre, __builtin_amdgcn_update_dpp(kMapId, pre, 0x118, 0xF, 0xF, false)); // row_shr:8
+        int entry = __builtin_amdgcn_update_dpp(0, pre, 0x111, 0xF, 0xF, false) & 3;
+        if (i16 == 0) entry = 0;
+        long long sum_nz = 0;
+        unsigned zmask = 0;
+        int fnz = 16;
+        if (mine) {
+            int state = entry;
+            SH.r1[nL + bb * 16 + scan4[i16]] = (int16_t)emit_level(c, tc, qd, i16 == 15, nib, i16, 0, state, zmask, sum_nz, fnz, ovf);
+        }
+        const int pf = row_min_i32(fnz);
+        if (mine && (zmask & 1u) && i16 > pf) sum_nz += SHT.lv[0];
+        const long long hi = sum_nz >> 24;
+        const int ra = row_sum_i32((int)(sum_nz & 0xFFFFFF)), rb = row_sum_i32((int)(hi & 0xFFFFFF)), rc = row_sum_i32((int)(hi >> 24));
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const long long a0 = (long long)(unsigned)__builtin_amdgcn_readlane(ra, 16 * b);
+            const long long a1 = (long long)(unsigned)__builtin_amdgcn_readlane(rb, 16 * b);
+            const long long a2 = (long long)__builtin_amdgcn_readlane(rc, 16 * b);
+            if (4 * ps + b < 2 * nc) {
+                lvl_c[(4 * ps + b) >> 1] += a0 + ((a1 + (a2 << 24)) << 24);
+                if (__builtin_amdgcn_readlane(pf, 16 * b) < 16) *any_c = true;
+            }
+        }
+    }
+    if (__ballot(ovf != 0) != 0ULL) *overflow = 1;
+    WSYNC();
+    PROF_MARK(q3_);
+    PROF_ADD2(PH_QTRACE, q2_, q3_);
+}
+
 // levels r1 (row-major) -> transposed dequantised coefficients in r2 (dT[x][i] = d[i][x]);
 // quantizer.rs:761-1079
 __device__ __forceinline__ void dequantize_t(Ctx c, int lg, int nb, int o1 = 0) {

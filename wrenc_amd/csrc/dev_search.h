@@ -9,7 +9,7 @@ namespace wrenc {
 // ---------------------------------------------------------------------------
 // Evaluation requests and the evaluator
 // ---------------------------------------------------------------------------
-enum { K_SADLIST = 0, K_FULL = 1, K_NOP = 2, K_SADSEARCH = 3, K_CCLMSEARCH = 4, K_LEAF4 = 5, K_LEAFC4 = 6 };
+enum { K_SADLIST = 0, K_FULL = 1, K_NOP = 2, K_SADSEARCH = 3, K_CCLMSEARCH = 4, K_LEAF4 = 5, K_LEAFC4 = 6, K_LEAF8 = 7 };
 #ifndef WRENC_POOL_MIN_TLG
 #define WRENC_POOL_MIN_TLG 3
 #endif
@@ -25,6 +25,10 @@ struct Req {
                     // K_LEAF4: the whole search of a 4x4 DUAL_TREE_LUMA leaf (:886-1078) in one request, its full candidates
                     // evaluated side by side in the wave's four 16-lane rows (leaf4_search): Res::imin = the mode, vmin = its cost;
                     // K_LEAFC4: the same for the DUAL_TREE_CHROMA leaf of a split 8x8 CU (:794-885; leafc4_search), mc = the DM mode
+                    // K_LEAF8: the whole search of an 8x8 SINGLE_TREE leaf (:886-1078) in one request, its full candidates
+                    // evaluated in packs of two and three (leaf8_search): Res::imin / imin2 = luma / chroma mode, vmin = the cost;
+                    // n = which parts run here (bit 0 pack {planar, DC}, bit 1 the SAD search + pack {cm, cm - 1, cm + 1},
+                    // bit 2 the CCLM part on the winner ml with DM chroma cost fcur)
     int comps;      // bit 0: luma block, bit 1: Cb+Cr pair
     int tx, ty, tlg;
     int ml, mc;     // K_FULL: luma / chroma mode
@@ -44,6 +48,7 @@ struct Req {
     // (the reference's cache_reconsts / restore_reconsts, block_splitter.rs:807-840, 1085-1145)
     int pre_copy, copy_comps, copy_slot, copy_tx, copy_ty, copy_tlg;
     unsigned long long modes_lo, modes_hi; // K_SADLIST: one byte per entry (8 + 8), the same mode for luma and chroma
+    float fcur;     // K_LEAF8, part 4 alone (team schedule): the winner's DM chroma cost (:1040)
 };
 
 struct Res {
@@ -53,6 +58,7 @@ struct Res {
     // K_SADLIST: costs of the first three entries, first minimum (strict <) and its index
     float v0, v1, v2, vmin;
     int imin;
+    int imin2;      // K_LEAF8: the chroma mode
 };
 
 __device__ __forceinline__ float uni_f(float v) { return __int_as_float(uni(__float_as_int(v))); }
@@ -68,7 +74,7 @@ __device__ __forceinline__ void full_front(const Ctx& c, const Req& q, int comp,
     if ((comp ? q.refs1 : q.refs0) && mode < LT_CCLM) build_refs(c, comp, q.tx, q.ty, q.tlg);
     PROF_MARK(t0_);
     PROF_ADD2(PH_REFS, tr0_, t0_);
-    predict<true>(c, comp, q.tx, q.ty, q.tlg, mode, rbase, !q.final);
+    predict<true>(c, comp, q.tx, q.ty, q.tlg, mode, rbase, q.final ? PRED_SCRATCH : PRED_TILE);
     PROF_MARK(t1_);
     PROF_ADD2(PH_PREDICT, t0_, t1_);
     fwd_dct_lg(c, lg, nb, rbase);
@@ -257,6 +263,7 @@ __device__ __forceinline__ void sad_search(const Ctx& c, const Req& q, int& cm_o
 
 __device__ __forceinline__ Res leaf4_search(const Ctx& c, const Req& q, int* overflow); // below, after the cost functions
 __device__ __forceinline__ Res leafc4_search(const Ctx& c, const Req& q, int* overflow);
+__device__ __forceinline__ Res leaf8_search(const Ctx& c, const Req& q, int* overflow);
 
 // The evaluator: every block evaluation of the search, of the regeneration and of the final pass
 // goes through this one inlined copy (the search logic below is a state machine that hands out
@@ -269,6 +276,7 @@ __device__ __forceinline__ Res evaluate(const Ctx& c, const PicBufs& pb, const R
     r.lvl_c = 0;
     r.v0 = r.v1 = r.v2 = r.vmin = 3.40282347e+38f;
     r.imin = 0;
+    r.imin2 = 0;
     PROF_MARK(tcp0_);
     if (q.pre_copy != COPY_NONE)
         copy_block(c, q.pre_copy, q.copy_comps, q.copy_slot, q.copy_tx, q.copy_ty, q.copy_tlg, q.copy_from);
@@ -278,6 +286,7 @@ __device__ __forceinline__ Res evaluate(const Ctx& c, const PicBufs& pb, const R
     if (q.stage) stage_org_leaf(c, q.stage, q.tx, q.ty, q.tlg);
     if (q.kind == K_LEAF4) return leaf4_search(c, q, overflow);
     if (q.kind == K_LEAFC4) return leafc4_search(c, q, overflow);
+    if (q.kind == K_LEAF8) return leaf8_search(c, q, overflow);
     int mc = q.mc;
     if (q.kind == K_CCLMSEARCH) {
         // get_chroma_intra_pred_aux_cost of LT, T, L_CCLM in one sample pass, then the pick of :847-854 (SADs are
@@ -766,6 +775,273 @@ __device__ __forceinline__ Res leafc4_search(const Ctx& c, const Req& q, int* ov
     return r;
 }
 
+// ---------------------------------------------------------------------------
+// K_LEAF8: the whole search of an 8x8 SINGLE_TREE leaf in one request (block_splitter.rs:886-1078 with a luma 8x8 block
+// and a Cb + Cr 4x4 pair per candidate).  At max-split-depth 2 these leaves are two thirds of a CTU's evaluations and
+// each one was a chain of short stages between control steps: 64 + 32 samples per candidate, a pooled 64-step trellis
+// walk per candidate between two workgroup barriers.  The full candidates of a leaf read only neighbours outside the
+// block (:887-898, :974), so they are evaluated in PACKS: pack A = {planar, DC}, then the SAD search, then pack B =
+// {cm, cm - 1, cm + 1}; a pack's candidates go through every stage together -- luma blocks one pass each, the 4x4
+// chroma blocks of all candidates four to a pass (predict4_lane), the transforms over nb blocks, and ONE trellis pass
+// for the pack's six or nine chains walked side by side by this wave alone (quantize_pk8: no workgroup barrier).
+// Predictions and reconstructions of the pack are parked in LDS (PRED_PARK); the running best candidate's
+// reconstruction goes to the tile when its pack is done, so there is no save / restore through global scratch.
+// Then the CCLM part (:1040-1072) as in K_CCLMSEARCH, the CCLM candidate's prediction and reconstruction in
+// registers: the tile keeps the DM chroma unless CCLM wins.  The decisions are the reference's, in its order: first
+// minimum of [planar, DC, cm, cm - 1, cm + 1] as a running strict-less update; DM on a tie with CCLM.
+// ---------------------------------------------------------------------------
+struct Pack8Out {
+    uint32_t ssd_y[3], ssd_c[3];
+    long long lvl_y[3], lvl_c[3];
+};
+__device__ __forceinline__ Pack8Out pack8_eval(const Ctx& c, const Req& q, int nc, int m0, int m1, int m2, int* overflow) {
+    Pack8Out o;
+    const int lane = lane_fresh();
+    const int row = lane >> 4, i16 = lane & 15;
+    const int nL = 64 * nc;
+    uint8_t* park = (uint8_t*)SH.decw + kParkByte;
+    const uint8_t* org = (const uint8_t*)SH.r2 + kOrgLeaf;
+    PROF_MARK(t0_);
+    // luma: one pass per candidate (a candidate outside 2..66 rides along as a zero block)
+#pragma unroll 1
+    for (int cd = 0; cd < nc; ++cd) {
+        const int mode = cd == 0 ? m0 : (cd == 1 ? m1 : m2);
+        if (mode != kNoMode) {
+            predict<true>(c, 0, q.tx, q.ty, 3, mode, 64 * cd, PRED_PARK);
+        } else {
+            SH.r1[64 * cd + lane] = 0;
+            park[64 * cd + lane] = 0;
+        }
+    }
+    // chroma: the 4x4 blocks of all candidates, four to a pass (row = block 2 cand + plane)
+#pragma unroll 1
+    for (int ps = 0; ps < 2; ++ps) {
+        if (4 * ps >= 2 * nc) continue;
+        const int blk = 4 * ps + row;
+        const int cd = blk >> 1, pl = blk & 1;
+        const int mode = cd == 0 ? m0 : (cd == 1 ? m1 : m2);
+        const bool in = blk < 2 * nc;
+        const bool on = in && mode != kNoMode;
+        const int v = predict4_lane(c, on ? mode : kNoMode, pl);
+        if (in) {
+            SH.r1[nL + 16 * blk + i16] = (int16_t)(on ? (int)org[256 + 16 * pl + i16] - v : 0);
+            park[nL + 16 * blk + i16] = (uint8_t)v;
+        }
+        WSYNC();
+    }
+    PROF_MARK(t1_);
+    PROF_ADD2(PH_PREDICT, t0_, t1_);
+    fwd_dct_lg(c, 3, nc, 0);
+    fwd_dct_lg(c, 2, 2 * nc, nL);
+    PROF_MARK(t2_);
+    PROF_ADD2(PH_FDCT, t1_, t2_);
+    bool any_y = false, any_c = false;
+    quantize_pk8(c, nc, overflow, o.lvl_y, o.lvl_c, &any_y, &any_c);
+    PROF_MARK(t3_);
+    if (any_y) { // (all levels zero: the residuals are zero too, and r1 already says so)
+        dequantize_t(c, 3, nc, 0);
+        inv_dct_lg(c, 3, nc, 0);
+    }
+    if (any_c) {
+        dequantize_t(c, 2, 2 * nc, nL);
+        inv_dct_lg(c, 2, 2 * nc, nL);
+    }
+    PROF_MARK(t4_);
+    PROF_ADD2(PH_IDCT, t3_, t4_);
+    // reconstruction (pred as i16 + res, clamp: :178) and SSD; the reconstruction takes the prediction's place
+#pragma unroll
+    for (int cd = 0; cd < 3; ++cd) {
+        o.ssd_y[cd] = 0;
+        o.ssd_c[cd] = 0;
+        if (cd < nc) {
+            int rec = (int16_t)((int)park[64 * cd + lane] + (int)SH.r1[64 * cd + lane]);
+            rec = min(max(rec, 0), 255);
+            park[64 * cd + lane] = (uint8_t)rec;
+            const int d = rec - (int)org[lane];
+            o.ssd_y[cd] = (uint32_t)wave_sum_i32(M24(d, d));
+        }
+    }
+#pragma unroll
+    for (int ps = 0; ps < 2; ++ps) {
+        if (4 * ps >= 2 * nc) continue;
+        const int blk = 4 * ps + row;
+        const bool in = blk < 2 * nc;
+        int dd = 0;
+        if (in) {
+            int rec = (int16_t)((int)park[nL + 16 * blk + i16] + (int)SH.r1[nL + 16 * blk + i16]);
+            rec = min(max(rec, 0), 255);
+            park[nL + 16 * blk + i16] = (uint8_t)rec;
+            const int d = rec - (int)org[256 + 16 * (blk & 1) + i16];
+            dd = M24(d, d);
+        }
+        const int rs = row_sum_i32(dd);
+        const uint32_t s01 = (uint32_t)(__builtin_amdgcn_readlane(rs, 0) + __builtin_amdgcn_readlane(rs, 16));
+        const uint32_t s23 = (uint32_t)(__builtin_amdgcn_readlane(rs, 32) + __builtin_amdgcn_readlane(rs, 48));
+        if (ps == 0) {
+            o.ssd_c[0] = s01;
+            o.ssd_c[1] = s23;
+        } else {
+            o.ssd_c[2] = s01;
+        }
+    }
+    WSYNC();
+    PROF_MARK(t5_);
+    PROF_ADD2(PH_RECON, t4_, t5_);
+    return o;
+}
+
+// a pack candidate's reconstruction from the park into the tile (luma 8x8, Cb and Cr 4x4)
+__device__ __forceinline__ void pack8_to_tile(const Req& q, int nc, int cd) {
+    const int lane = lane_fresh();
+    const uint8_t* park = (const uint8_t*)SH.decw + kParkByte;
+    rec_put(0, q.tx + (lane & 7), q.ty + (lane >> 3), park[64 * cd + lane]);
+    if (lane < 32) {
+        const int pl = lane >> 4, i = lane & 15;
+        rec_put(1 + pl, (q.tx >> 1) + (i & 3), (q.ty >> 1) + (i >> 2), park[64 * nc + 32 * cd + lane]);
+    }
+    WSYNC();
+}
+
+__device__ __forceinline__ Res leaf8_search(const Ctx& c, const Req& q, int* overflow) {
+    Res r;
+    r.ssd_y = 0;
+    r.ssd_c = 0;
+    r.lvl_y = 0;
+    r.lvl_c = 0;
+    r.v0 = r.v1 = r.v2 = 3.40282347e+38f;
+    r.imin = PLANAR;
+    r.imin2 = PLANAR;
+    const int lane = lane_fresh();
+    if (q.refs0) build_refs(c, 0, q.tx, q.ty, 3);
+    if (q.refs1) build_refs(c, 1, q.tx, q.ty, 3);
+    float best = 3.40282347e+38f;
+    int best_mode = q.ml, best_cls = 0;
+    EvalParts eb;
+    eb.ssd_y = eb.ssd_c = 0;
+    eb.lvl_y = eb.lvl_c = 0;
+    bool first_ = true;
+#define LEAF8_CANDIDATE(P, B, M)                                                                                       \
+    do {                                                                                                               \
+        EvalParts e_;                                                                                                  \
+        e_.ssd_y = (P).ssd_y[B];                                                                                       \
+        e_.ssd_c = (P).ssd_c[B];                                                                                       \
+        e_.lvl_y = (P).lvl_y[B];                                                                                       \
+        e_.lvl_c = (P).lvl_c[B];                                                                                       \
+        const int cls_ = mpm_class(c, q.tx, q.ty, 3, (M));                                                             \
+        const float val_ = uni_f(assemble_cost(c, TREE_SINGLE, cls_, (M), e_));                                        \
+        if (c.trace && lane == 0) /* (team schedule: each part is traced by the member that runs it) */                \
+            TRACE_REC(c.ctu_x + q.tx, c.ctu_y + q.ty, 3, TREE_SINGLE, 1, (M), (M), __float_as_int(val_));              \
+        if (first_ || val_ < best) {                                                                                   \
+            best = val_;                                                                                               \
+            best_mode = (M);                                                                                           \
+            best_cls = cls_;                                                                                           \
+            eb = e_;                                                                                                   \
+            win_ = (B);                                                                                                \
+        }                                                                                                              \
+        first_ = false;                                                                                                \
+    } while (0)
+    if (q.n & 1) {
+        // pack A: planar and DC (:887-898)
+        const Pack8Out a = pack8_eval(c, q, 2, PLANAR, DC, kNoMode, overflow);
+        int win_ = -1;
+        LEAF8_CANDIDATE(a, 0, PLANAR);
+        LEAF8_CANDIDATE(a, 1, DC);
+        pack8_to_tile(q, 2, win_);
+    }
+    if (q.n & 2) {
+        int cm;
+        unsigned smin;
+        sad_search(c, q, cm, smin);
+        cm = uni(cm);
+        // pack B: step_search(mode, 1, _, aux = false) on {cm, cm - 1, cm + 1} (:974)
+        const int lo = !(cm < 3) ? cm - 1 : kNoMode, hi = !(cm + 1 > 66) ? cm + 1 : kNoMode;
+        const Pack8Out b = pack8_eval(c, q, 3, cm, lo, hi, overflow);
+        int win_ = -1;
+        LEAF8_CANDIDATE(b, 0, cm);
+        if (lo != kNoMode) LEAF8_CANDIDATE(b, 1, lo);
+        if (hi != kNoMode) LEAF8_CANDIDATE(b, 2, hi);
+        if (win_ >= 0) pack8_to_tile(q, 3, win_);
+    }
+#undef LEAF8_CANDIDATE
+    r.vmin = best;
+    r.imin = best_mode;
+    r.imin2 = best_mode;
+    r.ssd_y = eb.ssd_y;
+    r.ssd_c = eb.ssd_c;
+    r.lvl_y = eb.lvl_y;
+    r.lvl_c = eb.lvl_c;
+    if (!(q.n & 4)) return r;
+    // ---- the CCLM part on the winner, whose reconstruction is in the tile (:1040-1072) ----
+    float cur;
+    if (q.n & 3) {
+        // :1040 get_chroma_intra_pred_cost(mode) repeats the winner's chroma evaluation: its parts are at hand
+        cur = uni_f(assemble_chroma_cost(c, best_mode, eb));
+        if (c.trace && lane == 0)
+            TRACE_REC(c.ctu_x + q.tx, c.ctu_y + q.ty, 3, TREE_SINGLE, 3, 0, best_mode, __float_as_int(cur));
+    } else {
+        cur = q.fcur; // (team schedule: the team decided the winner, every member assembled this cost)
+    }
+    const unsigned acc = sad_list_cclm(c, q.tx, q.ty, 3);
+    const unsigned lt = (unsigned)__builtin_amdgcn_readlane((int)acc, 0), t = (unsigned)__builtin_amdgcn_readlane((int)acc, 1),
+                   l = (unsigned)__builtin_amdgcn_readlane((int)acc, 2);
+    if (c.trace && lane < 3)
+        TRACE_REC(c.ctu_x + q.tx, c.ctu_y + q.ty, 3, TREE_SINGLE, 2, 0, lane == 0 ? LT_CCLM : (lane == 1 ? T_CCLM : L_CCLM),
+                  __float_as_int((float)acc));
+    const int cm = (lt <= t && lt <= l) ? LT_CCLM : (t <= l ? T_CCLM : L_CCLM);
+    PROF_MARK(t0_);
+    const CclmParams cpv = cclm_params(c, 1 + (lane & 1), q.tx, q.ty, 3, cm);
+    const int a0 = __builtin_amdgcn_readlane(cpv.a, 0), a1 = __builtin_amdgcn_readlane(cpv.a, 1);
+    const int k0 = __builtin_amdgcn_readlane(cpv.k, 0), k1 = __builtin_amdgcn_readlane(cpv.k, 1);
+    const int b0 = __builtin_amdgcn_readlane(cpv.b, 0), b1 = __builtin_amdgcn_readlane(cpv.b, 1);
+    const bool flat128 = __builtin_amdgcn_readlane((int)cpv.flat128, 0) != 0;
+    const bool avail_l = __builtin_amdgcn_readlane((int)cpv.avail_l, 0) != 0;
+    const int row = lane >> 4, i = lane & 15, x = i & 3, y = i >> 2;
+    const int pl = row & 1;
+    const bool mine = row < 2; // rows 0 / 1 = Cb / Cr
+    int v = 128;
+    if (mine && !flat128) {
+        const int ds = cclm_ds6(c, q.tx, q.ty, 2 * y, 2 * x, avail_l);
+        v = (M24(ds, pl ? a1 : a0) >> (pl ? k1 : k0)) + (pl ? b1 : b0);
+        v = min(max(v, 0), 255);
+    }
+    const int org = ((const uint8_t*)SH.r2)[kOrgLeaf + 256 + 16 * pl + i];
+    if (mine) SH.r1[lane] = (int16_t)(org - v);
+    WSYNC();
+    PROF_MARK(t1_);
+    PROF_ADD2(PH_PREDICT, t0_, t1_);
+    fwd_dct_lg(c, 2, 2, 0);
+    long long lvl[4];
+    int any_mask = 0;
+    quantize_p16(c, 2, overflow, lvl, &any_mask);
+    if (any_mask) {
+        dequantize_t(c, 2, 2, 0);
+        inv_dct_lg(c, 2, 2, 0);
+    }
+    int rec = (int16_t)(v + (int)SH.r1[mine ? lane : 0]);
+    rec = min(max(rec, 0), 255);
+    const int d = rec - org;
+    const int rs = row_sum_i32(mine ? M24(d, d) : 0);
+    EvalParts e = eb;
+    e.ssd_c = (uint32_t)(__builtin_amdgcn_readlane(rs, 0) + __builtin_amdgcn_readlane(rs, 16));
+    e.lvl_c = lvl[0] + lvl[1];
+    const float cclm_cost = uni_f(assemble_chroma_cost(c, cm, e));
+    if (c.trace && lane == 0) TRACE_REC(c.ctu_x + q.tx, c.ctu_y + q.ty, 3, TREE_SINGLE, 3, 0, cm, __float_as_int(cclm_cost));
+    const bool dm_wins = cur == fminf(cclm_cost, fminf(cur, 3.40282347e+38f));
+    // :1062-1072 final get_intra_pred_cost: the winner's luma with the DM chroma (still in the tile) or the CCLM chroma
+    if (!dm_wins && mine) rec_put(1 + pl, (q.tx >> 1) + x, (q.ty >> 1) + y, rec);
+    WSYNC();
+    if (q.n & 3) {
+        r.vmin = dm_wins ? uni_f(assemble_cost(c, TREE_SINGLE, best_cls, best_mode, eb))
+                         : uni_f(assemble_cost(c, TREE_SINGLE, best_cls, cm, e));
+        r.imin2 = dm_wins ? best_mode : cm;
+    } else { // part 4 alone: the CCLM candidate's mode and chroma parts, the team assembles the rest
+        r.imin = cm;
+        r.ssd_c = e.ssd_c;
+        r.lvl_c = e.lvl_c;
+    }
+    return r;
+}
+
 // the decision maps of a block: at most 8 x 8 units of 4x4 (one lane each), sizes are powers of two
 __device__ __forceinline__ void fill_maps(int bx, int by, int lg, int luma_mode, int chroma_mode, bool luma,
                                           bool chroma) {
@@ -821,7 +1097,7 @@ __device__ __forceinline__ void req_copy(Req& q, int mode, int comps, int slot, 
 
 enum {
     C_START = 0, C_PLANAR, C_DCM, C_LIST, C_PAIR_EMIT, C_PAIR, C_F0, C_F1, C_F2, C_WIN, C_CX, C_CCLM, C_DM,
-    C_DC_START, C_DC2, C_DC3, C_DC4, C_DC5, C_L4, C_LC4
+    C_DC_START, C_DC2, C_DC3, C_DC4, C_DC5, C_L4, C_LC4, C_L8
 };
 
 __device__ __forceinline__ void leaf_init(LeafSt& s, int tree, int bx, int by, int lg, int dm_mode) {
@@ -933,6 +1209,25 @@ __device__ __forceinline__ void leaf_leaf4(LeafSF& s, Req& q, int cont) {
     s.cont = (uint8_t)cont;
 }
 
+// the whole search of an 8x8 SINGLE_TREE leaf as one request (K_LEAF8, leaf8_search); parts: bit 0 pack {planar, DC},
+// bit 1 SAD search + pack {cm, cm - 1, cm + 1}, bit 2 the CCLM part
+#ifndef WRENC_LEAF8
+#define WRENC_LEAF8 1
+#endif
+__device__ __forceinline__ bool leaf_is_leaf8(const LeafSF& s) { return WRENC_LEAF8 && s.tree == TREE_SINGLE && s.lg == 3; }
+__device__ __forceinline__ void leaf_leaf8(LeafSF& s, Req& q, int parts, int cont) {
+    req_full(q, 3, s.bx, s.by, s.lg, 0, 0, false, true, s.need_refs0 != 0, s.need_refs1 != 0, false);
+    q.kind = K_LEAF8;
+    q.n = parts;
+    q.tree = s.tree;
+    q.fcur = 0.0f;
+    leaf_attach_org(s, q);
+    leaf_attach_save(s, q);
+    s.need_refs0 = 0;
+    s.need_refs1 = 0;
+    s.cont = (uint8_t)cont;
+}
+
 __device__ __forceinline__ EvalParts res_parts(const Res& r) {
     EvalParts e;
     e.ssd_y = r.ssd_y;
@@ -996,8 +1291,17 @@ __device__ __forceinline__ bool leaf_step(const Ctx& c, LeafSF& s, const Res& r,
                 leaf_leaf4(s, q, C_L4);
                 return true;
             }
+            if (leaf_is_leaf8(s)) { // an 8x8 single-tree leaf: the whole search in one request, candidates in packs
+                leaf_leaf8(s, q, 7, C_L8);
+                return true;
+            }
             leaf_full(s, q, both, PLANAR, PLANAR, true, C_PLANAR);
             return true;
+        case C_L8:
+            s.cost = r.vmin;
+            s.luma_mode = (uint8_t)r.imin;
+            s.chroma_mode = (uint8_t)r.imin2;
+            return false;
         case C_L4:
             s.cost = r.vmin;
             s.luma_mode = (uint8_t)r.imin;
@@ -1170,7 +1474,14 @@ __device__ __forceinline__ float xv0(const Ctx& c, int par, int m) { return __in
 
 __device__ __forceinline__ void team_publish(const Req& q, const Res& r, int par) {
     XRes x;
-    if (q.kind == K_FULL || q.kind == K_CCLMSEARCH) {
+    if (q.kind == K_LEAF8) {
+        // a half of the packed search: its best candidate's parts, the mode in the top byte of ssd_y; the CCLM part:
+        // the picked mode in ssd_y, the CCLM candidate's chroma parts
+        x.ssd_y = (q.n & 4) ? (uint32_t)r.imin : (r.ssd_y | ((uint32_t)r.imin << 24));
+        x.ssd_c = r.ssd_c;
+        x.lvl_y = r.lvl_y;
+        x.lvl_c = r.lvl_c;
+    } else if (q.kind == K_FULL || q.kind == K_CCLMSEARCH) {
         x.ssd_y = q.kind == K_CCLMSEARCH ? (uint32_t)r.imin : r.ssd_y; // a chroma-only request: the picked mode rides here
         x.ssd_c = r.ssd_c;
         x.lvl_y = r.lvl_y;
@@ -1184,7 +1495,7 @@ __device__ __forceinline__ void team_publish(const Req& q, const Res& r, int par
     if (LANE == 0) SH.xr[par] = x;
 }
 
-enum { TC_START = 0, TC_A, TC_D, TC_E, TC_F, TC_DONE, TC_DC_START, TC_DC_A, TC_DC_B, TC_L4 };
+enum { TC_START = 0, TC_A, TC_D, TC_E, TC_F, TC_DONE, TC_DC_START, TC_DC_A, TC_DC_B, TC_L4, TC_L8A, TC_L8B };
 
 // a member with nothing to evaluate in a stage
 __device__ __forceinline__ void team_idle(Req& q) {
@@ -1228,6 +1539,18 @@ __device__ __forceinline__ bool leaf_step_team(const Ctx& c, CtuSt& t, LeafSF& s
                 q.xchg = true;
                 return true;
             }
+            if (leaf_is_leaf8(s)) {
+                // an 8x8 single-tree leaf: the packed search in two halves side by side -- member 0 pack {planar, DC},
+                // member 1 the SAD search and pack {cm, cm - 1, cm + 1} -- then the CCLM part on the member that holds
+                // the winner (its tile has the winner's reconstruction already), then everybody pulls from it
+                if (me < 2)
+                    leaf_leaf8(s, q, 1 + me, TC_L8A);
+                else
+                    team_idle(q);
+                s.cont = TC_L8A;
+                q.xchg = true;
+                return true;
+            }
             if (me == 0) {
                 leaf_full(s, q, both, PLANAR, PLANAR, true, TC_A, true);
             } else if (me == 1) {
@@ -1249,6 +1572,55 @@ __device__ __forceinline__ bool leaf_step_team(const Ctx& c, CtuSt& t, LeafSF& s
             s.luma_mode = (uint8_t)m;
             s.chroma_mode = (uint8_t)m;
             team_defer_pull(t, s, 1, holder);
+            return false;
+        }
+        case TC_L8A: {
+            // first minimum of [planar, DC | cm, cm - 1, cm + 1]: the second half wins only if strictly cheaper; each
+            // half published its best candidate's parts with the mode in the top byte of ssd_y (an 8x8 SSD is < 2^23)
+            EvalParts e0 = xparts(c, par, 0), e1 = xparts(c, par, 1);
+            const int m0 = (int)(e0.ssd_y >> 24), m1 = (int)(e1.ssd_y >> 24);
+            e0.ssd_y &= 0xFFFFFFu;
+            e1.ssd_y &= 0xFFFFFFu;
+            const int cls0 = mpm_class(c, s.bx, s.by, s.lg, m0), cls1 = mpm_class(c, s.bx, s.by, s.lg, m1);
+            const float va = uni_f(assemble_cost(c, tree, cls0, m0, e0)), vb = uni_f(assemble_cost(c, tree, cls1, m1, e1));
+            const int holder = vb < va ? 1 : 0;
+            const int m = holder ? m1 : m0;
+            s.holder = (uint8_t)holder;
+            s.best_cost = holder ? vb : va;
+            put_parts(s.e_best, holder ? e1 : e0);
+            s.mode = (uint8_t)m;
+            s.best_cls = (uint8_t)(holder ? cls1 : cls0);
+            // :1040 the winner's chroma cost; the CCLM part (three probes, the pick, the evaluation, DM against CCLM) runs
+            // on the holder alone
+            s.cur_cost = uni_f(assemble_chroma_cost(c, m, s.e_best.get()));
+            if (me == holder) {
+                if (c.trace && LANE == 0)
+                    TRACE_REC(c.ctu_x + s.bx, c.ctu_y + s.by, s.lg, tree, 3, 0, m, __float_as_int((float)s.cur_cost));
+                leaf_leaf8(s, q, 4, TC_L8B);
+                q.ml = m;
+                q.fcur = s.cur_cost;
+            } else {
+                team_idle(q);
+            }
+            s.cont = TC_L8B;
+            q.xchg = true;
+            return true;
+        }
+        case TC_L8B: {
+            const int holder = s.holder;
+            const EvalParts rp = xparts(c, par, holder); // ssd_y: the CCLM mode picked; ssd_c / lvl_c: its chroma parts
+            const int cm = (int)rp.ssd_y;
+            EvalParts e = s.e_best.get();
+            e.ssd_c = rp.ssd_c;
+            e.lvl_c = rp.lvl_c;
+            const float cclm_cost = uni_f(assemble_chroma_cost(c, cm, e));
+            const float cur = s.cur_cost;
+            const bool dm_wins = cur == fminf(cclm_cost, fminf(cur, 3.40282347e+38f));
+            const int m = s.mode, bcls = s.best_cls;
+            s.luma_mode = (uint8_t)m;
+            s.chroma_mode = (uint8_t)(dm_wins ? m : cm);
+            s.cost = dm_wins ? uni_f(assemble_cost(c, tree, bcls, m, s.e_best.get())) : uni_f(assemble_cost(c, tree, bcls, cm, e));
+            team_defer_pull(t, s, 3, holder);
             return false;
         }
         case TC_A: {
