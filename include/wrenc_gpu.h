@@ -159,6 +159,15 @@ int wrenc_gpu_stats_enable(wrenc_gpu_ctx* ctx, int on);
  * timing was on (wrenc_gpu_stats_enable) when that call was queued. */
 int wrenc_gpu_last_encode_stats(wrenc_gpu_ctx* ctx, float* total_ms, float* kernel_ms_sum,
                                 int* n_launches);
+/* The same per kernel: out[0] = ctu_search_kernel (one wavefront per CTU), out[1] = ctu_search_team_kernel (four per
+ * CTU): summed HIP-event durations of its launches in the last encode call, their number, and the CTU-pictures
+ * (CTUs x pictures) they searched -- what a roofline per launch of ONE kernel needs. */
+typedef struct wrenc_gpu_kernel_stats {
+    float ms_sum;
+    int32_t launches;
+    int64_t ctu_pictures;
+} wrenc_gpu_kernel_stats;
+int wrenc_gpu_last_encode_kernel_stats(wrenc_gpu_ctx* ctx, wrenc_gpu_kernel_stats out[2]);
 
 /* Samples where the final pass reconstruction differed from what the search left
  * (expected 0; SURVEY.md 3.4 "treat as a property to test"), accumulated since

@@ -375,6 +375,16 @@ __device__ __forceinline__ Ctx uni(Ctx c) {
     return c;
 }
 
+// Unroll knobs of the stage loops (experiments: tools/README.md); 0 = the compiler's choice
+#define WRENC_PRAGMA_(x) _Pragma(#x)
+#define WRENC_UNROLL(n) WRENC_PRAGMA_(unroll n)
+#ifndef WRENC_U_DCT
+#define WRENC_U_DCT 1
+#endif
+#ifndef WRENC_U_SAD
+#define WRENC_U_SAD 0
+#endif
+
 // One wave per block: LDS operations of a wave are issued and serviced in program order,
 // so "synchronising" only has to stop the compiler from reordering LDS accesses.
 #define WSYNC()                                                  \

@@ -856,6 +856,9 @@ __device__ __forceinline__ unsigned sad_list_angular(const Ctx& c, int comps, in
             const int oL0 = comp == 0 ? (filt ? R_LF : R_L0) : R_LC0;
             const int oA0 = comp == 0 ? (filt ? R_AF : R_A0) : R_AC0;
             int sad = 0;
+#if WRENC_U_SAD > 0
+            WRENC_UNROLL(WRENC_U_SAD)
+#endif
             for (int i = LANE; i < nb * nn; i += 64) {
                 const int blk = i >> (2 * lg);
                 const int ii = i & (nn - 1);

@@ -43,7 +43,7 @@ __device__ void fwd_dct(Ctx c, int nb, int o1, LDS_AS int32_t* h) {
 #pragma unroll 1
     for (int b0 = 0; b0 < nb; b0 += per) {
         // stage 1: H[u][y] = (sum_x T[u][x] r[y][x] + d) >> (LG-1)   (:2139-2209); rows of the round's blocks
-#pragma unroll 1
+WRENC_UNROLL(WRENC_U_DCT)
         for (int yy = g; yy < per * N; yy += G) {
             const uint32_t* row = (const uint32_t*)&SH.r1[o1 + (b0 * N + yy) * N];
             int acc = 0;
@@ -54,7 +54,7 @@ __device__ void fwd_dct(Ctx c, int nb, int o1, LDS_AS int32_t* h) {
         }
         WSYNC();
         // stage 2: C[v][x] = (sum_y T[v][y] H[x][y] + d) >> (LG+6)  (:2246-2316); lane v = u
-#pragma unroll 1
+WRENC_UNROLL(WRENC_U_DCT)
         for (int xx = g; xx < per * N; xx += G) {
             const int blk = xx >> LG, x = xx & (N - 1);
             const LDS_AS int32_t* col = &h[blk * (N * HS) + x * HS];
@@ -90,7 +90,7 @@ __device__ void inv_dct(Ctx c, int nb, int o1) {
         for (int k = 0; k < N / 2; ++k) t[k] = src[k];
     }
     // stage 1 (vertical): V[y][x] = clamp16((sum_i T[i][y] d[i][x] + 64) >> 7); lane y = u
-#pragma unroll 1
+WRENC_UNROLL(WRENC_U_DCT)
     for (int xx = g; xx < nb * N; xx += G) {
         const uint32_t* col = (const uint32_t*)&dqt[xx * N]; // dT[blk][x][.]
         int acc = 0;
@@ -103,7 +103,7 @@ __device__ void inv_dct(Ctx c, int nb, int o1) {
     }
     WSYNC();
     // stage 2 (horizontal): r[y][x] = (sum_i T[i][x] V[y][i] + 2048) >> 12; lane x = u
-#pragma unroll 1
+WRENC_UNROLL(WRENC_U_DCT)
     for (int yy = g; yy < nb * N; yy += G) {
         const uint32_t* row = (const uint32_t*)&vbuf[yy * N];
         uint32_t rv[N / 2];

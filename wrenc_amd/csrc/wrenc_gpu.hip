@@ -410,6 +410,8 @@ struct wrenc_gpu_ctx {
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;
     std::vector<hipEvent_t> ev_pool;
     int last_launches = 0;
+    std::vector<char> launch_team;             // per launch of the last call: the team kernel?
+    std::vector<long long> launch_ctus;        // ... and the CTU-pictures it searched
     bool stats_enabled = false; // per-launch timing events: bench / profiling only (wrenc_gpu_stats_enable)
     int schedule = WRENC_GPU_SCHEDULE_AUTO;
     int last_schedule = WRENC_GPU_SCHEDULE_WAVE; // what the most recent encode call ran
@@ -885,6 +887,8 @@ int wrenc_gpu_encode(wrenc_gpu_ctx* ctx, int first_slot, int n_pictures) {
     HIP_TRY(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
     for (int l = 1; l < n_lanes; ++l) HIP_TRY(ctx, hipStreamWaitEvent(ctx->lanes[l - 1], ctx->ev_fork, 0));
     int launches = 0;
+    ctx->launch_team.clear();
+    ctx->launch_ctus.clear();
     for (int d = 0; d < ndiag; ++d) {
         // rows r with 0 <= d - 2r < cols
         int r_min = d - (cols - 1);
@@ -916,6 +920,8 @@ int wrenc_gpu_encode(wrenc_gpu_ctx* ctx, int first_slot, int n_pictures) {
                                    ctx->d_slot_map, ctx->d_mismatch, ctx->d_overflow);
             HIP_TRY(ctx, hipGetLastError());
             if (timed) HIP_TRY(ctx, hipEventRecord(ctx->ev_pool[2 * launches + 1], st));
+            ctx->launch_team.push_back(team ? 1 : 0);
+            ctx->launch_ctus.push_back((long long)count * lane_pics);
             ++launches;
         }
     }
@@ -1021,6 +1027,24 @@ int wrenc_gpu_last_encode_stats(wrenc_gpu_ctx* ctx, float* total_ms, float* kern
     if (total_ms) *total_ms = t;
     if (kernel_ms_sum) *kernel_ms_sum = sum;
     if (n_launches) *n_launches = ctx->last_launches;
+    return WRENC_GPU_OK;
+}
+
+int wrenc_gpu_last_encode_kernel_stats(wrenc_gpu_ctx* ctx, wrenc_gpu_kernel_stats out[2]) {
+    if (!ctx || !out) return WRENC_GPU_EINVAL;
+    if (!ctx->stats_enabled) return fail(ctx, WRENC_GPU_ESTATE, "per-launch timing is off (wrenc_gpu_stats_enable)");
+    if (!ctx->stats_valid) return fail(ctx, WRENC_GPU_ESTATE, "no encode has been queued since timing was switched on");
+    HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
+    HIP_TRY(ctx, hipEventSynchronize(ctx->ev_end));
+    for (int k = 0; k < 2; ++k) out[k] = wrenc_gpu_kernel_stats{0.f, 0, 0};
+    for (int i = 0; i < ctx->last_launches; ++i) {
+        float ms = 0.f;
+        HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev_pool[2 * i], ctx->ev_pool[2 * i + 1]));
+        wrenc_gpu_kernel_stats& o = out[ctx->launch_team[(size_t)i] ? 1 : 0];
+        o.ms_sum += ms;
+        o.launches += 1;
+        o.ctu_pictures += ctx->launch_ctus[(size_t)i];
+    }
     return WRENC_GPU_OK;
 }
 

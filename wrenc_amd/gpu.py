@@ -20,7 +20,7 @@ LIB_PATH = os.environ.get("WRENC_GPU_LIB", os.path.join(_HERE, "csrc", "libwrenc
 EXPORTED_SYMBOLS = [
     "wrenc_gpu_default_config", "wrenc_gpu_config_extra_params", "wrenc_gpu_create", "wrenc_gpu_destroy", "wrenc_gpu_last_error",
     "wrenc_gpu_upload", "wrenc_gpu_encode", "wrenc_gpu_sync", "wrenc_gpu_download",
-    "wrenc_gpu_alloc_host", "wrenc_gpu_free_host", "wrenc_gpu_encode_picture", "wrenc_gpu_set_schedule", "wrenc_gpu_last_schedule", "wrenc_gpu_stats_enable", "wrenc_gpu_last_encode_stats", "wrenc_gpu_final_pass_mismatches",
+    "wrenc_gpu_alloc_host", "wrenc_gpu_free_host", "wrenc_gpu_encode_picture", "wrenc_gpu_set_schedule", "wrenc_gpu_last_schedule", "wrenc_gpu_stats_enable", "wrenc_gpu_last_encode_stats", "wrenc_gpu_last_encode_kernel_stats", "wrenc_gpu_final_pass_mismatches",
     "wrenc_gpu_test_fwd_dct", "wrenc_gpu_test_inv_dct", "wrenc_gpu_test_quantize",
     "wrenc_gpu_test_dequantize", "wrenc_gpu_test_predict", "wrenc_gpu_test_fwd_dct32", "wrenc_gpu_test_inv_dct32", "wrenc_gpu_test_quantize_p16", "wrenc_gpu_test_set_wave_slots",
 ]
@@ -246,6 +246,16 @@ class Encoder:
         t, k, n = C.c_float(), C.c_float(), C.c_int()
         self._check(self.lib.wrenc_gpu_last_encode_stats(self.ctx, C.byref(t), C.byref(k), C.byref(n)))
         return {"total_ms": t.value, "kernel_ms_sum": k.value, "n_launches": n.value}
+
+    def last_encode_kernel_stats(self):
+        """Per kernel of the last encode call: {"wave": {...}, "team": {...}} with ms_sum, launches, ctu_pictures."""
+        class KS(C.Structure):
+            _fields_ = [("ms_sum", C.c_float), ("launches", C.c_int32), ("ctu_pictures", C.c_int64)]
+        out = (KS * 2)()
+        self.lib.wrenc_gpu_last_encode_kernel_stats.argtypes = [C.c_void_p, C.c_void_p]
+        self._check(self.lib.wrenc_gpu_last_encode_kernel_stats(self.ctx, out))
+        return {n: {"ms_sum": out[i].ms_sum, "launches": out[i].launches, "ctu_pictures": out[i].ctu_pictures}
+                for i, n in enumerate(("wave", "team"))}
 
     def final_pass_mismatches(self):
         v = C.c_longlong()
