@@ -768,65 +768,228 @@ __device__ __forceinline__ void quantize_p16(Ctx c, int nb, int* overflow, long 
     PROF_ADD2(PH_QTRACE, q2_, q3_);
 }
 
-// Dependent quantisation of the transform blocks of nc <= 3 CANDIDATES of one 8x8 single-tree CU at once (the packed
-// 8x8 leaf search, dev_search.h K_LEAF8): per candidate a luma 8x8 block at r1[64 c ..] and its Cb | Cr 4x4 blocks at
-// r1[64 nc + 32 c ..].  Every block is a chain of its own and the chains do not depend on each other, so they are walked
-// SIDE BY SIDE by this wave alone -- no pooling over the workgroup, no barrier: a ROUND gives each of the wave's four
-// 16-lane rows one chain's next 16 positions (the chunk entries of 64 positions, one lane each), then one quad per row
-// walks them.  Rounds 0..3 take the luma chains' sub-blocks (DC end first) in rows 0 .. nc - 1 and chroma blocks in the
-// remaining rows; with three candidates a fifth round takes the last two chroma blocks.  The serial part of a pack is
-// 4 (5) x 16 steps for up to nine chains, where the one-candidate-per-request search walked 64 positions per candidate
-// between two workgroup barriers.  Same arithmetic as quantize(): chunk_entry, the one-compare walk, the forward trace
-// by composed state maps, emit_level.  Levels in place; per candidate the level cost of the luma block and of the
-// chroma pair (block_splitter.rs:436-458) and whether any level of the pack's luma / chroma blocks is non-zero.
-// Scratch: r2[0, 192 nc) scan-order coefficients, r1 chunk entries, decw[0, 144) decisions, q_pm.
-__device__ __forceinline__ void quantize_pk8(Ctx c, int nc, int* overflow, long long lvl_y[3], long long lvl_c[3], bool* any_y,
-                                             bool* any_c) {
+// ---------------------------------------------------------------------------
+// Packed quantisation: the transform blocks of nc CANDIDATES of one single-tree CU at once (the packed leaf searches,
+// dev_search.h K_LEAF8 / K_LEAF16).  LGL = log2 of the luma block: 3 (8x8 CU, nc <= 3) or 4 (16x16 CU, nc <= 2).
+// Layout in r1: the candidates' luma blocks [c][PL], then their chroma blocks [c][Cb | Cr][PC], PC = PL / 4.
+// Every block is a chain of its own and the chains do not depend on each other, so they are walked SIDE BY SIDE by
+// this wave alone -- no pooling over the workgroup, no barrier.  A ROUND gives each of the wave's four 16-lane rows the
+// next 16 positions (one 4x4 sub-block) of one chain: the 64 lanes compute the chunk entries of those 64 positions,
+// then one quad per row walks them.  Rows 0 .. nc - 1 take the luma chains (DC end first); the other rows, and all
+// rows once the luma chains are done, take the chroma chains one after the other, a chain staying in its row until
+// it is finished.  The serial part of a pack of three 8x8 candidates is 5 x 16 steps for nine chains, of two 16x16
+// candidates 16 x 16 steps for six chains -- where the one-candidate-per-request search walked the luma chain of each
+// candidate between two workgroup barriers per 64 positions.  Same arithmetic as quantize(): chunk_entry, the
+// one-compare walk, the forward trace by composed state maps, emit_level.  Levels in place; per candidate the level
+// cost of the luma block and of the chroma pair (block_splitter.rs:436-458) and whether any level of the pack's luma /
+// chroma blocks is non-zero.
+// Scratch: r2[0, 3 PL nc) scan-order coefficients, r1 chunk entries, decw decisions (72 / 192 u16), q_pm.
+// ---------------------------------------------------------------------------
+
+// forward trace + level cost of up to four blocks of 64 positions, block b = row b (16 lanes, four consecutive
+// positions per lane: they lie in one sub-block); levels to r1[rbase + 64 b + scan[p]]; per block the level cost and
+// "has a non-zero level"
+__device__ __forceinline__ void trace_rows64(const Ctx& c, int nblk, const int16_t* tcs, const uint16_t* dec16, int rbase,
+                                             const CONST_AS uint16_t* scan, int sh, int off, long long lvl[4], bool any[4], int& ovf) {
+    const int lane = lane_fresh();
+    const int row = lane >> 4, i16 = lane & 15;
+    const CONST_AS DevConst* k = c.k;
+    const bool act = row < nblk;
+    const int b = act ? row : 0;
+    const int p0 = i16 * 4;
+    const int16_t* btcs = tcs + b * 64;
+    const DecMasks dm = dec_masks(dec16 + b * 16, p0);
+    int fmap = kMapId;
+    if (act) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int p = p0 + j;
+            const int tc = btcs[p];
+            fmap = compose_map(position_map(tc, quotient(k, tc, sh, off), p == 63, dec_nib(dm, p)), fmap);
+        }
+    }
+    int pre = fmap;
+    pre = compose_map(pre, __builtin_amdgcn_update_dpp(kMapId, pre, 0x111, 0xF, 0xF, false)); // row_shr:1
+    pre = compose_map(pre, __builtin_amdgcn_update_dpp(kMapId, pre, 0x112, 0xF, 0xF, false)); // row_shr:2
+    pre = compose_map(pre, __builtin_amdgcn_update_dpp(kMapId, pre, 0x114, 0xF, 0xF, false)); // row_shr:4
+    pre = compose_map(pre, __builtin_amdgcn_update_dpp(kMapId, pre, 0x118, 0xF, 0xF, false)); // row_shr:8
+    int entry = __builtin_amdgcn_update_dpp(0, pre, 0x111, 0xF, 0xF, false) & 3; // state after the previous lane of the row
+    if (i16 == 0) entry = 0;
+    long long sum_nz = 0;
+    unsigned zmask = 0;
+    int fnz = 64;
+    if (act) {
+        int state = entry;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int p = p0 + j;
+            const int tc = btcs[p];
+            SH.r1[rbase + b * 64 + scan[p]] = (int16_t)emit_level(c, tc, quotient(k, tc, sh, off), p == 63, dec_nib(dm, p), p, j, state,
+                                                                  zmask, sum_nz, fnz, ovf);
+        }
+    }
+    const int pf = row_min_i32(fnz); // zeros before a block's first non-zero level cost nothing
+    if (act) sum_nz += (long long)__popc(zmask >> min(max(pf - p0 + 1, 0), 16)) * SHT.lv[0];
+    const long long hi = sum_nz >> 24;
+    const int ra = row_sum_i32((int)(sum_nz & 0xFFFFFF)), rb = row_sum_i32((int)(hi & 0xFFFFFF)), rc = row_sum_i32((int)(hi >> 24));
+#pragma unroll
+    for (int bb = 0; bb < 4; ++bb) {
+        const long long a0 = (long long)(unsigned)__builtin_amdgcn_readlane(ra, 16 * bb);
+        const long long a1 = (long long)(unsigned)__builtin_amdgcn_readlane(rb, 16 * bb);
+        const long long a2 = (long long)__builtin_amdgcn_readlane(rc, 16 * bb);
+        lvl[bb] = a0 + ((a1 + (a2 << 24)) << 24);
+        any[bb] = __builtin_amdgcn_readlane(pf, 16 * bb) < 64;
+    }
+}
+
+// the same for up to four blocks of 16 positions, one position per lane (as quantize_p16)
+__device__ __forceinline__ void trace_rows16(const Ctx& c, int nblk, const int16_t* tcs, const uint16_t* dec16, int rbase,
+                                             const CONST_AS uint16_t* scan, int sh, int off, long long lvl[4], bool any[4], int& ovf) {
+    const int lane = lane_fresh();
+    const int row = lane >> 4, i16 = lane & 15;
+    const CONST_AS DevConst* k = c.k;
+    const bool mine = row < nblk;
+    const int bb = mine ? row : 0;
+    const int tc = mine ? (int)tcs[bb * 16 + i16] : 0;
+    const int qd = quotient(k, tc, sh, off);
+    const DecMasks dm = dec_masks(dec16 + bb * 4, 0);
+    const int nib = dec_nib(dm, i16);
+    int pre = mine ? position_map(tc, qd, i16 == 15, nib) : kMapId;
+    pre = compose_map(pre, __builtin_amdgcn_update_dpp(kMapId, pre, 0x111, 0xF, 0xF, false)); // row_shr:1
+    pre = compose_map(pre, __builtin_amdgcn_update_dpp(kMapId, pre, 0x112, 0xF, 0xF, false)); // row_shr:2
+    pre = compose_map(pre, __builtin_amdgcn_update_dpp(kMapId, pre, 0x114, 0xF, 0xF, false)); // row_shr:4
+    pre = compose_map(pre, __builtin_amdgcn_update_dpp(kMapId, pre, 0x118, 0xF, 0xF, false)); // row_shr:8
+    int entry = __builtin_amdgcn_update_dpp(0, pre, 0x111, 0xF, 0xF, false) & 3;
+    if (i16 == 0) entry = 0;
+    long long sum_nz = 0;
+    unsigned zmask = 0;
+    int fnz = 16;
+    if (mine) {
+        int state = entry;
+        SH.r1[rbase + bb * 16 + scan[i16]] = (int16_t)emit_level(c, tc, qd, i16 == 15, nib, i16, 0, state, zmask, sum_nz, fnz, ovf);
+    }
+    const int pf = row_min_i32(fnz);
+    if (mine && (zmask & 1u) && i16 > pf) sum_nz += SHT.lv[0];
+    const long long hi = sum_nz >> 24;
+    const int ra = row_sum_i32((int)(sum_nz & 0xFFFFFF)), rb = row_sum_i32((int)(hi & 0xFFFFFF)), rc = row_sum_i32((int)(hi >> 24));
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        const long long a0 = (long long)(unsigned)__builtin_amdgcn_readlane(ra, 16 * b);
+        const long long a1 = (long long)(unsigned)__builtin_amdgcn_readlane(rb, 16 * b);
+        const long long a2 = (long long)__builtin_amdgcn_readlane(rc, 16 * b);
+        lvl[b] = a0 + ((a1 + (a2 << 24)) << 24);
+        any[b] = __builtin_amdgcn_readlane(pf, 16 * b) < 16;
+    }
+}
+
+// the same for ONE block of 256 positions over the whole wave (four consecutive positions per lane), as quantize()
+__device__ __forceinline__ void trace_wave256(const Ctx& c, const int16_t* tcs, const uint16_t* dec16, int rbase,
+                                              const CONST_AS uint16_t* scan, int sh, int off, long long* lvl, bool* any, int& ovf) {
+    const int lane = lane_fresh();
+    const CONST_AS DevConst* k = c.k;
+    const int p0 = lane * 4;
+    const DecMasks dm = dec_masks(dec16, p0);
+    int fmap = kMapId;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int p = p0 + j;
+        const int tc = tcs[p];
+        fmap = compose_map(position_map(tc, quotient(k, tc, sh, off), p == 255, dec_nib(dm, p)), fmap);
+    }
+    int pre = fmap;
+    pre = compose_map(pre, __builtin_amdgcn_update_dpp(kMapId, pre, 0x111, 0xF, 0xF, false)); // row_shr:1
+    pre = compose_map(pre, __builtin_amdgcn_update_dpp(kMapId, pre, 0x112, 0xF, 0xF, false)); // row_shr:2
+    pre = compose_map(pre, __builtin_amdgcn_update_dpp(kMapId, pre, 0x114, 0xF, 0xF, false)); // row_shr:4
+    pre = compose_map(pre, __builtin_amdgcn_update_dpp(kMapId, pre, 0x118, 0xF, 0xF, false)); // row_shr:8
+    pre = compose_map(pre, __builtin_amdgcn_update_dpp(kMapId, pre, 0x142, 0xA, 0xF, false)); // row_bcast:15 -> rows 1, 3
+    pre = compose_map(pre, __builtin_amdgcn_update_dpp(kMapId, pre, 0x143, 0xC, 0xF, false)); // row_bcast:31 -> rows 2, 3
+    int entry = __builtin_amdgcn_update_dpp(0, pre, 0x138, 0xF, 0xF, false) & 3; // wave_shr:1
+    if (lane == 0) entry = 0;
+    long long sum_nz = 0;
+    unsigned zmask = 0;
+    int fnz = 256;
+    {
+        int state = entry;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int p = p0 + j;
+            const int tc = tcs[p];
+            SH.r1[rbase + scan[p]] = (int16_t)emit_level(c, tc, quotient(k, tc, sh, off), p == 255, dec_nib(dm, p), p, j, state, zmask,
+                                                         sum_nz, fnz, ovf);
+        }
+    }
+    const int pf = wave_min_i32(fnz);
+    sum_nz += (long long)__popc(zmask >> min(max(pf - p0 + 1, 0), 16)) * SHT.lv[0];
+    *any = pf < 256;
+    *lvl = wave_sum_i64(sum_nz);
+}
+
+template <int LGL>
+__device__ __forceinline__ void quantize_pk(Ctx c, int nc, int* overflow, long long lvl_y[3], long long lvl_c[3], bool* any_y,
+                                            bool* any_c) {
+    static_assert(LGL == 3 || LGL == 4, "8x8 and 16x16 CUs");
     c = uni(c);
     nc = uni(nc);
     const int lane = lane_fresh();
     const CONST_AS DevConst* k = c.k;
-    constexpr int shl = 8 + 3 - 5 + 1, offl = (1 << shl) >> 1; // quantizer.rs:558-569
-    constexpr int shc = 8 + 2 - 5 + 1, offc = (1 << shc) >> 1;
+    constexpr int PL = 1 << (2 * LGL), PC = PL / 4;       // positions of a luma / chroma block
+    constexpr int SBL = PL / 16, SBC = PC / 16;           // their 4x4 sub-blocks
+    constexpr int shl = 8 + LGL - 5 + 1, offl = (1 << shl) >> 1; // quantizer.rs:558-569
+    constexpr int shc = shl - 1, offc = (1 << shc) >> 1;
     const int lsc = k->lsc;
-    const CONST_AS uint16_t* scan8 = k->scan_idx[1];
-    const CONST_AS uint16_t* scan4 = k->scan_idx[0];
+    const CONST_AS uint16_t* scanl = k->scan_idx[LGL - 2];
+    const CONST_AS uint16_t* scanc = k->scan_idx[LGL - 3];
     int16_t* tcs = (int16_t*)SH.r2;
     int32_t* cc = (int32_t*)SH.r1;
-    uint16_t* dec16 = (uint16_t*)SH.decw;  // luma candidate c: [16 c + 4 sub-block + state]; chroma block b: [48 + 4 b + state]
-    uint16_t* ist = &SH.q_pm[1][0][0];     // first significant position: [c] luma candidate c, [4 + b] chroma block b
+    uint16_t* dec16 = (uint16_t*)SH.decw;  // luma candidate c: [4 SBL c + 4 sb + state]; chroma chain b: [4 SBL nc + 4 SBC b + 4 sb + state]
+    uint16_t* ist = &SH.q_pm[1][0][0];     // first significant position: [c] luma candidate c, [4 + b] chroma chain b
     const int row = lane >> 4, i16 = lane & 15;
-    const int nL = 64 * nc;
+    const int nL = PL * nc;
+    const int nch = 2 * nc;                // chroma chains: 2 c + plane
     PROF_MARK(q0_);
     lvl_y[0] = lvl_y[1] = lvl_y[2] = 0;
     lvl_c[0] = lvl_c[1] = lvl_c[2] = 0;
     *any_y = false;
     *any_c = false;
+    // ---- coefficients into scan order, the first significant position of every chain ----
     int nzl = 0;
+#pragma unroll 1
+    for (int cd = 0; cd < nc; ++cd) {
+        int first = PL;
 #pragma unroll
-    for (int cd = 0; cd < 3; ++cd) {
-        if (cd < nc) {
-            const int tc = SH.r1[cd * 64 + scan8[lane]];
+        for (int p = lane; p < PL; p += 64) {
+            const int tc = SH.r1[cd * PL + scanl[p]];
             nzl |= tc;
-            tcs[cd * 64 + lane] = (int16_t)tc;
-            const int qd = quotient(k, tc, shl, offl);
-            const int first = wave_min_i32((tc != 0 && (qd >> 1) > 0) ? lane : 64);
-            if (lane == 0) ist[cd] = (uint16_t)first;
+            tcs[cd * PL + p] = (int16_t)tc;
+            if (tc != 0 && (quotient(k, tc, shl, offl) >> 1) > 0) first = min(first, p);
         }
+        first = wave_min_i32(first);
+        if (lane == 0) ist[cd] = (uint16_t)first;
     }
+    if constexpr (LGL == 3) {
 #pragma unroll
-    for (int ps = 0; ps < 2; ++ps) {
-        const int blk = 4 * ps + row;
-        const bool mine = blk < 2 * nc;
-        int tc = 0, qd = 0;
-        if (mine) {
-            tc = SH.r1[nL + blk * 16 + scan4[i16]];
-            nzl |= tc;
-            tcs[nL + blk * 16 + i16] = (int16_t)tc;
-            qd = quotient(k, tc, shc, offc);
+        for (int ps = 0; ps < 2; ++ps) {
+            const int blk = 4 * ps + row;
+            const bool mine = blk < nch;
+            int tc = 0, qd = 0;
+            if (mine) {
+                tc = SH.r1[nL + blk * 16 + scanc[i16]];
+                nzl |= tc;
+                tcs[nL + blk * 16 + i16] = (int16_t)tc;
+                qd = quotient(k, tc, shc, offc);
+            }
+            const int first = row_min_i32((tc != 0 && (qd >> 1) > 0) ? i16 : 16);
+            if (mine && i16 == 0) ist[4 + blk] = (uint16_t)first;
         }
-        const int first = row_min_i32((tc != 0 && (qd >> 1) > 0) ? i16 : 16);
-        if (mine && i16 == 0) ist[4 + blk] = (uint16_t)first;
+    } else {
+#pragma unroll 1
+        for (int b = 0; b < nch; ++b) {
+            const int tc = SH.r1[nL + b * PC + scanc[lane]];
+            nzl |= tc;
+            tcs[nL + b * PC + lane] = (int16_t)tc;
+            const int first = wave_min_i32((tc != 0 && (quotient(k, tc, shc, offc) >> 1) > 0) ? lane : PC);
+            if (lane == 0) ist[4 + b] = (uint16_t)first;
+        }
     }
     if (__ballot(nzl != 0) == 0ULL) return; // every block of the pack is zero: the levels are the zeros already in r1
     WSYNC();
@@ -837,25 +1000,45 @@ __device__ __forceinline__ void quantize_pk8(Ctx c, int nc, int* overflow, long 
     const int cls = st == 0 ? 0 : (st == 1 ? 1 : 2);
     int C = 0;
     int ovf = 0;
-    const int nrounds = nc == 3 ? 5 : 4;
+    // the rows' chroma chains (uniform): chain in the row (-1: none), its sub-blocks still to walk
+    int rchain[4] = {-1, -1, -1, -1}, rleft[4] = {0, 0, 0, 0};
+    int next_chain = 0;
 #pragma unroll 1
-    for (int r = 0; r < nrounds; ++r) {
-        const int nlum = r < 4 ? nc : 0;                // rows 0 .. nlum - 1: luma candidates
-        const int cstart = r * (4 - nc);                // first chroma block of the round
-        const int ccount = max(0, min(4 - nlum, 2 * nc - cstart));
-        const int base0 = 48 - 16 * r;                  // the luma chains' positions of the round
+    for (int r = 0;; ++r) {
+        const int nlum = r < SBL ? nc : 0;              // rows 0 .. nlum - 1: the luma candidates' sub-block SBL - 1 - r
+        bool fresh[4];                                  // the row starts a chain in this round (its path costs start at 0)
+        bool any_row = nlum > 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            fresh[j] = false;
+            if (j < nlum) continue;
+            if (rleft[j] == 0) {
+                rchain[j] = -1;
+                if (next_chain < nch) {
+                    rchain[j] = next_chain++;
+                    rleft[j] = SBC;
+                    fresh[j] = true;
+                }
+            }
+            any_row = any_row || rchain[j] >= 0;
+        }
+        if (!any_row) break;
+        const int base0 = PL - 16 * (r + 1);            // the luma chains' positions of the round
+        // this lane's row: luma candidate, or chroma chain + sub-block
+        const bool is_l = row < nlum;
+        const int mychain = row == 0 ? rchain[0] : (row == 1 ? rchain[1] : (row == 2 ? rchain[2] : rchain[3]));
+        const int myleft = row == 0 ? rleft[0] : (row == 1 ? rleft[1] : (row == 2 ? rleft[2] : rleft[3]));
+        const bool is_c = !is_l && mychain >= 0;
+        const int cbase = 16 * (myleft - 1);            // the chroma chain's positions of the round
         {
-            const bool is_l = row < nlum;
-            const int j = row - nlum;
-            const bool mine = is_l || j < ccount;
-            const int blk = cstart + j;
-            const int p = is_l ? base0 + i16 : i16;
+            const bool mine = is_l || is_c;
+            const int p = (is_l ? base0 : cbase) + i16;
             const int sh = is_l ? shl : shc, off = is_l ? offl : offc;
             int par0 = 0, par1 = 0, adj = 0;
             if (mine) {
-                const int tc = tcs[is_l ? row * 64 + p : nL + blk * 16 + p];
-                const int first = ist[is_l ? row : 4 + blk];
-                chunk_entry(c, cc + lane * 6, tc, quotient(k, tc, sh, off), p == (is_l ? 63 : 15), p <= first, sh, off, lsc, ldq1,
+                const int tc = tcs[is_l ? row * PL + p : nL + mychain * PC + p];
+                const int first = ist[is_l ? row : 4 + mychain];
+                chunk_entry(c, cc + lane * 6, tc, quotient(k, tc, sh, off), p == (is_l ? PL - 1 : PC - 1), p <= first, sh, off, lsc, ldq1,
                             &par0, &par1, &adj, &ovf);
             }
             const unsigned long long b0 = __ballot(mine && par0), b1 = __ballot(mine && par1), ba = __ballot(mine && adj);
@@ -869,10 +1052,13 @@ __device__ __forceinline__ void quantize_pk8(Ctx c, int nc, int* overflow, long 
         WSYNC();
         PROF_MARK(qb1_);
         if (quad < 4) {
-            const bool is_l = quad < nlum;
-            const int j = quad - nlum;
-            if (is_l || j < ccount) {
-                if (!is_l) C = 0; // a chroma block is a chain of its own
+            // (quad q walks row q: the same selects with the quad number)
+            const bool wl = quad < nlum;
+            const int wchain = quad == 0 ? rchain[0] : (quad == 1 ? rchain[1] : (quad == 2 ? rchain[2] : rchain[3]));
+            const int wleft = quad == 0 ? rleft[0] : (quad == 1 ? rleft[1] : (quad == 2 ? rleft[2] : rleft[3]));
+            const bool wfresh = quad == 0 ? fresh[0] : (quad == 1 ? fresh[1] : (quad == 2 ? fresh[2] : fresh[3]));
+            if (wl || wchain >= 0) {
+                if (!wl && wfresh) C = 0; // a new chain
                 const int32_t* wcc = cc + quad * 16 * 6;
                 const uint16_t* pm = SH.q_pm[0][quad];
                 const unsigned parmask = pm[st > 1 ? 1 : 0];
@@ -898,106 +1084,61 @@ __device__ __forceinline__ void quantize_pk8(Ctx c, int nc, int* overflow, long 
                 int m = min(C, dpp_quad<0xB1>(C)); // renormalise (see quantize())
                 m = min(m, dpp_quad<0x4E>(m));
                 C -= m;
-                dec16[(is_l ? quad * 16 + (base0 >> 4) * 4 : 48 + (cstart + j) * 4) + st] = (uint16_t)bits;
+                dec16[(wl ? 4 * SBL * quad + 4 * (SBL - 1 - r) : 4 * SBL * nc + 4 * SBC * wchain + 4 * (wleft - 1)) + st] = (uint16_t)bits;
             }
         }
         WSYNC();
         PROF_MARK(qb2_);
         PROF_ADD2(PH_QB_WALK, qb1_, qb2_);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (j >= nlum && rchain[j] >= 0) --rleft[j];
     }
     PROF_MARK(q2_);
     PROF_ADD2(PH_QBACK, q1_, q2_);
     // ---- forward trace from state 0 (quantizer.rs:686-721) + level cost ----
-    // luma: row = candidate, four consecutive positions per lane (they lie in one sub-block)
-    {
-        const bool act = row < nc;
-        const int cd = act ? row : 0;
-        const int p0 = i16 * 4;
-        const int16_t* btcs = tcs + cd * 64;
-        const DecMasks dm = dec_masks(dec16 + cd * 16, p0);
-        int fmap = kMapId;
-        if (act) {
+    if constexpr (LGL == 3) {
+        long long l4[4];
+        bool a4[4];
+        trace_rows64(c, nc, tcs, dec16, 0, scanl, shl, offl, l4, a4, ovf);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int p = p0 + j;
-                const int tc = btcs[p];
-                fmap = compose_map(position_map(tc, quotient(k, tc, shl, offl), p == 63, dec_nib(dm, p)), fmap);
-            }
-        }
-        int pre = fmap;
-        pre = compose_map(pre, __builtin_amdgcn_update_dpp(kMapId, pre, 0x111, 0xF, 0xF, false)); // row_shr:1
-        pre = compose_map(pre, __builtin_amdgcn_update_dpp(kMapId, pre, 0x112, 0xF, 0xF, false)); // row_shr:2
-        pre = compose_map(pre, __builtin_amdgcn_update_dpp(kMapId, pre, 0x114, 0xF, 0xF, false)); // row_shr:4
-        pre = compose_map(pre, __builtin_amdgcn_update_dpp(kMapId, pre, 0x118, 0xF, 0xF, false)); // row_shr:8
-        int entry = __builtin_amdgcn_update_dpp(0, pre, 0x111, 0xF, 0xF, false) & 3; // state after the previous lane of the row
-        if (i16 == 0) entry = 0;
-        long long sum_nz = 0;
-        unsigned zmask = 0;
-        int fnz = 64;
-        if (act) {
-            int state = entry;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int p = p0 + j;
-                const int tc = btcs[p];
-                SH.r1[cd * 64 + scan8[p]] = (int16_t)emit_level(c, tc, quotient(k, tc, shl, offl), p == 63, dec_nib(dm, p), p, j, state,
-                                                                zmask, sum_nz, fnz, ovf);
-            }
-        }
-        const int pf = row_min_i32(fnz); // zeros before a block's first non-zero level cost nothing
-        if (act) sum_nz += (long long)__popc(zmask >> min(max(pf - p0 + 1, 0), 16)) * SHT.lv[0];
-        const long long hi = sum_nz >> 24;
-        const int ra = row_sum_i32((int)(sum_nz & 0xFFFFFF)), rb = row_sum_i32((int)(hi & 0xFFFFFF)), rc = row_sum_i32((int)(hi >> 24));
-#pragma unroll
-        for (int b = 0; b < 3; ++b) {
-            const long long a0 = (long long)(unsigned)__builtin_amdgcn_readlane(ra, 16 * b);
-            const long long a1 = (long long)(unsigned)__builtin_amdgcn_readlane(rb, 16 * b);
-            const long long a2 = (long long)__builtin_amdgcn_readlane(rc, 16 * b);
+        for (int b = 0; b < 3; ++b)
             if (b < nc) {
-                lvl_y[b] = a0 + ((a1 + (a2 << 24)) << 24);
-                if (__builtin_amdgcn_readlane(pf, 16 * b) < 64) *any_y = true;
+                lvl_y[b] = l4[b];
+                if (a4[b]) *any_y = true;
             }
-        }
-    }
-    // chroma: row = block 4 ps + row, one position per lane (as quantize_p16)
 #pragma unroll
-    for (int ps = 0; ps < 2; ++ps) {
-        if (4 * ps >= 2 * nc) continue; // (uniform)
-        const int blk = 4 * ps + row;
-        const bool mine = blk < 2 * nc;
-        const int bb = mine ? blk : 0;
-        const int tc = mine ? (int)tcs[nL + bb * 16 + i16] : 0;
-        const int qd = quotient(k, tc, shc, offc);
-        const DecMasks dm = dec_masks(dec16 + 48 + bb * 4, 0);
-        const int nib = dec_nib(dm, i16);
-        int pre = mine ? position_map(tc, qd, i16 == 15, nib) : kMapId;
-        pre = compose_map(pre, __builtin_amdgcn_update_dpp(kMapId, pre, 0x111, 0xF, 0xF, false)); // row_shr:1
-        pre = compose_map(pre, __builtin_amdgcn_update_dpp(kMapId, pre, 0x112, 0xF, 0xF, false)); // row_shr:2
-        pre = compose_map(pre, __builtin_amdgcn_update_dpp(kMapId, pre, 0x114, 0xF, 0xF, false)); // row_shr:4
-        pre = compose_map(pre, __builtin_amdgcn_update_dpp(kMapId, pre, 0x118, 0xF, 0xF, false)); // row_shr:8
-        int entry = __builtin_amdgcn_update_dpp(0, pre, 0x111, 0xF, 0xF, false) & 3;
-        if (i16 == 0) entry = 0;
-        long long sum_nz = 0;
-        unsigned zmask = 0;
-        int fnz = 16;
-        if (mine) {
-            int state = entry;
-            SH.r1[nL + bb * 16 + scan4[i16]] = (int16_t)emit_level(c, tc, qd, i16 == 15, nib, i16, 0, state, zmask, sum_nz, fnz, ovf);
-        }
-        const int pf = row_min_i32(fnz);
-        if (mine && (zmask & 1u) && i16 > pf) sum_nz += SHT.lv[0];
-        const long long hi = sum_nz >> 24;
-        const int ra = row_sum_i32((int)(sum_nz & 0xFFFFFF)), rb = row_sum_i32((int)(hi & 0xFFFFFF)), rc = row_sum_i32((int)(hi >> 24));
+        for (int ps = 0; ps < 2; ++ps) {
+            if (4 * ps >= nch) continue; // (uniform)
+            trace_rows16(c, min(4, nch - 4 * ps), tcs + nL + 64 * ps, dec16 + 4 * SBL * nc + 16 * ps, nL + 64 * ps, scanc, shc, offc, l4, a4, ovf);
 #pragma unroll
-        for (int b = 0; b < 4; ++b) {
-            const long long a0 = (long long)(unsigned)__builtin_amdgcn_readlane(ra, 16 * b);
-            const long long a1 = (long long)(unsigned)__builtin_amdgcn_readlane(rb, 16 * b);
-            const long long a2 = (long long)__builtin_amdgcn_readlane(rc, 16 * b);
-            if (4 * ps + b < 2 * nc) {
-                lvl_c[(4 * ps + b) >> 1] += a0 + ((a1 + (a2 << 24)) << 24);
-                if (__builtin_amdgcn_readlane(pf, 16 * b) < 16) *any_c = true;
+            for (int b = 0; b < 4; ++b)
+                if (4 * ps + b < nch) {
+                    lvl_c[(4 * ps + b) >> 1] += l4[b];
+                    if (a4[b]) *any_c = true;
+                }
+        }
+    } else {
+#pragma unroll 1
+        for (int cd = 0; cd < nc; ++cd) {
+            long long l1;
+            bool a1;
+            trace_wave256(c, tcs + cd * PL, dec16 + 4 * SBL * cd, cd * PL, scanl, shl, offl, &l1, &a1, ovf);
+            if (cd == 0)
+                lvl_y[0] = l1;
+            else
+                lvl_y[1] = l1;
+            if (a1) *any_y = true;
+        }
+        long long l4[4];
+        bool a4[4];
+        trace_rows64(c, nch, tcs + nL, dec16 + 4 * SBL * nc, nL, scanc, shc, offc, l4, a4, ovf); // four 8x8 chroma blocks at most
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+            if (b < nch) {
+                lvl_c[b >> 1] += l4[b];
+                if (a4[b]) *any_c = true;
             }
-        }
     }
     if (__ballot(ovf != 0) != 0ULL) *overflow = 1;
     WSYNC();

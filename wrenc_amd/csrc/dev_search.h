@@ -9,7 +9,7 @@ namespace wrenc {
 // ---------------------------------------------------------------------------
 // Evaluation requests and the evaluator
 // ---------------------------------------------------------------------------
-enum { K_SADLIST = 0, K_FULL = 1, K_NOP = 2, K_SADSEARCH = 3, K_CCLMSEARCH = 4, K_LEAF4 = 5, K_LEAFC4 = 6, K_LEAF8 = 7 };
+enum { K_SADLIST = 0, K_FULL = 1, K_NOP = 2, K_SADSEARCH = 3, K_CCLMSEARCH = 4, K_LEAF4 = 5, K_LEAFC4 = 6, K_LEAF8 = 7, K_LEAF16 = 8 };
 #ifndef WRENC_POOL_MIN_TLG
 #define WRENC_POOL_MIN_TLG 3
 #endif
@@ -29,6 +29,8 @@ struct Req {
                     // evaluated in packs of two and three (leaf8_search): Res::imin / imin2 = luma / chroma mode, vmin = the cost;
                     // n = which parts run here (bit 0 pack {planar, DC}, bit 1 the SAD search + pack {cm, cm - 1, cm + 1},
                     // bit 2 the CCLM part on the winner ml with DM chroma cost fcur)
+                    // K_LEAF16: the five full candidates of a 16x16 SINGLE_TREE leaf and its SAD search in one request, the
+                    // candidates in packs of two (leaf16_search): Res::imin = the best luma mode, vmin = its cost, + its parts
     int comps;      // bit 0: luma block, bit 1: Cb+Cr pair
     int tx, ty, tlg;
     int ml, mc;     // K_FULL: luma / chroma mode
@@ -264,6 +266,7 @@ __device__ __forceinline__ void sad_search(const Ctx& c, const Req& q, int& cm_o
 __device__ __forceinline__ Res leaf4_search(const Ctx& c, const Req& q, int* overflow); // below, after the cost functions
 __device__ __forceinline__ Res leafc4_search(const Ctx& c, const Req& q, int* overflow);
 __device__ __forceinline__ Res leaf8_search(const Ctx& c, const Req& q, int* overflow);
+__device__ __forceinline__ Res leaf16_search(const Ctx& c, const Req& q, int* overflow);
 
 // The evaluator: every block evaluation of the search, of the regeneration and of the final pass
 // goes through this one inlined copy (the search logic below is a state machine that hands out
@@ -287,6 +290,7 @@ __device__ __forceinline__ Res evaluate(const Ctx& c, const PicBufs& pb, const R
     if (q.kind == K_LEAF4) return leaf4_search(c, q, overflow);
     if (q.kind == K_LEAFC4) return leafc4_search(c, q, overflow);
     if (q.kind == K_LEAF8) return leaf8_search(c, q, overflow);
+    if (q.kind == K_LEAF16) return leaf16_search(c, q, overflow);
     int mc = q.mc;
     if (q.kind == K_CCLMSEARCH) {
         // get_chroma_intra_pred_aux_cost of LT, T, L_CCLM in one sample pass, then the pick of :847-854 (SADs are
@@ -783,7 +787,7 @@ __device__ __forceinline__ Res leafc4_search(const Ctx& c, const Req& q, int* ov
 // block (:887-898, :974), so they are evaluated in PACKS: pack A = {planar, DC}, then the SAD search, then pack B =
 // {cm, cm - 1, cm + 1}; a pack's candidates go through every stage together -- luma blocks one pass each, the 4x4
 // chroma blocks of all candidates four to a pass (predict4_lane), the transforms over nb blocks, and ONE trellis pass
-// for the pack's six or nine chains walked side by side by this wave alone (quantize_pk8: no workgroup barrier).
+// for the pack's six or nine chains walked side by side by this wave alone (quantize_pk: no workgroup barrier).
 // Predictions and reconstructions of the pack are parked in LDS (PRED_PARK); the running best candidate's
 // reconstruction goes to the tile when its pack is done, so there is no save / restore through global scratch.
 // Then the CCLM part (:1040-1072) as in K_CCLMSEARCH, the CCLM candidate's prediction and reconstruction in
@@ -836,7 +840,7 @@ __device__ __forceinline__ Pack8Out pack8_eval(const Ctx& c, const Req& q, int n
     PROF_MARK(t2_);
     PROF_ADD2(PH_FDCT, t1_, t2_);
     bool any_y = false, any_c = false;
-    quantize_pk8(c, nc, overflow, o.lvl_y, o.lvl_c, &any_y, &any_c);
+    quantize_pk<3>(c, nc, overflow, o.lvl_y, o.lvl_c, &any_y, &any_c);
     PROF_MARK(t3_);
     if (any_y) { // (all levels zero: the residuals are zero too, and r1 already says so)
         dequantize_t(c, 3, nc, 0);
@@ -1042,6 +1046,186 @@ __device__ __forceinline__ Res leaf8_search(const Ctx& c, const Req& q, int* ove
     return r;
 }
 
+// ---------------------------------------------------------------------------
+// K_LEAF16: the full candidates of a 16x16 SINGLE_TREE leaf in one request (block_splitter.rs:886-1037), in packs of
+// TWO: {planar, DC}, the SAD search, {cm, cm - 1}, {cm + 1}.  Two candidates' residuals (2 x (256 + 2 x 64) i16) are
+// what r1 holds; a pack goes through prediction, transforms and reconstruction block after block as the single
+// evaluation does, and through ONE trellis pass for its six chains (quantize_pk<4>: the two luma chains side by side,
+// the four chroma chains riding along, this wave alone, no workgroup barrier) -- three walks of 256 steps per leaf
+// instead of five pooled ones, and one control step instead of six.  LDS has no room to park two candidates'
+// predictions (768 B), so they go to this wave's kilobyte of global scratch (PRED_SCRATCH, the final pass's
+// buffer; every lane re-reads exactly the bytes it wrote); the running best candidate's reconstruction goes from there
+// to the tile when its pack is done.  The CCLM part follows as its own request (leaf_step, C_WINNER): its DM-chroma
+// restore takes the winner from slot 0, where the request after this one saves it.
+// ---------------------------------------------------------------------------
+struct Pack16Out {
+    uint32_t ssd_y[2], ssd_c[2];
+    long long lvl_y[3], lvl_c[3];
+};
+__device__ __forceinline__ Pack16Out pack16_eval(const Ctx& c, const Req& q, int nc, int m0, int m1, int* overflow) {
+    Pack16Out o;
+    const int lane = lane_fresh();
+    const int nL = 256 * nc;
+    GLOBAL_AS uint8_t* park = (GLOBAL_AS uint8_t*)c.pred_scratch;
+    const uint8_t* org = (const uint8_t*)SH.r2 + kOrgLeaf; // luma 256 | Cb 64 | Cr 64
+    PROF_MARK(t0_);
+#pragma unroll 1
+    for (int cd = 0; cd < nc; ++cd) {
+        const int mode = cd == 0 ? m0 : m1;
+        if (mode != kNoMode) {
+            predict<true>(c, 0, q.tx, q.ty, 4, mode, 256 * cd, PRED_SCRATCH);
+            predict<true>(c, 1, q.tx, q.ty, 4, mode, nL + 128 * cd, PRED_SCRATCH);
+        } else { // a candidate outside 2..66 rides along as a zero block
+            for (int i = lane; i < 256; i += 64) {
+                SH.r1[256 * cd + i] = 0;
+                park[256 * cd + i] = 0;
+            }
+            for (int i = lane; i < 128; i += 64) {
+                SH.r1[nL + 128 * cd + i] = 0;
+                park[nL + 128 * cd + i] = 0;
+            }
+            WSYNC();
+        }
+    }
+    PROF_MARK(t1_);
+    PROF_ADD2(PH_PREDICT, t0_, t1_);
+    fwd_dct_lg(c, 4, nc, 0);
+    fwd_dct_lg(c, 3, 2 * nc, nL);
+    PROF_MARK(t2_);
+    PROF_ADD2(PH_FDCT, t1_, t2_);
+    bool any_y = false, any_c = false;
+    quantize_pk<4>(c, nc, overflow, o.lvl_y, o.lvl_c, &any_y, &any_c);
+    PROF_MARK(t3_);
+    if (any_y) {
+        dequantize_t(c, 4, nc, 0);
+        inv_dct_lg(c, 4, nc, 0);
+    }
+    if (any_c) {
+        dequantize_t(c, 3, 2 * nc, nL);
+        inv_dct_lg(c, 3, 2 * nc, nL);
+    }
+    PROF_MARK(t4_);
+    PROF_ADD2(PH_IDCT, t3_, t4_);
+#pragma unroll
+    for (int cd = 0; cd < 2; ++cd) {
+        o.ssd_y[cd] = 0;
+        o.ssd_c[cd] = 0;
+        if (cd < nc) {
+            int py = 0, pc = 0;
+#pragma unroll
+            for (int kq = 0; kq < 4; ++kq) {
+                const int i = lane + 64 * kq;
+                int rec = (int16_t)((int)park[256 * cd + i] + (int)SH.r1[256 * cd + i]); // pred as i16 + res, clamp (:178)
+                rec = min(max(rec, 0), 255);
+                park[256 * cd + i] = (uint8_t)rec;
+                const int d = rec - (int)org[i];
+                py += M24(d, d);
+            }
+#pragma unroll
+            for (int kq = 0; kq < 2; ++kq) {
+                const int i = lane + 64 * kq;
+                int rec = (int16_t)((int)park[nL + 128 * cd + i] + (int)SH.r1[nL + 128 * cd + i]);
+                rec = min(max(rec, 0), 255);
+                park[nL + 128 * cd + i] = (uint8_t)rec;
+                const int d = rec - (int)org[256 + i];
+                pc += M24(d, d);
+            }
+            o.ssd_y[cd] = (uint32_t)wave_sum_i32(py);
+            o.ssd_c[cd] = (uint32_t)wave_sum_i32(pc);
+        }
+    }
+    WSYNC();
+    PROF_MARK(t5_);
+    PROF_ADD2(PH_RECON, t4_, t5_);
+    return o;
+}
+
+// a pack candidate's reconstruction from the parking scratch into the tile (luma 16x16, Cb and Cr 8x8)
+__device__ __forceinline__ void pack16_to_tile(const Ctx& c, const Req& q, int nc, int cd) {
+    const int lane = lane_fresh();
+    const GLOBAL_AS uint8_t* park = (const GLOBAL_AS uint8_t*)c.pred_scratch;
+#pragma unroll
+    for (int kq = 0; kq < 4; ++kq) {
+        const int i = lane + 64 * kq;
+        rec_put(0, q.tx + (i & 15), q.ty + (i >> 4), park[256 * cd + i]);
+    }
+#pragma unroll
+    for (int kq = 0; kq < 2; ++kq) {
+        const int i = lane + 64 * kq;
+        rec_put(1 + (i >> 6), (q.tx >> 1) + (i & 7), (q.ty >> 1) + ((i & 63) >> 3), park[256 * nc + 128 * cd + i]);
+    }
+    WSYNC();
+}
+
+__device__ __forceinline__ Res leaf16_search(const Ctx& c, const Req& q, int* overflow) {
+    Res r;
+    r.v0 = r.v1 = r.v2 = 3.40282347e+38f;
+    const int lane = lane_fresh();
+    if (q.refs0) build_refs(c, 0, q.tx, q.ty, 4);
+    if (q.refs1) build_refs(c, 1, q.tx, q.ty, 4);
+    float best = 3.40282347e+38f;
+    int best_mode = PLANAR;
+    EvalParts eb;
+    eb.ssd_y = eb.ssd_c = 0;
+    eb.lvl_y = eb.lvl_c = 0;
+    bool first_ = true;
+#define LEAF16_CANDIDATE(P, B, M)                                                                                      \
+    do {                                                                                                               \
+        EvalParts e_;                                                                                                  \
+        e_.ssd_y = (P).ssd_y[B];                                                                                       \
+        e_.ssd_c = (P).ssd_c[B];                                                                                       \
+        e_.lvl_y = (P).lvl_y[B];                                                                                       \
+        e_.lvl_c = (P).lvl_c[B];                                                                                       \
+        const int cls_ = mpm_class(c, q.tx, q.ty, 4, (M));                                                             \
+        const float val_ = uni_f(assemble_cost(c, TREE_SINGLE, cls_, (M), e_));                                        \
+        if (c.trace && lane == 0)                                                                                      \
+            TRACE_REC(c.ctu_x + q.tx, c.ctu_y + q.ty, 4, TREE_SINGLE, 1, (M), (M), __float_as_int(val_));              \
+        if (first_ || val_ < best) {                                                                                   \
+            best = val_;                                                                                               \
+            best_mode = (M);                                                                                           \
+            eb = e_;                                                                                                   \
+            win_ = (B);                                                                                                \
+        }                                                                                                              \
+        first_ = false;                                                                                                \
+    } while (0)
+    {
+        // planar and DC (:887-898)
+        const Pack16Out a = pack16_eval(c, q, 2, PLANAR, DC, overflow);
+        int win_ = -1;
+        LEAF16_CANDIDATE(a, 0, PLANAR);
+        LEAF16_CANDIDATE(a, 1, DC);
+        pack16_to_tile(c, q, 2, win_);
+    }
+    int cm;
+    unsigned smin;
+    sad_search(c, q, cm, smin);
+    cm = uni(cm);
+    // step_search(mode, 1, _, aux = false) on {cm, cm - 1, cm + 1} (:974): {cm, cm - 1}, then cm + 1
+    const int lo = !(cm < 3) ? cm - 1 : kNoMode, hi = !(cm + 1 > 66) ? cm + 1 : kNoMode;
+    {
+        const Pack16Out b = pack16_eval(c, q, 2, cm, lo, overflow);
+        int win_ = -1;
+        LEAF16_CANDIDATE(b, 0, cm);
+        if (lo != kNoMode) LEAF16_CANDIDATE(b, 1, lo);
+        if (win_ >= 0) pack16_to_tile(c, q, 2, win_);
+    }
+    if (hi != kNoMode) {
+        const Pack16Out b = pack16_eval(c, q, 1, hi, kNoMode, overflow);
+        int win_ = -1;
+        LEAF16_CANDIDATE(b, 0, hi);
+        if (win_ >= 0) pack16_to_tile(c, q, 1, win_);
+    }
+#undef LEAF16_CANDIDATE
+    r.vmin = best;
+    r.imin = best_mode;
+    r.imin2 = best_mode;
+    r.ssd_y = eb.ssd_y;
+    r.ssd_c = eb.ssd_c;
+    r.lvl_y = eb.lvl_y;
+    r.lvl_c = eb.lvl_c;
+    return r;
+}
+
 // the decision maps of a block: at most 8 x 8 units of 4x4 (one lane each), sizes are powers of two
 __device__ __forceinline__ void fill_maps(int bx, int by, int lg, int luma_mode, int chroma_mode, bool luma,
                                           bool chroma) {
@@ -1097,7 +1281,7 @@ __device__ __forceinline__ void req_copy(Req& q, int mode, int comps, int slot, 
 
 enum {
     C_START = 0, C_PLANAR, C_DCM, C_LIST, C_PAIR_EMIT, C_PAIR, C_F0, C_F1, C_F2, C_WIN, C_CX, C_CCLM, C_DM,
-    C_DC_START, C_DC2, C_DC3, C_DC4, C_DC5, C_L4, C_LC4, C_L8
+    C_DC_START, C_DC2, C_DC3, C_DC4, C_DC5, C_L4, C_LC4, C_L8, C_L16, C_WINNER
 };
 
 __device__ __forceinline__ void leaf_init(LeafSt& s, int tree, int bx, int by, int lg, int dm_mode) {
@@ -1228,6 +1412,16 @@ __device__ __forceinline__ void leaf_leaf8(LeafSF& s, Req& q, int parts, int con
     s.cont = (uint8_t)cont;
 }
 
+// the full candidates of a 16x16 SINGLE_TREE leaf as one request (K_LEAF16, leaf16_search); wave schedule only
+#ifndef WRENC_LEAF16
+#define WRENC_LEAF16 1
+#endif
+__device__ __forceinline__ bool leaf_is_leaf16(const LeafSF& s) { return WRENC_LEAF16 && s.tree == TREE_SINGLE && s.lg == 4; }
+__device__ __forceinline__ void leaf_leaf16(LeafSF& s, Req& q, int cont) {
+    leaf_leaf8(s, q, 3, cont);
+    q.kind = K_LEAF16;
+}
+
 __device__ __forceinline__ EvalParts res_parts(const Res& r) {
     EvalParts e;
     e.ssd_y = r.ssd_y;
@@ -1295,8 +1489,21 @@ __device__ __forceinline__ bool leaf_step(const Ctx& c, LeafSF& s, const Res& r,
                 leaf_leaf8(s, q, 7, C_L8);
                 return true;
             }
+            if (leaf_is_leaf16(s)) { // a 16x16 leaf: its five full candidates and the SAD search in one request
+                leaf_leaf16(s, q, C_L16);
+                return true;
+            }
             leaf_full(s, q, both, PLANAR, PLANAR, true, C_PLANAR);
             return true;
+        case C_L16: // the winner of [planar, DC, cm, cm - 1, cm + 1] is in the tile; it is saved by the next request
+            s.best_cost = r.vmin;
+            put_parts(s.e_best, rp);
+            s.mode = (uint8_t)r.imin;
+            s.best_cls = (uint8_t)mpm_class(c, s.bx, s.by, s.lg, r.imin);
+            s.need_save = 1;
+            s.tile_best = 1;
+            cont = C_WINNER;
+            break;
         case C_L8:
             s.cost = r.vmin;
             s.luma_mode = (uint8_t)r.imin;
@@ -1345,8 +1552,11 @@ __device__ __forceinline__ bool leaf_step(const Ctx& c, LeafSF& s, const Res& r,
             leaf_full(s, q, both, cm + 1, cm + 1, !(cm + 1 > 66), C_F2);
             return true;
         }
-        case C_F2: {
+        case C_F2:
             LEAF_CANDIDATE(s.cur_mode + 1);
+            cont = C_WINNER;
+            break;
+        case C_WINNER: {
             s.cost = s.best_cost;
             const int m = s.mode;
             s.luma_mode = (uint8_t)m;
@@ -2127,8 +2337,8 @@ __device__ __forceinline__ void encode_ctu(Ctx& c, const PicBufs& pb, int ctu_co
         r = evaluate(c, pb, q, overflow);
         PROF_MARK(te1_);
         PROF_ADDM(q.kind == K_NOP ? 3 : 1, te0_, te1_);
-        PROF_ADD2(PH_EV + (((q.kind & 7) * 4 + ((q.kind == K_NOP ? q.copy_tlg : q.tlg) - 2)) & 31), te0_, te1_); // by request kind and block size
-        PROF_ADD2(PH_EVN + (((q.kind & 7) * 4 + ((q.kind == K_NOP ? q.copy_tlg : q.tlg) - 2)) & 31), 0, 1);
+        PROF_ADD2(PH_EV + (((q.kind & 15) * 4 + ((q.kind == K_NOP ? q.copy_tlg : q.tlg) - 2)) & 63), te0_, te1_); // by request kind and block size
+        PROF_ADD2(PH_EVN + (((q.kind & 15) * 4 + ((q.kind == K_NOP ? q.copy_tlg : q.tlg) - 2)) & 63), 0, 1);
 #ifdef WRENC_PROFILE
         if (LANE == 0 && WAVE < 4 && cb_ < 12) s_prof[PH_ST + 4 * cb_ + WAVE] += te1_ - te0_; // eval time by step origin, member
         if (threadIdx.x == 0 && cb_ < 12) s_prof[PH_STN + cb_] += 1;
