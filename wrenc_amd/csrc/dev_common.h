@@ -265,7 +265,10 @@ struct CtuSt {
     // team schedule: a decided leaf's winner still to be pulled into every member's tile, done by the driver loop
     // before the next evaluation.  dp0 = on | comps << 1 | from << 3 | (lg - 2) << 5, dp1 = bx / 4 | (by / 4) << 3
     UF<uint8_t> dp0, dp1;
+    // level schedule (team kernel at max-split-depth 3, dev_search.h): on | this member's unit | end of its final-pass range
+    UF<uint8_t> lvmode, lv_i, zend;
     UF<float> ret, ns_cost_cur, split8, ctu_cost;
+    UF<float> lv_acc0, lv_acc1; // level schedule: running split cost of the open 32x32 / 16x16 node
     LeafSt leaf;
 };
 
@@ -330,6 +333,8 @@ struct Ctx {
     int cu32_mode;    // in-CTU neighbour lookups during search resolve to the root CU
     int write;        // 0 for a padding wave (batch not a multiple of WPB): compute, never store
     int member;       // team schedule: this wave's place in its team of kTeam waves (0 otherwise)
+    int store;        // team schedule: this wave's final-pass blocks are of a real picture (it stores their levels); = write otherwise
+    int solo;         // team kernel: no pooled (workgroup-wide) trellis walk, whatever a request says
     int trace;        // diagnostic trace: this wave's evaluations are of a real picture
 };
 
@@ -347,10 +352,20 @@ constexpr int kWorkgroupsPerCU = 20 / WPB;
 // Team schedule: kTeam waves share ONE CTU (independent candidates of a leaf search run side by side), a
 // workgroup holds WPB / kTeam teams = the same CTU of that many pictures.
 constexpr int kTeam = 4;
+// Level schedule: what the members of a team tell each other about the node being decided at tree level L (0: 32x32,
+// 1: 16x16, 2: 8x8) -- the unsplit candidate's cost and modes from member L, the split candidate's cost from member
+// L + 1 -- and the arrival counters of the two meeting points of a decision (monotone over a CTU).
+struct LvBox {
+    float ns_cost[3], split[3];
+    uint8_t ml[3], mc[3];
+    uint16_t pad_;
+    uint32_t cnt[3][2];
+};
 struct LdsTab {
     int32_t ldq[256];
     int32_t lv[256];
     int8_t fc[32][4]; // common.rs:153 (copied from the constant block)
+    LvBox lvb;
 #ifdef WRENC_EXP_LDS_PAD
     char pad[WRENC_EXP_LDS_PAD]; // occupancy experiments only (profiles/r02_issue_model.md)
 #endif
@@ -371,6 +386,8 @@ __device__ __forceinline__ Ctx uni(Ctx c) {
     c.cu32_mode = uni(c.cu32_mode);
     c.write = uni(c.write);
     c.member = uni(c.member);
+    c.store = uni(c.store);
+    c.solo = uni(c.solo);
     c.trace = uni(c.trace);
     return c;
 }

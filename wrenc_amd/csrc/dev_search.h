@@ -97,7 +97,7 @@ __device__ __forceinline__ uint32_t full_back(const Ctx& c, const PicBufs& pb, c
     const int obyte = org_byte(comp, q.tlg);
     const bool olds = q.tlg <= 4;
     PROF_MARK(t3_);
-    if (q.final && c.write) {
+    if (q.final && c.store) {
         const int stride = c.W >> cs;
         const size_t at = (size_t)((c.ctu_y + q.ty) >> cs) * stride + ((c.ctu_x + q.tx) >> cs);
         GLOBAL_AS int16_t* lev0 = AS_GLOBAL(int16_t, pb.lev[0]) + plane_off(c, comp) + at;
@@ -131,7 +131,7 @@ __device__ __forceinline__ uint32_t full_back(const Ctx& c, const PicBufs& pb, c
     const uint32_t ssd = (uint32_t)wave_sum_i32((int)part); // <= 1024 * 255^2: fits 32 bits
     if (q.final) {
         const int changed = wave_sum_i32(diff);
-        if (changed && LANE == 0 && c.write) atomicAdd(c.mismatch, (unsigned long long)changed);
+        if (changed && LANE == 0 && c.store) atomicAdd(c.mismatch, (unsigned long long)changed);
     }
     WSYNC();
     PROF_MARK(t6_);
@@ -313,7 +313,7 @@ __device__ __forceinline__ Res evaluate(const Ctx& c, const PicBufs& pb, const R
         // Pooling the Viterbi walk of the workgroup's WPB blocks pays for long walks; a block of few positions walks
         // faster alone than the two workgroup barriers per chunk cost (WRENC_POOL_MIN_TLG: smallest CU size, log2,
         // whose transform blocks are pooled; every wave of the workgroup evaluates the same size, so they agree)
-        const bool pooled = q.shared && q.tlg >= WRENC_POOL_MIN_TLG;
+        const bool pooled = q.shared && !c.solo && q.tlg >= WRENC_POOL_MIN_TLG;
         #ifdef WRENC_EXP_NO_MERGED
         const bool merged = false;
 #else
@@ -766,7 +766,7 @@ __device__ __forceinline__ Res leafc4_search(const Ctx& c, const Req& q, int* ov
     ed.lvl_c = lvl[2] + lvl[3];
     const float c0 = uni_f(assemble_chroma_cost(c, cm, ec));
     const float dm_cost = uni_f(assemble_chroma_cost(c, dm, ed));
-    if (c.write && lane == 0) {
+    if (c.trace && lane == 0) {
         TRACE_REC(c.ctu_x + q.tx, c.ctu_y + q.ty, 3, q.tree, 3, 0, cm, __float_as_int(c0));
         TRACE_REC(c.ctu_x + q.tx, c.ctu_y + q.ty, 3, q.tree, 3, 0, dm, __float_as_int(dm_cost));
     }
@@ -1472,7 +1472,7 @@ __device__ __forceinline__ bool leaf_step(const Ctx& c, LeafSF& s, const Res& r,
         if (s.op_act) {
             cls = mpm_class(c, s.bx, s.by, s.lg, s.op_ml);
             val = uni_f(assemble_cost(c, tree, cls, s.op_mc, rp));
-            if (c.write && LANE == 0)
+            if (c.trace && LANE == 0)
                 TRACE_REC(c.ctu_x + s.bx, c.ctu_y + s.by, s.lg, tree, 1, s.op_ml, s.op_mc, __float_as_int(val));
         } else {
             val = 3.40282347e+38f; // a skipped evaluation is f32::MAX in the reference
@@ -1573,7 +1573,7 @@ __device__ __forceinline__ bool leaf_step(const Ctx& c, LeafSF& s, const Res& r,
             }
             // :1040 get_chroma_intra_pred_cost(mode) repeats the winner's chroma evaluation: re-use it
             s.cur_cost = uni_f(assemble_chroma_cost(c, m, s.e_best.get()));
-            if (c.write && LANE == 0)
+            if (c.trace && LANE == 0)
                 TRACE_REC(c.ctu_x + s.bx, c.ctu_y + s.by, s.lg, tree, 3, 0, m, __float_as_int((float)s.cur_cost));
             // the three CCLM probes, the pick and the evaluation of the picked mode in one request (K_CCLMSEARCH)
             leaf_cclmsearch(s, q, C_CCLM);
@@ -1589,7 +1589,7 @@ __device__ __forceinline__ bool leaf_step(const Ctx& c, LeafSF& s, const Res& r,
             e.ssd_c = rp.ssd_c;
             e.lvl_c = rp.lvl_c;
             const float cclm_cost = uni_f(assemble_chroma_cost(c, s.cclm_mode, e));
-            if (c.write && LANE == 0)
+            if (c.trace && LANE == 0)
                 TRACE_REC(c.ctu_x + s.bx, c.ctu_y + s.by, s.lg, tree, 3, 0, s.cclm_mode, __float_as_int(cclm_cost));
             const float cur = s.cur_cost;
             const bool dm_wins = cur == fminf(cclm_cost, fminf(cur, 3.40282347e+38f));
@@ -1625,14 +1625,14 @@ __device__ __forceinline__ bool leaf_step(const Ctx& c, LeafSF& s, const Res& r,
         case C_DC3:
             s.cclm_mode = (uint8_t)r.imin;
             s.c0 = uni_f(assemble_chroma_cost(c, s.cclm_mode, rp));
-            if (c.write && LANE == 0)
+            if (c.trace && LANE == 0)
                 TRACE_REC(c.ctu_x + s.bx, c.ctu_y + s.by, s.lg, tree, 3, 0, s.cclm_mode, __float_as_int((float)s.c0));
             leaf_full(s, q, 2, 0, s.dm_mode, true, C_DC4);
             req_copy(q, COPY_SAVE, 2, 0, s.bx, s.by, s.lg); // keep the CCLM reconstruction (:807-840)
             return true;
         case C_DC4: {
             const float dm_cost = uni_f(assemble_chroma_cost(c, s.dm_mode, rp));
-            if (c.write && LANE == 0)
+            if (c.trace && LANE == 0)
                 TRACE_REC(c.ctu_x + s.bx, c.ctu_y + s.by, s.lg, tree, 3, 0, s.dm_mode, __float_as_int(dm_cost));
             const float cost = fminf(s.c0, fminf(dm_cost, 3.40282347e+38f));
             s.luma_mode = 0;
@@ -1998,6 +1998,135 @@ __device__ __forceinline__ bool leaf_step_team(const Ctx& c, CtuSt& t, LeafSF& s
     }
 }
 
+// ---------------------------------------------------------------------------
+// Level schedule (team kernel at max-split-depth 3): after the team has searched the CTU's 32x32 candidate together
+// (every in-CTU cost needs that candidate's luma mode: SURVEY.md Q7), the members take one TREE LEVEL each and run
+// ahead side by side: member 1 the four 16x16 leaf searches, member 2 the sixteen 8x8 ones, member 3 the sixteen
+// 8x8 SPLITS (four 4x4 luma leaves + the chroma leaf each); member 0 keeps the 32x32 candidate in its tile.  A
+// node's unsplit search and the search of everything below it read only neighbours outside the node
+// (block_splitter.rs:1081-1123), so the levels depend on each other only through DECISIONS: node (L, i) is decided --
+// unsplit against the sum of its decided children, :1116-1145 -- by the members L .. 3 together once member L has
+// searched it and its children are decided; whoever lost copies the winner's reconstruction and decision maps from
+// the tile of the member that holds them (LDS to LDS), so every member's tile shows later blocks exactly the
+// neighbourhood the reference's depth-first search shows them.  Each member runs the ordinary one-wave leaf search
+// (leaf_step with the packed requests K_LEAF16 / K_LEAF8 / K_LEAF4 / K_LEAFC4), solo trellis walks throughout.
+// A decision has two meeting points (everybody arrived: the costs are posted; everybody has copied: tiles may be
+// written again); they are counters in LDS that the members of the decision poll -- a workgroup barrier would also
+// stop the members of other levels, who are in the middle of their own searches.  Same decisions, same f32 sums in
+// the same order as ctu_step's depth-first walk; the final pass is shared by quadrant (every member ends with the
+// final tile and maps).
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void lv_meet(int L, int which, int target) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    if (LANE == 0) {
+        __hip_atomic_fetch_add(&SHT.lvb.cnt[L][which], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        // (bounded: a member that never arrives must not hang the device; the cap is seconds, a CTU takes milliseconds,
+        // and the host reports it: SHT.lvb.pad_ -> WRENC_GPU_EHIP through the overflow word, bit 1)
+        int polls = 0;
+        while (__hip_atomic_load(&SHT.lvb.cnt[L][which], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < (unsigned)target) {
+            __builtin_amdgcn_s_sleep(2);
+            if (++polls > (1 << 23)) {
+                SHT.lvb.pad_ = 1;
+                break;
+            }
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    WSYNC();
+}
+// position of node i of tree level L in z-order (L = 0: the CTU, 1: 16x16, 2: 8x8)
+__device__ __forceinline__ void lv_node(int L, int i, int& bx, int& by) {
+    if (L == 0) {
+        bx = by = 0;
+    } else if (L == 1) {
+        bx = (i & 1) * 16;
+        by = (i >> 1) * 16;
+    } else {
+        const int qd = i >> 2, sb = i & 3;
+        bx = (qd & 1) * 16 + (sb & 1) * 8;
+        by = (qd >> 1) * 16 + (sb >> 1) * 8;
+    }
+}
+// the decision maps of a block from member `from`'s LDS (the split candidate's: they differ per 4x4 unit)
+__device__ __forceinline__ void lv_pull_maps(const Ctx& c, int from, int bx, int by, int lg) {
+    const Lds& src = team_lds(c, from);
+    const int l4 = lg - 2;
+    if (LANE < (1 << (2 * l4))) {
+        const int idx = ((by >> 2) + (LANE >> l4)) * 8 + (bx >> 2) + (LANE & ((1 << l4) - 1));
+        SH.cu_log2[idx] = src.cu_log2[idx];
+        SH.luma_mode[idx] = src.luma_mode[idx];
+    }
+    const int l8 = lg - 3;
+    if (LANE < (1 << (2 * l8))) {
+        const int idx = ((by >> 3) + (LANE >> l8)) * 4 + (bx >> 3) + (LANE & ((1 << l8) - 1));
+        SH.chroma_mode[idx] = src.chroma_mode[idx];
+    }
+    WSYNC();
+}
+// block from member `from`'s tile into this member's (copy_block's COPY_PULL without its workgroup barrier)
+__device__ __forceinline__ void lv_pull(const Ctx& c, int from, int tx, int ty, int tlg) {
+    const Lds& src = team_lds(c, from);
+    const int words = 1 << (2 * tlg - 2);
+    for (int w = LANE; w < words; w += 64) {
+        const int row = (4 * w) >> tlg, col = (4 * w) & ((1 << tlg) - 1);
+        const int at = (ty + row) * 36 + tx + col + 4;
+        *(uint32_t*)&SH.recY[at] = *(const uint32_t*)&src.recY[at];
+    }
+    const int lg = tlg - 1;
+    const int cwords = 1 << (2 * lg - 2); // per plane
+    for (int w = LANE; w < 2 * cwords; w += 64) {
+        const int pl = w >= cwords ? 1 : 0;
+        const int ww = w - pl * cwords;
+        const int row = (4 * ww) >> lg, col = (4 * ww) & ((1 << lg) - 1);
+        const int at = ((ty >> 1) + row) * 20 + (tx >> 1) + col + 4;
+        *(uint32_t*)&SH.recC[pl][at] = *(const uint32_t*)&src.recC[pl][at];
+    }
+    WSYNC();
+}
+// Decision of node (L, idx), by members L .. 3: returns the decided cost (block_splitter.rs:1125-1151)
+__device__ __forceinline__ float lv_decide(const Ctx& c, int L, int idx) {
+    const int me = c.member;
+    const int nmem = kTeam - L;
+    PROF_MARK(tx0_);
+    lv_meet(L, 0, (idx + 1) * nmem);
+    PROF_MARK(tx1_);
+    PROF_ADD2(PH_XCHG, tx0_, tx1_);
+    PROF_ADDM(2, tx0_, tx1_);
+    const float ns = uni_f(SHT.lvb.ns_cost[L]), sp = uni_f(SHT.lvb.split[L]);
+    const int ml = uni((int)SHT.lvb.ml[L]), mc = uni((int)SHT.lvb.mc[L]);
+    int bx, by;
+    lv_node(L, idx, bx, by);
+    const int lg = 5 - L;
+    const bool unsplit = sp > ns; // :1125-1145 (ties => split)
+    if (unsplit) {
+        if (me > L) lv_pull(c, L, bx, by, lg);
+        fill_maps(bx, by, lg, ml, mc, true, true);
+    } else if (me == L) {
+        lv_pull(c, L + 1, bx, by, lg);
+        lv_pull_maps(c, L + 1, bx, by, lg);
+    }
+    PROF_MARK(tx2_);
+    lv_meet(L, 1, (idx + 1) * nmem);
+    PROF_MARK(tx3_);
+    PROF_ADD2(PH_COPY, tx1_, tx2_);
+    PROF_ADD2(PH_XCHG, tx2_, tx3_);
+    PROF_ADDM(2, tx2_, tx3_);
+    return unsplit ? ns : sp;
+}
+__device__ __forceinline__ void lv_post_unsplit(int L, float ns, int ml, int mc) {
+    if (LANE == 0) {
+        SHT.lvb.ns_cost[L] = ns;
+        SHT.lvb.ml[L] = (uint8_t)ml;
+        SHT.lvb.mc[L] = (uint8_t)mc;
+    }
+}
+__device__ __forceinline__ void lv_post_split(int L, float sp) {
+    if (LANE == 0) SHT.lvb.split[L] = sp;
+}
+#ifndef WRENC_LEVELS
+#define WRENC_LEVELS 1
+#endif
+
 // split_ct (block_splitter.rs:782-1154) for one CTU + the final pass (ctu_encoder.rs:1421-1461):
 // exhaustive quad-tree search as an explicit depth-first walk (level 0 = 32x32 ... level 2 = 8x8;
 // an 8x8 node's split is four DUAL_TREE_LUMA 4x4 leaves + one DUAL_TREE_CHROMA 4x4 leaf,
@@ -2007,7 +2136,8 @@ __device__ __forceinline__ bool leaf_step_team(const Ctx& c, CtuSt& t, LeafSF& s
 // slots in global scratch they were saved to (copy_block): the reference's cache_reconsts /
 // restore_reconsts (block_splitter.rs:807-840, 1085-1145), with the saved planes kept in L2/HBM
 // instead of LDS.
-enum { T_START = 0, T_ENTER, T_NODE_LEAF, T_LEAF4_EMIT, T_LEAF4, T_LEAFC, T_REGEN_DONE, T_RETURN, T_FINAL_Z, T_FZ_TAIL, T_FZ_NEXT };
+enum { T_START = 0, T_ENTER, T_NODE_LEAF, T_LEAF4_EMIT, T_LEAF4, T_LEAFC, T_REGEN_DONE, T_RETURN, T_FINAL_Z, T_FZ_TAIL, T_FZ_NEXT,
+       T_LV_UNIT, T_LV_LEAFDONE, T_LV_UP };
 
 template <bool TEAM>
 __device__ __forceinline__ bool ctu_step(Ctx& c, const Res& r, Req& q) {
@@ -2018,7 +2148,7 @@ __device__ __forceinline__ bool ctu_step(Ctx& c, const Res& r, Req& q) {
         if (in_leaf) {
             // team schedule: the results of the previous requests are in the members' XRes of parity xpar ^ 1
             LeafSF ls = snap_leaf(t.leaf);
-            if (TEAM ? leaf_step_team(c, t, ls, q, t.xpar ^ 1, r) : leaf_step(c, ls, r, q)) {
+            if ((TEAM && !t.lvmode) ? leaf_step_team(c, t, ls, q, t.xpar ^ 1, r) : leaf_step(c, ls, r, q)) {
                 if (t.pend) { // the first request of a node's first child saves the unsplit candidate
                     req_copy(q, COPY_SAVE, 3, t.pslot, t.pbx, t.pby, t.plg);
                     t.pend = 0;
@@ -2041,7 +2171,7 @@ __device__ __forceinline__ bool ctu_step(Ctx& c, const Res& r, Req& q) {
             const int lg = 5 - t.level;
             t.lg = (uint8_t)lg;
             leaf_init(t.leaf, TREE_SINGLE, t.bx, t.by, lg, 0);
-            if (TEAM) t.leaf.cont = TC_START;
+            if (TEAM && !t.lvmode) t.leaf.cont = TC_START;
             in_leaf = true;
             cont = T_NODE_LEAF;
             break;
@@ -2058,6 +2188,25 @@ __device__ __forceinline__ bool ctu_step(Ctx& c, const Res& r, Req& q) {
             if (t.max_depth - level == 0) {
                 t.ret = ns;
                 cont = T_RETURN;
+                break;
+            }
+            if (TEAM && WRENC_LEVELS && t.max_depth == 3) {
+                // ---- level schedule from here on (see lv_decide): every member has searched the 32x32 candidate ----
+                if (t.dp0) { // its winner into every member's tile first (team_defer_pull)
+                    const int dp = t.dp0, dq = t.dp1;
+                    t.dp0 = 0;
+                    copy_block(c, COPY_PULL, (dp >> 1) & 3, 0, (dq & 7) << 2, (dq >> 3) << 2, (dp >> 5) + 2, (dp >> 3) & 3);
+                }
+                t.lvmode = 1;
+                t.lv_i = 0;
+                t.lv_acc0 = 0.0f;
+                t.lv_acc1 = 0.0f;
+                if (c.member == 0) {
+                    lv_post_unsplit(0, ns, ml, mc);
+                    cont = T_LV_UP;
+                } else {
+                    cont = T_LV_UNIT;
+                }
                 break;
             }
             // the unsplit candidate's reconstruction goes to slot 1 + level (cache_reconsts, :1085-1100)
@@ -2088,7 +2237,7 @@ __device__ __forceinline__ bool ctu_step(Ctx& c, const Res& r, Req& q) {
         case T_LEAF4_EMIT: {
             const int i8 = t.i8;
             leaf_init(t.leaf, TREE_DUAL_LUMA, t.bx + (i8 & 1) * 4, t.by + (i8 >> 1) * 4, 2, 0);
-            if (TEAM) t.leaf.cont = TC_START;
+            if (TEAM && !t.lvmode) t.leaf.cont = TC_START;
             in_leaf = true;
             cont = T_LEAF4;
             break;
@@ -2105,7 +2254,7 @@ __device__ __forceinline__ bool ctu_step(Ctx& c, const Res& r, Req& q) {
             // DM = luma mode of the CU covering the parent's centre (block_splitter.rs:795-805)
             const int bx = t.bx, by = t.by;
             leaf_init(t.leaf, TREE_DUAL_CHROMA, bx, by, 3, uni((int)SH.luma_mode[((by + 4) >> 2) * 8 + ((bx + 4) >> 2)]));
-            if (TEAM) t.leaf.cont = TC_DC_START;
+            if (TEAM && !t.lvmode) t.leaf.cont = TC_DC_START;
             in_leaf = true;
             cont = T_LEAFC;
             break;
@@ -2113,6 +2262,11 @@ __device__ __forceinline__ bool ctu_step(Ctx& c, const Res& r, Req& q) {
         case T_LEAFC: {
             fill_maps(t.bx, t.by, 3, 0, t.leaf.chroma_mode, false, true);
             const float split8 = t.split8 + t.leaf.cost;
+            if (TEAM && t.lvmode) { // member 3's unit is done: the split candidate of 8x8 node lv_i
+                lv_post_split(2, split8);
+                cont = T_LV_UP;
+                break;
+            }
             if (split8 > t.ns_cost_cur) { // :1125-1145: the unsplit 8x8 wins, put it back
                 t.rbx = t.bx;
                 t.rby = t.by;
@@ -2146,10 +2300,10 @@ __device__ __forceinline__ bool ctu_step(Ctx& c, const Res& r, Req& q) {
                     t.cont = T_RETURN;
                     return true;
                 }
-                if (TEAM && c.member != 0) { // the final pass is one chain of dependent blocks: member 0 alone
-                    t.cont = T_START;
-                    return false;
-                }
+                // final pass: every block reads only final neighbours, and every member's tile and maps are final, so the
+                // team shares it by 16x16 quadrant (a CU is emitted by the member that owns its top-left unit)
+                t.z = (uint8_t)(TEAM ? 16 * c.member : 0);
+                t.zend = (uint8_t)(TEAM ? 16 * c.member + 16 : 64);
                 cont = T_FINAL_Z;
                 break;
             }
@@ -2190,11 +2344,69 @@ __device__ __forceinline__ bool ctu_step(Ctx& c, const Res& r, Req& q) {
             t.ret = acc;
             break; // cont stays T_RETURN
         }
+        // ---- level schedule: this member's next unit (members 1, 2: a leaf search; member 3: an 8x8 split) ----
+        case T_LV_UNIT: {
+            const int me = c.member, i = t.lv_i;
+            int bx, by;
+            lv_node(me == 1 ? 1 : 2, i, bx, by);
+            t.bx = (uint8_t)bx;
+            t.by = (uint8_t)by;
+            if (me == 3) { // four DUAL_TREE_LUMA 4x4 leaves, then the DUAL_TREE_CHROMA leaf (T_LEAF4_EMIT .. T_LEAFC)
+                t.lg = 3;
+                t.split8 = 0.0f;
+                t.i8 = 0;
+                cont = T_LEAF4_EMIT;
+                break;
+            }
+            const int lg = me == 1 ? 4 : 3;
+            t.lg = (uint8_t)lg;
+            leaf_init(t.leaf, TREE_SINGLE, bx, by, lg, 0);
+            in_leaf = true;
+            cont = T_LV_LEAFDONE;
+            break;
+        }
+        case T_LV_LEAFDONE: { // members 1, 2: the unsplit candidate of node (member, lv_i)
+            const int me = c.member;
+            lv_post_unsplit(me, t.leaf.cost, t.leaf.luma_mode, t.leaf.chroma_mode);
+            cont = T_LV_UP;
+            break;
+        }
+        case T_LV_UP: { // the decisions this member takes part in now, deepest first
+            const int me = c.member, i = t.lv_i;
+            if (me >= 2) {
+                const float d2 = lv_decide(c, 2, i);
+                const float a1 = uni_f(t.lv_acc1 + d2); // children in z-order, f32, from 0.0 (:1116-1123)
+                t.lv_acc1 = a1;
+                if ((i & 3) != 3) {
+                    t.lv_i = (uint8_t)(i + 1);
+                    cont = T_LV_UNIT;
+                    break;
+                }
+                if (me == 2) lv_post_split(1, a1);
+                t.lv_acc1 = 0.0f;
+            }
+            if (me >= 1) {
+                const int i1 = me == 1 ? i : (i >> 2);
+                const float d1 = lv_decide(c, 1, i1);
+                const float a0 = uni_f(t.lv_acc0 + d1);
+                t.lv_acc0 = a0;
+                if (i1 != 3) {
+                    t.lv_i = (uint8_t)(i + 1);
+                    cont = T_LV_UNIT;
+                    break;
+                }
+                if (me == 1) lv_post_split(0, a0);
+            }
+            t.ret = lv_decide(c, 0, 0);
+            t.level = 0;
+            cont = T_RETURN;
+            break;
+        }
         // ---- final pass (ctu_encoder.rs:1421-1461): coding order = z-order over the 4x4 units; a
         // CU is emitted at its top-left unit (luma TB, then the chroma TBs) ----
         case T_FINAL_Z: {
             const int z = t.z;
-            if (z == 64) {
+            if (z == t.zend) {
                 t.cont = T_START;
                 return false;
             }
@@ -2242,6 +2454,8 @@ __device__ __forceinline__ void load_tables(Ctx c) {
         SHT.lv[i] = (int32_t)c.k->lv[i];
     }
     for (int i = threadIdx.x; i < 128; i += blockDim.x) ((int8_t*)SHT.fc)[i] = ((const CONST_AS int8_t*)c.k->fc)[i];
+    if (threadIdx.x < 6) (&SHT.lvb.cnt[0][0])[threadIdx.x] = 0; // level schedule: the meeting points of this CTU's decisions
+    if (threadIdx.x == 0) SHT.lvb.pad_ = 0;
     __syncthreads();
 }
 
@@ -2303,6 +2517,7 @@ __device__ __forceinline__ void encode_ctu(Ctx& c, const PicBufs& pb, int ctu_co
     SH.st.pend = 0;
     SH.st.dp0 = 0;
     SH.st.xpar = 0;
+    SH.st.lvmode = 0;
     if (LANE == 0) SH.q_pm[0][0][3] = 0; // parity of the pooled quantisation calls (dev_quant.h, zero_flag_cell)
     SH.st.max_depth = (uint8_t)k->max_depth;
     Res r = {};

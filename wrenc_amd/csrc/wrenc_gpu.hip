@@ -101,6 +101,8 @@ __global__ __launch_bounds__(64 * WPB, 5) void ctu_search_kernel(const DevConst*
     c.mismatch = mismatch;
     c.write = pic < n_pictures ? 1 : 0;
     c.trace = c.write;
+    c.store = c.write;
+    c.solo = 0;
     c.member = 0;
     if (pic >= n_pictures) pic = n_pictures - 1; // padding wave: same work, no stores
     const PicBufs pb = slots[first_slot + pic];
@@ -135,6 +137,8 @@ __global__ __launch_bounds__(64 * WPB, 5) void ctu_search_team_kernel(const DevC
     c.member = WAVE & (kTeam - 1);
     c.trace = pic < n_pictures ? 1 : 0;
     c.write = (c.trace && c.member == 0) ? 1 : 0; // one member stores the picture's results
+    c.store = c.trace;                            // (every member stores the levels of its share of the final pass)
+    c.solo = 1;
     if (pic >= n_pictures) pic = n_pictures - 1;  // padding team: same work, no stores
     const PicBufs pb = slots[first_slot + pic];
     c.org = (const GLOBAL_AS uint8_t*)pb.org_t + (size_t)(row * k->ctu_cols + col) * kOrgTile;
@@ -145,6 +149,7 @@ __global__ __launch_bounds__(64 * WPB, 5) void ctu_search_team_kernel(const DevC
     int ovf = 0;
     encode_ctu<true>(c, pb, col, row, &ovf);
     if (ovf && LANE == 0) atomicOr(overflow, 1);
+    if (SHT.lvb.pad_ && LANE == 0) atomicOr(overflow, 2); // a meeting point of the level schedule timed out
     release_scratch(slot_map, scratch_slot);
 }
 
@@ -952,6 +957,7 @@ int wrenc_gpu_sync(wrenc_gpu_ctx* ctx) {
     for (hipStream_t st : ctx->lanes) HIP_TRY(ctx, hipStreamSynchronize(st));
     int ovf = 0;
     HIP_TRY(ctx, hipMemcpy(&ovf, ctx->d_overflow, sizeof(int), hipMemcpyDeviceToHost));
+    if (ovf & 2) return fail(ctx, WRENC_GPU_EHIP, "internal: a team member never reached a meeting point of the level schedule");
     if (ovf) return fail(ctx, WRENC_GPU_ELEVEL, "a quantised level reached 1024 (reference panics: block_splitter.rs:453)");
     return WRENC_GPU_OK;
 }
@@ -982,6 +988,7 @@ int wrenc_gpu_download(wrenc_gpu_ctx* ctx, int slot, wrenc_gpu_picture* out) {
     int ovf = 0;
     HIP_TRY(ctx, hipMemcpyAsync(&ovf, ctx->d_overflow, sizeof(int), hipMemcpyDeviceToHost, cs));
     HIP_TRY(ctx, hipStreamSynchronize(cs));
+    if (ovf & 2) return fail(ctx, WRENC_GPU_EHIP, "internal: a team member never reached a meeting point of the level schedule");
     if (ovf) return fail(ctx, WRENC_GPU_ELEVEL, "a quantised level reached 1024 (reference panics: block_splitter.rs:453)");
     return WRENC_GPU_OK;
 }
