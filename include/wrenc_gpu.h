@@ -192,6 +192,12 @@ int wrenc_gpu_test_fwd_dct32(wrenc_gpu_ctx* ctx, const int16_t* res, int count, 
  * use_mfma = 1 is what the search kernel runs (four v_mfma_i32_32x32x32_i8), 0 the v_dot2 version it replaced. */
 int wrenc_gpu_test_inv_dct32(wrenc_gpu_ctx* ctx, const int16_t* deq, int count, int16_t* res,
                              int use_mfma, int reps, float* kernel_ms);
+/* The packed quantiser of the 8x8 / 16x16 leaf searches (quantize_pk, wrenc_amd/csrc/dev_quant.h): `n_packs` packs of
+ * `nc` candidates (log2n = 3: nc 1..3, log2n = 4: nc 1..2); a pack is nc luma blocks of side 1 << log2n, then per candidate
+ * its Cb and Cr block of half that side, all row-major int16 coefficients back to back (nc * 1.5 * 4^log2n values).
+ * levels: the same layout; level_cost: per pack and candidate {luma block, chroma pair} (block_splitter.rs:436-458). */
+int wrenc_gpu_test_quantize_pk(wrenc_gpu_ctx* ctx, const int16_t* coef, int log2n, int nc, int n_packs, int16_t* levels,
+                               int64_t* level_cost);
 int wrenc_gpu_test_inv_dct(wrenc_gpu_ctx* ctx, const int16_t* deq, int log2n, int count,
                            int16_t* res);                               /* transformer.rs:2380 */
 int wrenc_gpu_test_quantize(wrenc_gpu_ctx* ctx, const int16_t* coef, int log2n, int count,

@@ -173,3 +173,59 @@ def test_fwd_dct32_refuses_residuals_outside_9_bits(enc):
     assert np.array_equal(got[1], po.fwd_dct(blocks[1]))
     small = np.full((1, 16, 16), -3000, np.int16)
     assert np.array_equal(enc.fwd_dct(small)[0], po.fwd_dct(small[0]))
+
+
+@pytest.mark.parametrize("log2n,nc", [(3, 1), (3, 2), (3, 3), (4, 1), (4, 2)])
+def test_quantize_packs_of_candidates(enc, log2n, nc):
+    """quantize_pk, the quantiser of the packed 8x8 / 16x16 leaf searches: the transform blocks of nc candidates (a luma
+    block and a Cb + Cr pair each) walked side by side, 16 positions per 16-lane row and round.  Every block equals the
+    reference's memoised DFS and its level cost (block_splitter.rs:436-458), whatever rides along in the pack: zero
+    blocks next to saturated ones, a single coefficient at either end of the scan, candidates that are all zero."""
+    from oracle import pyoracle as po
+    n, nch = 1 << log2n, 1 << (log2n - 1)
+    rng = np.random.default_rng(1200 + 10 * log2n + nc)
+    n_packs = 37
+
+    def block(side, it):
+        decay = np.exp(-np.add.outer(np.arange(side), np.arange(side)) / (side / 3.0))
+        scale = [3, 30, 200, 1500, 9000][it % 5]
+        b = (rng.standard_normal((side, side)) * scale * decay).clip(-32768, 32767).astype(np.int16)
+        if it % 7 == 3:
+            b[:] = 0
+        if it % 11 == 5:
+            b = rng.integers(-3, 4, (side, side)).astype(np.int16)
+        if it % 13 == 6:
+            b[:] = 0
+            b[0, 0] = [1, -1, 40, -40][it % 4]
+        if it % 17 == 9:
+            b[:] = 0
+            b[side - 1, side - 1] = [2, -700][it % 2]
+        return b
+
+    packs, blocks = [], []
+    it = 0
+    for p in range(n_packs):
+        luma = [block(n, it + c) for c in range(nc)]
+        chroma = [block(nch, it + 3 + k) for k in range(2 * nc)]
+        it += 9
+        if p == 5:                      # a pack with nothing to code at all
+            luma = [np.zeros_like(b) for b in luma]
+            chroma = [np.zeros_like(b) for b in chroma]
+        packs.append(np.concatenate([b.ravel() for b in luma + chroma]))
+        blocks.append((luma, chroma))
+    levels, cost = enc.quantize_pk(np.stack(packs), log2n, nc)
+    for p, (luma, chroma) in enumerate(blocks):
+        at = 0
+        for c in range(nc):
+            ref = po.quantize(luma[c], 32)
+            assert np.array_equal(levels[p, at:at + n * n].reshape(n, n), ref), (p, c, "luma")
+            assert int(cost[p, c, 0]) == po.level_cost(ref), (p, c, "luma cost")
+            at += n * n
+        for c in range(nc):
+            want = 0
+            for pl in range(2):
+                ref = po.quantize(chroma[2 * c + pl], 32)
+                assert np.array_equal(levels[p, at:at + nch * nch].reshape(nch, nch), ref), (p, c, pl)
+                want += po.level_cost(ref)
+                at += nch * nch
+            assert int(cost[p, c, 1]) == want, (p, c, "chroma cost")

@@ -251,6 +251,32 @@ __global__ __launch_bounds__(64) void test_quantize_p16_kernel(const DevConst* _
     }
 }
 
+// quantize_pk (the packed leaf searches' quantiser): one wave per pack of nc candidates
+__global__ __launch_bounds__(64) void test_quantize_pk_kernel(const DevConst* __restrict__ k, const int16_t* in, int lgl, int nc,
+                                                              int16_t* out, long long* cost, int* overflow) {
+    Ctx c = {};
+    c.k = (const CONST_AS DevConst*)k;
+    load_tables(c);
+    const int total = nc * 3 * (1 << (2 * lgl)) / 2;
+    for (int i = threadIdx.x; i < total; i += 64) SH.r1[i] = in[(size_t)blockIdx.x * total + i];
+    WSYNC();
+    int ovf = 0;
+    bool any_y = false, any_c = false;
+    long long ly[3], lc[3];
+    if (lgl == 3)
+        quantize_pk<3>(c, nc, &ovf, ly, lc, &any_y, &any_c);
+    else
+        quantize_pk<4>(c, nc, &ovf, ly, lc, &any_y, &any_c);
+    for (int i = threadIdx.x; i < total; i += 64) out[(size_t)blockIdx.x * total + i] = SH.r1[i];
+    if (threadIdx.x == 0) {
+        for (int b = 0; b < nc; ++b) {
+            cost[((size_t)blockIdx.x * nc + b) * 2] = ly[b];
+            cost[((size_t)blockIdx.x * nc + b) * 2 + 1] = lc[b];
+        }
+        if (ovf) atomicOr(overflow, 1);
+    }
+}
+
 __global__ __launch_bounds__(64) void test_dequantize_kernel(const DevConst* __restrict__ k,
                                                              const int16_t* in, int lg, int16_t* out) {
     Ctx c = {};
@@ -1225,6 +1251,34 @@ int wrenc_gpu_test_quantize_p16(wrenc_gpu_ctx* ctx, const int16_t* coef, int cou
     }
     (void)hipFree(d_cost);
     return rc;
+}
+
+int wrenc_gpu_test_quantize_pk(wrenc_gpu_ctx* ctx, const int16_t* coef, int log2n, int nc, int n_packs, int16_t* levels,
+                               int64_t* level_cost) {
+    if (!ctx || !coef || !levels || !level_cost) return WRENC_GPU_EINVAL;
+    if (!((log2n == 3 && nc >= 1 && nc <= 3) || (log2n == 4 && nc >= 1 && nc <= 2)) || n_packs < 1)
+        return fail(ctx, WRENC_GPU_EINVAL, "wrenc_gpu_test_quantize_pk: log2n 3 with nc 1..3 or log2n 4 with nc 1..2");
+    HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
+    const size_t total = (size_t)n_packs * nc * 3 * ((size_t)1 << (2 * log2n)) / 2;
+    int16_t *d_in = nullptr, *d_out = nullptr;
+    long long* d_cost = nullptr;
+    hipError_t e = hipMalloc((void**)&d_in, total * sizeof(int16_t));
+    if (e == hipSuccess) e = hipMalloc((void**)&d_out, total * sizeof(int16_t));
+    if (e == hipSuccess) e = hipMalloc((void**)&d_cost, sizeof(long long) * 2 * nc * n_packs);
+    if (e == hipSuccess) e = hipMemcpy(d_in, coef, total * sizeof(int16_t), hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(test_quantize_pk_kernel, dim3(n_packs), dim3(64), 0, ctx->stream, ctx->d_const, d_in, log2n, nc, d_out,
+                           d_cost, ctx->d_overflow);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e == hipSuccess) e = hipMemcpy(levels, d_out, total * sizeof(int16_t), hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(level_cost, d_cost, sizeof(long long) * 2 * nc * n_packs, hipMemcpyDeviceToHost);
+    if (d_in) (void)hipFree(d_in);
+    if (d_out) (void)hipFree(d_out);
+    if (d_cost) (void)hipFree(d_cost);
+    if (e != hipSuccess) return fail(ctx, WRENC_GPU_EHIP, hipGetErrorString(e));
+    return WRENC_GPU_OK;
 }
 
 int wrenc_gpu_test_predict(wrenc_gpu_ctx* ctx, const uint8_t* rec_y, const uint8_t* rec_cb, const uint8_t* rec_cr,

@@ -22,7 +22,7 @@ EXPORTED_SYMBOLS = [
     "wrenc_gpu_upload", "wrenc_gpu_encode", "wrenc_gpu_sync", "wrenc_gpu_download",
     "wrenc_gpu_alloc_host", "wrenc_gpu_free_host", "wrenc_gpu_encode_picture", "wrenc_gpu_set_schedule", "wrenc_gpu_last_schedule", "wrenc_gpu_stats_enable", "wrenc_gpu_last_encode_stats", "wrenc_gpu_last_encode_kernel_stats", "wrenc_gpu_final_pass_mismatches",
     "wrenc_gpu_test_fwd_dct", "wrenc_gpu_test_inv_dct", "wrenc_gpu_test_quantize",
-    "wrenc_gpu_test_dequantize", "wrenc_gpu_test_predict", "wrenc_gpu_test_fwd_dct32", "wrenc_gpu_test_inv_dct32", "wrenc_gpu_test_quantize_p16", "wrenc_gpu_test_set_wave_slots",
+    "wrenc_gpu_test_dequantize", "wrenc_gpu_test_predict", "wrenc_gpu_test_fwd_dct32", "wrenc_gpu_test_inv_dct32", "wrenc_gpu_test_quantize_p16", "wrenc_gpu_test_quantize_pk", "wrenc_gpu_test_set_wave_slots",
 ]
 
 
@@ -332,6 +332,18 @@ class Encoder:
         cost = np.zeros(count, np.int64)
         self.lib.wrenc_gpu_test_quantize_p16.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         self._check(self.lib.wrenc_gpu_test_quantize_p16(self.ctx, _p(arr), count, _p(out), _p(cost)))
+        return out, cost
+
+    def quantize_pk(self, packs, log2n, nc):
+        """Packs of nc candidates (each: luma block, then Cb and Cr of half the side) through the packed quantiser of
+        the 8x8 / 16x16 leaf searches.  packs: (n_packs, nc * 1.5 * 4^log2n) int16; returns (levels, cost[n_packs, nc, 2])."""
+        arr = np.ascontiguousarray(packs, np.int16)
+        n_packs = arr.shape[0]
+        assert arr.shape[1] == nc * 3 * (1 << (2 * log2n)) // 2
+        out = np.zeros_like(arr)
+        cost = np.zeros((n_packs, nc, 2), np.int64)
+        self.lib.wrenc_gpu_test_quantize_pk.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        self._check(self.lib.wrenc_gpu_test_quantize_pk(self.ctx, _p(arr), int(log2n), int(nc), n_packs, _p(out), _p(cost)))
         return out, cost
 
     def quantize(self, blocks):
