@@ -123,6 +123,32 @@ int wrenc_gpu_sync(wrenc_gpu_ctx* ctx);
  * read-back of one set overlaps the search of the other. */
 int wrenc_gpu_download(wrenc_gpu_ctx* ctx, int slot, wrenc_gpu_picture* out);
 
+/* Compact read-back.  The level planes of a picture are mostly zeros (6 bytes per luma sample on the bus for a few
+ * hundred coded bytes); a device pass behind the search packs them: one bit per 4x4 BLOCK OF LEVELS (picture-aligned,
+ * luma plane, then Cb, then Cr, each in raster order of its 4x4 blocks: (W/4)(H/4) + 2 (W/8)(H/8) bits, bit b of word
+ * b / 32) and, for the blocks with a non-zero level, the 16 levels (row-major) back to back in mask order.
+ * wrenc_gpu_download_compact reads back `n` slots in one call: per picture the mask, its count of coded blocks, their
+ * levels (up to payload_cap blocks: WRENC_GPU_ENOMEM with n_blocks set to the need if a picture has more), the maps,
+ * and the reconstruction when asked for.  Blocking; waits for the encode call of the slots and nothing queued later.
+ * wrenc_gpu_expand_levels is the host-side inverse (no device involved): dense level planes as wrenc_gpu_download
+ * fills them, for consumers of the plane layout (wrenc_bs_write_picture). */
+typedef struct wrenc_gpu_compact {
+    uint32_t* mask;         /* wrenc_gpu_compact_mask_words(width, height) words */
+    int16_t* payload;       /* payload_cap x 16 levels */
+    size_t payload_cap;     /* in blocks of 16 levels */
+    size_t n_blocks;        /* out: coded blocks of this picture */
+    uint8_t* cu_log2_size;  /* as in wrenc_gpu_picture; any may be NULL */
+    uint8_t* luma_mode;
+    uint8_t* chroma_mode;
+    uint8_t* rec_y;
+    uint8_t* rec_cb;
+    uint8_t* rec_cr;
+} wrenc_gpu_compact;
+size_t wrenc_gpu_compact_mask_words(int width, int height);
+int wrenc_gpu_download_compact(wrenc_gpu_ctx* ctx, int first_slot, int n, wrenc_gpu_compact* out);
+void wrenc_gpu_expand_levels(int width, int height, const uint32_t* mask, const int16_t* payload, int16_t* lev_y,
+                             int16_t* lev_cb, int16_t* lev_cr);
+
 /* Page-locked host memory for the planes handed to wrenc_gpu_upload / wrenc_gpu_download: transfers from
  * and to it run at PCIe rate and truly asynchronously (pageable buffers are staged by the runtime at a
  * fraction of that).  Optional: any host memory works.  Free with wrenc_gpu_free_host before destroy. */

@@ -94,6 +94,12 @@ public:
         done_ = 0;
         cv_.notify_all();
     }
+    // more indices for the function given to start(): count .. count + more - 1
+    void extend(int more) {
+        std::lock_guard<std::mutex> g(m_);
+        count_ += more;
+        cv_.notify_all();
+    }
     void wait() {
         std::unique_lock<std::mutex> g(m_);
         idle_.wait(g, [this] { return done_ == count_; });
@@ -125,7 +131,9 @@ struct HostSet { // one (device, slot set) unit: page-locked planes of one batch
     int base = 0;               // first slot of the set in its context
     uint8_t* in = nullptr;      // batch x (Y | Cb | Cr)
     uint8_t* rec = nullptr;     // batch x (Y | Cb | Cr), only with --reconst
-    int16_t* lev = nullptr;     // batch x (Y | Cb | Cr) levels
+    int16_t* lev = nullptr;     // batch x room for every 4x4 block of levels; the compact read-back fills the coded ones
+    uint32_t* mask = nullptr;   // batch x mask of coded 4x4 blocks (wrenc_gpu_download_compact)
+    std::vector<wrenc_gpu_compact> cps;
     uint8_t* maps = nullptr;    // batch x (cu_log2_size | luma_mode | chroma_mode)
     std::vector<std::vector<uint8_t>> nal; // per picture
     std::vector<int> status;
@@ -230,6 +238,7 @@ int main(int argc, char** argv) {
 
     const size_t ysz = (size_t)w * h, csz = ysz / 4, pic = ysz + 2 * csz;
     const size_t n4 = ysz / 16, n8 = ysz / 64, maps = 2 * n4 + n8;
+    const size_t mask_words = wrenc_gpu_compact_mask_words(w, h), level_blocks = pic / 16;
     std::vector<HostSet> units((size_t)(per_dev * n_dev));
     for (size_t u = 0; u < units.size(); ++u) {
         HostSet& s = units[u];
@@ -238,8 +247,10 @@ int main(int argc, char** argv) {
         s.in = (uint8_t*)wrenc_gpu_alloc_host(s.ctx, pic * batch);
         s.lev = (int16_t*)wrenc_gpu_alloc_host(s.ctx, pic * batch * sizeof(int16_t));
         s.maps = (uint8_t*)wrenc_gpu_alloc_host(s.ctx, maps * batch);
+        s.mask = (uint32_t*)wrenc_gpu_alloc_host(s.ctx, mask_words * sizeof(uint32_t) * batch);
+        s.cps.resize((size_t)batch);
         if (frec) s.rec = (uint8_t*)wrenc_gpu_alloc_host(s.ctx, pic * batch);
-        if (!s.in || !s.lev || !s.maps || (frec && !s.rec)) fatal("%s", wrenc_gpu_last_error(s.ctx));
+        if (!s.in || !s.lev || !s.maps || !s.mask || (frec && !s.rec)) fatal("%s", wrenc_gpu_last_error(s.ctx));
         s.nal.resize((size_t)batch);
         s.status.assign((size_t)batch, 0);
         s.len.assign((size_t)batch, 0);
@@ -259,14 +270,56 @@ int main(int argc, char** argv) {
     long poc = 0, pictures = 0;
     unsigned long long bytes = 0;
     // read + upload the next batch into the unit's slots and start its search (asynchronous)
+    // A regular input file is read by several threads at once (pread at picture offsets): one thread copies a
+    // picture of 3 MB out of the page cache in about a millisecond, and the first batch's read is the one part of the
+    // run that nothing overlaps.  A pipe is read in order by this thread.
+    const bool seekable = fin != stdin && lseek(fileno(fin), 0, SEEK_CUR) != (off_t)-1;
+    const int n_readers = seekable ? (n_threads < 8 ? n_threads : 8) : 1;
     const auto submit = [&](HostSet& s) {
         s.count = 0;
         s.first_poc = (int)poc;
-        for (int k = 0; k < batch && poc + k < num_pictures; ++k) {
-            uint8_t* p = s.in + pic * k;
-            if (!read_exact(fin, p, pic)) die("input ended after %ld of %ld pictures", poc + k, num_pictures);
-            gpu_check(s, wrenc_gpu_upload(s.ctx, s.base + k, p, p + ysz, p + ysz + csz, (size_t)w, (size_t)w / 2));
-            ++s.count;
+        int want = 0;
+        while (want < batch && poc + want < num_pictures) ++want;
+        if (seekable && want > 0) { // (always pread then: the FILE's own position is never used)
+            // readers fill the pictures (striped), this thread uploads each one as soon as it is there
+            std::vector<std::atomic<int>> ready((size_t)want);
+            for (auto& r : ready) r.store(0);
+            std::vector<std::thread> readers;
+            for (int t = 0; t < n_readers; ++t)
+                readers.emplace_back([&, t] {
+                    for (int k = t; k < want; k += n_readers) {
+                        uint8_t* p = s.in + pic * k;
+                        size_t got = 0;
+                        const off_t at = (off_t)((size_t)(poc + k) * pic);
+                        while (got < pic) {
+                            const ssize_t r = pread(fileno(fin), p + got, pic - got, at + (off_t)got);
+                            if (r <= 0) break;
+                            got += (size_t)r;
+                        }
+                        ready[(size_t)k].store(got == pic ? 1 : -1, std::memory_order_release);
+                    }
+                });
+            int short_at = -1;
+            for (int k = 0; k < want; ++k) {
+                int st;
+                while ((st = ready[(size_t)k].load(std::memory_order_acquire)) == 0) std::this_thread::yield();
+                if (st < 0) {
+                    short_at = k;
+                    break;
+                }
+                uint8_t* p = s.in + pic * k;
+                gpu_check(s, wrenc_gpu_upload(s.ctx, s.base + k, p, p + ysz, p + ysz + csz, (size_t)w, (size_t)w / 2));
+                ++s.count;
+            }
+            for (std::thread& t : readers) t.join();
+            if (short_at >= 0) die("input ended after %ld of %ld pictures", poc + short_at, num_pictures);
+        } else {
+            for (int k = 0; k < want; ++k) {
+                uint8_t* p = s.in + pic * k;
+                if (!read_exact(fin, p, pic)) die("input ended after %ld of %ld pictures", poc + k, num_pictures);
+                gpu_check(s, wrenc_gpu_upload(s.ctx, s.base + k, p, p + ysz, p + ysz + csz, (size_t)w, (size_t)w / 2));
+                ++s.count;
+            }
         }
         if (s.count) gpu_check(s, wrenc_gpu_encode(s.ctx, s.base, s.count));
         poc += s.count;
@@ -274,12 +327,17 @@ int main(int argc, char** argv) {
     Pool pool(n_threads);
     const size_t first_guess = ysz / 2 + 65536;
     // slices of the unit's batch on the pool; flush() collects them in picture order
+    // (started empty: the pictures are handed to the pool as their read-back completes, pool.extend)
     const auto start_slices = [&](HostSet& s) {
         s.bs_count = s.count;
         s.bs_first_poc = s.first_poc;
-        pool.start(s.bs_count, [&s, w, h, qp, pic, ysz, csz, maps, n4, first_guess](int k) {
+        pool.start(0, [&s, w, h, qp, pic, ysz, csz, maps, n4, first_guess, mask_words](int k) {
             const uint8_t* m = s.maps + maps * k;
-            const int16_t* l = s.lev + pic * k;
+            // the level planes the stream writer reads, rebuilt from the compact record in this thread's own buffer
+            static thread_local std::vector<int16_t> dense;
+            if (dense.size() < pic) dense.resize(pic);
+            int16_t* l = dense.data();
+            wrenc_gpu_expand_levels(w, h, s.mask + mask_words * k, s.lev + pic * k, l, l + ysz, l + ysz + csz);
             const wrenc_bs_record rec = {m, m + n4, m + 2 * n4, l, l + ysz, l + ysz + csz};
             std::vector<uint8_t>& out = s.nal[(size_t)k];
             // wrenc_bs_picture_bound is the proven worst case (12 bytes per luma sample); real pictures need a
@@ -314,16 +372,19 @@ int main(int argc, char** argv) {
     HostSet* pending = nullptr;
     for (size_t head = 0; units[head].count > 0; head = (head + 1) % units.size()) {
         HostSet& s = units[head];
-        for (int k = 0; k < s.count; ++k) {
-            uint8_t* m = s.maps + maps * k;
-            int16_t* l = s.lev + pic * k;
-            uint8_t* r = frec ? s.rec + pic * k : nullptr;
-            wrenc_gpu_picture out = {r, r ? r + ysz : nullptr, r ? r + ysz + csz : nullptr, l, l + ysz, l + ysz + csz,
-                                     m, m + n4, m + 2 * n4, nullptr};
-            gpu_check(s, wrenc_gpu_download(s.ctx, s.base + k, &out));
-        }
+        // the previous batch's slices have been written while this batch was searched; then this batch is read back
+        // in ONE compact call (waits for its search): per picture the mask of coded 4x4 blocks of levels, those blocks,
+        // and the maps -- a few per cent of the 6 bytes per luma sample the level planes take
         if (pending) flush(*pending);
         start_slices(s);
+        for (int k = 0; k < s.count; ++k) {
+            uint8_t* m = s.maps + maps * k;
+            uint8_t* r = frec ? s.rec + pic * k : nullptr;
+            s.cps[(size_t)k] = wrenc_gpu_compact{s.mask + mask_words * k, s.lev + pic * k, level_blocks, 0, m, m + n4, m + 2 * n4,
+                                                 r, r ? r + ysz : nullptr, r ? r + ysz + csz : nullptr};
+        }
+        gpu_check(s, wrenc_gpu_download_compact(s.ctx, s.base, s.count, s.cps.data()));
+        pool.extend(s.count);
         pending = &s;
         s.count = 0;
         if (poc < num_pictures) {
@@ -347,6 +408,7 @@ int main(int argc, char** argv) {
         wrenc_gpu_free_host(s.ctx, s.in);
         wrenc_gpu_free_host(s.ctx, s.lev);
         wrenc_gpu_free_host(s.ctx, s.maps);
+        wrenc_gpu_free_host(s.ctx, s.mask);
         wrenc_gpu_free_host(s.ctx, s.rec);
     }
     for (wrenc_gpu_ctx* ctx : ctxs) wrenc_gpu_destroy(ctx);

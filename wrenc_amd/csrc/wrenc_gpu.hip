@@ -84,6 +84,76 @@ __global__ __launch_bounds__(64) void retile_kernel(const uint8_t* __restrict__ 
     }
 }
 
+// Compact read-back (include/wrenc_gpu.h): one workgroup per picture walks the picture's 4x4 blocks of levels in mask
+// order, 1024 at a time: a thread loads one block (four 8-byte rows), the waves' ballots are the mask words, and the
+// blocks with a non-zero level go to the payload at the running count + their rank (wave ballots, one LDS scan over
+// the 16 waves).  The planes are read once at HBM rate; what crosses PCIe afterwards is the mask and the coded blocks.
+__global__ __launch_bounds__(1024) void compact_levels_kernel(const PicBufs* __restrict__ slots, int first_slot, int W, int H,
+                                                               uint32_t* masks, size_t mask_words, int16_t* payloads,
+                                                               size_t payload_stride_blocks, unsigned* counts) {
+    __shared__ unsigned s_wave[16];
+    __shared__ unsigned s_base;
+    const PicBufs pb = slots[first_slot + blockIdx.x];
+    const int16_t* lev = pb.lev[0];
+    uint32_t* mask = masks + (size_t)blockIdx.x * mask_words;
+    int4* pay = (int4*)(payloads + (size_t)blockIdx.x * payload_stride_blocks * 16);
+    const int bw = W >> 2, bh = H >> 2;                 // luma plane in 4x4 blocks
+    const int nl = bw * bh, ncb = nl >> 2, total = nl + 2 * ncb;
+    const size_t wh = (size_t)W * H;
+    if (threadIdx.x == 0) s_base = 0;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int b0 = 0; b0 < total; b0 += 1024) {
+        const int b = b0 + threadIdx.x;
+        int2 r0 = {0, 0}, r1 = {0, 0}, r2 = {0, 0}, r3 = {0, 0};
+        if (b < total) {
+            // plane, block row / column, stride
+            int pb_ = b, pw = bw;
+            size_t off = 0;
+            int stride = W;
+            if (b >= nl) {
+                const int c = b - nl;
+                const int pl = c >= ncb ? 1 : 0;
+                pb_ = c - pl * ncb;
+                pw = bw >> 1;
+                stride = W >> 1;
+                off = wh + (size_t)pl * (wh >> 2);
+            }
+            const int by = pb_ / pw, bx = pb_ - by * pw;
+            const int16_t* p = lev + off + (size_t)(4 * by) * stride + 4 * bx;
+            r0 = *(const int2*)p;
+            r1 = *(const int2*)(p + stride);
+            r2 = *(const int2*)(p + 2 * stride);
+            r3 = *(const int2*)(p + 3 * stride);
+        }
+        const bool nz = (r0.x | r0.y | r1.x | r1.y | r2.x | r2.y | r3.x | r3.y) != 0;
+        const unsigned long long bal = __ballot(nz);
+        if (lane == 0) {
+            if (b < total) mask[b >> 5] = (uint32_t)bal;
+            if (b + 32 < total) mask[(b >> 5) + 1] = (uint32_t)(bal >> 32);
+            s_wave[wave] = (unsigned)__popcll(bal);
+        }
+        __syncthreads();
+        unsigned before = s_base;
+        for (int wv = 0; wv < wave; ++wv) before += s_wave[wv];
+        if (nz) {
+            const size_t at = (size_t)before + (unsigned)__popcll(bal & ((1ULL << lane) - 1ULL));
+            if (at < payload_stride_blocks) {
+                pay[2 * at] = make_int4(r0.x, r0.y, r1.x, r1.y);
+                pay[2 * at + 1] = make_int4(r2.x, r2.y, r3.x, r3.y);
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            unsigned sum = 0;
+            for (int wv = 0; wv < 16; ++wv) sum += s_wave[wv];
+            s_base += sum;
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) counts[blockIdx.x] = s_base;
+}
+
 // Wave schedule: one workgroup = the same CTU of WPB consecutive pictures, one wave each.
 __global__ __launch_bounds__(64 * WPB, 5) void ctu_search_kernel(const DevConst* __restrict__ k,
                                                               const PicBufs* __restrict__ slots, int first_slot,
@@ -444,6 +514,11 @@ struct wrenc_gpu_ctx {
     std::vector<char> launch_team;             // per launch of the last call: the team kernel?
     std::vector<long long> launch_ctus;        // ... and the CTU-pictures it searched
     bool stats_enabled = false; // per-launch timing events: bench / profiling only (wrenc_gpu_stats_enable)
+    // compact read-back: device scratch for one call (masks, payloads with room for every block, counts), grown on demand
+    uint32_t* d_cmask = nullptr;
+    int16_t* d_cpayload = nullptr;
+    unsigned* d_ccount = nullptr;
+    int compact_cap = 0; // pictures the scratch holds
     int schedule = WRENC_GPU_SCHEDULE_AUTO;
     int last_schedule = WRENC_GPU_SCHEDULE_WAVE; // what the most recent encode call ran
     bool stats_valid = false;
@@ -728,6 +803,9 @@ void wrenc_gpu_destroy(wrenc_gpu_ctx* ctx) {
     if (ctx->d_overflow) (void)hipFree(ctx->d_overflow);
     if (ctx->d_pred_scratch) (void)hipFree(ctx->d_pred_scratch);
     if (ctx->d_slot_map) (void)hipFree(ctx->d_slot_map);
+    if (ctx->d_cmask) (void)hipFree(ctx->d_cmask);
+    if (ctx->d_cpayload) (void)hipFree(ctx->d_cpayload);
+    if (ctx->d_ccount) (void)hipFree(ctx->d_ccount);
     if (ctx->ev_begin) (void)hipEventDestroy(ctx->ev_begin);
     if (ctx->ev_end) (void)hipEventDestroy(ctx->ev_end);
     for (hipEvent_t e : ctx->ev_pool) (void)hipEventDestroy(e);
@@ -1017,6 +1095,110 @@ int wrenc_gpu_download(wrenc_gpu_ctx* ctx, int slot, wrenc_gpu_picture* out) {
     if (ovf & 2) return fail(ctx, WRENC_GPU_EHIP, "internal: a team member never reached a meeting point of the level schedule");
     if (ovf) return fail(ctx, WRENC_GPU_ELEVEL, "a quantised level reached 1024 (reference panics: block_splitter.rs:453)");
     return WRENC_GPU_OK;
+}
+
+size_t wrenc_gpu_compact_mask_words(int width, int height) {
+    const size_t blocks = (size_t)(width / 4) * (height / 4) * 3 / 2;
+    return (blocks + 31) / 32;
+}
+
+int wrenc_gpu_download_compact(wrenc_gpu_ctx* ctx, int first_slot, int n, wrenc_gpu_compact* out) {
+    if (!ctx || !out) return WRENC_GPU_EINVAL;
+    if (first_slot < 0 || n < 1 || first_slot + n > ctx->cfg.n_slots) return fail(ctx, WRENC_GPU_EINVAL, "slot range out of bounds");
+    for (int s = first_slot; s < first_slot + n; ++s)
+        if (ctx->state[s] != 2) return fail(ctx, WRENC_GPU_ESTATE, "slot has not been encoded");
+    HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
+    const wrenc_gpu_config& c = ctx->cfg;
+    const size_t mask_words = wrenc_gpu_compact_mask_words(c.width, c.height);
+    const size_t blocks = (size_t)(c.width / 4) * (c.height / 4) * 3 / 2;
+    if (ctx->compact_cap < n) {
+        if (ctx->d_cmask) (void)hipFree(ctx->d_cmask);
+        if (ctx->d_cpayload) (void)hipFree(ctx->d_cpayload);
+        if (ctx->d_ccount) (void)hipFree(ctx->d_ccount);
+        ctx->d_cmask = nullptr;
+        ctx->d_cpayload = nullptr;
+        ctx->d_ccount = nullptr;
+        ctx->compact_cap = 0;
+        HIP_TRY(ctx, hipMalloc((void**)&ctx->d_cmask, (size_t)n * mask_words * sizeof(uint32_t)));
+        HIP_TRY(ctx, hipMalloc((void**)&ctx->d_cpayload, (size_t)n * blocks * 16 * sizeof(int16_t)));
+        HIP_TRY(ctx, hipMalloc((void**)&ctx->d_ccount, (size_t)n * sizeof(unsigned)));
+        ctx->compact_cap = n;
+    }
+    hipStream_t cs = ctx->copy_stream;
+    hipEvent_t last = nullptr; // the slots of one call usually share one encode call's event
+    for (int s = first_slot; s < first_slot + n; ++s)
+        if (ctx->slot_event[s] && ctx->slot_event[s] != last) {
+            last = ctx->slot_event[s];
+            HIP_TRY(ctx, hipStreamWaitEvent(cs, last, 0));
+        }
+    hipLaunchKernelGGL(compact_levels_kernel, dim3(n), dim3(1024), 0, cs, ctx->d_slots, first_slot, c.width, c.height, ctx->d_cmask,
+                       mask_words, ctx->d_cpayload, blocks, ctx->d_ccount);
+    HIP_TRY(ctx, hipGetLastError());
+    std::vector<unsigned> counts((size_t)n);
+    int ovf = 0;
+    HIP_TRY(ctx, hipMemcpyAsync(counts.data(), ctx->d_ccount, (size_t)n * sizeof(unsigned), hipMemcpyDeviceToHost, cs));
+    HIP_TRY(ctx, hipMemcpyAsync(&ovf, ctx->d_overflow, sizeof(int), hipMemcpyDeviceToHost, cs));
+    HIP_TRY(ctx, hipStreamSynchronize(cs));
+    if (ovf & 2) return fail(ctx, WRENC_GPU_EHIP, "internal: a team member never reached a meeting point of the level schedule");
+    if (ovf) return fail(ctx, WRENC_GPU_ELEVEL, "a quantised level reached 1024 (reference panics: block_splitter.rs:453)");
+    bool short_buf = false;
+    const size_t n4 = (size_t)(c.width / 4) * (c.height / 4), n8 = (size_t)(c.width / 8) * (c.height / 8);
+    for (int k = 0; k < n; ++k) {
+        wrenc_gpu_compact& o = out[k];
+        const PicBufs& b = ctx->slots[first_slot + k];
+        o.n_blocks = counts[(size_t)k];
+        if (o.mask) HIP_TRY(ctx, hipMemcpyAsync(o.mask, ctx->d_cmask + (size_t)k * mask_words, mask_words * sizeof(uint32_t), hipMemcpyDeviceToHost, cs));
+        if (o.n_blocks > o.payload_cap || (o.n_blocks && !o.payload)) {
+            short_buf = true;
+        } else if (o.n_blocks) {
+            HIP_TRY(ctx, hipMemcpyAsync(o.payload, ctx->d_cpayload + (size_t)k * blocks * 16, o.n_blocks * 16 * sizeof(int16_t),
+                                        hipMemcpyDeviceToHost, cs));
+        }
+        if (o.cu_log2_size) HIP_TRY(ctx, hipMemcpyAsync(o.cu_log2_size, b.cu_log2, n4, hipMemcpyDeviceToHost, cs));
+        if (o.luma_mode) HIP_TRY(ctx, hipMemcpyAsync(o.luma_mode, b.luma_mode, n4, hipMemcpyDeviceToHost, cs));
+        if (o.chroma_mode) HIP_TRY(ctx, hipMemcpyAsync(o.chroma_mode, b.chroma_mode, n8, hipMemcpyDeviceToHost, cs));
+        uint8_t* rec[3] = {o.rec_y, o.rec_cb, o.rec_cr};
+        for (int p = 0; p < 3; ++p)
+            if (rec[p]) HIP_TRY(ctx, hipMemcpyAsync(rec[p], b.rec[p], plane_bytes(c, p, 1), hipMemcpyDeviceToHost, cs));
+    }
+    HIP_TRY(ctx, hipStreamSynchronize(cs));
+    if (short_buf) return fail(ctx, WRENC_GPU_ENOMEM, "wrenc_gpu_download_compact: payload_cap is smaller than n_blocks of a picture");
+    return WRENC_GPU_OK;
+}
+
+void wrenc_gpu_expand_levels(int width, int height, const uint32_t* mask, const int16_t* payload, int16_t* lev_y, int16_t* lev_cb,
+                             int16_t* lev_cr) {
+    const size_t wh = (size_t)width * height;
+    memset(lev_y, 0, wh * sizeof(int16_t));
+    memset(lev_cb, 0, wh / 4 * sizeof(int16_t));
+    memset(lev_cr, 0, wh / 4 * sizeof(int16_t));
+    const int bw = width / 4, bh = height / 4;
+    const size_t nl = (size_t)bw * bh, ncb = nl / 4, total = nl + 2 * ncb;
+    size_t at = 0;
+    for (size_t w0 = 0; w0 < total; w0 += 32) {
+        uint32_t m = mask[w0 >> 5];
+        while (m) {
+            const int bit = __builtin_ctz(m);
+            m &= m - 1;
+            const size_t b = w0 + (size_t)bit;
+            if (b >= total) break;
+            int16_t* plane = lev_y;
+            size_t pb_ = b;
+            int pw = bw, stride = width;
+            if (b >= nl) {
+                const size_t cidx = b - nl;
+                const int pl = cidx >= ncb ? 1 : 0;
+                pb_ = cidx - (size_t)pl * ncb;
+                pw = bw / 2;
+                stride = width / 2;
+                plane = pl ? lev_cr : lev_cb;
+            }
+            const size_t by = pb_ / (size_t)pw, bx = pb_ - by * (size_t)pw;
+            int16_t* d = plane + (4 * by) * (size_t)stride + 4 * bx;
+            const int16_t* s = payload + 16 * at++;
+            for (int r = 0; r < 4; ++r) memcpy(d + (size_t)r * stride, s + 4 * r, 4 * sizeof(int16_t));
+        }
+    }
 }
 
 void* wrenc_gpu_alloc_host(wrenc_gpu_ctx* ctx, size_t bytes) {

@@ -19,7 +19,7 @@ LIB_PATH = os.environ.get("WRENC_GPU_LIB", os.path.join(_HERE, "csrc", "libwrenc
 
 EXPORTED_SYMBOLS = [
     "wrenc_gpu_default_config", "wrenc_gpu_config_extra_params", "wrenc_gpu_create", "wrenc_gpu_destroy", "wrenc_gpu_last_error",
-    "wrenc_gpu_upload", "wrenc_gpu_encode", "wrenc_gpu_sync", "wrenc_gpu_download",
+    "wrenc_gpu_upload", "wrenc_gpu_encode", "wrenc_gpu_sync", "wrenc_gpu_download", "wrenc_gpu_download_compact", "wrenc_gpu_compact_mask_words", "wrenc_gpu_expand_levels",
     "wrenc_gpu_alloc_host", "wrenc_gpu_free_host", "wrenc_gpu_encode_picture", "wrenc_gpu_set_schedule", "wrenc_gpu_last_schedule", "wrenc_gpu_stats_enable", "wrenc_gpu_last_encode_stats", "wrenc_gpu_last_encode_kernel_stats", "wrenc_gpu_final_pass_mismatches",
     "wrenc_gpu_test_fwd_dct", "wrenc_gpu_test_inv_dct", "wrenc_gpu_test_quantize",
     "wrenc_gpu_test_dequantize", "wrenc_gpu_test_predict", "wrenc_gpu_test_fwd_dct32", "wrenc_gpu_test_inv_dct32", "wrenc_gpu_test_quantize_p16", "wrenc_gpu_test_quantize_pk", "wrenc_gpu_test_set_wave_slots",
@@ -44,6 +44,12 @@ class Picture(C.Structure):
         ("cu_log2_size", C.c_void_p), ("luma_mode", C.c_void_p), ("chroma_mode", C.c_void_p),
         ("ctu_cost", C.c_void_p),
     ]
+
+
+class Compact(C.Structure):
+    _fields_ = [("mask", C.c_void_p), ("payload", C.c_void_p), ("payload_cap", C.c_size_t), ("n_blocks", C.c_size_t),
+                ("cu_log2_size", C.c_void_p), ("luma_mode", C.c_void_p), ("chroma_mode", C.c_void_p),
+                ("rec_y", C.c_void_p), ("rec_cb", C.c_void_p), ("rec_cr", C.c_void_p)]
 
 
 class WrencGpuError(RuntimeError):
@@ -177,6 +183,41 @@ class Encoder:
 
     def sync(self):
         self._check(self.lib.wrenc_gpu_sync(self.ctx))
+
+    def download_compact(self, first_slot, n, payload_cap=None):
+        """The compact read-back of n slots (include/wrenc_gpu.h): per picture (mask, payload[:n_blocks], maps dict)."""
+        w, h = self.width, self.height
+        self.lib.wrenc_gpu_compact_mask_words.restype = C.c_size_t
+        self.lib.wrenc_gpu_compact_mask_words.argtypes = [C.c_int, C.c_int]
+        words = self.lib.wrenc_gpu_compact_mask_words(w, h)
+        blocks = (w // 4) * (h // 4) * 3 // 2
+        cap = blocks if payload_cap is None else payload_cap
+        outs = (Compact * n)()
+        keep = []
+        for k in range(n):
+            mask = np.zeros(words, np.uint32)
+            pay = np.zeros((max(cap, 1), 16), np.int16)
+            maps = {"cu_log2_size": np.zeros((h // 4, w // 4), np.uint8), "luma_mode": np.zeros((h // 4, w // 4), np.uint8),
+                    "chroma_mode": np.zeros((h // 8, w // 8), np.uint8)}
+            outs[k].mask, outs[k].payload, outs[k].payload_cap = _p(mask).value, _p(pay).value, cap
+            for name, arr in maps.items():
+                setattr(outs[k], name, _p(arr).value)
+            keep.append((mask, pay, maps))
+        self.lib.wrenc_gpu_download_compact.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        self._check(self.lib.wrenc_gpu_download_compact(self.ctx, first_slot, n, outs))
+        return [(m, p[:outs[k].n_blocks], maps) for k, (m, p, maps) in enumerate(keep)]
+
+    def expand_levels(self, mask, payload):
+        """Dense level planes from a compact record (host only)."""
+        w, h = self.width, self.height
+        ly = np.empty((h, w), np.int16)
+        lcb = np.empty((h // 2, w // 2), np.int16)
+        lcr = np.empty((h // 2, w // 2), np.int16)
+        pay = np.ascontiguousarray(payload, np.int16)
+        self.lib.wrenc_gpu_expand_levels.restype = None
+        self.lib.wrenc_gpu_expand_levels.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        self.lib.wrenc_gpu_expand_levels(w, h, _p(mask), _p(pay), _p(ly), _p(lcb), _p(lcr))
+        return ly, lcb, lcr
 
     def alloc_host(self, nbytes):
         """A page-locked uint8 array (wrenc_gpu_alloc_host): transfers from / to it run at PCIe rate.  Freed
