@@ -29,7 +29,7 @@ names = (["predict", "fdct", "q_pre", "q_back", "q_trace", "deq", "idct", "recon
          + ["cbn%d" % i for i in range(32)] + ["y2"] + ["mem_%s_m%d" % (k, m) for k in ("ctrl", "eval", "xchg", "nop") for m in range(4)] + ["y3"]
          + ["st%d_m%d" % (k, m) for k in range(12) for m in range(4)] + ["y4"] + ["stn%d" % k for k in range(12)] + ["y5"]
          + ["ev%d" % i for i in range(64)] + ["y6"] + ["evn%d" % i for i in range(64)] + ["y7"] + ["quant_t%d" % (4 << i) for i in range(4)])
-KINDS = ["sadlist", "full", "nop/copy", "sadsearch", "cclmsearch", "leaf4", "leafc4", "leaf8", "leaf16"] + ["?"] * 7
+KINDS = ["sadlist", "full", "nop/copy", "sadsearch", "cclmsearch", "leaf4", "leafc4", "leaf8", "leaf16", "split8"] + ["?"] * 6
 N = len(names)
 out = (C.c_ulonglong * N)()
 enc.lib.wrenc_gpu_prof_read.argtypes = [C.c_void_p, C.c_void_p, C.c_int]

@@ -9,11 +9,18 @@ namespace wrenc {
 // ---------------------------------------------------------------------------
 // Evaluation requests and the evaluator
 // ---------------------------------------------------------------------------
-enum { K_SADLIST = 0, K_FULL = 1, K_NOP = 2, K_SADSEARCH = 3, K_CCLMSEARCH = 4, K_LEAF4 = 5, K_LEAFC4 = 6, K_LEAF8 = 7, K_LEAF16 = 8 };
+enum { K_SADLIST = 0, K_FULL = 1, K_NOP = 2, K_SADSEARCH = 3, K_CCLMSEARCH = 4, K_LEAF4 = 5, K_LEAFC4 = 6, K_LEAF8 = 7, K_LEAF16 = 8, K_SPLIT8 = 9 };
 #ifndef WRENC_POOL_MIN_TLG
 #define WRENC_POOL_MIN_TLG 3
 #endif
 enum { COPY_NONE = 0, COPY_SAVE = 1, COPY_RESTORE = 2, COPY_PULL = 3 };
+// build knobs (tools/README.md): the level schedule of the team kernel at max-split-depth 3; an 8x8 CU's split as one request
+#ifndef WRENC_LEVELS
+#define WRENC_LEVELS 1
+#endif
+#ifndef WRENC_SPLIT8
+#define WRENC_SPLIT8 1
+#endif
 
 struct Req {
     int kind;       // K_SADLIST: predict + SAD of a list of modes (block_splitter.rs:64-108, 476-522);
@@ -29,6 +36,8 @@ struct Req {
                     // evaluated in packs of two and three (leaf8_search): Res::imin / imin2 = luma / chroma mode, vmin = the cost;
                     // n = which parts run here (bit 0 pack {planar, DC}, bit 1 the SAD search + pack {cm, cm - 1, cm + 1},
                     // bit 2 the CCLM part on the winner ml with DM chroma cost fcur)
+                    // K_SPLIT8: the split candidate of an 8x8 CU in one request: its four DUAL_TREE_LUMA 4x4 leaf searches, then the
+                    // DUAL_TREE_CHROMA one (split8_search); Res::vmin = the split cost (:1116-1123)
                     // K_LEAF16: the five full candidates of a 16x16 SINGLE_TREE leaf and its SAD search in one request, the
                     // candidates in packs of two (leaf16_search): Res::imin = the best luma mode, vmin = its cost, + its parts
     int comps;      // bit 0: luma block, bit 1: Cb+Cr pair
@@ -267,10 +276,14 @@ __device__ __forceinline__ Res leaf4_search(const Ctx& c, const Req& q, int* ove
 __device__ __forceinline__ Res leafc4_search(const Ctx& c, const Req& q, int* overflow);
 __device__ __forceinline__ Res leaf8_search(const Ctx& c, const Req& q, int* overflow);
 __device__ __forceinline__ Res leaf16_search(const Ctx& c, const Req& q, int* overflow);
+__device__ __forceinline__ Res split8_search(const Ctx& c, const Req& q, int* overflow);
 
 // The evaluator: every block evaluation of the search, of the regeneration and of the final pass
 // goes through this one inlined copy (the search logic below is a state machine that hands out
 // evaluation requests; no function calls in the hot path).
+// D3: the kernel serves max-split-depth 3 (the only depth at which an 8x8 CU splits into 4x4 leaves): the kernels for
+// the smaller depths are built without that code.
+template <bool D3>
 __device__ __forceinline__ Res evaluate(const Ctx& c, const PicBufs& pb, const Req& q, int* overflow) {
     Res r;
     r.ssd_y = 0;
@@ -287,10 +300,14 @@ __device__ __forceinline__ Res evaluate(const Ctx& c, const PicBufs& pb, const R
     PROF_ADD2(PH_COPY, tcp0_, tcp1_);
     if (q.kind == K_NOP) return r;
     if (q.stage) stage_org_leaf(c, q.stage, q.tx, q.ty, q.tlg);
-    if (q.kind == K_LEAF4) return leaf4_search(c, q, overflow);
-    if (q.kind == K_LEAFC4) return leafc4_search(c, q, overflow);
+    // (with K_SPLIT8 and the level schedule on, nothing asks for a 4x4 leaf by itself: one copy of the two searches less)
+    if (D3 && !(WRENC_SPLIT8 && WRENC_LEVELS)) {
+        if (q.kind == K_LEAF4) return leaf4_search(c, q, overflow);
+        if (q.kind == K_LEAFC4) return leafc4_search(c, q, overflow);
+    }
     if (q.kind == K_LEAF8) return leaf8_search(c, q, overflow);
     if (q.kind == K_LEAF16) return leaf16_search(c, q, overflow);
+    if (D3 && q.kind == K_SPLIT8) return split8_search(c, q, overflow);
     int mc = q.mc;
     if (q.kind == K_CCLMSEARCH) {
         // get_chroma_intra_pred_aux_cost of LT, T, L_CCLM in one sample pass, then the pick of :847-854 (SADs are
@@ -1244,6 +1261,58 @@ __device__ __forceinline__ void fill_maps(int bx, int by, int lg, int luma_mode,
 }
 
 
+// K_SPLIT8: the split candidate of an 8x8 CU (ctu.rs:1990-2063: four DUAL_TREE_LUMA 4x4 CUs, then the DUAL_TREE_CHROMA
+// CU) in ONE request: leaf4_search four times, leafc4_search once, with what the tree walk did between them -- the
+// leaf's originals staged, the decision maps filled (the chroma leaf's DM mode is the luma mode of the 4x4 covering
+// the parent's centre, block_splitter.rs:795-805), the costs summed in z-order in f32 from 0.0 (:1116-1123).  Five control
+// steps of 3-6 k cycles each fewer per 8x8 node, 80 per CTU at max-split-depth 3.
+// (Only the kernels built for max-split-depth 3 contain it, D3 below: inlined into the one evaluator of a kernel that also
+// serves depth 2, which never splits an 8x8, it cost that depth 2.5 %; as an out-of-line function it cost both depths more.)
+__device__ __forceinline__ Res split8_search(const Ctx& c, const Req& q, int* overflow) {
+    Res r;
+    r.ssd_y = 0;
+    r.ssd_c = 0;
+    r.lvl_y = 0;
+    r.lvl_c = 0;
+    r.v0 = r.v1 = r.v2 = 3.40282347e+38f;
+    r.imin = 0;
+    r.imin2 = 0;
+    float split8 = 0.0f;
+#pragma unroll 1
+    for (int i8 = 0; i8 < 4; ++i8) {
+        Req ql = {}; // (only what leaf4_search reads: a copy of q would keep thirty scalars alive across the four searches)
+        ql.kind = K_LEAF4;
+        ql.comps = 1;
+        ql.tx = q.tx + (i8 & 1) * 4;
+        ql.ty = q.ty + (i8 >> 1) * 4;
+        ql.tlg = 2;
+        ql.refs0 = true;
+        ql.refs1 = false;
+        ql.n = 3;
+        ql.tree = TREE_DUAL_LUMA;
+        stage_org_leaf(c, 1, ql.tx, ql.ty, 2);
+        const Res rl = leaf4_search(c, ql, overflow);
+        fill_maps(ql.tx, ql.ty, 2, rl.imin, 0, true, false);
+        split8 = uni_f(split8 + rl.vmin);
+    }
+    Req qc = {};
+    qc.kind = K_LEAFC4;
+    qc.tx = q.tx;
+    qc.ty = q.ty;
+    qc.comps = 2;
+    qc.tlg = 3;
+    qc.ml = 0;
+    qc.mc = uni((int)SH.luma_mode[((q.ty + 4) >> 2) * 8 + ((q.tx + 4) >> 2)]); // DM = the luma mode at the parent's centre
+    qc.refs0 = false;
+    qc.refs1 = true;
+    qc.tree = TREE_DUAL_CHROMA;
+    stage_org_leaf(c, 2, q.tx, q.ty, 3);
+    const Res rc = leafc4_search(c, qc, overflow);
+    fill_maps(q.tx, q.ty, 3, 0, rc.imin, false, true);
+    r.vmin = uni_f(split8 + rc.vmin);
+    return r;
+}
+
 // ---------------------------------------------------------------------------
 // Search control as state machines: a step function runs until it needs a block evaluated, stores
 // the request and where to continue, and returns true; the driver evaluates the block and calls
@@ -1460,6 +1529,7 @@ __device__ __forceinline__ void put_parts(EvalPartsSF& d, const EvalParts& e) {
 // (s.cost, s.luma_mode, s.chroma_mode).  The reference's "first minimum wins" selections are kept
 // as strict-less running updates in the reference's candidate order; a candidate = one request
 // (luma block and chroma pair together, SAD candidates as one list).
+template <bool D3>
 __device__ __forceinline__ bool leaf_step(const Ctx& c, LeafSF& s, const Res& r, Req& q) {
     const int tree = s.tree;
     const int both = tree == TREE_SINGLE ? 3 : 1;
@@ -1481,7 +1551,7 @@ __device__ __forceinline__ bool leaf_step(const Ctx& c, LeafSF& s, const Res& r,
     for (;;) {
         switch (cont) {
         case C_START: // candidates {0,1,2,7,13,18,23,29,34,39,45,50,55,60,66} (:887)
-            if (leaf_is_leaf4(s)) { // a 4x4 luma leaf: the whole search in one request
+            if (D3 && leaf_is_leaf4(s)) { // a 4x4 luma leaf: the whole search in one request
                 leaf_leaf4(s, q, C_L4);
                 return true;
             }
@@ -2123,9 +2193,7 @@ __device__ __forceinline__ void lv_post_unsplit(int L, float ns, int ml, int mc)
 __device__ __forceinline__ void lv_post_split(int L, float sp) {
     if (LANE == 0) SHT.lvb.split[L] = sp;
 }
-#ifndef WRENC_LEVELS
-#define WRENC_LEVELS 1
-#endif
+
 
 // split_ct (block_splitter.rs:782-1154) for one CTU + the final pass (ctu_encoder.rs:1421-1461):
 // exhaustive quad-tree search as an explicit depth-first walk (level 0 = 32x32 ... level 2 = 8x8;
@@ -2137,9 +2205,9 @@ __device__ __forceinline__ void lv_post_split(int L, float sp) {
 // restore_reconsts (block_splitter.rs:807-840, 1085-1145), with the saved planes kept in L2/HBM
 // instead of LDS.
 enum { T_START = 0, T_ENTER, T_NODE_LEAF, T_LEAF4_EMIT, T_LEAF4, T_LEAFC, T_REGEN_DONE, T_RETURN, T_FINAL_Z, T_FZ_TAIL, T_FZ_NEXT,
-       T_LV_UNIT, T_LV_LEAFDONE, T_LV_UP };
+       T_LV_UNIT, T_LV_LEAFDONE, T_LV_UP, T_SPLIT8 };
 
-template <bool TEAM>
+template <bool TEAM, bool D3>
 __device__ __forceinline__ bool ctu_step(Ctx& c, const Res& r, Req& q) {
     CtuSt& t = SH.st;
     bool in_leaf = t.in_leaf != 0;
@@ -2148,7 +2216,7 @@ __device__ __forceinline__ bool ctu_step(Ctx& c, const Res& r, Req& q) {
         if (in_leaf) {
             // team schedule: the results of the previous requests are in the members' XRes of parity xpar ^ 1
             LeafSF ls = snap_leaf(t.leaf);
-            if ((TEAM && !t.lvmode) ? leaf_step_team(c, t, ls, q, t.xpar ^ 1, r) : leaf_step(c, ls, r, q)) {
+            if ((TEAM && !t.lvmode) ? leaf_step_team(c, t, ls, q, t.xpar ^ 1, r) : leaf_step<D3>(c, ls, r, q)) {
                 if (t.pend) { // the first request of a node's first child saves the unsplit candidate
                     req_copy(q, COPY_SAVE, 3, t.pslot, t.pbx, t.pby, t.plg);
                     t.pend = 0;
@@ -2190,7 +2258,7 @@ __device__ __forceinline__ bool ctu_step(Ctx& c, const Res& r, Req& q) {
                 cont = T_RETURN;
                 break;
             }
-            if (TEAM && WRENC_LEVELS && t.max_depth == 3) {
+            if (TEAM && WRENC_LEVELS && D3 && t.max_depth == 3) {
                 // ---- level schedule from here on (see lv_decide): every member has searched the 32x32 candidate ----
                 if (t.dp0) { // its winner into every member's tile first (team_defer_pull)
                     const int dp = t.dp0, dq = t.dp1;
@@ -2223,66 +2291,113 @@ __device__ __forceinline__ bool ctu_step(Ctx& c, const Res& r, Req& q) {
                 SH.child[level] = 0;
             }
             WSYNC();
-            if (lg > 3) {
+            if (lg > 3 || !D3) { // (an 8x8 node splits at max-split-depth 3 only)
                 t.level = (uint8_t)(level + 1); // descend into child 0 (same top-left corner)
                 cont = T_ENTER;
                 break;
             }
             // 8x8: four DUAL_TREE_LUMA 4x4 leaves, then the DUAL_TREE_CHROMA leaf
+            if (WRENC_SPLIT8) { // ... as one request (K_SPLIT8)
+                req_full(q, 3, t.bx, t.by, 3, 0, 0, false, true, false, false, false);
+                q.kind = K_SPLIT8;
+                q.stage = 0;
+                q.tree = TREE_DUAL_LUMA;
+                if (t.pend) { // the unsplit 8x8 candidate is saved first
+                    req_copy(q, COPY_SAVE, 3, t.pslot, t.pbx, t.pby, t.plg);
+                    t.pend = 0;
+                }
+                t.cont = T_SPLIT8;
+                return true;
+            }
             t.split8 = 0.0f;
             t.i8 = 0;
             cont = T_LEAF4_EMIT;
             break;
         }
+        case T_SPLIT8: {
+            if constexpr (D3) { // the split candidate of the 8x8 node came back: against the unsplit one, as T_LEAFC does
+                const float split8 = r.vmin;
+                if (TEAM && t.lvmode) { // level schedule: member 3's unit is done
+                    lv_post_split(2, split8);
+                    cont = T_LV_UP;
+                    break;
+                }
+                if (split8 > t.ns_cost_cur) { // :1125-1145: the unsplit 8x8 wins, put it back
+                    t.rbx = t.bx;
+                    t.rby = t.by;
+                    t.rlg = t.lg;
+                    t.rl = t.ns_luma_cur;
+                    t.rc = t.ns_chroma_cur;
+                    q.kind = K_NOP;
+                    q.xchg = false;
+                    req_copy(q, COPY_RESTORE, 3, 1 + t.level, t.rbx, t.rby, t.rlg);
+                    t.cont = T_REGEN_DONE;
+                    return true;
+                }
+                t.ret = split8;
+                cont = T_RETURN;
+                break;
+            }
+            }
+            break;
         case T_LEAF4_EMIT: {
-            const int i8 = t.i8;
-            leaf_init(t.leaf, TREE_DUAL_LUMA, t.bx + (i8 & 1) * 4, t.by + (i8 >> 1) * 4, 2, 0);
-            if (TEAM && !t.lvmode) t.leaf.cont = TC_START;
-            in_leaf = true;
-            cont = T_LEAF4;
+            if constexpr (D3) {
+                const int i8 = t.i8;
+                leaf_init(t.leaf, TREE_DUAL_LUMA, t.bx + (i8 & 1) * 4, t.by + (i8 >> 1) * 4, 2, 0);
+                if (TEAM && !t.lvmode) t.leaf.cont = TC_START;
+                in_leaf = true;
+                cont = T_LEAF4;
+                break;
+            }
+            }
             break;
-        }
         case T_LEAF4: {
-            fill_maps(t.leaf.bx, t.leaf.by, 2, t.leaf.luma_mode, 0, true, false);
-            t.split8 = t.split8 + t.leaf.cost;
-            const int i8 = t.i8 + 1;
-            t.i8 = (uint8_t)i8;
-            if (i8 < 4) {
-                cont = T_LEAF4_EMIT;
+            if constexpr (D3) {
+                fill_maps(t.leaf.bx, t.leaf.by, 2, t.leaf.luma_mode, 0, true, false);
+                t.split8 = t.split8 + t.leaf.cost;
+                const int i8 = t.i8 + 1;
+                t.i8 = (uint8_t)i8;
+                if (i8 < 4) {
+                    cont = T_LEAF4_EMIT;
+                    break;
+                }
+                // DM = luma mode of the CU covering the parent's centre (block_splitter.rs:795-805)
+                const int bx = t.bx, by = t.by;
+                leaf_init(t.leaf, TREE_DUAL_CHROMA, bx, by, 3, uni((int)SH.luma_mode[((by + 4) >> 2) * 8 + ((bx + 4) >> 2)]));
+                if (TEAM && !t.lvmode) t.leaf.cont = TC_DC_START;
+                in_leaf = true;
+                cont = T_LEAFC;
                 break;
             }
-            // DM = luma mode of the CU covering the parent's centre (block_splitter.rs:795-805)
-            const int bx = t.bx, by = t.by;
-            leaf_init(t.leaf, TREE_DUAL_CHROMA, bx, by, 3, uni((int)SH.luma_mode[((by + 4) >> 2) * 8 + ((bx + 4) >> 2)]));
-            if (TEAM && !t.lvmode) t.leaf.cont = TC_DC_START;
-            in_leaf = true;
-            cont = T_LEAFC;
+            }
             break;
-        }
         case T_LEAFC: {
-            fill_maps(t.bx, t.by, 3, 0, t.leaf.chroma_mode, false, true);
-            const float split8 = t.split8 + t.leaf.cost;
-            if (TEAM && t.lvmode) { // member 3's unit is done: the split candidate of 8x8 node lv_i
-                lv_post_split(2, split8);
-                cont = T_LV_UP;
+            if constexpr (D3) {
+                fill_maps(t.bx, t.by, 3, 0, t.leaf.chroma_mode, false, true);
+                const float split8 = t.split8 + t.leaf.cost;
+                if (TEAM && t.lvmode) { // member 3's unit is done: the split candidate of 8x8 node lv_i
+                    lv_post_split(2, split8);
+                    cont = T_LV_UP;
+                    break;
+                }
+                if (split8 > t.ns_cost_cur) { // :1125-1145: the unsplit 8x8 wins, put it back
+                    t.rbx = t.bx;
+                    t.rby = t.by;
+                    t.rlg = t.lg;
+                    t.rl = t.ns_luma_cur;
+                    t.rc = t.ns_chroma_cur;
+                    q.kind = K_NOP;
+                    q.xchg = false;
+                    req_copy(q, COPY_RESTORE, 3, 1 + t.level, t.rbx, t.rby, t.rlg);
+                    t.cont = T_REGEN_DONE;
+                    return true;
+                }
+                t.ret = split8;
+                cont = T_RETURN;
                 break;
             }
-            if (split8 > t.ns_cost_cur) { // :1125-1145: the unsplit 8x8 wins, put it back
-                t.rbx = t.bx;
-                t.rby = t.by;
-                t.rlg = t.lg;
-                t.rl = t.ns_luma_cur;
-                t.rc = t.ns_chroma_cur;
-                q.kind = K_NOP;
-                q.xchg = false;
-                req_copy(q, COPY_RESTORE, 3, 1 + t.level, t.rbx, t.rby, t.rlg);
-                t.cont = T_REGEN_DONE;
-                return true;
             }
-            t.ret = split8;
-            cont = T_RETURN;
             break;
-        }
         case T_REGEN_DONE:
             fill_maps(t.rbx, t.rby, t.rlg, t.rl, t.rc, true, true);
             t.ret = uni_f(SH.ns_cost[t.level]);
@@ -2346,62 +2461,79 @@ __device__ __forceinline__ bool ctu_step(Ctx& c, const Res& r, Req& q) {
         }
         // ---- level schedule: this member's next unit (members 1, 2: a leaf search; member 3: an 8x8 split) ----
         case T_LV_UNIT: {
-            const int me = c.member, i = t.lv_i;
-            int bx, by;
-            lv_node(me == 1 ? 1 : 2, i, bx, by);
-            t.bx = (uint8_t)bx;
-            t.by = (uint8_t)by;
-            if (me == 3) { // four DUAL_TREE_LUMA 4x4 leaves, then the DUAL_TREE_CHROMA leaf (T_LEAF4_EMIT .. T_LEAFC)
-                t.lg = 3;
-                t.split8 = 0.0f;
-                t.i8 = 0;
-                cont = T_LEAF4_EMIT;
+            if constexpr (TEAM && D3) {
+                const int me = c.member, i = t.lv_i;
+                int bx, by;
+                lv_node(me == 1 ? 1 : 2, i, bx, by);
+                t.bx = (uint8_t)bx;
+                t.by = (uint8_t)by;
+                if (me == 3) { // four DUAL_TREE_LUMA 4x4 leaves, then the DUAL_TREE_CHROMA leaf
+                    t.lg = 3;
+                    if (WRENC_SPLIT8) { // ... as one request (K_SPLIT8)
+                        req_full(q, 3, bx, by, 3, 0, 0, false, true, false, false, false);
+                        q.kind = K_SPLIT8;
+                        q.stage = 0;
+                        q.tree = TREE_DUAL_LUMA;
+                        t.cont = T_SPLIT8;
+                        return true;
+                    }
+                    t.split8 = 0.0f;
+                    t.i8 = 0;
+                    cont = T_LEAF4_EMIT;
+                    break;
+                }
+                const int lg = me == 1 ? 4 : 3;
+                t.lg = (uint8_t)lg;
+                leaf_init(t.leaf, TREE_SINGLE, bx, by, lg, 0);
+                in_leaf = true;
+                cont = T_LV_LEAFDONE;
                 break;
             }
-            const int lg = me == 1 ? 4 : 3;
-            t.lg = (uint8_t)lg;
-            leaf_init(t.leaf, TREE_SINGLE, bx, by, lg, 0);
-            in_leaf = true;
-            cont = T_LV_LEAFDONE;
-            break;
-        }
-        case T_LV_LEAFDONE: { // members 1, 2: the unsplit candidate of node (member, lv_i)
-            const int me = c.member;
-            lv_post_unsplit(me, t.leaf.cost, t.leaf.luma_mode, t.leaf.chroma_mode);
-            cont = T_LV_UP;
-            break;
-        }
-        case T_LV_UP: { // the decisions this member takes part in now, deepest first
-            const int me = c.member, i = t.lv_i;
-            if (me >= 2) {
-                const float d2 = lv_decide(c, 2, i);
-                const float a1 = uni_f(t.lv_acc1 + d2); // children in z-order, f32, from 0.0 (:1116-1123)
-                t.lv_acc1 = a1;
-                if ((i & 3) != 3) {
-                    t.lv_i = (uint8_t)(i + 1);
-                    cont = T_LV_UNIT;
-                    break;
-                }
-                if (me == 2) lv_post_split(1, a1);
-                t.lv_acc1 = 0.0f;
             }
-            if (me >= 1) {
-                const int i1 = me == 1 ? i : (i >> 2);
-                const float d1 = lv_decide(c, 1, i1);
-                const float a0 = uni_f(t.lv_acc0 + d1);
-                t.lv_acc0 = a0;
-                if (i1 != 3) {
-                    t.lv_i = (uint8_t)(i + 1);
-                    cont = T_LV_UNIT;
-                    break;
-                }
-                if (me == 1) lv_post_split(0, a0);
-            }
-            t.ret = lv_decide(c, 0, 0);
-            t.level = 0;
-            cont = T_RETURN;
             break;
-        }
+        case T_LV_LEAFDONE: {
+            if constexpr (TEAM && D3) { // members 1, 2: the unsplit candidate of node (member, lv_i)
+                const int me = c.member;
+                lv_post_unsplit(me, t.leaf.cost, t.leaf.luma_mode, t.leaf.chroma_mode);
+                cont = T_LV_UP;
+                break;
+            }
+            }
+            break;
+        case T_LV_UP: {
+            if constexpr (TEAM && D3) { // the decisions this member takes part in now, deepest first
+                const int me = c.member, i = t.lv_i;
+                if (me >= 2) {
+                    const float d2 = lv_decide(c, 2, i);
+                    const float a1 = uni_f(t.lv_acc1 + d2); // children in z-order, f32, from 0.0 (:1116-1123)
+                    t.lv_acc1 = a1;
+                    if ((i & 3) != 3) {
+                        t.lv_i = (uint8_t)(i + 1);
+                        cont = T_LV_UNIT;
+                        break;
+                    }
+                    if (me == 2) lv_post_split(1, a1);
+                    t.lv_acc1 = 0.0f;
+                }
+                if (me >= 1) {
+                    const int i1 = me == 1 ? i : (i >> 2);
+                    const float d1 = lv_decide(c, 1, i1);
+                    const float a0 = uni_f(t.lv_acc0 + d1);
+                    t.lv_acc0 = a0;
+                    if (i1 != 3) {
+                        t.lv_i = (uint8_t)(i + 1);
+                        cont = T_LV_UNIT;
+                        break;
+                    }
+                    if (me == 1) lv_post_split(0, a0);
+                }
+                t.ret = lv_decide(c, 0, 0);
+                t.level = 0;
+                cont = T_RETURN;
+                break;
+            }
+            }
+            break;
         // ---- final pass (ctu_encoder.rs:1421-1461): coding order = z-order over the 4x4 units; a
         // CU is emitted at its top-left unit (luma TB, then the chroma TBs) ----
         case T_FINAL_Z: {
@@ -2460,7 +2592,7 @@ __device__ __forceinline__ void load_tables(Ctx c) {
 }
 
 
-template <bool TEAM>
+template <bool TEAM, bool D3>
 __device__ __forceinline__ void encode_ctu(Ctx& c, const PicBufs& pb, int ctu_col, int ctu_row, int* overflow) {
     const CONST_AS DevConst* k = c.k;
     const int W = k->W;
@@ -2528,7 +2660,7 @@ __device__ __forceinline__ void encode_ctu(Ctx& c, const PicBufs& pb, int ctu_co
         const int cb_ = SH.st.in_leaf ? (int)SH.st.leaf.cont : 20 + (int)SH.st.cont;
 #endif
         PROF_MARK(tc0_);
-        const bool more = ctu_step<TEAM>(c, r, q);
+        const bool more = ctu_step<TEAM, D3>(c, r, q);
         PROF_MARK(tc1_);
         PROF_ADD2(PH_CTRL, tc0_, tc1_);
         PROF_ADDM(0, tc0_, tc1_);
@@ -2549,7 +2681,7 @@ __device__ __forceinline__ void encode_ctu(Ctx& c, const PicBufs& pb, int ctu_co
         r = Res{};
 #else
         PROF_MARK(te0_);
-        r = evaluate(c, pb, q, overflow);
+        r = evaluate<D3>(c, pb, q, overflow);
         PROF_MARK(te1_);
         PROF_ADDM(q.kind == K_NOP ? 3 : 1, te0_, te1_);
         PROF_ADD2(PH_EV + (((q.kind & 15) * 4 + ((q.kind == K_NOP ? q.copy_tlg : q.tlg) - 2)) & 63), te0_, te1_); // by request kind and block size

@@ -155,6 +155,8 @@ __global__ __launch_bounds__(1024) void compact_levels_kernel(const PicBufs* __r
 }
 
 // Wave schedule: one workgroup = the same CTU of WPB consecutive pictures, one wave each.
+// D3: built for max-split-depth 3 (with the 4x4 leaves of split 8x8 CUs) or for the smaller depths (without)
+template <bool D3>
 __global__ __launch_bounds__(64 * WPB, 5) void ctu_search_kernel(const DevConst* __restrict__ k,
                                                               const PicBufs* __restrict__ slots, int first_slot,
                                                               int n_pictures, int diag, int r_min, int count,
@@ -182,13 +184,14 @@ __global__ __launch_bounds__(64 * WPB, 5) void ctu_search_kernel(const DevConst*
     c.pred_scratch = pred_scratch + ((size_t)scratch_slot * WPB + WAVE) * kWaveScratch;
     c.slots = (GLOBAL_AS uint8_t*)(c.pred_scratch + 1024);
     int ovf = 0;
-    encode_ctu<false>(c, pb, col, row, &ovf);
+    encode_ctu<false, D3>(c, pb, col, row, &ovf);
     if (ovf && LANE == 0) atomicOr(overflow, 1);
     release_scratch(slot_map, scratch_slot);
 }
 
 // Team schedule: one workgroup = the same CTU of WPB / kTeam consecutive pictures, kTeam waves each
 // (dev_search.h, leaf_step_team).  For encode calls with too few pictures to fill the GPU one wave per CTU.
+template <bool D3>
 __global__ __launch_bounds__(64 * WPB, 5) void ctu_search_team_kernel(const DevConst* __restrict__ k,
                                                                    const PicBufs* __restrict__ slots, int first_slot,
                                                                    int n_pictures, int diag, int r_min, int count,
@@ -217,7 +220,7 @@ __global__ __launch_bounds__(64 * WPB, 5) void ctu_search_team_kernel(const DevC
     c.pred_scratch = pred_scratch + ((size_t)scratch_slot * WPB + WAVE) * kWaveScratch;
     c.slots = (GLOBAL_AS uint8_t*)(c.pred_scratch + 1024);
     int ovf = 0;
-    encode_ctu<true>(c, pb, col, row, &ovf);
+    encode_ctu<true, D3>(c, pb, col, row, &ovf);
     if (ovf && LANE == 0) atomicOr(overflow, 1);
     if (SHT.lvb.pad_ && LANE == 0) atomicOr(overflow, 2); // a meeting point of the level schedule timed out
     release_scratch(slot_map, scratch_slot);
@@ -996,6 +999,7 @@ int wrenc_gpu_encode(wrenc_gpu_ctx* ctx, int first_slot, int n_pictures) {
     HIP_TRY(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
     for (int l = 1; l < n_lanes; ++l) HIP_TRY(ctx, hipStreamWaitEvent(ctx->lanes[l - 1], ctx->ev_fork, 0));
     int launches = 0;
+    const bool d3 = ctx->cfg.max_split_depth == 3; // the kernels built with / without the 4x4 leaves of split 8x8 CUs
     ctx->launch_team.clear();
     ctx->launch_ctus.clear();
     for (int d = 0; d < ndiag; ++d) {
@@ -1018,15 +1022,22 @@ int wrenc_gpu_encode(wrenc_gpu_ctx* ctx, int first_slot, int n_pictures) {
             if (lane_pics <= 0) continue;
             hipStream_t st = l == 0 ? ctx->stream : ctx->lanes[l - 1];
             if (timed) HIP_TRY(ctx, hipEventRecord(ctx->ev_pool[2 * launches], st));
-            if (team)
-                hipLaunchKernelGGL(ctu_search_team_kernel, dim3(count * ((lane_pics + kTeamsPerGroup - 1) / kTeamsPerGroup)),
-                                   dim3(64 * WPB), 0, st, ctx->d_const,
-                                   ctx->d_slots, lane_first, lane_pics, d, r_min, count, ctx->d_pred_scratch,
-                                   ctx->d_slot_map, ctx->d_mismatch, ctx->d_overflow);
-            else
-                hipLaunchKernelGGL(ctu_search_kernel, dim3(count * (g1 - g0)), dim3(64 * WPB), 0, st, ctx->d_const,
-                                   ctx->d_slots, lane_first, lane_pics, d, r_min, count, ctx->d_pred_scratch,
-                                   ctx->d_slot_map, ctx->d_mismatch, ctx->d_overflow);
+            const dim3 grid(team ? count * ((lane_pics + kTeamsPerGroup - 1) / kTeamsPerGroup) : count * (g1 - g0));
+#define WRENC_LAUNCH(KERNEL)                                                                                                   \
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(KERNEL), grid, dim3(64 * WPB), 0, st, ctx->d_const, ctx->d_slots, lane_first, lane_pics, d, \
+                       r_min, count, ctx->d_pred_scratch, ctx->d_slot_map, ctx->d_mismatch, ctx->d_overflow)
+            if (team) {
+                if (d3)
+                    WRENC_LAUNCH(ctu_search_team_kernel<true>);
+                else
+                    WRENC_LAUNCH(ctu_search_team_kernel<false>);
+            } else {
+                if (d3)
+                    WRENC_LAUNCH(ctu_search_kernel<true>);
+                else
+                    WRENC_LAUNCH(ctu_search_kernel<false>);
+            }
+#undef WRENC_LAUNCH
             HIP_TRY(ctx, hipGetLastError());
             if (timed) HIP_TRY(ctx, hipEventRecord(ctx->ev_pool[2 * launches + 1], st));
             ctx->launch_team.push_back(team ? 1 : 0);
