@@ -12,7 +12,8 @@ enum { TREE_SINGLE = 0, TREE_DUAL_LUMA = 1, TREE_DUAL_CHROMA = 2 };
 struct DevConst {
     int32_t W, H, qp, max_depth, ctu_cols, ctu_rows;
     int32_t lsc;              // quantizer.rs:617-622 (16*LEVEL_SCALE[0][(qp+1)%6]) << ((qp+1)/6)
-    uint64_t div_magic;       // floor(2^47 / lsc) + 1: exact n / lsc for n < 2^26
+    uint32_t div_magic;       // floor(2^k / lsc) + 1, k = 26 + ceil(log2 lsc): exact n / lsc = mul_hi(n, magic) >> (k - 32) for n < 2^26
+    uint32_t div_shift;       // k - 32
     int64_t lambda_q;
     float lambda_rd;
     float lambda_rd_chroma;

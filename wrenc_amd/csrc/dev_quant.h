@@ -88,12 +88,12 @@ __device__ __forceinline__ int ldq_fast(const Ctx& c, int idx) {
 }
 
 // |(tc << sh) - off| / lsc, the quotient every decision of a position starts from (quantizer.rs:378, :441); 0 for a
-// zero coefficient.  Recomputed where it is needed (a shift, a 32 x 32 -> 64 multiply by the reciprocal) rather
+// zero coefficient.  Recomputed where it is needed (a shift, one v_mul_hi_u32 by a 32-bit reciprocal, a shift) rather
 // than kept per position: the 2 KB that array took are what lets a fifth workgroup fit the CU's LDS.
 __device__ __forceinline__ int quotient(const CONST_AS DevConst* k, int tc, int sh, int off) {
     int S = (int)((unsigned)tc << sh) - off;
     if (tc < 0) S = -S;
-    return tc == 0 ? 0 : (int)(((unsigned long long)(unsigned)S * k->div_magic) >> 47);
+    return tc == 0 ? 0 : (int)(__umulhi((unsigned)S, k->div_magic) >> k->div_shift);
 }
 
 // Chunk entry of one position (see the comment above kNoBranch): writes (u, w) of the three state

@@ -561,7 +561,15 @@ void fill_dev_const(const wrenc_gpu_config& cfg, DevConst& k) {
     k.ctu_rows = cfg.height / 32;
     static const int level_scale[6] = {40, 45, 51, 57, 64, 72}; // quantizer.rs:8
     k.lsc = (16 * level_scale[(cfg.qp + 1) % 6]) << ((cfg.qp + 1) / 6);
-    k.div_magic = ((1ULL << 47) / (uint64_t)k.lsc) + 1;
+    {
+        // n / lsc for n < 2^26 (|tc << sh| of a 16-bit coefficient) as mul_hi(n, m) >> s: with k = 26 + ceil(log2 lsc) and
+        // m = floor(2^k / lsc) + 1 the error n (m lsc - 2^k) / (lsc 2^k) stays below 1 / lsc, and m < 2^28 fits 32 bits
+        int lg = 0;
+        while ((1 << lg) < k.lsc) ++lg;
+        const int kk = 26 + lg;
+        k.div_magic = (uint32_t)(((1ULL << kk) / (uint64_t)k.lsc) + 1);
+        k.div_shift = (uint32_t)(kk - 32);
+    }
     k.lambda_q = cfg.lambda_q;
     k.lambda_rd = cfg.lambda_rd;
     k.lambda_rd_chroma = cfg.lambda_rd_chroma;
