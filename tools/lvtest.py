@@ -2,7 +2,7 @@ import sys, numpy as np
 sys.path.insert(0, '/root/repo')
 from wrenc_amd import gpu, synth
 from oracle import pyoracle as po
-for (w, h, qp, depth) in [(64, 64, 32, 3), (96, 64, 27, 3), (64, 64, 32, 2)]:
+for (w, h, qp, depth) in [(64, 64, 32, 3), (96, 64, 27, 3), (64, 64, 32, 2), (96, 96, 37, 1), (64, 32, 22, 0), (128, 96, 30, 2)]:
     y, cb, cr = synth.synth_textured_frame(w, h, 3)
     enc = gpu.Encoder(w, h, qp=qp, max_split_depth=depth, schedule=2)
     got = enc.encode_picture(y, cb, cr)

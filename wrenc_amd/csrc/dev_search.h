@@ -21,6 +21,9 @@ enum { COPY_NONE = 0, COPY_SAVE = 1, COPY_RESTORE = 2, COPY_PULL = 3 };
 #ifndef WRENC_SPLIT8
 #define WRENC_SPLIT8 1
 #endif
+#ifndef WRENC_LEVELS_ALL_DEPTHS  // 0: the level schedule at max-split-depth 3 only, round 2's team below
+#define WRENC_LEVELS_ALL_DEPTHS 1
+#endif
 
 struct Req {
     int kind;       // K_SADLIST: predict + SAD of a list of modes (block_splitter.rs:64-108, 476-522);
@@ -2156,7 +2159,8 @@ __device__ __forceinline__ void lv_pull(const Ctx& c, int from, int tx, int ty, 
 // Decision of node (L, idx), by members L .. 3: returns the decided cost (block_splitter.rs:1125-1151)
 __device__ __forceinline__ float lv_decide(const Ctx& c, int L, int idx) {
     const int me = c.member;
-    const int nmem = kTeam - L;
+    const int dl = c.k->max_depth;                      // levels 1 .. dl are searched by members 1 .. dl
+    const int nmem = L == 0 ? kTeam : dl - L + 1;       // (the CTU's decision: everybody, idle members included)
     PROF_MARK(tx0_);
     lv_meet(L, 0, (idx + 1) * nmem);
     PROF_MARK(tx1_);
@@ -2171,7 +2175,7 @@ __device__ __forceinline__ float lv_decide(const Ctx& c, int L, int idx) {
     if (unsplit) {
         if (me > L) lv_pull(c, L, bx, by, lg);
         fill_maps(bx, by, lg, ml, mc, true, true);
-    } else if (me == L) {
+    } else if (me == L || me > dl) { // (members without a level hold nothing of the split candidate either)
         lv_pull(c, L + 1, bx, by, lg);
         lv_pull_maps(c, L + 1, bx, by, lg);
     }
@@ -2258,7 +2262,7 @@ __device__ __forceinline__ bool ctu_step(Ctx& c, const Res& r, Req& q) {
                 cont = T_RETURN;
                 break;
             }
-            if (TEAM && WRENC_LEVELS && D3 && t.max_depth == 3) {
+            if (TEAM && WRENC_LEVELS && (WRENC_LEVELS_ALL_DEPTHS || D3)) { // (max-split-depth >= 1 here)
                 // ---- level schedule from here on (see lv_decide): every member has searched the 32x32 candidate ----
                 if (t.dp0) { // its winner into every member's tile first (team_defer_pull)
                     const int dp = t.dp0, dq = t.dp1;
@@ -2269,12 +2273,9 @@ __device__ __forceinline__ bool ctu_step(Ctx& c, const Res& r, Req& q) {
                 t.lv_i = 0;
                 t.lv_acc0 = 0.0f;
                 t.lv_acc1 = 0.0f;
-                if (c.member == 0) {
-                    lv_post_unsplit(0, ns, ml, mc);
-                    cont = T_LV_UP;
-                } else {
-                    cont = T_LV_UNIT;
-                }
+                if (c.member == 0) lv_post_unsplit(0, ns, ml, mc);
+                // (members 1 .. max-split-depth take a level; member 0 and the others wait for the CTU's decision)
+                cont = (c.member == 0 || c.member > t.max_depth) ? T_LV_UP : T_LV_UNIT;
                 break;
             }
             // the unsplit candidate's reconstruction goes to slot 1 + level (cache_reconsts, :1085-1100)
@@ -2461,26 +2462,28 @@ __device__ __forceinline__ bool ctu_step(Ctx& c, const Res& r, Req& q) {
         }
         // ---- level schedule: this member's next unit (members 1, 2: a leaf search; member 3: an 8x8 split) ----
         case T_LV_UNIT: {
-            if constexpr (TEAM && D3) {
+            if constexpr (TEAM && (WRENC_LEVELS_ALL_DEPTHS || D3)) {
                 const int me = c.member, i = t.lv_i;
                 int bx, by;
                 lv_node(me == 1 ? 1 : 2, i, bx, by);
                 t.bx = (uint8_t)bx;
                 t.by = (uint8_t)by;
-                if (me == 3) { // four DUAL_TREE_LUMA 4x4 leaves, then the DUAL_TREE_CHROMA leaf
-                    t.lg = 3;
-                    if (WRENC_SPLIT8) { // ... as one request (K_SPLIT8)
-                        req_full(q, 3, bx, by, 3, 0, 0, false, true, false, false, false);
-                        q.kind = K_SPLIT8;
-                        q.stage = 0;
-                        q.tree = TREE_DUAL_LUMA;
-                        t.cont = T_SPLIT8;
-                        return true;
+                if constexpr (D3) {
+                    if (me == 3) { // four DUAL_TREE_LUMA 4x4 leaves, then the DUAL_TREE_CHROMA leaf
+                        t.lg = 3;
+                        if (WRENC_SPLIT8) { // ... as one request (K_SPLIT8)
+                            req_full(q, 3, bx, by, 3, 0, 0, false, true, false, false, false);
+                            q.kind = K_SPLIT8;
+                            q.stage = 0;
+                            q.tree = TREE_DUAL_LUMA;
+                            t.cont = T_SPLIT8;
+                            return true;
+                        }
+                        t.split8 = 0.0f;
+                        t.i8 = 0;
+                        cont = T_LEAF4_EMIT;
+                        break;
                     }
-                    t.split8 = 0.0f;
-                    t.i8 = 0;
-                    cont = T_LEAF4_EMIT;
-                    break;
                 }
                 const int lg = me == 1 ? 4 : 3;
                 t.lg = (uint8_t)lg;
@@ -2492,19 +2495,24 @@ __device__ __forceinline__ bool ctu_step(Ctx& c, const Res& r, Req& q) {
             }
             break;
         case T_LV_LEAFDONE: {
-            if constexpr (TEAM && D3) { // members 1, 2: the unsplit candidate of node (member, lv_i)
+            if constexpr (TEAM && (WRENC_LEVELS_ALL_DEPTHS || D3)) {
                 const int me = c.member;
-                lv_post_unsplit(me, t.leaf.cost, t.leaf.luma_mode, t.leaf.chroma_mode);
+                if (me < t.max_depth) { // the unsplit candidate of node (member, lv_i), to be decided against its children
+                    lv_post_unsplit(me, t.leaf.cost, t.leaf.luma_mode, t.leaf.chroma_mode);
+                } else {                // the deepest level: the leaf is the node's decision
+                    fill_maps(t.bx, t.by, t.lg, t.leaf.luma_mode, t.leaf.chroma_mode, true, true);
+                }
                 cont = T_LV_UP;
                 break;
             }
             }
             break;
         case T_LV_UP: {
-            if constexpr (TEAM && D3) { // the decisions this member takes part in now, deepest first
-                const int me = c.member, i = t.lv_i;
-                if (me >= 2) {
-                    const float d2 = lv_decide(c, 2, i);
+            if constexpr (TEAM && (WRENC_LEVELS_ALL_DEPTHS || D3)) { // the decisions this member takes part in now, deepest first
+                const int me = c.member, i = t.lv_i, dl = t.max_depth;
+                if (me >= 2 && me <= dl) {
+                    // an 8x8 node: decided against its split at max-split-depth 3, final at depth 2
+                    const float d2 = dl == 3 ? lv_decide(c, 2, i) : (float)t.leaf.cost;
                     const float a1 = uni_f(t.lv_acc1 + d2); // children in z-order, f32, from 0.0 (:1116-1123)
                     t.lv_acc1 = a1;
                     if ((i & 3) != 3) {
@@ -2515,9 +2523,9 @@ __device__ __forceinline__ bool ctu_step(Ctx& c, const Res& r, Req& q) {
                     if (me == 2) lv_post_split(1, a1);
                     t.lv_acc1 = 0.0f;
                 }
-                if (me >= 1) {
+                if (me >= 1 && me <= dl) {
                     const int i1 = me == 1 ? i : (i >> 2);
-                    const float d1 = lv_decide(c, 1, i1);
+                    const float d1 = dl >= 2 ? lv_decide(c, 1, i1) : (float)t.leaf.cost; // (depth 1: the 16x16 leaf is final)
                     const float a0 = uni_f(t.lv_acc0 + d1);
                     t.lv_acc0 = a0;
                     if (i1 != 3) {
