@@ -175,11 +175,12 @@ __device__ __forceinline__ int emit_level(const Ctx& c, int tc, int qd, bool dcn
     return q;
 }
 
-// bits = 2 * bits + (kb < ka): the compare sets VCC, v_addc shifts it in (one instruction instead of
-// a select and an or)
+// bits = 2 * bits + (kb < ka).  Path costs stay below 2^30 (above), so kb < ka is the sign of kb - ka, and
+// v_alignbit_b32(bits, kb - ka, 31) shifts it in: two plain VALU instructions that the scheduler can put behind the
+// step's v_and, where the DPP read of the next step needs two wait states anyway (the inline-asm v_cmp + v_addc pair
+// this replaces was opaque to the hazard recogniser, which added an s_nop 1 to every step).
 __device__ __forceinline__ unsigned shift_in_less(unsigned bits, int kb, int ka) {
-    asm("v_cmp_lt_i32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(bits) : "v"(kb), "v"(ka) : "vcc");
-    return bits;
+    return __builtin_amdgcn_alignbit(bits, (unsigned)(kb - ka), 31);
 }
 
 // Dependent quantisation of nb transform blocks of side n (nb = 1 luma, 2 = Cb+Cr pair):
