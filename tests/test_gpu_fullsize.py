@@ -115,3 +115,29 @@ def test_4320p_decoder_check(built, depth, tex):
     _top_rows_equal_oracle(rec, y, cb, cr, qp, depth, rows=32)
     if depth == 3:
         assert set(np.unique(rec["cu_log2_size"])) >= {2, 3, 4}
+
+
+@pytest.mark.parametrize("w,h,depth", [(3840, 2176, 3), (1920, 1088, 2)])
+def test_schedules_agree_at_full_size(built, w, h, depth):
+    """One wavefront per CTU (ctu_search_kernel) and the level schedule (four wavefronts per CTU, one tree level each,
+    ctu_search_team_kernel) produce the same record for whole pictures of BASELINE's sizes: every plane, mode map and f32
+    CTU cost -- with real anti-diagonals (up to 60 CTUs), pictures of different content in one workgroup, a padding
+    wave; and the stream written from either record is the same."""
+    from wrenc_amd import bitstream as bs, gpu, synth
+    qp = 32
+    frames = [synth.synth_textured_frame(w, h, 3), synth.synth_frame(w, h, 4), synth.synth_textured_frame(w, h, 5)]
+    recs = {}
+    for schedule in (1, 2):
+        enc = gpu.Encoder(w, h, qp=qp, max_split_depth=depth, n_slots=3, schedule=schedule)
+        for s, f in enumerate(frames):
+            enc.upload(s, *f)
+        enc.encode(0, 3)
+        enc.sync()
+        assert enc.final_pass_mismatches() == 0
+        assert enc.last_schedule() == schedule
+        recs[schedule] = [enc.download(s) for s in range(3)]
+        enc.close()
+    for s in range(3):
+        for k in KEYS + ("ctu_cost",):
+            assert np.array_equal(recs[1][s][k], recs[2][s][k]), (s, k)
+    assert bs.write_picture(w, h, qp, 0, recs[1][0]) == bs.write_picture(w, h, qp, 0, recs[2][0])

@@ -1975,6 +1975,22 @@ __device__ __forceinline__ bool leaf_step_team(const Ctx& c, CtuSt& t, LeafSF& s
                 team_defer_pull(t, s, 1, holder);
                 return false;
             }
+            if (WRENC_LEVELS && (WRENC_LEVELS_ALL_DEPTHS || c.k->max_depth == 3) && s.lg == 5 && c.k->max_depth >= 1) {
+                // The CTU's 32x32 candidate, and the level schedule follows: its LUMA mode is all the other levels need
+                // (their MPM classes), and it is decided now.  Everybody pulls the winner (member 0 keeps
+                // the candidate for the CTU's decision); then members 1 .. 3 are done with this leaf and start their
+                // levels, while member 0 finishes the candidate alone -- its CCLM part as the one-wave search does it
+                // (leaf_step from C_WINNER: the winner saved to slot 0 by the CCLM request, restored from there if DM wins).
+                team_defer_pull(t, s, 3, holder);
+                if (me != 0) return false;
+                s.need_save = 1;
+                s.tile_best = 1;
+                s.cont = C_WINNER;
+                t.lvmode = 1; // from here on ctu_step runs this member's leaf through leaf_step; an empty request first
+                team_idle(q); // (the driver loop pulls the winner in front of it, as the others do at the switch)
+                q.xchg = false;
+                return true;
+            }
             // :1040 the winner's chroma cost, then the three CCLM probes side by side on the winner's luma
             s.cur_cost = uni_f(assemble_chroma_cost(c, m, s.e_best.get()));
             if (c.write && LANE == 0)
