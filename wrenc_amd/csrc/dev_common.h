@@ -361,6 +361,11 @@ struct LvBox {
     uint8_t ml[3], mc[3];
     uint16_t pad_;
     uint32_t cnt[3][2];
+    // the pack-A server (member 0 runs pack {planar, DC} of member 2's 8x8 leaves, dev_search.h lv_serve): server is
+    // polling | jobs posted / done / consumed | member 2 has no more jobs; the posted job's block
+    uint32_t srv_ready, job_posted, job_done, job_ack, job_fin;
+    uint32_t job4_posted, job4_done, job4_ack, job4_fin; // the same for member 3's 4x4 luma leaves
+    uint8_t job_bx, job_by, job4_bx, job4_by;
 };
 struct LdsTab {
     int32_t ldq[256];

@@ -9,7 +9,7 @@ namespace wrenc {
 // ---------------------------------------------------------------------------
 // Evaluation requests and the evaluator
 // ---------------------------------------------------------------------------
-enum { K_SADLIST = 0, K_FULL = 1, K_NOP = 2, K_SADSEARCH = 3, K_CCLMSEARCH = 4, K_LEAF4 = 5, K_LEAFC4 = 6, K_LEAF8 = 7, K_LEAF16 = 8, K_SPLIT8 = 9 };
+enum { K_SADLIST = 0, K_FULL = 1, K_NOP = 2, K_SADSEARCH = 3, K_CCLMSEARCH = 4, K_LEAF4 = 5, K_LEAFC4 = 6, K_LEAF8 = 7, K_LEAF16 = 8, K_SPLIT8 = 9, K_SERVE4 = 10 };
 #ifndef WRENC_POOL_MIN_TLG
 #define WRENC_POOL_MIN_TLG 3
 #endif
@@ -20,6 +20,9 @@ enum { COPY_NONE = 0, COPY_SAVE = 1, COPY_RESTORE = 2, COPY_PULL = 3 };
 #endif
 #ifndef WRENC_SPLIT8
 #define WRENC_SPLIT8 1
+#endif
+#ifndef WRENC_SERVER // level schedule: member 0, idle once the 32x32 candidate is done, runs pack {planar, DC} of member 2's 8x8 leaves
+#define WRENC_SERVER 1
 #endif
 #ifndef WRENC_LEVELS_ALL_DEPTHS  // 0: the level schedule at max-split-depth 3 only, round 2's team below
 #define WRENC_LEVELS_ALL_DEPTHS 1
@@ -280,6 +283,7 @@ __device__ __forceinline__ Res leafc4_search(const Ctx& c, const Req& q, int* ov
 __device__ __forceinline__ Res leaf8_search(const Ctx& c, const Req& q, int* overflow);
 __device__ __forceinline__ Res leaf16_search(const Ctx& c, const Req& q, int* overflow);
 __device__ __forceinline__ Res split8_search(const Ctx& c, const Req& q, int* overflow);
+__device__ __forceinline__ void serve_pack4(const Ctx& c, const Req& q, int* overflow);
 
 // The evaluator: every block evaluation of the search, of the regeneration and of the final pass
 // goes through this one inlined copy (the search logic below is a state machine that hands out
@@ -311,6 +315,10 @@ __device__ __forceinline__ Res evaluate(const Ctx& c, const PicBufs& pb, const R
     if (q.kind == K_LEAF8) return leaf8_search(c, q, overflow);
     if (q.kind == K_LEAF16) return leaf16_search(c, q, overflow);
     if (D3 && q.kind == K_SPLIT8) return split8_search(c, q, overflow);
+    if (D3 && WRENC_SERVER && q.kind == K_SERVE4) { // (team kernel, member 0 only)
+        serve_pack4(c, q, overflow);
+        return r;
+    }
     int mc = q.mc;
     if (q.kind == K_CCLMSEARCH) {
         // get_chroma_intra_pred_aux_cost of LT, T, L_CCLM in one sample pass, then the pick of :847-854 (SADs are
@@ -608,6 +616,32 @@ __device__ __forceinline__ int pick_cclm(float lt, float t, float l) {
 // 2..66 is not evaluated (f32::MAX there).  The best candidate's reconstruction goes to the tile when its pack is
 // done (nothing reads the block's own area meanwhile: the reference samples are cached); no save / restore at all.
 // ---------------------------------------------------------------------------
+// the LDS working set of member m of this wave's team
+__device__ __forceinline__ const Lds& team_lds(const Ctx& c, int m) { return SHW[(WAVE & ~(kTeam - 1)) + m]; }
+
+// Level schedule, the pack-A server (see lv_decide for the schedule): polled LDS words, bounded like lv_meet
+__device__ __forceinline__ unsigned lv_word(const uint32_t* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ void lv_word_add(uint32_t* p) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    if (LANE == 0) __hip_atomic_fetch_add(p, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ void lv_word_wait(const uint32_t* p, unsigned target) {
+    if (LANE == 0) {
+        int polls = 0;
+        while (lv_word(p) < target) {
+            __builtin_amdgcn_s_sleep(2);
+            if (++polls > (1 << 23)) {
+                SHT.lvb.pad_ = 1;
+                break;
+            }
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    WSYNC();
+}
+
 struct Pack4Out {
     uint32_t ssd[3];
     long long lvl[3];
@@ -689,7 +723,19 @@ __device__ __forceinline__ Res leaf4_search(const Ctx& c, const Req& q, int* ove
     } while (0)
     bool first_ = true;
     // q.n: which half runs here (team schedule: member 0 takes pack A, member 1 the SAD search and pack B; 3 = both)
-    if (q.n & 1) {
+    // level schedule (team kernel): member 3's 4x4 luma leaves get their pack A from member 0, the server (serve_pack4;
+    // the same protocol as for member 2's 8x8 leaves, leaf8_search)
+    constexpr int kSrv4Byte = 448; // in the server's decw: 2 x 16 reconstructed samples, then ssd[2] (u32), lvl[2] (i64)
+    const bool served = WRENC_SERVER && c.solo && c.member == 3 && q.n == 3 && lv_word(&SHT.lvb.srv_ready) != 0;
+    unsigned my_job = 0;
+    if (served) {
+        if (lane == 0) {
+            SHT.lvb.job4_bx = (uint8_t)q.tx;
+            SHT.lvb.job4_by = (uint8_t)q.ty;
+        }
+        my_job = uni((int)lv_word(&SHT.lvb.job4_posted)) + 1u;
+        lv_word_add(&SHT.lvb.job4_posted);
+    } else if (q.n & 1) {
         // pack A: planar and DC (:887-898)
         const Pack4Out a = pack4_eval(c, q, 2, PLANAR, DC, kNoMode, overflow);
         int win_ = -1;
@@ -713,10 +759,55 @@ __device__ __forceinline__ Res leaf4_search(const Ctx& c, const Req& q, int* ove
         if (row == win_) rec_put(0, q.tx + x, q.ty + y, b.rec);
         WSYNC();
     }
+    if (served) {
+        // [planar, DC] from the server against pack B's first minimum, which wins only if strictly cheaper
+        lv_word_wait(&SHT.lvb.job4_done, my_job);
+        const uint8_t* sv = (const uint8_t*)team_lds(c, 0).decw + kSrv4Byte;
+        const float bestB = best;
+        const int modeB = best_mode;
+        Pack4Out a;
+#pragma unroll
+        for (int k2 = 0; k2 < 2; ++k2) {
+            a.ssd[k2] = (uint32_t)uni((int)((const uint32_t*)(sv + 32))[k2]);
+            const unsigned long long lv = ((const unsigned long long*)(sv + 40))[k2];
+            a.lvl[k2] = (long long)(((unsigned long long)(unsigned)uni((int)(lv >> 32)) << 32) | (unsigned)uni((int)lv));
+        }
+        first_ = true;
+        int win_ = -1;
+        LEAF4_CANDIDATE(a, 0, PLANAR);
+        LEAF4_CANDIDATE(a, 1, DC);
+        if (bestB < best) {
+            best = bestB;
+            best_mode = modeB;
+        } else {
+            if (lane < 16) rec_put(0, q.tx + x, q.ty + y, sv[16 * win_ + lane]);
+            WSYNC();
+        }
+        lv_word_add(&SHT.lvb.job4_ack);
+    }
 #undef LEAF4_CANDIDATE
     r.vmin = best;
     r.imin = best_mode;
     return r;
+}
+
+// The server's side of a 4x4 leaf (level schedule, q.kind K_SERVE4): reference samples and originals of the block from
+// member 3's LDS, pack {planar, DC}, the two candidates' reconstructions and parts to decw[448 ..] of this wave.
+__device__ __forceinline__ void serve_pack4(const Ctx& c, const Req& q, int* overflow) {
+    const int lane = lane_fresh();
+    const Lds& own = team_lds(c, 3);
+    for (int w = lane; w < 98; w += 64) ((uint32_t*)SH.refs)[w] = ((const uint32_t*)own.refs)[w];
+    if (lane < 4) ((uint32_t*)SH.r2)[kOrgLeaf / 4 + lane] = ((const uint32_t*)own.r2)[kOrgLeaf / 4 + lane];
+    WSYNC();
+    const Pack4Out a = pack4_eval(c, q, 2, PLANAR, DC, kNoMode, overflow);
+    uint8_t* sv = (uint8_t*)SH.decw + 448;
+    if (lane < 32) sv[lane] = (uint8_t)a.rec;
+    if (lane < 2) {
+        ((uint32_t*)(sv + 32))[lane] = lane ? a.ssd[1] : a.ssd[0];
+        ((long long*)(sv + 40))[lane] = lane ? a.lvl[1] : a.lvl[0];
+    }
+    WSYNC();
+    lv_word_add(&SHT.lvb.job4_done);
 }
 
 // K_LEAFC4: the DUAL_TREE_CHROMA leaf of a split 8x8 CU (block_splitter.rs:794-885) in one request.  The three CCLM
@@ -964,7 +1055,39 @@ __device__ __forceinline__ Res leaf8_search(const Ctx& c, const Req& q, int* ove
         }                                                                                                              \
         first_ = false;                                                                                                \
     } while (0)
-    if (q.n & 1) {
+    // Level schedule (team kernel): member 0, idle once the CTU's 32x32 candidate is done, SERVES pack A of member 2's 8x8
+    // leaves.  q.n & 16: this is the server's request -- reference samples and originals of the block from member 2's
+    // LDS, pack {planar, DC}, the candidates' parts to xr[0 .. 1], their reconstructions stay in this wave's park.
+    if (q.n & 16) {
+        const Lds& own = team_lds(c, 2);
+        for (int w = lane; w < 98; w += 64) ((uint32_t*)SH.refs)[w] = ((const uint32_t*)own.refs)[w];
+        for (int w = lane; w < 96; w += 64) ((uint32_t*)SH.r2)[kOrgLeaf / 4 + w] = ((const uint32_t*)own.r2)[kOrgLeaf / 4 + w];
+        WSYNC();
+        const Pack8Out a = pack8_eval(c, q, 2, PLANAR, DC, kNoMode, overflow);
+        if (lane < 2) {
+            XRes x;
+            x.ssd_y = lane ? a.ssd_y[1] : a.ssd_y[0];
+            x.ssd_c = lane ? a.ssd_c[1] : a.ssd_c[0];
+            x.lvl_y = lane ? a.lvl_y[1] : a.lvl_y[0];
+            x.lvl_c = lane ? a.lvl_c[1] : a.lvl_c[0];
+            SH.xr[lane] = x;
+        }
+        WSYNC();
+        lv_word_add(&SHT.lvb.job_done);
+        return r;
+    }
+    // member 2 of a team in the level schedule, and the server is polling: post the job (the block's reference samples
+    // and originals are ready and stay untouched until the leaf is decided), skip pack A here, merge its results below
+    const bool served = WRENC_SERVER && c.solo && c.member == 2 && (q.n & 7) == 7 && lv_word(&SHT.lvb.srv_ready) != 0;
+    unsigned my_job = 0;
+    if (served) {
+        if (lane == 0) {
+            SHT.lvb.job_bx = (uint8_t)q.tx;
+            SHT.lvb.job_by = (uint8_t)q.ty;
+        }
+        my_job = uni((int)lv_word(&SHT.lvb.job_posted)) + 1u;
+        lv_word_add(&SHT.lvb.job_posted);
+    } else if (q.n & 1) {
         // pack A: planar and DC (:887-898)
         const Pack8Out a = pack8_eval(c, q, 2, PLANAR, DC, kNoMode, overflow);
         int win_ = -1;
@@ -985,6 +1108,44 @@ __device__ __forceinline__ Res leaf8_search(const Ctx& c, const Req& q, int* ove
         if (lo != kNoMode) LEAF8_CANDIDATE(b, 1, lo);
         if (hi != kNoMode) LEAF8_CANDIDATE(b, 2, hi);
         if (win_ >= 0) pack8_to_tile(q, 3, win_);
+    }
+    if (served) {
+        // the server's pack A: first minimum of [planar, DC] against the first minimum of pack B found above; the
+        // reference's order is [planar, DC, cm, cm - 1, cm + 1], so pack B's best wins only if strictly cheaper
+        lv_word_wait(&SHT.lvb.job_done, my_job);
+        const Lds& srv = team_lds(c, 0);
+        const float bestB = best;
+        const int modeB = best_mode, clsB = best_cls;
+        const EvalParts ebB = eb;
+        first_ = true;
+        int win_ = -1;
+        Pack8Out a;
+#pragma unroll
+        for (int k2 = 0; k2 < 2; ++k2) {
+            const XRes& x = srv.xr[k2];
+            a.ssd_y[k2] = (uint32_t)uni((int)x.ssd_y);
+            a.ssd_c[k2] = (uint32_t)uni((int)x.ssd_c);
+            const unsigned long long ly = (unsigned long long)x.lvl_y, lc = (unsigned long long)x.lvl_c;
+            a.lvl_y[k2] = (long long)(((unsigned long long)(unsigned)uni((int)(ly >> 32)) << 32) | (unsigned)uni((int)ly));
+            a.lvl_c[k2] = (long long)(((unsigned long long)(unsigned)uni((int)(lc >> 32)) << 32) | (unsigned)uni((int)lc));
+        }
+        LEAF8_CANDIDATE(a, 0, PLANAR);
+        LEAF8_CANDIDATE(a, 1, DC);
+        if (bestB < best) { // pack B's best stays (its reconstruction is in the tile already)
+            best = bestB;
+            best_mode = modeB;
+            best_cls = clsB;
+            eb = ebB;
+        } else {            // a candidate of pack A: its reconstruction from the server's park
+            const uint8_t* park = (const uint8_t*)srv.decw + kParkByte;
+            rec_put(0, q.tx + (lane & 7), q.ty + (lane >> 3), park[64 * win_ + lane]);
+            if (lane < 32) {
+                const int pl2 = lane >> 4, i2 = lane & 15;
+                rec_put(1 + pl2, (q.tx >> 1) + (i2 & 3), (q.ty >> 1) + (i2 >> 2), park[128 + 32 * win_ + lane]);
+            }
+            WSYNC();
+        }
+        lv_word_add(&SHT.lvb.job_ack);
     }
 #undef LEAF8_CANDIDATE
     r.vmin = best;
@@ -1737,7 +1898,6 @@ __device__ __forceinline__ bool leaf_step(const Ctx& c, LeafSF& s, const Res& r,
 // winner from the slot of the member that holds it, so all tiles agree again before the next block.
 // Quantisation is solo (every member walks its own trellis): between exchanges the members run freely.
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ const Lds& team_lds(const Ctx& c, int m) { return SHW[(WAVE & ~(kTeam - 1)) + m]; }
 
 // published result of member m in the exchange that just completed (parity par)
 __device__ __forceinline__ EvalParts xparts(const Ctx& c, int par, int m) {
@@ -2225,7 +2385,7 @@ __device__ __forceinline__ void lv_post_split(int L, float sp) {
 // restore_reconsts (block_splitter.rs:807-840, 1085-1145), with the saved planes kept in L2/HBM
 // instead of LDS.
 enum { T_START = 0, T_ENTER, T_NODE_LEAF, T_LEAF4_EMIT, T_LEAF4, T_LEAFC, T_REGEN_DONE, T_RETURN, T_FINAL_Z, T_FZ_TAIL, T_FZ_NEXT,
-       T_LV_UNIT, T_LV_LEAFDONE, T_LV_UP, T_SPLIT8 };
+       T_LV_UNIT, T_LV_LEAFDONE, T_LV_UP, T_SPLIT8, T_LV_SERVE };
 
 template <bool TEAM, bool D3>
 __device__ __forceinline__ bool ctu_step(Ctx& c, const Res& r, Req& q) {
@@ -2526,6 +2686,12 @@ __device__ __forceinline__ bool ctu_step(Ctx& c, const Res& r, Req& q) {
         case T_LV_UP: {
             if constexpr (TEAM && (WRENC_LEVELS_ALL_DEPTHS || D3)) { // the decisions this member takes part in now, deepest first
                 const int me = c.member, i = t.lv_i, dl = t.max_depth;
+                if (WRENC_SERVER && me == 0 && dl >= 2 && !t.lv_i) { // (lv_i of member 0: 1 = the server is through)
+                    cont = T_LV_SERVE;
+                    break;
+                }
+                if (WRENC_SERVER && me == 2 && me <= dl && i == 15) lv_word_add(&SHT.lvb.job_fin); // no more 8x8 leaves
+                if (WRENC_SERVER && D3 && me == 3 && i == 15) lv_word_add(&SHT.lvb.job4_fin);              // ... 4x4 leaves
                 if (me >= 2 && me <= dl) {
                     // an 8x8 node: decided against its split at max-split-depth 3, final at depth 2
                     const float d2 = dl == 3 ? lv_decide(c, 2, i) : (float)t.leaf.cost;
@@ -2555,6 +2721,69 @@ __device__ __forceinline__ bool ctu_step(Ctx& c, const Res& r, Req& q) {
                 t.level = 0;
                 cont = T_RETURN;
                 break;
+            }
+            }
+            break;
+        case T_LV_SERVE: {
+            if constexpr (TEAM && (WRENC_LEVELS_ALL_DEPTHS || D3)) {
+                // Member 0 between its 32x32 candidate and the CTU's decision: pack {planar, DC} of member 2's 8x8 leaves
+                // (leaf8_search, q.n & 16), one job at a time: wait for a job or for "no more jobs", wait until the
+                // previous job's results have been taken, run it.
+                if (LANE == 0) SHT.lvb.srv_ready = 1;
+                const bool two = D3 && t.max_depth == 3; // member 3 posts jobs too
+                const unsigned served8 = uni((int)lv_word(&SHT.lvb.job_done)), served4 = uni((int)lv_word(&SHT.lvb.job4_done));
+                int what = 0; // 1: a job of member 2, 3: of member 3, 2: both are through
+                if (LANE == 0) {
+                    int polls = 0;
+                    for (;;) {
+                        const unsigned p8 = lv_word(&SHT.lvb.job_posted), p4 = lv_word(&SHT.lvb.job4_posted);
+                        if (two && p4 > served4) { // (the shorter job first: member 3's level is the longer one)
+                            what = 3;
+                            break;
+                        }
+                        if (p8 > served8) {
+                            what = 1;
+                            break;
+                        }
+                        if (lv_word(&SHT.lvb.job_fin) != 0 && (!two || lv_word(&SHT.lvb.job4_fin) != 0) &&
+                            lv_word(&SHT.lvb.job_posted) == served8 && lv_word(&SHT.lvb.job4_posted) == served4) {
+                            what = 2;
+                            break;
+                        }
+                        __builtin_amdgcn_s_sleep(2);
+                        if (++polls > (1 << 23)) {
+                            SHT.lvb.pad_ = 1;
+                            what = 2;
+                            break;
+                        }
+                    }
+                }
+                what = uni(what);
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                if (what == 2) {
+                    t.lv_i = 1;
+                    cont = T_LV_UP;
+                    break;
+                }
+                if (what == 3) {
+                    lv_word_wait(&SHT.lvb.job4_ack, served4); // the previous results have been taken
+                    req_full(q, 1, uni((int)SHT.lvb.job4_bx), uni((int)SHT.lvb.job4_by), 2, 0, 0, false, true, false, false, false);
+                    q.kind = K_SERVE4;
+                    q.n = 1;
+                    q.stage = 0;
+                    q.tree = TREE_DUAL_LUMA;
+                    t.cont = T_LV_SERVE;
+                    return true;
+                }
+                lv_word_wait(&SHT.lvb.job_ack, served8); // the previous job's reconstructions are still in this wave's park
+                req_full(q, 3, uni((int)SHT.lvb.job_bx), uni((int)SHT.lvb.job_by), 3, 0, 0, false, true, false, false, false);
+                q.kind = K_LEAF8;
+                q.n = 16;
+                q.stage = 0;
+                q.tree = TREE_SINGLE;
+                q.fcur = 0.0f;
+                t.cont = T_LV_SERVE;
+                return true;
             }
             }
             break;
@@ -2612,6 +2841,7 @@ __device__ __forceinline__ void load_tables(Ctx c) {
     for (int i = threadIdx.x; i < 128; i += blockDim.x) ((int8_t*)SHT.fc)[i] = ((const CONST_AS int8_t*)c.k->fc)[i];
     if (threadIdx.x < 6) (&SHT.lvb.cnt[0][0])[threadIdx.x] = 0; // level schedule: the meeting points of this CTU's decisions
     if (threadIdx.x == 0) SHT.lvb.pad_ = 0;
+    if (threadIdx.x < 9) (&SHT.lvb.srv_ready)[threadIdx.x] = 0;
     __syncthreads();
 }
 
