@@ -162,8 +162,10 @@ int wrenc_gpu_encode_picture(wrenc_gpu_ctx* ctx, const uint8_t* y, const uint8_t
 /* How an encode call maps CTUs to wavefronts.  Results are identical (bit-exact) either way.
  *   WAVE: one wavefront per CTU, a workgroup = the same CTU of 4 pictures.  Highest throughput, but it needs
  *         hundreds of pictures in flight to fill the GPU (a picture offers only one anti-diagonal of CTUs at a time).
- *   TEAM: four wavefronts per CTU: the candidates of a leaf search that do not depend on each other
- *         (block_splitter.rs:887-898, 905-974) run side by side.  Shorter CTU latency, for calls with few pictures.
+ *   TEAM: four wavefronts per CTU.  After they have searched the CTU's 32x32 candidate together, each takes one level of
+ *         the quad-tree and runs ahead (a node's unsplit search and the search of everything below it read only neighbours
+ *         outside the node, block_splitter.rs:1081-1123); the levels meet at the split decisions, and the wavefront left
+ *         without a level serves candidate packs to the others.  Shorter CTU latency, for calls with few pictures.
  *   AUTO (default): decided per anti-diagonal of CTUs: TEAM while pictures x CTUs of the diagonal cannot fill the GPU
  *         with one wave each, WAVE beyond. */
 enum wrenc_gpu_schedule { WRENC_GPU_SCHEDULE_AUTO = 0, WRENC_GPU_SCHEDULE_WAVE = 1, WRENC_GPU_SCHEDULE_TEAM = 2 };

@@ -134,3 +134,48 @@ def test_synth_is_deterministic():
     y0, cb0, cr0 = synth.synth_frame(64, 64, 0)
     assert np.array_equal(g["y"], y0) and np.array_equal(g["cb"], cb0) and np.array_equal(g["cr"], cr0)
     assert len(h) == 64
+
+
+def test_expand_levels_is_the_inverse_of_the_compact_layout(built):
+    """wrenc_gpu_expand_levels (host only, no device): the compact read-back's layout -- one mask bit per picture-aligned
+    4x4 block of levels (luma plane, then Cb, then Cr, raster order of the blocks), the coded blocks' 16 levels row-major in
+    mask order -- rebuilt here from random sparse level planes and expanded back by the library."""
+    import ctypes as C
+    from wrenc_amd import gpu
+    lib = C.CDLL(gpu.LIB_PATH)
+    lib.wrenc_gpu_compact_mask_words.restype = C.c_size_t
+    lib.wrenc_gpu_compact_mask_words.argtypes = [C.c_int, C.c_int]
+    lib.wrenc_gpu_expand_levels.restype = None
+    lib.wrenc_gpu_expand_levels.argtypes = [C.c_int, C.c_int] + [C.c_void_p] * 5
+    rng = np.random.default_rng(31)
+    for w, h in ((64, 32), (96, 64), (32, 32)):
+        planes = []
+        for pw, ph in ((w, h), (w // 2, h // 2), (w // 2, h // 2)):
+            p = np.zeros((ph, pw), np.int16)
+            coded = rng.random((ph // 4, pw // 4)) < 0.3
+            for by, bx in zip(*np.nonzero(coded)):
+                blk = rng.integers(-300, 300, (4, 4)).astype(np.int16) * (rng.random((4, 4)) < 0.4)
+                blk[rng.integers(4), rng.integers(4)] = rng.integers(1, 900) * (1 if rng.random() < 0.5 else -1)   # really coded
+                p[4 * by:4 * by + 4, 4 * bx:4 * bx + 4] = blk
+            planes.append(p)
+        bits, payload = [], []
+        for p in planes:
+            ph, pw = p.shape
+            for by in range(ph // 4):
+                for bx in range(pw // 4):
+                    blk = p[4 * by:4 * by + 4, 4 * bx:4 * bx + 4]
+                    bits.append(bool(np.any(blk)))
+                    if bits[-1]:
+                        payload.append(blk.reshape(16))
+        words = lib.wrenc_gpu_compact_mask_words(w, h)
+        assert words == (len(bits) + 31) // 32 == ((w // 4) * (h // 4) * 3 // 2 + 31) // 32
+        mask = np.zeros(words, np.uint32)
+        for i, b in enumerate(bits):
+            if b:
+                mask[i >> 5] |= np.uint32(1) << np.uint32(i & 31)
+        pay = np.ascontiguousarray(np.stack(payload) if payload else np.zeros((1, 16), np.int16), np.int16)
+        out = [np.full_like(p, 7) for p in planes]     # (the library must clear what it does not code)
+        ptr = lambda a: a.ctypes.data_as(C.c_void_p)
+        lib.wrenc_gpu_expand_levels(w, h, ptr(mask), ptr(pay), ptr(out[0]), ptr(out[1]), ptr(out[2]))
+        for got, want in zip(out, planes):
+            assert np.array_equal(got, want)
