@@ -333,10 +333,21 @@ __device__ __forceinline__ void stage_org_leaf(const Ctx& c, int comps, int tx, 
 // reconstruction with the search's, keeps the tile and parks the prediction in global scratch.
 // A PACK of candidates evaluated side by side (dev_search.h, K_LEAF8) parks each candidate's prediction in LDS
 // instead: PRED_PARK, byte kParkByte + i of decw (behind the pack's trellis decisions).
-enum { PRED_SCRATCH = 0, PRED_TILE = 1, PRED_PARK = 2 };
+enum { PRED_SCRATCH = 0, PRED_TILE = 1, PRED_PARK = 2, PRED_PARK16 = 3 };
 constexpr int kParkByte = 160; // 144 bytes of decisions in front, 288 bytes of predictions (3 x (64 + 16 + 16)) behind
+// PRED_PARK16: a pack of TWO 16x16 candidates (K_LEAF16) has no one free region for its 768 bytes of predictions, but
+// three that add up to exactly that: the last 512 bytes of r1 (two candidates' residuals fill the first 1536; chunk
+// entries, levels and the inverse transform stay inside them) for the luma predictions, 128 bytes of r2 between the
+// scan-order coefficients (1536) and the leaf's originals (kOrgLeaf) for candidate 0's chroma pair, the last 128 bytes
+// of decw behind the pack's 384 bytes of decisions for candidate 1's.  park16(i) = the byte of sample index i of the
+// pack's layout (luma [cand][256], then chroma [cand][Cb | Cr][64]; nl = 256 x candidates).
+__device__ __forceinline__ uint8_t* park16(int i, int nl) {
+    if (i < nl) return (uint8_t*)SH.r1 + 1536 + i;
+    const int j = i - nl;
+    return j < 128 ? (uint8_t*)SH.r2 + 1536 + j : (uint8_t*)SH.decw + 384 + (j - 128);
+}
 template <bool full>
-__device__ __forceinline__ int emit_sample(const Ctx& c, int o, int i, int v, int pc, int x, int y, int to_tile) {
+__device__ __forceinline__ int emit_sample(const Ctx& c, int o, int i, int v, int pc, int x, int y, int to_tile, int nl = 0) {
     const int d = o - v;
     if (full) { // i already includes the block's base in r1 / the prediction scratch
         SH.r1[i] = (int16_t)d;
@@ -344,6 +355,8 @@ __device__ __forceinline__ int emit_sample(const Ctx& c, int o, int i, int v, in
             rec_put(pc, x, y, v);
         else if (to_tile == PRED_PARK)
             ((uint8_t*)SH.decw)[kParkByte + i] = (uint8_t)v;
+        else if (to_tile == PRED_PARK16)
+            *park16(i, nl) = (uint8_t)v;
         else
             c.pred_scratch[i] = (uint8_t)v;
     }
@@ -358,10 +371,11 @@ __device__ __forceinline__ int emit_sample(const Ctx& c, int o, int i, int v, in
 // Returns the lane's partial sum of |org - pred| (the SAD of block_splitter.rs:96-104).
 template <bool full>
 __device__ __forceinline__ int predict(Ctx c, int comp, int tx, int ty, int tlg, int mode, int rbase = 0,
-                                       int to_tile = PRED_TILE) {
+                                       int to_tile = PRED_TILE, int nl = 0) {
     c = uni(c);
     rbase = uni(rbase);
     to_tile = uni(to_tile);
+    nl = uni(nl);
     comp = uni(comp);
     tx = uni(tx);
     ty = uni(ty);
@@ -397,7 +411,7 @@ __device__ __forceinline__ int predict(Ctx c, int comp, int tx, int ty, int tlg,
                 v = (M24(ds, blk ? a1 : a0) >> (blk ? k1 : k0)) + (blk ? b1 : b0);
                 v = min(max(v, 0), 255);
             }
-            sad += emit_sample<full>(c, o, rbase + i, v, comp + blk, cx + x, cy + y, to_tile);
+            sad += emit_sample<full>(c, o, rbase + i, v, comp + blk, cx + x, cy + y, to_tile, nl);
         }
         WSYNC();
         return sad;
@@ -438,7 +452,7 @@ __device__ __forceinline__ int predict(Ctx c, int comp, int tx, int ty, int tlg,
             const int wl = pdpc_w(n_scale, x), wt = pdpc_w(n_scale, y);
             v = (int16_t)(M24(L[y + 1], wl) + M24(A[x], wt) + M24(64 - wt - wl, v) + 32) >> 6;
             v = min(max(v, 0), 255);
-            sad += emit_sample<full>(c, o, rbase + i, v, comp + blk, cx + x, cy + y, to_tile);
+            sad += emit_sample<full>(c, o, rbase + i, v, comp + blk, cx + x, cy + y, to_tile, nl);
         }
         WSYNC();
         return sad;
@@ -527,7 +541,7 @@ __device__ __forceinline__ int predict(Ctx c, int comp, int tx, int ty, int tlg,
             v = (int16_t)(M24(rl, wl) + M24(rt, wt) + M24(64 - wt - wl, v) + 32) >> 6;
             v = min(max(v, 0), 255);
         }
-        sad += emit_sample<full>(c, o, rbase + i, v, comp + blk, cx + x, cy + y, to_tile);
+        sad += emit_sample<full>(c, o, rbase + i, v, comp + blk, cx + x, cy + y, to_tile, nl);
     }
     WSYNC();
     return sad;

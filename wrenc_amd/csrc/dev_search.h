@@ -1233,10 +1233,9 @@ __device__ __forceinline__ Res leaf8_search(const Ctx& c, const Req& q, int* ove
 // what r1 holds; a pack goes through prediction, transforms and reconstruction block after block as the single
 // evaluation does, and through ONE trellis pass for its six chains (quantize_pk<4>: the two luma chains side by side,
 // the four chroma chains riding along, this wave alone, no workgroup barrier) -- three walks of 256 steps per leaf
-// instead of five pooled ones, and one control step instead of six.  LDS has no room to park two candidates'
-// predictions (768 B), so they go to this wave's kilobyte of global scratch (PRED_SCRATCH, the final pass's
-// buffer; every lane re-reads exactly the bytes it wrote); the running best candidate's reconstruction goes from there
-// to the tile when its pack is done.  The CCLM part follows as its own request (leaf_step, C_WINNER): its DM-chroma
+// instead of five pooled ones, and one control step instead of six.  The two candidates' predictions (768 B) are parked in
+// the three corners of LDS the pack leaves free (PRED_PARK16, dev_predict.h); the running best candidate's reconstruction
+// goes from there to the tile when its pack is done.  The CCLM part follows as its own request (leaf_step, C_WINNER): its DM-chroma
 // restore takes the winner from slot 0, where the request after this one saves it.
 // ---------------------------------------------------------------------------
 struct Pack16Out {
@@ -1247,23 +1246,22 @@ __device__ __forceinline__ Pack16Out pack16_eval(const Ctx& c, const Req& q, int
     Pack16Out o;
     const int lane = lane_fresh();
     const int nL = 256 * nc;
-    GLOBAL_AS uint8_t* park = (GLOBAL_AS uint8_t*)c.pred_scratch;
     const uint8_t* org = (const uint8_t*)SH.r2 + kOrgLeaf; // luma 256 | Cb 64 | Cr 64
     PROF_MARK(t0_);
 #pragma unroll 1
     for (int cd = 0; cd < nc; ++cd) {
         const int mode = cd == 0 ? m0 : m1;
         if (mode != kNoMode) {
-            predict<true>(c, 0, q.tx, q.ty, 4, mode, 256 * cd, PRED_SCRATCH);
-            predict<true>(c, 1, q.tx, q.ty, 4, mode, nL + 128 * cd, PRED_SCRATCH);
+            predict<true>(c, 0, q.tx, q.ty, 4, mode, 256 * cd, PRED_PARK16, nL);
+            predict<true>(c, 1, q.tx, q.ty, 4, mode, nL + 128 * cd, PRED_PARK16, nL);
         } else { // a candidate outside 2..66 rides along as a zero block
             for (int i = lane; i < 256; i += 64) {
                 SH.r1[256 * cd + i] = 0;
-                park[256 * cd + i] = 0;
+                *park16(256 * cd + i, nL) = 0;
             }
             for (int i = lane; i < 128; i += 64) {
                 SH.r1[nL + 128 * cd + i] = 0;
-                park[nL + 128 * cd + i] = 0;
+                *park16(nL + 128 * cd + i, nL) = 0;
             }
             WSYNC();
         }
@@ -1296,18 +1294,20 @@ __device__ __forceinline__ Pack16Out pack16_eval(const Ctx& c, const Req& q, int
 #pragma unroll
             for (int kq = 0; kq < 4; ++kq) {
                 const int i = lane + 64 * kq;
-                int rec = (int16_t)((int)park[256 * cd + i] + (int)SH.r1[256 * cd + i]); // pred as i16 + res, clamp (:178)
+                uint8_t* pk = park16(256 * cd + i, nL);
+                int rec = (int16_t)((int)*pk + (int)SH.r1[256 * cd + i]); // pred as i16 + res, clamp (:178)
                 rec = min(max(rec, 0), 255);
-                park[256 * cd + i] = (uint8_t)rec;
+                *pk = (uint8_t)rec;
                 const int d = rec - (int)org[i];
                 py += M24(d, d);
             }
 #pragma unroll
             for (int kq = 0; kq < 2; ++kq) {
                 const int i = lane + 64 * kq;
-                int rec = (int16_t)((int)park[nL + 128 * cd + i] + (int)SH.r1[nL + 128 * cd + i]);
+                uint8_t* pk = park16(nL + 128 * cd + i, nL);
+                int rec = (int16_t)((int)*pk + (int)SH.r1[nL + 128 * cd + i]);
                 rec = min(max(rec, 0), 255);
-                park[nL + 128 * cd + i] = (uint8_t)rec;
+                *pk = (uint8_t)rec;
                 const int d = rec - (int)org[256 + i];
                 pc += M24(d, d);
             }
@@ -1321,19 +1321,18 @@ __device__ __forceinline__ Pack16Out pack16_eval(const Ctx& c, const Req& q, int
     return o;
 }
 
-// a pack candidate's reconstruction from the parking scratch into the tile (luma 16x16, Cb and Cr 8x8)
+// a pack candidate's reconstruction from its park (park16) into the tile (luma 16x16, Cb and Cr 8x8)
 __device__ __forceinline__ void pack16_to_tile(const Ctx& c, const Req& q, int nc, int cd) {
     const int lane = lane_fresh();
-    const GLOBAL_AS uint8_t* park = (const GLOBAL_AS uint8_t*)c.pred_scratch;
 #pragma unroll
     for (int kq = 0; kq < 4; ++kq) {
         const int i = lane + 64 * kq;
-        rec_put(0, q.tx + (i & 15), q.ty + (i >> 4), park[256 * cd + i]);
+        rec_put(0, q.tx + (i & 15), q.ty + (i >> 4), *park16(256 * cd + i, 256 * nc));
     }
 #pragma unroll
     for (int kq = 0; kq < 2; ++kq) {
         const int i = lane + 64 * kq;
-        rec_put(1 + (i >> 6), (q.tx >> 1) + (i & 7), (q.ty >> 1) + ((i & 63) >> 3), park[256 * nc + 128 * cd + i]);
+        rec_put(1 + (i >> 6), (q.tx >> 1) + (i & 7), (q.ty >> 1) + ((i & 63) >> 3), *park16(256 * nc + 128 * cd + i, 256 * nc));
     }
     WSYNC();
 }
