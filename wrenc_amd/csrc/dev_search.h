@@ -1938,6 +1938,9 @@ __device__ __forceinline__ void team_publish(const Req& q, const Res& r, int par
 }
 
 enum { TC_START = 0, TC_A, TC_D, TC_E, TC_F, TC_DONE, TC_DC_START, TC_DC_A, TC_DC_B, TC_L4, TC_L8A, TC_L8B };
+// round 2's team stages for the nodes below the CTU (8x8 and 4x4 leaves, the chroma leaf): only built when the level
+// schedule does not take those nodes
+#define WRENC_OLD_TEAM_SMALL_LEAVES (!(WRENC_LEVELS && WRENC_LEVELS_ALL_DEPTHS))
 
 // a member with nothing to evaluate in a stage
 __device__ __forceinline__ void team_idle(Req& q) {
@@ -1968,6 +1971,7 @@ __device__ __forceinline__ bool leaf_step_team(const Ctx& c, CtuSt& t, LeafSF& s
     for (;;) {
         switch (cont) {
         case TC_START: // stage A: planar | DC | the directional SAD search (:887-973)
+#if WRENC_OLD_TEAM_SMALL_LEAVES // (the level schedule takes every node below the CTU: these stages of round 2's team are unreachable)
             if (leaf_is_leaf4(s)) {
                 // a 4x4 luma leaf: the packed search in two halves side by side -- member 0 planar and DC, member 1
                 // the SAD search and {cm, cm - 1, cm + 1} -- one exchange, then everybody pulls the winner
@@ -1993,6 +1997,7 @@ __device__ __forceinline__ bool leaf_step_team(const Ctx& c, CtuSt& t, LeafSF& s
                 q.xchg = true;
                 return true;
             }
+#endif
             if (me == 0) {
                 leaf_full(s, q, both, PLANAR, PLANAR, true, TC_A, true);
             } else if (me == 1) {
@@ -2005,6 +2010,7 @@ __device__ __forceinline__ bool leaf_step_team(const Ctx& c, CtuSt& t, LeafSF& s
             s.cont = TC_A;
             q.xchg = true;
             return true;
+#if WRENC_OLD_TEAM_SMALL_LEAVES // (the level schedule takes every node below the CTU: these stages of round 2's team are unreachable)
         case TC_L4: {
             // first minimum of [planar, DC | cm, cm - 1, cm + 1]: the second half wins only if strictly cheaper
             const float va = xvmin(c, par, 0), vb = xvmin(c, par, 1);
@@ -2065,6 +2071,7 @@ __device__ __forceinline__ bool leaf_step_team(const Ctx& c, CtuSt& t, LeafSF& s
             team_defer_pull(t, s, 3, holder);
             return false;
         }
+#endif
         case TC_A: {
             const EvalParts e0 = xparts(c, par, 0), e1 = xparts(c, par, 1);
             const float v0 = uni_f(assemble_cost(c, tree, 0, PLANAR, e0));
@@ -2204,6 +2211,7 @@ __device__ __forceinline__ bool leaf_step_team(const Ctx& c, CtuSt& t, LeafSF& s
         case TC_DONE:
             return false;
         // ---- DUAL_TREE_CHROMA leaf (:794-885): the three CCLM probes and the DM evaluation side by side ----
+#if WRENC_OLD_TEAM_SMALL_LEAVES // (the level schedule takes every node below the CTU: these stages of round 2's team are unreachable)
         case TC_DC_START: // the three CCLM probes and the DM evaluation side by side
             if (me < 3) {
                 leaf_sadlist(s, q, 2, 1, (uint32_t)(me == 0 ? LT_CCLM : (me == 1 ? T_CCLM : L_CCLM)), 0, 0, 0, false, TC_DC_A);
@@ -2227,7 +2235,10 @@ __device__ __forceinline__ bool leaf_step_team(const Ctx& c, CtuSt& t, LeafSF& s
             q.xchg = true;
             return true;
         }
-        default: { // TC_DC_B
+#endif
+        default: // (TC_DC_B)
+#if WRENC_OLD_TEAM_SMALL_LEAVES // (the level schedule takes every node below the CTU: these stages of round 2's team are unreachable)
+        {
             const float c0 = uni_f(assemble_chroma_cost(c, s.cclm_mode, xparts(c, par, 0)));
             const float dm_cost = s.cur_cost;
             if (c.write && LANE == 0) {
@@ -2242,6 +2253,9 @@ __device__ __forceinline__ bool leaf_step_team(const Ctx& c, CtuSt& t, LeafSF& s
             team_defer_pull(t, s, 2, dm ? 3 : 0); // member 3 evaluated DM, member 0 the CCLM mode
             return false;
         }
+#else
+            return false;
+#endif
         }
     }
 }
