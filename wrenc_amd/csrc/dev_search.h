@@ -499,8 +499,12 @@ __device__ __forceinline__ int nb_luma_mode(Ctx c, int x, int y, bool* exists) {
 
 // mode class index for the header-bit table: 0 planar, 1..5 mpm_idx, 6..66 remainder
 // (ctu.rs:1498-1635)
-__device__ __forceinline__ int mpm_class(const Ctx& c, int bx, int by, int lg, int mode) {
-    if (mode == PLANAR) return 0;
+// The MPM list of a block (ctu.rs:1498-1635) depends on the block alone, not on the candidate mode: the packed leaf
+// searches derive it once per leaf (mpm_list) and classify their five candidates against it (mpm_class_of).
+struct MpmList {
+    int k0, k1, k2, k3, k4;
+};
+__device__ __forceinline__ MpmList mpm_list(const Ctx& c, int bx, int by, int lg) {
     const int n = 1 << lg;
     bool le, ae;
     int left = nb_luma_mode(c, bx - 1, by + n - 1, &le);
@@ -558,14 +562,29 @@ __device__ __forceinline__ int mpm_class(const Ctx& c, int bx, int by, int lg, i
         k3 = 46;
         k4 = 54;
     }
-    if (k0 == mode) return 1;
-    if (k1 == mode) return 2;
-    if (k2 == mode) return 3;
-    if (k3 == mode) return 4;
-    if (k4 == mode) return 5;
+    MpmList l;
+    l.k0 = k0;
+    l.k1 = k1;
+    l.k2 = k2;
+    l.k3 = k3;
+    l.k4 = k4;
+    return l;
+}
+// mode class index for the header-bit table: 0 planar, 1..5 mpm_idx, 6..66 remainder
+__device__ __forceinline__ int mpm_class_of(const MpmList& l, int mode) {
+    if (mode == PLANAR) return 0;
+    if (l.k0 == mode) return 1;
+    if (l.k1 == mode) return 2;
+    if (l.k2 == mode) return 3;
+    if (l.k3 == mode) return 4;
+    if (l.k4 == mode) return 5;
     // remainder = mode - 1 - #(candidates below mode) after sorting (:1613-1628)
-    const int smaller = (k0 < mode) + (k1 < mode) + (k2 < mode) + (k3 < mode) + (k4 < mode);
+    const int smaller = (l.k0 < mode) + (l.k1 < mode) + (l.k2 < mode) + (l.k3 < mode) + (l.k4 < mode);
     return 6 + (mode - 1 - smaller);
+}
+__device__ __forceinline__ int mpm_class(const Ctx& c, int bx, int by, int lg, int mode) {
+    if (mode == PLANAR) return 0;
+    return mpm_class_of(mpm_list(c, bx, by, lg), mode);
 }
 
 __device__ __forceinline__ float rd_cost(unsigned long long ssd, long long level, float lambda) {
@@ -703,6 +722,7 @@ __device__ __forceinline__ Res leaf4_search(const Ctx& c, const Req& q, int* ove
     int best_mode = PLANAR;
     // one candidate of a pack that has come back: its cost, the trace record, the running first minimum; returns
     // whether it is the new best
+    const MpmList mpl_ = mpm_list(c, q.tx, q.ty, 2);
 #define LEAF4_CANDIDATE(P, B, M)                                                                                       \
     do {                                                                                                               \
         EvalParts e_;                                                                                                  \
@@ -710,7 +730,7 @@ __device__ __forceinline__ Res leaf4_search(const Ctx& c, const Req& q, int* ove
         e_.ssd_c = 0;                                                                                                  \
         e_.lvl_y = (P).lvl[B];                                                                                         \
         e_.lvl_c = 0;                                                                                                  \
-        const int cls_ = mpm_class(c, q.tx, q.ty, 2, (M));                                                             \
+        const int cls_ = mpm_class_of(mpl_, (M));                                                                      \
         const float val_ = uni_f(assemble_cost(c, TREE_DUAL_LUMA, cls_, (M), e_));                                     \
         if (c.trace && lane == 0) /* (team schedule: each half is traced by the member that runs it) */                \
             TRACE_REC(c.ctu_x + q.tx, c.ctu_y + q.ty, 2, TREE_DUAL_LUMA, 1, (M), (M), __float_as_int(val_));           \
@@ -1035,6 +1055,7 @@ __device__ __forceinline__ Res leaf8_search(const Ctx& c, const Req& q, int* ove
     eb.ssd_y = eb.ssd_c = 0;
     eb.lvl_y = eb.lvl_c = 0;
     bool first_ = true;
+    const MpmList mpl_ = mpm_list(c, q.tx, q.ty, 3);
 #define LEAF8_CANDIDATE(P, B, M)                                                                                       \
     do {                                                                                                               \
         EvalParts e_;                                                                                                  \
@@ -1042,7 +1063,7 @@ __device__ __forceinline__ Res leaf8_search(const Ctx& c, const Req& q, int* ove
         e_.ssd_c = (P).ssd_c[B];                                                                                       \
         e_.lvl_y = (P).lvl_y[B];                                                                                       \
         e_.lvl_c = (P).lvl_c[B];                                                                                       \
-        const int cls_ = mpm_class(c, q.tx, q.ty, 3, (M));                                                             \
+        const int cls_ = mpm_class_of(mpl_, (M));                                                                      \
         const float val_ = uni_f(assemble_cost(c, TREE_SINGLE, cls_, (M), e_));                                        \
         if (c.trace && lane == 0) /* (team schedule: each part is traced by the member that runs it) */                \
             TRACE_REC(c.ctu_x + q.tx, c.ctu_y + q.ty, 3, TREE_SINGLE, 1, (M), (M), __float_as_int(val_));              \
@@ -1349,6 +1370,7 @@ __device__ __forceinline__ Res leaf16_search(const Ctx& c, const Req& q, int* ov
     eb.ssd_y = eb.ssd_c = 0;
     eb.lvl_y = eb.lvl_c = 0;
     bool first_ = true;
+    const MpmList mpl_ = mpm_list(c, q.tx, q.ty, 4);
 #define LEAF16_CANDIDATE(P, B, M)                                                                                      \
     do {                                                                                                               \
         EvalParts e_;                                                                                                  \
@@ -1356,7 +1378,7 @@ __device__ __forceinline__ Res leaf16_search(const Ctx& c, const Req& q, int* ov
         e_.ssd_c = (P).ssd_c[B];                                                                                       \
         e_.lvl_y = (P).lvl_y[B];                                                                                       \
         e_.lvl_c = (P).lvl_c[B];                                                                                       \
-        const int cls_ = mpm_class(c, q.tx, q.ty, 4, (M));                                                             \
+        const int cls_ = mpm_class_of(mpl_, (M));                                                                      \
         const float val_ = uni_f(assemble_cost(c, TREE_SINGLE, cls_, (M), e_));                                        \
         if (c.trace && lane == 0)                                                                                      \
             TRACE_REC(c.ctu_x + q.tx, c.ctu_y + q.ty, 4, TREE_SINGLE, 1, (M), (M), __float_as_int(val_));              \
