@@ -175,6 +175,10 @@ int wrenc_gpu_last_schedule(const wrenc_gpu_ctx* ctx); /* what the most recent e
  * device holds, CUs x waves per CU), so that a SMALL encode call mixes TEAM and WAVE diagonals as a big one does on
  * the real figure (tests/test_gpu_groups.py).  slots <= 0 restores the device's value.  Results do not depend on it. */
 int wrenc_gpu_test_set_wave_slots(wrenc_gpu_ctx* ctx, long long slots);
+/* Test entry: how many workgroups since context creation found the scratch partition of their XCD full and took a
+ * region of the shared overflow partition instead (wrenc_gpu.hip, acquire_scratch).  0 on MI355X: the saved
+ * reconstructions of the search then stay behind the L2 of the XCD that wrote them.  Waits for the device. */
+int wrenc_gpu_test_scratch_overflows(wrenc_gpu_ctx* ctx, long long* count);
 
 /* Per-launch timing (two HIP events around every kernel launch) is OFF by default: the product path
  * (CLI, native program) never reads it.  bench.py / profiling switch it on.  While it is on, an encode

@@ -141,3 +141,26 @@ def test_schedules_agree_at_full_size(built, w, h, depth):
         for k in KEYS + ("ctu_cost",):
             assert np.array_equal(recs[1][s][k], recs[2][s][k]), (s, k)
     assert bs.write_picture(w, h, qp, 0, recs[1][0]) == bs.write_picture(w, h, qp, 0, recs[2][0])
+
+
+@pytest.mark.parametrize("schedule", [1, 2])
+def test_a_full_gpu_keeps_its_scratch_behind_the_xcds_own_l2(built, schedule):
+    """Enough pictures in flight to have every CU hold its five workgroups: each workgroup takes its scratch region
+    (the saved reconstructions of the search) from the partition of the XCD it runs on, none has to fall back to the
+    shared overflow partition (include/wrenc_gpu.h, wrenc_gpu_test_scratch_overflows), the final pass reproduces the
+    search everywhere, and the same input gives the same record in the first and in the last slot."""
+    from wrenc_amd import gpu, synth
+    w, h, qp, depth, n = 1920, 1088, 32, 2, 96
+    frames = [synth.synth_textured_frame(w, h, 7), synth.synth_frame(w, h, 2)]
+    enc = gpu.Encoder(w, h, qp=qp, max_split_depth=depth, n_slots=n, schedule=schedule)
+    for s in range(n):
+        enc.upload(s, *frames[0 if s in (0, n - 1) else 1 - (s & 1)])
+    for _ in range(2):
+        enc.encode(0, n)
+    enc.sync()
+    assert enc.final_pass_mismatches() == 0
+    assert enc.test_scratch_overflows() == 0
+    a, b = enc.download(0), enc.download(n - 1)
+    enc.close()
+    for k in KEYS + ("ctu_cost",):
+        assert np.array_equal(a[k], b[k]), k

@@ -52,12 +52,14 @@ struct DevConst {
 #define AS_GLOBAL(T, p) ((GLOBAL_AS T*)(p))
 #define LDS_AS __attribute__((address_space(3)))
 
-// Per-wave global scratch: 1 KB of prediction bytes, then kReconSlots saved reconstructions
-// (slot 0: best candidate of the running leaf; 1 + level: unsplit candidate of the open node at
-// that tree level), each 1024 B luma + 2 x 256 B chroma.
+// Per-wave global scratch: 1 KB of prediction bytes (final pass), then kReconSlots saved reconstructions (slot 0: best
+// candidate of the running leaf, up to 32x32; 1 + level: unsplit candidate of the open node at that tree level, i.e.
+// 32x32, 16x16, 8x8), each the block's luma samples followed by its Cb and Cr samples, back to back: 36 cache lines per
+// wave, so that the regions of the workgroups resident on an XCD fit its L2 (wrenc_gpu.hip, acquire_scratch).
 constexpr int kReconSlots = 4;
 constexpr int kSlotBytes = 1536;
-constexpr int kWaveScratch = 1024 + kReconSlots * kSlotBytes;
+__host__ __device__ constexpr int slot_offset(int slot) { return slot < 2 ? slot * kSlotBytes : (slot == 2 ? 2 * kSlotBytes : 2 * kSlotBytes + 384); }
+constexpr int kWaveScratch = 1024 + 2 * kSlotBytes + 384 + 128;
 
 // One picture's device buffers.
 // Layout of the two CTU-granular buffers of a picture (what one CTU needs sits in whole cache lines of its own;

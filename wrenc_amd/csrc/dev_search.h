@@ -185,7 +185,8 @@ __device__ __forceinline__ void copy_block(const Ctx& c, int mode, int comps, in
         __syncthreads(); // nobody writes its tile again before every member has pulled
         return;
     }
-    GLOBAL_AS uint32_t* g = (GLOBAL_AS uint32_t*)(c.slots + slot * kSlotBytes);
+    GLOBAL_AS uint32_t* g = (GLOBAL_AS uint32_t*)(c.slots + slot_offset(slot));
+    const int cbase = 1 << (2 * tlg - 2); // the chroma planes follow the block's luma words
     if (comps & 1) {
         const int words = 1 << (2 * tlg - 2);
         for (int w = LANE; w < words; w += 64) {
@@ -206,9 +207,9 @@ __device__ __forceinline__ void copy_block(const Ctx& c, int mode, int comps, in
             const int row = (4 * ww) >> lg, col = (4 * ww) & ((1 << lg) - 1);
             uint32_t* l = (uint32_t*)&SH.recC[pl][((ty >> 1) + row) * 20 + (tx >> 1) + col + 4];
             if (mode == COPY_SAVE)
-                g[256 + pl * 64 + ww] = *l;
+                g[cbase + w] = *l;
             else
-                *l = g[256 + pl * 64 + ww];
+                *l = g[cbase + w];
         }
     }
     WSYNC();

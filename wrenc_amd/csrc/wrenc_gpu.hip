@@ -26,29 +26,52 @@ using namespace wrenc;
 // ---------------------------------------------------------------------------
 // kernels
 // ---------------------------------------------------------------------------
-// scratch regions for resident workgroups: 16384 / WPB = 4096 regions of WPB x kWaveScratch bytes (64 bitmap words of
-// 64 bits), against kWorkgroupsPerCU x 256 CUs = 1280 workgroups resident at once
-constexpr int kScratchSlots = 16384 / WPB; // >= the workgroups resident at once (a power of two, >= 64)
+// Scratch regions for resident workgroups (WPB x kWaveScratch bytes each: the saved reconstructions of dev_search.h
+// copy_block), handed out through a bitmap.  The pool covers the workgroups that can be resident at once, not the
+// ones of a launch, and it is PARTITIONED BY XCD: a workgroup takes the lowest free region of the partition of the XCD
+// it runs on (s_getreg XCC_ID).  The regions in use on an XCD are then the same 160 or so (32 CUs x kWorkgroupsPerCU)
+// for the whole run, written and re-read through that XCD's own L2 only: about 2 MB that can stay in the 4 MB L2
+// instead of going out to the fabric with every save, and no other L2 ever holds a line of them, so giving a region
+// back needs no L2 write-back.  (Round 2 picked a region anywhere in a pool of 4096 from a hash of the workgroup
+// index and ran __threadfence() = buffer_wbl2 sc1 + buffer_inv sc1 at every workgroup's end: every saved
+// reconstruction went out to memory.)  A region is only ever used by one workgroup at a time and nothing is read
+// that the same workgroup did not write, so its contents need no hand-over.
+// Should a partition ever be full (another device, another occupancy) a workgroup takes a region of the OVERFLOW
+// partition, which any XCD may use and whose users write their L2 lines back before they release it, as round 2 did;
+// the word behind the bitmap counts how often that happened (wrenc_gpu_test_scratch_overflows: 0 on MI355X).
+constexpr int kXcdMax = 8;
+constexpr int kRegionsPerXcd = 256;    // whole bitmap words; >= CUs per XCD x kWorkgroupsPerCU (32 x 5 = 160)
+constexpr int kAffineRegions = kXcdMax * kRegionsPerXcd;
+constexpr int kOverflowRegions = 2048; // >= every workgroup that can be resident, should XCC_ID not tell them apart
+constexpr int kScratchSlots = kAffineRegions + kOverflowRegions;
+constexpr int kSlotMapWords = kScratchSlots / 64 + 1; // + the overflow counter
 
-// Per-workgroup global scratch comes from a pool of kScratchSlots regions handed out through a
-// bitmap: the pool covers the workgroups that can be resident at once (kWorkgroupsPerCU per CU), not the ones
-// of a launch, so the scratch that is live stays small enough to live in L2 / Infinity Cache
-// whatever the batch size.  A slot is only ever used by one workgroup at a time and nothing is
-// read that the same workgroup did not write, so its contents need no hand-over.
-// (The slot number travels through a cell of wave 0's LDS that the search only uses later.)
+__device__ __forceinline__ int xcc_id() {
+    // hwreg(HW_REG_XCC_ID = 20, offset 0, size 4): the XCD this wave runs on
+    return (int)(__builtin_amdgcn_s_getreg(20 | (0 << 6) | ((4 - 1) << 11)) & (kXcdMax - 1));
+}
+// the lowest free region of bitmap words [w0, w0 + nw), or -1 if they are all taken
+__device__ __forceinline__ int take_region(unsigned long long* slot_map, unsigned w0, unsigned nw) {
+    for (unsigned w = w0; w < w0 + nw; ++w) {
+        unsigned long long cur = __hip_atomic_load(&slot_map[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        while (~cur) {
+            const int b = __ffsll((unsigned long long)~cur) - 1;
+            const unsigned long long bit = 1ULL << b;
+            const unsigned long long old = atomicOr(&slot_map[w], bit);
+            if (!(old & bit)) return (int)(w * 64 + b);
+            cur = old; // somebody else got it: look again in what the word held then
+        }
+    }
+    return -1;
+}
+// (The region number travels through a cell of wave 0's LDS that the search only uses later.)
 __device__ __forceinline__ int acquire_scratch(unsigned long long* slot_map) {
     if (threadIdx.x == 0) {
-        unsigned w = ((blockIdx.x * 2654435761u) >> 16) & (kScratchSlots / 64 - 1); // start word
-        int slot = -1;
-        while (slot < 0) {
-            const unsigned long long cur = __hip_atomic_load(&slot_map[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (~cur) {
-                const int b = __ffsll((unsigned long long)~cur) - 1;
-                const unsigned long long bit = 1ULL << b;
-                if (!(atomicOr(&slot_map[w], bit) & bit)) slot = (int)(w * 64 + b);
-            } else {
-                w = (w + 1) & (kScratchSlots / 64 - 1);
-            }
+        int slot = take_region(slot_map, (unsigned)xcc_id() * (kRegionsPerXcd / 64), kRegionsPerXcd / 64);
+        if (slot < 0) {
+            atomicAdd(&slot_map[kScratchSlots / 64], 1ULL);
+            // the overflow partition has a region for every workgroup that can be resident: a free one turns up
+            while (slot < 0) slot = take_region(slot_map, kAffineRegions / 64, kOverflowRegions / 64);
         }
         SHW[0].q_istar[0] = slot;
     }
@@ -57,9 +80,9 @@ __device__ __forceinline__ int acquire_scratch(unsigned long long* slot_map) {
     __syncthreads(); // everybody has read the cell before the search may overwrite it
     return scratch_slot;
 }
-// give the scratch slot back once every wave's stores to it are out
+// give the scratch region back once every wave is through with it
 __device__ __forceinline__ void release_scratch(unsigned long long* slot_map, int scratch_slot) {
-    __threadfence();
+    if (scratch_slot >= kAffineRegions) __threadfence(); // overflow partition: the next user may sit behind another L2
     __syncthreads();
     if (threadIdx.x == 0) atomicAnd(&slot_map[scratch_slot >> 6], ~(1ULL << (scratch_slot & 63)));
 }
@@ -980,8 +1003,8 @@ int wrenc_gpu_encode(wrenc_gpu_ctx* ctx, int first_slot, int n_pictures) {
     const int n_lanes = total_groups < kEncodeLanes ? total_groups : kEncodeLanes;
     if (!ctx->d_pred_scratch) {
         HIP_TRY(ctx, hipMalloc((void**)&ctx->d_pred_scratch, (size_t)kScratchSlots * WPB * kWaveScratch));
-        HIP_TRY(ctx, hipMalloc((void**)&ctx->d_slot_map, kScratchSlots / 8));
-        HIP_TRY(ctx, hipMemset(ctx->d_slot_map, 0, kScratchSlots / 8));
+        HIP_TRY(ctx, hipMalloc((void**)&ctx->d_slot_map, kSlotMapWords * 8));
+        HIP_TRY(ctx, hipMemset(ctx->d_slot_map, 0, kSlotMapWords * 8));
     }
     const bool timed = ctx->stats_enabled;
     if (timed) {
@@ -997,7 +1020,7 @@ int wrenc_gpu_encode(wrenc_gpu_ctx* ctx, int first_slot, int n_pictures) {
     // end).  A kernel that was aborted would leave its bits set for good, so the map is cleared whenever no
     // encode call is in flight (the last call's completion event has been reached).
     if (ctx->last_done == nullptr || hipEventQuery(ctx->last_done) == hipSuccess)
-        HIP_TRY(ctx, hipMemsetAsync(ctx->d_slot_map, 0, kScratchSlots / 8, ctx->stream));
+        HIP_TRY(ctx, hipMemsetAsync(ctx->d_slot_map, 0, kScratchSlots / 8, ctx->stream)); // (not the overflow counter)
     if (ctx->uploads_pending) {
         HIP_TRY(ctx, hipEventRecord(ctx->ev_uploaded, ctx->copy_stream));
         HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_uploaded, 0));
@@ -1295,6 +1318,18 @@ int wrenc_gpu_last_schedule(const wrenc_gpu_ctx* ctx) { return ctx ? ctx->last_s
 int wrenc_gpu_test_set_wave_slots(wrenc_gpu_ctx* ctx, long long slots) {
     if (!ctx) return WRENC_GPU_EINVAL;
     ctx->wave_slots = slots > 0 ? slots : ctx->device_wave_slots;
+    return WRENC_GPU_OK;
+}
+
+int wrenc_gpu_test_scratch_overflows(wrenc_gpu_ctx* ctx, long long* count) {
+    if (!ctx || !count) return WRENC_GPU_EINVAL;
+    *count = 0;
+    if (!ctx->d_slot_map) return WRENC_GPU_OK; // no encode call yet
+    HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
+    HIP_TRY(ctx, hipDeviceSynchronize());
+    unsigned long long v = 0;
+    HIP_TRY(ctx, hipMemcpy(&v, ctx->d_slot_map + kScratchSlots / 64, sizeof(v), hipMemcpyDeviceToHost));
+    *count = (long long)v;
     return WRENC_GPU_OK;
 }
 
