@@ -201,9 +201,10 @@ typedef struct wrenc_gpu_kernel_stats {
 } wrenc_gpu_kernel_stats;
 int wrenc_gpu_last_encode_kernel_stats(wrenc_gpu_ctx* ctx, wrenc_gpu_kernel_stats out[2]);
 
-/* Samples where the final pass reconstruction differed from what the search left
- * (expected 0; SURVEY.md 3.4 "treat as a property to test"), accumulated since
- * context creation. */
+/* Transform blocks (a luma block, or a Cb + Cr pair) whose final-pass reconstruction differed from what
+ * the search left in their place (expected 0; SURVEY.md 3.4 "treat as a property to test"), accumulated
+ * since context creation.  Compared through a position-weighted checksum of the block's samples: a
+ * change of any one sample is always seen. */
 int wrenc_gpu_final_pass_mismatches(wrenc_gpu_ctx* ctx, long long* count);
 
 /* ---- kernel-level entry points (parity tests of the building blocks) ----

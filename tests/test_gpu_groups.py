@@ -95,3 +95,36 @@ def test_auto_schedule_mixing_team_and_wave_diagonals(built, n_pictures, w, h, q
     enc.sync()
     assert enc.last_schedule() == 2                          # the device's own figure: all teams at this size
     enc.close()
+
+
+@pytest.mark.parametrize("schedule", [1, 2])
+@pytest.mark.parametrize("w,h,qp,depth", [(96, 64, 32, 2), (64, 64, 27, 3), (64, 96, 37, 0)])
+def test_slots_reused_by_pictures_with_other_zero_blocks(built, w, h, qp, depth, schedule):
+    """The final pass writes the levels of the transform blocks that have any and zeroes only the blocks that held
+    levels of the slot's previous picture (PicBufs::lev_dirty): rounds of pictures with very different sets of zero
+    blocks (flat, noise, stripes, smooth, textured, rotated over the slots; compact read-back in between) must each
+    read back, dense and compact, exactly as the oracle's record -- a level left over from an earlier round, or a
+    block cleared that the round did code, shows as a difference."""
+    from wrenc_amd import gpu, synth
+    from oracle import pyoracle as po
+    kinds = [lambda i: content("flat", w, h, 7 + i), lambda i: content("noise", w, h, 11 + i),
+             lambda i: synth.synth_frame(w, h, i), lambda i: synth.synth_textured_frame(w, h, i),
+             lambda i: content("stripes20", w, h, 3 + i), lambda i: content("flat", w, h, 90 + i)]
+    n = 5
+    enc = gpu.Encoder(w, h, qp=qp, max_split_depth=depth, n_slots=n, schedule=schedule)
+    for rnd in range(len(kinds) + 1):
+        frames = [kinds[(rnd + s) % len(kinds)](rnd) for s in range(n)]
+        for s, f in enumerate(frames):
+            enc.upload(s, *f)
+        enc.encode(0, n)
+        enc.sync()
+        assert enc.final_pass_mismatches() == 0
+        comp = enc.download_compact(0, n)
+        for s, f in enumerate(frames):
+            ref = po.encode_picture(*f, qp, depth)
+            got = enc.download(s)
+            for k in KEYS:
+                assert np.array_equal(got[k], ref[k]), (rnd, s, k)
+            ly, lcb, lcr = enc.expand_levels(comp[s][0], comp[s][1])
+            assert np.array_equal(ly, ref["lev_y"]) and np.array_equal(lcb, ref["lev_cb"]) and np.array_equal(lcr, ref["lev_cr"]), (rnd, s)
+    enc.close()

@@ -52,14 +52,13 @@ struct DevConst {
 #define AS_GLOBAL(T, p) ((GLOBAL_AS T*)(p))
 #define LDS_AS __attribute__((address_space(3)))
 
-// Per-wave global scratch: 1 KB of prediction bytes (final pass), then kReconSlots saved reconstructions (slot 0: best
-// candidate of the running leaf, up to 32x32; 1 + level: unsplit candidate of the open node at that tree level, i.e.
-// 32x32, 16x16, 8x8), each the block's luma samples followed by its Cb and Cr samples, back to back: 36 cache lines per
-// wave, so that the regions of the workgroups resident on an XCD fit its L2 (wrenc_gpu.hip, acquire_scratch).
+// Per-wave global scratch: kReconSlots saved reconstructions (slot 0: best candidate of the running leaf, up to 32x32;
+// 1 + level: unsplit candidate of the open node at that tree level, i.e. 32x32, 16x16, 8x8), each the block's luma
+// samples followed by its Cb and Cr samples, back to back: 28 cache lines per wave.
 constexpr int kReconSlots = 4;
 constexpr int kSlotBytes = 1536;
 __host__ __device__ constexpr int slot_offset(int slot) { return slot < 2 ? slot * kSlotBytes : (slot == 2 ? 2 * kSlotBytes : 2 * kSlotBytes + 384); }
-constexpr int kWaveScratch = 1024 + 2 * kSlotBytes + 384 + 128;
+constexpr int kWaveScratch = 2 * kSlotBytes + 384 + 128;
 
 // One picture's device buffers.
 // Layout of the two CTU-granular buffers of a picture (what one CTU needs sits in whole cache lines of its own;
@@ -75,6 +74,10 @@ struct PicBufs {
     uint8_t* border;
     uint8_t* rec[3];
     int16_t* lev[3];
+    // per CTU four words (one per 16x16 quadrant): which 4x4 blocks of lev[] may hold a non-zero level.  The planes start
+    // zeroed and every encode keeps the rule "a block whose bit is clear is zero", so the final pass stores the levels of
+    // the transform blocks that have any, zeroes the ones that had some the last time, and leaves the rest alone.
+    uint32_t* lev_dirty;
     uint8_t* cu_log2;
     uint8_t* luma_mode;
     uint8_t* chroma_mode;
@@ -175,6 +178,7 @@ struct LeafSt {
     UF<uint8_t> luma_mode, chroma_mode; // result
     UF<uint8_t> best_cls;               // header-bit class (mpm_class) of the best luma mode
     UF<uint8_t> need_save, tile_best;   // best candidate's reconstruction: not saved yet / still in the tile
+    UF<uint8_t> slot;                   // the scratch slot the best candidate's reconstruction is saved to
     UF<float> best_cost;                // best of {planar, DC} so far / of {planar, DC, dir}
     UF<float> cur_cost, c0;
     UF<float> cost;                     // result
@@ -214,7 +218,7 @@ struct EvalPartsSF {
 };
 struct LeafSF {
     SF<uint8_t> cont, op_ml, op_mc, op_act, tree, bx, by, lg, need_refs0, need_refs1, need_org, step, cur_mode, mode,
-        cclm_mode, dm_mode, holder, evalr, luma_mode, chroma_mode, best_cls, need_save, tile_best;
+        cclm_mode, dm_mode, holder, evalr, luma_mode, chroma_mode, best_cls, need_save, tile_best, slot;
     SF<float> best_cost, cur_cost, c0, cost;
     EvalPartsSF e_best;
 };
@@ -233,7 +237,7 @@ __device__ __forceinline__ LeafSF snap_leaf(LeafSt& l) {
     SNAP_U8(cont); SNAP_U8(op_ml); SNAP_U8(op_mc); SNAP_U8(op_act); SNAP_U8(tree); SNAP_U8(bx); SNAP_U8(by); SNAP_U8(lg);
     SNAP_U8(need_refs0); SNAP_U8(need_refs1); SNAP_U8(need_org); SNAP_U8(step); SNAP_U8(cur_mode); SNAP_U8(mode);
     SNAP_U8(cclm_mode); SNAP_U8(dm_mode); SNAP_U8(holder); SNAP_U8(evalr); SNAP_U8(luma_mode); SNAP_U8(chroma_mode);
-    SNAP_U8(best_cls); SNAP_U8(need_save); SNAP_U8(tile_best);
+    SNAP_U8(best_cls); SNAP_U8(need_save); SNAP_U8(tile_best); SNAP_U8(slot);
     SNAP_F32(best_cost); SNAP_F32(cur_cost); SNAP_F32(c0); SNAP_F32(cost);
 #undef SNAP_U8
 #undef SNAP_F32
@@ -270,6 +274,7 @@ struct CtuSt {
     UF<uint8_t> dp0, dp1;
     // level schedule (team kernel at max-split-depth 3, dev_search.h): on | this member's unit | end of its final-pass range
     UF<uint8_t> lvmode, lv_i, zend;
+    UF<uint8_t> fz_on;               // the final pass has begun (Lds::lev_was / lev_now are loaded)
     UF<float> ret, ns_cost_cur, split8, ctu_cost;
     UF<float> lv_acc0, lv_acc1; // level schedule: running split cost of the open 32x32 / 16x16 node
     LeafSt leaf;
@@ -310,13 +315,24 @@ struct __attribute__((aligned(16))) Lds {
     uint32_t decw[128];        // trellis decisions: 4 bits per position, 8 positions per word
     int32_t q_istar[2];        // shared-Viterbi hand-off, per block: first position with a non-zero state-0 level
     int32_t q_active;          // this wave's TB takes part in the shared Viterbi
+    uint32_t fsum;             // final pass: checksum of the search's reconstruction of the block being re-made
     uint16_t q_pm[3][4][4];    // per block and sub-block of the chunk: parity masks (delta 0, 1), state-0 flag
     uint8_t cu_log2[64];       // per 4x4 luma unit
     uint8_t luma_mode[64];
     uint8_t chroma_mode[16];   // per 8x8 luma unit
     uint8_t left_mode[8];      // luma mode of the CU left of the CTU, per 4 rows
-    float ns_cost[4];          // per tree level: no-split cost, running split cost
-    float split_cost[4];
+    // per tree level: no-split cost, running split cost (the search of the wave schedule); in the final pass the same
+    // cells hold the CTU's "these 4x4 blocks of levels may be non-zero in the slot's planes" bits, one word per 16x16
+    // quadrant (bits 0..15: luma units, 16..19: chroma blocks): as the previous encode of the slot left them / as
+    // this one leaves them (dev_search.h full_back)
+    union {
+        float ns_cost[4];
+        uint32_t lev_was[4];
+    };
+    union {
+        float split_cost[4];
+        uint32_t lev_now[4];
+    };
     uint8_t ns_luma[4], ns_chroma[4], child[4];
     CtuSt st;                  // state of the search (dev_search.h)
     XRes xr[2];                // team schedule: this member's published result, double-buffered by stage parity
@@ -329,7 +345,7 @@ struct Ctx {
     const CONST_AS DevConst* k;         // constant address space: uniform reads become scalar loads
     const GLOBAL_AS uint8_t* org;       // originals of THIS CTU: the kOrgTile bytes of its tile in PicBufs::org_t (read-only)
     int W, WH;                          // luma width, luma plane size
-    uint8_t* pred_scratch;              // 1 KB per wave in HBM: prediction bytes between predict and recon
+    uint8_t* pred_scratch;              // building-block test kernel only (PRED_SCRATCH): where predict() puts its bytes
     GLOBAL_AS uint8_t* slots;           // kReconSlots saved reconstructions of this wave (see copy_block)
     unsigned long long* mismatch;
     int ctu_x, ctu_y; // luma, picture coordinates

@@ -80,18 +80,40 @@ struct Res {
 
 __device__ __forceinline__ float uni_f(float v) { return __int_as_float(uni(__float_as_int(v))); }
 
+// The final pass's self-check ("the final pass reproduces the search" as a property to test): a
+// position-weighted sum, mod 2^32, of the samples of a block's reconstruction in the tile (comp 0: luma block, 1: chroma
+// pair).  Every weight is odd, so a change of any ONE sample changes the sum; changes of several samples cancel with
+// probability 2^-32.  (Until round 3 the final pass kept its prediction in global scratch so that the tile still held
+// the search's reconstruction when the new one was made, and compared them sample by sample: 1.5 KB per CTU written to
+// memory and read back, per block a store -> load round trip through L2.)
+__device__ __forceinline__ unsigned checksum_weight(int i) { return (2u * (unsigned)i + 1u) * 0x9E3779B1u; }
+__device__ __forceinline__ unsigned tile_checksum(int comp, int cx, int cy, int lg) {
+    const int n = 1 << lg, nn = n * n, nb = comp ? 2 : 1;
+    unsigned h = 0;
+    for (int i = LANE; i < nb * nn; i += 64) {
+        const int blk = i >> (2 * lg), ii = i & (nn - 1);
+        h += (unsigned)rec_get(comp + blk, cx + (ii & (n - 1)), cy + (ii >> lg)) * checksum_weight(i);
+    }
+    return (unsigned)wave_sum_i32((int)h);
+}
+
 // First half of a full evaluation of one component (comp 0: luma block, 1: chroma pair): reference
 // samples, prediction, forward transform.  Residual / coefficients at r1[rbase ..], prediction bytes
-// in the tile (final pass: at pred_scratch[rbase ..]).
+// in the tile (the final pass first takes the checksum of what the search left there).
 __device__ __forceinline__ void full_front(const Ctx& c, const Req& q, int comp, int mode, int rbase) {
     const int cs = comp ? 1 : 0;
     const int nb = comp ? 2 : 1;
     const int lg = q.tlg - cs;
     PROF_MARK(tr0_);
     if ((comp ? q.refs1 : q.refs0) && mode < LT_CCLM) build_refs(c, comp, q.tx, q.ty, q.tlg);
+    if (q.final) {
+        const unsigned h = tile_checksum(comp, q.tx >> cs, q.ty >> cs, lg);
+        if (LANE == 0) SH.fsum = h;
+        WSYNC();
+    }
     PROF_MARK(t0_);
     PROF_ADD2(PH_REFS, tr0_, t0_);
-    predict<true>(c, comp, q.tx, q.ty, q.tlg, mode, rbase, q.final ? PRED_SCRATCH : PRED_TILE);
+    predict<true>(c, comp, q.tx, q.ty, q.tlg, mode, rbase, PRED_TILE);
     PROF_MARK(t1_);
     PROF_ADD2(PH_PREDICT, t0_, t1_);
     fwd_dct_lg(c, lg, nb, rbase);
@@ -112,14 +134,33 @@ __device__ __forceinline__ uint32_t full_back(const Ctx& c, const PicBufs& pb, c
     const int obyte = org_byte(comp, q.tlg);
     const bool olds = q.tlg <= 4;
     PROF_MARK(t3_);
+    // Final pass: the levels go to the slot's planes -- the 4x4 blocks of them that have any.  A block of zeros is only
+    // written where the planes may still hold levels of the slot's previous picture (PicBufs::lev_dirty, loaded into
+    // Lds::lev_was when the final pass began): nearly every 4x4 block of nearly all content is zero, and was.
+    // A lane takes one row of a 4x4 block (four levels, one 8-byte store), the four rows of a block sit in one quad.
     if (q.final && c.store) {
         const int stride = c.W >> cs;
         const size_t at = (size_t)((c.ctu_y + q.ty) >> cs) * stride + ((c.ctu_x + q.tx) >> cs);
         GLOBAL_AS int16_t* lev0 = AS_GLOBAL(int16_t, pb.lev[0]) + plane_off(c, comp) + at;
         GLOBAL_AS int16_t* lev1 = AS_GLOBAL(int16_t, pb.lev[0]) + plane_off(c, 2) + at;
-        for (int i = LANE; i < nb * nn; i += 64) {
-            const int blk = i >> (2 * lg), ii = i & (nn - 1);
-            (blk ? lev1 : lev0)[(size_t)(ii >> lg) * stride + (ii & (n - 1))] = SH.r1[rbase + i];
+        const int lgb = lg - 2;                                  // 4x4 blocks per side of the transform block, log2
+        const int u0x = (q.tx >> cs) >> 2, u0y = (q.ty >> cs) >> 2; // its place among the CTU's 4x4 blocks of the plane
+        const uint32_t w0 = (uint32_t)uni((int)SH.lev_was[0]), w1 = (uint32_t)uni((int)SH.lev_was[1]),
+                       w2 = (uint32_t)uni((int)SH.lev_was[2]), w3 = (uint32_t)uni((int)SH.lev_was[3]);
+        for (int j = LANE; j < (nb << (2 * lg - 2)); j += 64) {
+            const int bq_ = j >> 2, r = j & 3;
+            const int pl = bq_ >> (2 * lgb), bq = bq_ & ((1 << (2 * lgb)) - 1);
+            const int bby = bq >> lgb, bbx = bq & ((1 << lgb) - 1);
+            const int y = 4 * bby + r, x = 4 * bbx;
+            const unsigned long long v = *(const unsigned long long*)&SH.r1[rbase + (pl << (2 * lg)) + (y << lg) + x];
+            const unsigned long long rows = __ballot(v != 0ULL);
+            const bool nzb = ((rows >> (LANE & 60)) & 15ULL) != 0; // the block has a level
+            const int ux = u0x + bbx, uy = u0y + bby;
+            const int quad = comp ? (uy >> 1) * 2 + (ux >> 1) : (uy >> 2) * 2 + (ux >> 2);
+            const int bit = comp ? 16 + (uy & 1) * 2 + (ux & 1) : (uy & 3) * 4 + (ux & 3);
+            const uint32_t wq = quad == 0 ? w0 : (quad == 1 ? w1 : (quad == 2 ? w2 : w3));
+            if (nzb && r == 0) atomicOr(&SH.lev_now[quad], 1u << bit);
+            if (nzb || ((wq >> bit) & 1u)) *(GLOBAL_AS unsigned long long*)&(pl ? lev1 : lev0)[(size_t)y * stride + x] = v;
         }
     }
     // all levels zero: the residual is zero too, and r1 (the levels) already says so
@@ -130,23 +171,23 @@ __device__ __forceinline__ uint32_t full_back(const Ctx& c, const PicBufs& pb, c
     PROF_ADD2(PH_DEQ, t3_, t4_);
     PROF_ADD2(PH_IDCT, t4_, t5_);
     unsigned int part = 0;
-    int diff = 0;
+    unsigned hs = 0;
     for (int i = LANE; i < nb * nn; i += 64) {
         const int blk = i >> (2 * lg), ii = i & (nn - 1);
         const int x = ii & (n - 1), y = ii >> lg;
         const int pc = comp + blk;
-        const int pred = q.final ? (int)c.pred_scratch[rbase + i] : rec_get(pc, cx + x, cy + y);
+        const int pred = rec_get(pc, cx + x, cy + y);
         int v = (int16_t)(pred + (int)SH.r1[rbase + i]); // pred as i16 + res, clamp (:178)
         v = min(max(v, 0), 255);
-        if (q.final && v != rec_get(pc, cx + x, cy + y)) ++diff;
+        if (q.final) hs += (unsigned)v * checksum_weight(i);
         rec_put(pc, cx + x, cy + y, v);
         const int d = v - (olds ? (int)((const uint8_t*)SH.r2)[obyte + i] : org_get(c, pc, cx + x, cy + y));
         part += (unsigned)M24(d, d);
     }
     const uint32_t ssd = (uint32_t)wave_sum_i32((int)part); // <= 1024 * 255^2: fits 32 bits
-    if (q.final) {
-        const int changed = wave_sum_i32(diff);
-        if (changed && LANE == 0 && c.store) atomicAdd(c.mismatch, (unsigned long long)changed);
+    if (q.final) { // the block's reconstruction must be what the search left in the tile (tile_checksum, full_front)
+        const bool changed = (unsigned)wave_sum_i32((int)hs) != (unsigned)uni((int)SH.fsum);
+        if (changed && LANE == 0 && c.store) atomicAdd(c.mismatch, 1ULL);
     }
     WSYNC();
     PROF_MARK(t6_);
@@ -1539,7 +1580,9 @@ enum {
     C_DC_START, C_DC2, C_DC3, C_DC4, C_DC5, C_L4, C_LC4, C_L8, C_L16, C_WINNER
 };
 
-__device__ __forceinline__ void leaf_init(LeafSt& s, int tree, int bx, int by, int lg, int dm_mode) {
+// slot: where the search keeps its best candidate's reconstruction (0 = the leaf's own slot; 1 + level when the wave
+// schedule goes on to test the block's split: the slot then already holds the unsplit candidate, see ctu_step)
+__device__ __forceinline__ void leaf_init(LeafSt& s, int tree, int bx, int by, int lg, int dm_mode, int slot = 0) {
     s.cont = (uint8_t)(tree == TREE_DUAL_CHROMA ? C_DC_START : C_START);
     s.tree = (uint8_t)tree;
     s.bx = (uint8_t)bx;
@@ -1551,6 +1594,7 @@ __device__ __forceinline__ void leaf_init(LeafSt& s, int tree, int bx, int by, i
     s.need_org = lg <= 4 ? 1 : 0;
     s.need_save = 0;
     s.tile_best = 0;
+    s.slot = (uint8_t)slot;
 }
 
 // a new best candidate's reconstruction is saved to slot 0 by the request that follows it (before
@@ -1558,7 +1602,7 @@ __device__ __forceinline__ void leaf_init(LeafSt& s, int tree, int bx, int by, i
 __device__ __forceinline__ void leaf_attach_save(LeafSF& s, Req& q) {
     q.pre_copy = COPY_NONE;
     if (s.need_save) {
-        req_copy(q, COPY_SAVE, s.tree == TREE_SINGLE ? 3 : 1, 0, s.bx, s.by, s.lg);
+        req_copy(q, COPY_SAVE, s.tree == TREE_SINGLE ? 3 : 1, s.slot, s.bx, s.by, s.lg);
         s.need_save = 0;
     }
 }
@@ -1574,7 +1618,7 @@ __device__ __forceinline__ void leaf_attach_org(LeafSF& s, Req& q) {
 __device__ __forceinline__ void leaf_copy_only(LeafSF& s, Req& q, int mode, int comps, int cont) {
     q.kind = K_NOP;
     q.xchg = false;
-    req_copy(q, mode, comps, 0, s.bx, s.by, s.lg);
+    req_copy(q, mode, comps, s.slot, s.bx, s.by, s.lg);
     s.cont = (uint8_t)cont;
 }
 
@@ -1833,7 +1877,7 @@ __device__ __forceinline__ bool leaf_step(const Ctx& c, LeafSF& s, const Res& r,
                 TRACE_REC(c.ctu_x + s.bx, c.ctu_y + s.by, s.lg, tree, 3, 0, m, __float_as_int((float)s.cur_cost));
             // the three CCLM probes, the pick and the evaluation of the picked mode in one request (K_CCLMSEARCH)
             leaf_cclmsearch(s, q, C_CCLM);
-            if (!in_tile) req_copy(q, COPY_RESTORE, 1, 0, s.bx, s.by, s.lg); // (its save went out earlier)
+            if (!in_tile) req_copy(q, COPY_RESTORE, 1, s.slot, s.bx, s.by, s.lg); // (its save went out earlier)
             return true;
         }
         case C_WIN:
@@ -1884,7 +1928,7 @@ __device__ __forceinline__ bool leaf_step(const Ctx& c, LeafSF& s, const Res& r,
             if (c.trace && LANE == 0)
                 TRACE_REC(c.ctu_x + s.bx, c.ctu_y + s.by, s.lg, tree, 3, 0, s.cclm_mode, __float_as_int((float)s.c0));
             leaf_full(s, q, 2, 0, s.dm_mode, true, C_DC4);
-            req_copy(q, COPY_SAVE, 2, 0, s.bx, s.by, s.lg); // keep the CCLM reconstruction (:807-840)
+            req_copy(q, COPY_SAVE, 2, s.slot, s.bx, s.by, s.lg); // keep the CCLM reconstruction (:807-840)
             return true;
         case C_DC4: {
             const float dm_cost = uni_f(assemble_chroma_cost(c, s.dm_mode, rp));
@@ -2434,7 +2478,7 @@ __device__ __forceinline__ bool ctu_step(Ctx& c, const Res& r, Req& q) {
             LeafSF ls = snap_leaf(t.leaf);
             if ((TEAM && !t.lvmode) ? leaf_step_team(c, t, ls, q, t.xpar ^ 1, r) : leaf_step<D3>(c, ls, r, q)) {
                 if (t.pend) { // the first request of a node's first child saves the unsplit candidate
-                    req_copy(q, COPY_SAVE, 3, t.pslot, t.pbx, t.pby, t.plg);
+                    req_copy(q, COPY_SAVE, t.pend, t.pslot, t.pbx, t.pby, t.plg);
                     t.pend = 0;
                 }
                 t.cont = (uint8_t)cont;
@@ -2454,7 +2498,9 @@ __device__ __forceinline__ bool ctu_step(Ctx& c, const Res& r, Req& q) {
         case T_ENTER: { // enter node (bx, by) at `level`: the unsplit candidate
             const int lg = 5 - t.level;
             t.lg = (uint8_t)lg;
-            leaf_init(t.leaf, TREE_SINGLE, t.bx, t.by, lg, 0);
+            // wave schedule, a node whose split is tested next: the search saves its best candidate straight to the
+            // node's slot 1 + level, which then holds the unsplit candidate without a save of its own (T_NODE_LEAF)
+            leaf_init(t.leaf, TREE_SINGLE, t.bx, t.by, lg, 0, (!TEAM && t.level < t.max_depth) ? 1 + t.level : 0);
             if (TEAM && !t.lvmode) t.leaf.cont = TC_START;
             in_leaf = true;
             cont = T_NODE_LEAF;
@@ -2490,8 +2536,10 @@ __device__ __forceinline__ bool ctu_step(Ctx& c, const Res& r, Req& q) {
                 cont = (c.member == 0 || c.member > t.max_depth) ? T_LV_UP : T_LV_UNIT;
                 break;
             }
-            // the unsplit candidate's reconstruction goes to slot 1 + level (cache_reconsts, :1085-1100)
-            t.pend = 1;
+            // the unsplit candidate's reconstruction goes to slot 1 + level (cache_reconsts, :1085-1100).  Wave schedule:
+            // the search saved its winner there already (luma and DM chroma, leaf_init above), so all that is left to
+            // save is the chroma pair when the CCLM candidate won; a packed 8x8 search (K_LEAF8) saved nothing.
+            t.pend = (uint8_t)((TEAM || (WRENC_LEAF8 && lg == 3)) ? 3 : (mc >= LT_CCLM ? 2 : 0));
             t.pbx = t.bx;
             t.pby = t.by;
             t.plg = (uint8_t)lg;
@@ -2516,7 +2564,7 @@ __device__ __forceinline__ bool ctu_step(Ctx& c, const Res& r, Req& q) {
                 q.stage = 0;
                 q.tree = TREE_DUAL_LUMA;
                 if (t.pend) { // the unsplit 8x8 candidate is saved first
-                    req_copy(q, COPY_SAVE, 3, t.pslot, t.pbx, t.pby, t.plg);
+                    req_copy(q, COPY_SAVE, t.pend, t.pslot, t.pbx, t.pby, t.plg);
                     t.pend = 0;
                 }
                 t.cont = T_SPLIT8;
@@ -2940,6 +2988,7 @@ __device__ __forceinline__ void encode_ctu(Ctx& c, const PicBufs& pb, int ctu_co
     SH.st.dp0 = 0;
     SH.st.xpar = 0;
     SH.st.lvmode = 0;
+    SH.st.fz_on = 0;
     if (LANE == 0) SH.q_pm[0][0][3] = 0; // parity of the pooled quantisation calls (dev_quant.h, zero_flag_cell)
     SH.st.max_depth = (uint8_t)k->max_depth;
     Res r = {};
@@ -2966,6 +3015,14 @@ __device__ __forceinline__ void encode_ctu(Ctx& c, const PicBufs& pb, int ctu_co
                 SH.st.dp0 = 0;
                 copy_block(c, COPY_PULL, (dp >> 1) & 3, 0, (dq & 7) << 2, (dq >> 3) << 2, (dp >> 5) + 2, (dp >> 3) & 3);
             }
+        }
+        if (q.final && !SH.st.fz_on) { // the first block of the final pass (the search no longer needs ns_cost / split_cost)
+            SH.st.fz_on = 1;
+            if (LANE < 4) {
+                SH.lev_was[LANE] = AS_GLOBAL(uint32_t, pb.lev_dirty)[(size_t)(ctu_row * k->ctu_cols + ctu_col) * 4 + LANE];
+                SH.lev_now[LANE] = 0;
+            }
+            WSYNC();
         }
 #ifdef WRENC_EXP_CTRL_ONLY // timing / counting experiment only (wrong results): the control flow without evaluations
         r = Res{};
@@ -2995,6 +3052,14 @@ __device__ __forceinline__ void encode_ctu(Ctx& c, const PicBufs& pb, int ctu_co
         }
     }
     const float cost = SH.st.ctu_cost;
+    // which blocks of levels this encode left non-zero: the words of the quadrants whose CUs this wave emitted (wave
+    // schedule: all four; a team member: its own, member 0 all four when the CTU is one 32x32 CU)
+    if (c.store && SH.st.fz_on) {
+        WSYNC();
+        const bool all4 = !TEAM || uni((int)SH.cu_log2[0]) == 5;
+        if (LANE < 4 && (all4 || LANE == c.member))
+            AS_GLOBAL(uint32_t, pb.lev_dirty)[(size_t)(ctu_row * k->ctu_cols + ctu_col) * 4 + LANE] = SH.lev_now[LANE];
+    }
     // store recon + decisions
     if (c.write) {
         for (int i = LANE; i < 1024 / 4; i += 64) {

@@ -204,8 +204,8 @@ __global__ __launch_bounds__(64 * WPB, 5) void ctu_search_kernel(const DevConst*
     c.org = (const GLOBAL_AS uint8_t*)pb.org_t + (size_t)(row * k->ctu_cols + col) * kOrgTile;
     c.W = k->W;
     c.WH = k->W * k->H;
-    c.pred_scratch = pred_scratch + ((size_t)scratch_slot * WPB + WAVE) * kWaveScratch;
-    c.slots = (GLOBAL_AS uint8_t*)(c.pred_scratch + 1024);
+    c.pred_scratch = nullptr;
+    c.slots = (GLOBAL_AS uint8_t*)(pred_scratch + ((size_t)scratch_slot * WPB + WAVE) * kWaveScratch);
     int ovf = 0;
     encode_ctu<false, D3>(c, pb, col, row, &ovf);
     if (ovf && LANE == 0) atomicOr(overflow, 1);
@@ -240,8 +240,8 @@ __global__ __launch_bounds__(64 * WPB, 5) void ctu_search_team_kernel(const DevC
     c.org = (const GLOBAL_AS uint8_t*)pb.org_t + (size_t)(row * k->ctu_cols + col) * kOrgTile;
     c.W = k->W;
     c.WH = k->W * k->H;
-    c.pred_scratch = pred_scratch + ((size_t)scratch_slot * WPB + WAVE) * kWaveScratch;
-    c.slots = (GLOBAL_AS uint8_t*)(c.pred_scratch + 1024);
+    c.pred_scratch = nullptr;
+    c.slots = (GLOBAL_AS uint8_t*)(pred_scratch + ((size_t)scratch_slot * WPB + WAVE) * kWaveScratch);
     int ovf = 0;
     encode_ctu<true, D3>(c, pb, col, row, &ovf);
     if (ovf && LANE == 0) atomicOr(overflow, 1);
@@ -532,7 +532,7 @@ struct wrenc_gpu_ctx {
     std::vector<int> state; // 0 empty, 1 uploaded, 2 encoded
     unsigned long long* d_mismatch = nullptr;
     int* d_overflow = nullptr;
-    uint8_t* d_pred_scratch = nullptr; // kScratchSlots x WPB x kWaveScratch: prediction bytes + saved reconstructions
+    uint8_t* d_pred_scratch = nullptr; // kScratchSlots x WPB x kWaveScratch: saved reconstructions (dev_search.h copy_block)
     unsigned long long* d_slot_map = nullptr; // kScratchSlots bits: scratch regions in use
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;
     std::vector<hipEvent_t> ev_pool;
@@ -826,6 +826,7 @@ void wrenc_gpu_destroy(wrenc_gpu_ctx* ctx) {
         if (b.border) (void)hipFree(b.border);
         if (b.rec[0]) (void)hipFree(b.rec[0]);
         if (b.lev[0]) (void)hipFree(b.lev[0]);
+        if (b.lev_dirty) (void)hipFree(b.lev_dirty);
         if (b.cu_log2) (void)hipFree(b.cu_log2);
         if (b.luma_mode) (void)hipFree(b.luma_mode);
         if (b.chroma_mode) (void)hipFree(b.chroma_mode);
@@ -947,6 +948,10 @@ int wrenc_gpu_create(const wrenc_gpu_config* cfg, wrenc_gpu_ctx** out) {
         CREATE_TRY(hipMalloc((void**)&b.lev[0], (wh + wh / 2) * sizeof(int16_t)));
         b.lev[1] = b.lev[0] + wh;
         b.lev[2] = b.lev[0] + wh + wh / 4;
+        // the planes start zeroed, with no block marked as holding levels (PicBufs::lev_dirty)
+        CREATE_TRY(hipMemsetAsync(b.lev[0], 0, (wh + wh / 2) * sizeof(int16_t), ctx->stream));
+        CREATE_TRY(hipMalloc((void**)&b.lev_dirty, n_ctus * 4 * sizeof(uint32_t)));
+        CREATE_TRY(hipMemsetAsync(b.lev_dirty, 0, n_ctus * 4 * sizeof(uint32_t), ctx->stream));
         CREATE_TRY(hipMalloc((void**)&b.cu_log2, (size_t)(cfg->width / 4) * (cfg->height / 4)));
         CREATE_TRY(hipMalloc((void**)&b.luma_mode, (size_t)(cfg->width / 4) * (cfg->height / 4)));
         CREATE_TRY(hipMalloc((void**)&b.chroma_mode, (size_t)(cfg->width / 8) * (cfg->height / 8)));
@@ -954,6 +959,7 @@ int wrenc_gpu_create(const wrenc_gpu_config* cfg, wrenc_gpu_ctx** out) {
     }
     CREATE_TRY(hipMalloc((void**)&ctx->d_slots, sizeof(PicBufs) * cfg->n_slots));
     CREATE_TRY(hipMemcpy(ctx->d_slots, ctx->slots.data(), sizeof(PicBufs) * cfg->n_slots, hipMemcpyHostToDevice));
+    CREATE_TRY(hipStreamSynchronize(ctx->stream)); // the level planes are zero before anything can reach them
 #undef CREATE_TRY
     *out = ctx;
     return WRENC_GPU_OK;
