@@ -47,14 +47,14 @@ def _gpu_trace(gpu, y, cb, cr, qp, depth, schedule):
 
 @pytest.mark.parametrize("kind,w,h,qp,depth", [
     ("tex", 64, 64, 32, 2), ("tex", 96, 64, 27, 3), ("cclm", 128, 64, 32, 2), ("stripes45", 64, 64, 27, 2),
-    ("noise", 64, 64, 37, 3), ("tex", 64, 32, 22, 1),
+    ("noise", 64, 64, 37, 3), ("tex", 64, 32, 22, 1), ("tex3", 96, 64, 32, 3), ("tex3", 128, 96, 37, 3),
 ])
 @pytest.mark.parametrize("schedule", [1, 2])    # one wave per CTU / a team of four waves per CTU
 def test_every_candidate_cost_matches_oracle(trace_gpu, kind, w, h, qp, depth, schedule):
     from oracle import pyoracle as po
     from wrenc_amd import synth
-    if kind == "tex":
-        y, cb, cr = synth.synth_textured_frame(w, h, 9)
+    if kind.startswith("tex"):
+        y, cb, cr = synth.synth_textured_frame(w, h, 3 if kind == "tex3" else 9)
     else:
         from test_gpu_content import _content
         y, cb, cr = _content(kind, w, h, 77)

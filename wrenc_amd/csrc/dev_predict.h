@@ -702,6 +702,9 @@ constexpr int kNoMode = 255; // list entry that is not evaluated (cost f32::MAX)
 //     during SAD lists), stride 4n per block;
 //   * a lane adds the SAD of entry mi into its accumulator when LANE == mi.
 // acc (lane mi): summed SAD of entry mi over the components; entries with mode kNoMode stay 0.
+#ifndef WRENC_SAD4X4
+#define WRENC_SAD4X4 1 // 0: one sample per lane and iteration (rounds 1 .. 3a; kept for A/B runs)
+#endif
 __device__ __forceinline__ unsigned sad_list_angular(const Ctx& c, int comps, int tx, int ty, int tlg, int nmodes,
                                                      unsigned long long modes_lo, unsigned long long modes_hi) {
     unsigned acc = 0;
@@ -782,6 +785,125 @@ __device__ __forceinline__ unsigned sad_list_angular(const Ctx& c, int comps, in
             }
         }
         WSYNC();
+#if WRENC_SAD4X4
+        if (nb * nn > 32) { // (4x4 luma blocks and 4x4 chroma pairs: the sample-per-lane code below keeps more lanes busy)
+            // ---- a lane predicts one 4x4 BLOCK of samples of one entry: the G = nb (n / 4)^2 blocks of an entry sit side
+            // by side in the wave, 64 / G entries share an iteration (32x32 luma: one entry per iteration, all 1024
+            // samples in it).  The four samples of a block that lie next to each other ACROSS the prediction direction (a
+            // row of the block for the vertical modes, a column for the horizontal ones) share the projection (i_idx,
+            // i_fact), the filter taps and one 7-byte window of the projected references; their four results are
+            // packed into a dword and meet the originals in one v_sad_u8 -- against the block's rows, or against its
+            // columns (the originals transposed once per lane, in front of the loop over the entries).
+            const int lgb = lg - 2;                        // blocks per side, log2
+            const int lgG = 2 * lgb + (nb == 2 ? 1 : 0);   // blocks per entry, log2
+            const int g = LANE & ((1 << lgG) - 1);
+            const int slot = LANE >> lgG;
+            const int blk = g >> (2 * lgb);
+            const int bq = g & ((1 << (2 * lgb)) - 1);
+            const int x0 = 4 * (bq & ((1 << lgb) - 1)), y0 = 4 * (bq >> lgb);
+            const uint32_t* orow = (const uint32_t*)((const uint8_t*)SH.r2 + obyte + blk * nn + y0 * n + x0);
+            const uint32_t o0 = orow[0], o1 = orow[n >> 2], o2 = orow[2 * (n >> 2)], o3 = orow[3 * (n >> 2)];
+            // the 4x4 bytes transposed: t_r = byte r of o0 | o1 | o2 | o3
+            const uint32_t a01 = __builtin_amdgcn_perm(o1, o0, 0x05010400u), b01 = __builtin_amdgcn_perm(o1, o0, 0x07030602u);
+            const uint32_t a23 = __builtin_amdgcn_perm(o3, o2, 0x05010400u), b23 = __builtin_amdgcn_perm(o3, o2, 0x07030602u);
+            const uint32_t t0 = __builtin_amdgcn_perm(a23, a01, 0x05040100u), t1 = __builtin_amdgcn_perm(a23, a01, 0x07060302u);
+            const uint32_t t2 = __builtin_amdgcn_perm(b23, b01, 0x05040100u), t3 = __builtin_amdgcn_perm(b23, b01, 0x07060302u);
+#ifndef WRENC_SAD_SUMS_AT
+#define WRENC_SAD_SUMS_AT 64
+#endif
+            uint32_t* sums = (uint32_t*)SH.decw + WRENC_SAD_SUMS_AT; // [entry]: the SAD of this component
+#pragma unroll 1
+            for (int base = 0; base < nmodes; base += 64 >> lgG) {
+                const int mi = base + slot;
+                const int mic = min(mi, 15);
+                const uint32_t pw = ptab[mic], pw2 = ptab2[mic];
+                const bool on = mi < nmodes && ((pw >> 17) & 1);
+                const int inv_angle = (int)(int16_t)(pw & 0xFFFF);
+                const bool vertical = (pw >> 16) & 1;
+                const int angle = on ? (int)(int16_t)(pw2 & 0xFFFF) : 0; // (a lane without an entry stays inside the tables)
+                const int flags = (int)((pw2 >> 16) & 0xFF);
+                const int mode = (int)(pw2 >> 24);
+                const bool filter_flag = flags & 1;
+                const int kind = (flags >> 1) & 3;
+                const int n_scale = flags >> 4;
+                const int a0 = vertical ? y0 : x0, c0 = vertical ? x0 : y0; // along / across the prediction direction
+                const bool filt = comp == 0 && nn > 32 && (mode == 2 || mode == 34 || mode == 66);
+                const int oL = blk ? R_LC1 : (comp == 0 ? (filt ? R_LF : R_L0) : R_LC0);
+                const int oA = blk ? R_AC1 : (comp == 0 ? (filt ? R_AF : R_A0) : R_AC0);
+                // PDPC (intra_predictor.rs:355-757) weighs by the position across the direction and is over after
+                // 3 << n_scale samples; its reference runs along it: left[] = L + 1 for the vertical modes, above[] = A
+                const bool pdpc = on && kind != 0 && c0 < (3 << n_scale);
+                const bool any_pdpc = __ballot(pdpc) != 0ULL;
+                const ref_t* side = SH.refs + (vertical ? oL + 1 : oA);
+                const int alrs = SH.refs[oL];
+                const int tb = (((mic << cs) + blk) << lgs) + n + c0;
+                // per sample across the direction (k): the PDPC weight, 0 for a lane without PDPC or beyond its reach, and
+                // where its reference sits relative to `along`
+                int wp[4], dk[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    wp[k] = pdpc ? pdpc_w(n_scale, c0 + k) : 0;
+                    dk[k] = kind == 1 ? 0 : ((M24(c0 + k + 1, inv_angle) + 256) >> 9);
+                }
+                int sad = 0;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int along = a0 + r;
+                    const int pr = M24(along + 1, angle);
+                    const int i_idx = pr >> 5, i_fact = pr & 31;
+                    const int ta = tb + i_idx; // the four samples' taps = ref[ta + k + 0..3]
+                    const uint32_t* tp = (const uint32_t*)(tab + (ta & ~3));
+                    const uint32_t w0 = tp[0], w1 = tp[1], w2 = tp[2];
+                    const uint32_t lo = __builtin_amdgcn_alignbyte(w1, w0, ta & 3), hi = __builtin_amdgcn_alignbyte(w2, w1, ta & 3);
+                    int v[4];
+                    const int wgt = comp == 0 ? (filter_flag ? 0x00102010 + (i_fact >> 1) * 0x0100FEFF : *(const int*)&SHT.fc[i_fact][0])
+                                              : (((32 - i_fact) << 8) | (i_fact << 16));
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const int taps = (int)(k == 0 ? lo : __builtin_amdgcn_alignbyte(hi, lo, k));
+                        if (comp == 0)
+                            v[k] = min(max(__builtin_amdgcn_sdot4(wgt, taps, 8192 + 32, false) >> 6, 0), 255);
+                        else
+                            v[k] = __builtin_amdgcn_sdot4(wgt, taps, 4096 + 16, false) >> 5;
+                    }
+                    if (any_pdpc) { // (wave-uniform; inside it every lane runs the same code: a lane without PDPC weighs by 0,
+                                    // as does a sample beyond 3 << n_scale, so what is read for those does not matter)
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            const int sv = side[pdpc ? along + dk[k] : 0];
+                            const int rs = kind == 1 ? (int)(int16_t)(sv - alrs + v[k]) : sv;
+                            const int pv = (int16_t)(M24(rs, wp[k]) + M24(64 - wp[k], v[k]) + 32) >> 6;
+                            v[k] = min(max(pv, 0), 255);
+                        }
+                    }
+                    const uint32_t packed = (uint32_t)v[0] | ((uint32_t)v[1] << 8) | ((uint32_t)v[2] << 16) | ((uint32_t)v[3] << 24);
+                    const uint32_t org = vertical ? (r == 0 ? o0 : (r == 1 ? o1 : (r == 2 ? o2 : o3)))
+                                                  : (r == 0 ? t0 : (r == 1 ? t1 : (r == 2 ? t2 : t3)));
+                    sad = (int)__builtin_amdgcn_sad_u8(packed, org, (uint32_t)sad);
+                }
+                if (!on) sad = 0;
+                // the entry's total: over the G lanes of its blocks
+                int tot = sad;
+                if (lgG >= 1) tot += dpp_mov<kDppSwap1>(tot);
+                if (lgG >= 2) tot += dpp_mov<kDppSwap2>(tot);
+                if (lgG >= 3) tot += dpp_mov<kDppRowHalfMirror>(tot);
+                if (lgG >= 4) tot += dpp_mov<kDppRowMirror>(tot);
+                if (lgG == 5) {
+                    const int ta_ = __builtin_amdgcn_readlane(tot, 0) + __builtin_amdgcn_readlane(tot, 16);
+                    const int tb_ = __builtin_amdgcn_readlane(tot, 32) + __builtin_amdgcn_readlane(tot, 48);
+                    tot = LANE < 32 ? ta_ : tb_;
+                } else if (lgG == 6) {
+                    tot = __builtin_amdgcn_readlane(tot, 0) + __builtin_amdgcn_readlane(tot, 16) + __builtin_amdgcn_readlane(tot, 32) +
+                          __builtin_amdgcn_readlane(tot, 48);
+                }
+                if (g == 0 && mi < nmodes) sums[mi] = (uint32_t)tot;
+            }
+            WSYNC();
+            if (LANE < nmodes) acc += sums[LANE];
+            WSYNC(); // the next component overwrites the tables
+            continue;
+        }
+#endif
         if (nb * nn <= 32) {
             // ---- small blocks (4x4 luma: 16 samples, 4x4 chroma pair: 32): 4 or 2 entries share an
             // iteration, the entry's parameters are per-lane values ----
