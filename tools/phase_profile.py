@@ -28,7 +28,9 @@ names = (["predict", "fdct", "q_pre", "q_back", "q_trace", "deq", "idct", "recon
          + ["x2", "qb_pre", "qb_wait1", "qb_walk", "qb_wait2", "t_xchg", "copy"] + ["cb%d" % i for i in range(32)] + ["y"]
          + ["cbn%d" % i for i in range(32)] + ["y2"] + ["mem_%s_m%d" % (k, m) for k in ("ctrl", "eval", "xchg", "nop") for m in range(4)] + ["y3"]
          + ["st%d_m%d" % (k, m) for k in range(12) for m in range(4)] + ["y4"] + ["stn%d" % k for k in range(12)] + ["y5"]
-         + ["ev%d" % i for i in range(64)] + ["y6"] + ["evn%d" % i for i in range(64)] + ["y7"] + ["quant_t%d" % (4 << i) for i in range(4)])
+         + ["ev%d" % i for i in range(64)] + ["y6"] + ["evn%d" % i for i in range(64)] + ["y7"] + ["quant_t%d" % (4 << i) for i in range(4)] + ["y8"]
+         + ["leaf8_packA", "leaf8_sad", "leaf8_packB", "leaf8_cclm", "leaf16_packA", "leaf16_sad", "leaf16_packB", "leaf16_packC",
+            "sad_tables", "sad_blocks", "sad_samples", "leaf8_cclm_sad"])
 KINDS = ["sadlist", "full", "nop/copy", "sadsearch", "cclmsearch", "leaf4", "leafc4", "leaf8", "leaf16", "split8"] + ["?"] * 6
 N = len(names)
 out = (C.c_ulonglong * N)()

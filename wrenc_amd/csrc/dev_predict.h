@@ -140,13 +140,35 @@ __device__ __forceinline__ int cclm_ds6(Ctx c, int tx, int ty, int sy, int sx, b
             cclm_w(c, tx, ty, sy, sx + 1, avail_l) + cclm_w(c, tx, ty, sy + 1, sx + 1, avail_l) + 4) >> 3;
 }
 
-// `comp` (plane 1 or 2) may differ per lane: everything that depends on it is per-lane data
+// the parameters of one mode and both planes as scalars (lanes l0: Cb, l0 + 1: Cr of a cclm_params result)
+struct CclmPick {
+    int a0, a1, k0, k1, b0, b1;
+    bool flat128, avail_l;
+};
+__device__ __forceinline__ CclmPick cclm_pick(const CclmParams& v, int l0) {
+    CclmPick p;
+    p.a0 = __builtin_amdgcn_readlane(v.a, l0);
+    p.a1 = __builtin_amdgcn_readlane(v.a, l0 + 1);
+    p.k0 = __builtin_amdgcn_readlane(v.k, l0);
+    p.k1 = __builtin_amdgcn_readlane(v.k, l0 + 1);
+    p.b0 = __builtin_amdgcn_readlane(v.b, l0);
+    p.b1 = __builtin_amdgcn_readlane(v.b, l0 + 1);
+    p.flat128 = __builtin_amdgcn_readlane((int)v.flat128, l0) != 0;
+    p.avail_l = __builtin_amdgcn_readlane((int)v.avail_l, l0) != 0;
+    return p;
+}
+// the lanes of the three modes in a cclm_params call that derives them side by side (cclm_params_all): mode index m
+// (0 LT_CCLM, 1 T_CCLM, 2 L_CCLM) = lanes 2 m (Cb) and 2 m + 1 (Cr)
+__device__ __forceinline__ int cclm_mode_index(int mode) { return mode == LT_CCLM ? 0 : (mode == T_CCLM ? 1 : 2); }
+
+// `comp` (plane 1 or 2) and `mode` may differ per lane: everything that depends on them is per-lane data.  (The three
+// modes of a block used to be derived one call after the other, and the picked one once more for its evaluation: four
+// times this serial code per leaf, 7 % of the kernel's time at max-split-depth 2.)
 __device__ __forceinline__ CclmParams cclm_params(Ctx c, int comp, int tx, int ty, int tlg, int mode) {
     c = uni(c);
     tx = uni(tx);
     ty = uni(ty);
     tlg = uni(tlg);
-    mode = uni(mode);
     CclmParams r;
     const int tn = 1 << tlg;
     const int tw = tn >> 1, th = tw;
@@ -156,14 +178,15 @@ __device__ __forceinline__ CclmParams cclm_params(Ctx c, int comp, int tx, int t
     const bool avail_t = nb_avail(c, gx, gy, tn, gx, gy - 1, false, false);
     r.avail_l = avail_l;
     int num_top_right = 0, num_below_left = 0;
-    if (mode == T_CCLM) {
+    // (wave-wide: the position is the lane, whichever mode the lane itself derives)
+    if (__ballot(mode == T_CCLM) != 0ULL) {
         const bool ar = above_right_avail(c, tx, ty, tlg), bl = below_left_avail(c, tx, ty, tlg);
         // run of available above-right samples (:1881-1893): one position per lane, then the length
         // of the leading run of set bits
         const bool a = LANE < tw && nb_avail(c, gx, gy, tn, gx + (tw + LANE) * 2, gy - 1, ar, bl);
         num_top_right = min((int)__ffsll(~__ballot(a)) - 1, tw);
     }
-    if (mode == L_CCLM) {
+    if (__ballot(mode == L_CCLM) != 0ULL) {
         const bool ar = above_right_avail(c, tx, ty, tlg), bl = below_left_avail(c, tx, ty, tlg);
         const bool a = LANE < th && nb_avail(c, gx, gy, tn, gx - 1, gy + (th + LANE) * 2, ar, bl);
         num_below_left = min((int)__ffsll(~__ballot(a)) - 1, th);
@@ -176,11 +199,7 @@ __device__ __forceinline__ CclmParams cclm_params(Ctx c, int comp, int tx, int t
         num_samp_t = (avail_t && mode == T_CCLM) ? tw + min(num_top_right, th) : 0;
         num_samp_l = (avail_l && mode == L_CCLM) ? th + min(num_below_left, tw) : 0;
     }
-    r.flat128 = (num_samp_l == 0 && num_samp_t == 0);
-    r.a = 0;
-    r.k = 0;
-    r.b = 128;
-    if (r.flat128) return r;
+    r.flat128 = (num_samp_l == 0 && num_samp_t == 0); // (such a lane runs along with counts of 0 and is overruled at the end)
     const bool b_ctu_boundary = ((c.ctu_y + ty) & 31) == 0;
     const int num_is_4 = !(avail_t && avail_l && mode == LT_CCLM) ? 1 : 0;
     int cnt_t = 0, cnt_l = 0;
@@ -267,7 +286,17 @@ __device__ __forceinline__ CclmParams cclm_params(Ctx c, int comp, int tx, int t
         r.k = 0;
         r.b = min_c;
     }
+    if (r.flat128) {
+        r.a = 0;
+        r.k = 0;
+        r.b = 128;
+    }
     return r;
+}
+// the three modes of a block, both planes, in one pass: lane 2 m + pl (cclm_mode_index)
+__device__ __forceinline__ CclmParams cclm_params_all(const Ctx& c, int tx, int ty, int tlg) {
+    const int m = (LANE >> 1) & 3;
+    return cclm_params(c, 1 + (LANE & 1), tx, ty, tlg, m == 1 ? T_CCLM : (m == 2 ? L_CCLM : LT_CCLM));
 }
 
 // Original sample for prediction index i (plane pc, component coordinates x, y).  A full
@@ -371,7 +400,7 @@ __device__ __forceinline__ int emit_sample(const Ctx& c, int o, int i, int v, in
 // Returns the lane's partial sum of |org - pred| (the SAD of block_splitter.rs:96-104).
 template <bool full>
 __device__ __forceinline__ int predict(Ctx c, int comp, int tx, int ty, int tlg, int mode, int rbase = 0,
-                                       int to_tile = PRED_TILE, int nl = 0) {
+                                       int to_tile = PRED_TILE, int nl = 0, const CclmPick* pick = nullptr) {
     c = uni(c);
     rbase = uni(rbase);
     to_tile = uni(to_tile);
@@ -392,12 +421,10 @@ __device__ __forceinline__ int predict(Ctx c, int comp, int tx, int ty, int tlg,
     int sad = 0;
     if (mode >= LT_CCLM) {
         // model parameters of both planes in one pass: odd lanes derive Cr, even lanes Cb
-        const CclmParams cpv = cclm_params(c, 1 + (LANE & 1), tx, ty, tlg, mode);
-        const int a0 = __builtin_amdgcn_readlane(cpv.a, 0), a1 = __builtin_amdgcn_readlane(cpv.a, 1);
-        const int k0 = __builtin_amdgcn_readlane(cpv.k, 0), k1 = __builtin_amdgcn_readlane(cpv.k, 1);
-        const int b0 = __builtin_amdgcn_readlane(cpv.b, 0), b1 = __builtin_amdgcn_readlane(cpv.b, 1);
-        const bool flat128 = __builtin_amdgcn_readlane((int)cpv.flat128, 0) != 0;
-        const bool avail_l = __builtin_amdgcn_readlane((int)cpv.avail_l, 0) != 0;
+        // (pick: the parameters are at hand from the block's CCLM SAD list, sad_list_cclm)
+        const CclmPick cp = pick ? *pick : cclm_pick(cclm_params(c, 1 + (LANE & 1), tx, ty, tlg, mode), 0);
+        const int a0 = cp.a0, a1 = cp.a1, k0 = cp.k0, k1 = cp.k1, b0 = cp.b0, b1 = cp.b1;
+        const bool flat128 = cp.flat128, avail_l = cp.avail_l;
         for (int i = LANE; i < nb * nn; i += 64) {
             const int blk = i >> (2 * lg);
             const int ii = i & (nn - 1);
@@ -644,7 +671,8 @@ __device__ __forceinline__ int predict4_lane(const Ctx& c, int mode, int pl = -1
 // L_CCLM, block_splitter.rs:476-522, 847-854): the down-sampled luma of a sample is the same for
 // the three modes, so it is computed once and the three linear models are applied to it.
 // Returns the SAD of mode m (0 LT, 1 T, 2 L) in lane m.
-__device__ __forceinline__ unsigned sad_list_cclm(const Ctx& c, int tx, int ty, int tlg) {
+// all (optional): the parameters of the three modes as cclm_params_all left them, for the evaluation of the picked one
+__device__ __forceinline__ unsigned sad_list_cclm(const Ctx& c, int tx, int ty, int tlg, CclmParams* all = nullptr) {
     const int lg = tlg - 1;
     const int n = 1 << lg;
     const int nn = n * n;
@@ -652,17 +680,17 @@ __device__ __forceinline__ unsigned sad_list_cclm(const Ctx& c, int tx, int ty, 
     // model parameters: odd lanes derive Cr, even lanes Cb (cclm_params), then made scalar
     int a[3][2], k[3][2], b[3][2];
     bool flat[3], avail_l = false;
+    const CclmParams cp = cclm_params_all(c, tx, ty, tlg);
+    if (all) *all = cp;
 #pragma unroll
     for (int m = 0; m < 3; ++m) {
-        const int mode = m == 0 ? LT_CCLM : (m == 1 ? T_CCLM : L_CCLM);
-        const CclmParams cp = cclm_params(c, 1 + (LANE & 1), tx, ty, tlg, mode);
 #pragma unroll
         for (int pl = 0; pl < 2; ++pl) {
-            a[m][pl] = __builtin_amdgcn_readlane(cp.a, pl);
-            k[m][pl] = __builtin_amdgcn_readlane(cp.k, pl);
-            b[m][pl] = __builtin_amdgcn_readlane(cp.b, pl);
+            a[m][pl] = __builtin_amdgcn_readlane(cp.a, 2 * m + pl);
+            k[m][pl] = __builtin_amdgcn_readlane(cp.k, 2 * m + pl);
+            b[m][pl] = __builtin_amdgcn_readlane(cp.b, 2 * m + pl);
         }
-        flat[m] = __builtin_amdgcn_readlane((int)cp.flat128, 0) != 0;
+        flat[m] = __builtin_amdgcn_readlane((int)cp.flat128, 2 * m) != 0;
         avail_l = __builtin_amdgcn_readlane((int)cp.avail_l, 0) != 0; // the same for the three modes
     }
     int s0 = 0, s1 = 0, s2 = 0;
@@ -754,6 +782,7 @@ __device__ __forceinline__ unsigned sad_list_angular(const Ctx& c, int comps, in
                 kind = 3;
             my_flags = (filter_flag ? 1 : 0) | (kind << 1) | (max(n_scale, 0) << 4);
         }
+        PROF_MARK(sl0_);
         if (LANE < nmodes) {
             ptab[LANE] = ((uint32_t)my_inv & 0xFFFFu) | (mm >= 34 ? 0x10000u : 0u) | (valid ? 0x20000u : 0u);
             ptab2[LANE] = ((uint32_t)my_angle & 0xFFFFu) | ((uint32_t)my_flags << 16) | ((uint32_t)mm << 24);
@@ -785,8 +814,16 @@ __device__ __forceinline__ unsigned sad_list_angular(const Ctx& c, int comps, in
             }
         }
         WSYNC();
+        PROF_MARK(sl1_);
+        PROF_ADD2(PH_LEAF + 8, sl0_, sl1_);
 #if WRENC_SAD4X4
-        if (nb * nn > 32) { // (4x4 luma blocks and 4x4 chroma pairs: the sample-per-lane code below keeps more lanes busy)
+        // An iteration of the block-per-lane code costs about nine of the sample-per-lane code below (16 samples a lane
+        // instead of one, PDPC for every lane as soon as one entry has it) and takes 64 / G entries, whatever the list's
+        // length: it pays when the list fills its iterations -- the 13 directional candidates at every size from 8x8, the
+        // two probes of a step-search round only for the big blocks.
+        const int lgG_ = 2 * (lg - 2) + (nb == 2 ? 1 : 0);
+        const int its4_ = (nmodes + (64 >> lgG_) - 1) >> (6 - lgG_), its1_ = nmodes * ((nb * nn + 63) >> 6);
+        if (nb * nn > 32 && its4_ * 9 < its1_) {
             // ---- a lane predicts one 4x4 BLOCK of samples of one entry: the G = nb (n / 4)^2 blocks of an entry sit side
             // by side in the wave, 64 / G entries share an iteration (32x32 luma: one entry per iteration, all 1024
             // samples in it).  The four samples of a block that lie next to each other ACROSS the prediction direction (a
@@ -901,6 +938,8 @@ __device__ __forceinline__ unsigned sad_list_angular(const Ctx& c, int comps, in
             WSYNC();
             if (LANE < nmodes) acc += sums[LANE];
             WSYNC(); // the next component overwrites the tables
+            PROF_MARK(sl2_);
+            PROF_ADD2(PH_LEAF + 9, sl1_, sl2_);
             continue;
         }
 #endif
@@ -974,6 +1013,8 @@ __device__ __forceinline__ unsigned sad_list_angular(const Ctx& c, int comps, in
                 }
             }
             WSYNC();
+            PROF_MARK(sl3_);
+            PROF_ADD2(PH_LEAF + 10, sl1_, sl3_);
             continue;
         }
         // ---- entry by entry: one predicted sample per lane and iteration, |org - pred| summed ----
@@ -1042,6 +1083,8 @@ __device__ __forceinline__ unsigned sad_list_angular(const Ctx& c, int comps, in
             acc += LANE == mi ? (unsigned)total : 0u;
         }
         WSYNC(); // the next component overwrites the tables
+        PROF_MARK(sl4_);
+        PROF_ADD2(PH_LEAF + 10, sl1_, sl4_);
     }
     return acc;
 }

@@ -100,7 +100,8 @@ __device__ __forceinline__ unsigned tile_checksum(int comp, int cx, int cy, int 
 // First half of a full evaluation of one component (comp 0: luma block, 1: chroma pair): reference
 // samples, prediction, forward transform.  Residual / coefficients at r1[rbase ..], prediction bytes
 // in the tile (the final pass first takes the checksum of what the search left there).
-__device__ __forceinline__ void full_front(const Ctx& c, const Req& q, int comp, int mode, int rbase) {
+__device__ __forceinline__ void full_front(const Ctx& c, const Req& q, int comp, int mode, int rbase,
+                                           const CclmPick* pick = nullptr) {
     const int cs = comp ? 1 : 0;
     const int nb = comp ? 2 : 1;
     const int lg = q.tlg - cs;
@@ -113,7 +114,7 @@ __device__ __forceinline__ void full_front(const Ctx& c, const Req& q, int comp,
     }
     PROF_MARK(t0_);
     PROF_ADD2(PH_REFS, tr0_, t0_);
-    predict<true>(c, comp, q.tx, q.ty, q.tlg, mode, rbase, PRED_TILE);
+    predict<true>(c, comp, q.tx, q.ty, q.tlg, mode, rbase, PRED_TILE, 0, pick);
     PROF_MARK(t1_);
     PROF_ADD2(PH_PREDICT, t0_, t1_);
     fwd_dct_lg(c, lg, nb, rbase);
@@ -362,11 +363,14 @@ __device__ __forceinline__ Res evaluate(const Ctx& c, const PicBufs& pb, const R
         return r;
     }
     int mc = q.mc;
+    CclmPick cpick_;
+    const bool have_pick = q.kind == K_CCLMSEARCH;
     if (q.kind == K_CCLMSEARCH) {
         // get_chroma_intra_pred_aux_cost of LT, T, L_CCLM in one sample pass, then the pick of :847-854 (SADs are
         // integers < 2^20: comparing them is comparing the reference's f32 values); the evaluation follows below
         if (q.tlg > 4) stage_org(c, 2, q.tx, q.ty, q.tlg);
-        const unsigned acc = sad_list_cclm(c, q.tx, q.ty, q.tlg);
+        CclmParams call_;
+        const unsigned acc = sad_list_cclm(c, q.tx, q.ty, q.tlg, &call_);
         const unsigned lt = (unsigned)__builtin_amdgcn_readlane((int)acc, 0), t = (unsigned)__builtin_amdgcn_readlane((int)acc, 1),
                        l = (unsigned)__builtin_amdgcn_readlane((int)acc, 2);
         if (c.trace && LANE < 3)
@@ -374,6 +378,7 @@ __device__ __forceinline__ Res evaluate(const Ctx& c, const PicBufs& pb, const R
                       __float_as_int((float)acc));
         mc = (lt <= t && lt <= l) ? LT_CCLM : (t <= l ? T_CCLM : L_CCLM);
         r.imin = mc;
+        cpick_ = cclm_pick(call_, 2 * cclm_mode_index(mc)); // the evaluation below predicts with these
     }
     if (q.kind == K_FULL || q.kind == K_CCLMSEARCH) {
         // A candidate of the search with an 8x8 or 16x16 luma block quantises its three transform
@@ -400,7 +405,7 @@ __device__ __forceinline__ Res evaluate(const Ctx& c, const PicBufs& pb, const R
                 for (int comp = 0; comp < 2; ++comp)
                     if ((cset >> comp) & 1) {
                         PROF_MARK(tf0_);
-                        full_front(c, q, comp, comp ? mc : q.ml, (merged && comp) ? p0 : 0);
+                        full_front(c, q, comp, comp ? mc : q.ml, (merged && comp) ? p0 : 0, (comp && have_pick) ? &cpick_ : nullptr);
                         PROF_MARK(tf1_);
                         PROF_ADD2(PH_PSZ + ((q.tlg - 2) * 2 + comp), tf0_, tf1_); // stage passes by block size and component
                         PROF_ADD2(PH_PCNT + ((q.tlg - 2) * 2 + comp), 0, 1);
@@ -886,7 +891,8 @@ __device__ __forceinline__ Res leafc4_search(const Ctx& c, const Req& q, int* ov
     const int lane = lane_fresh();
     const int dm = q.mc;
     // get_chroma_intra_pred_aux_cost of LT, T, L_CCLM in one sample pass, then the pick (SADs are integers < 2^20)
-    const unsigned acc = sad_list_cclm(c, q.tx, q.ty, 3);
+    CclmParams call_;
+    const unsigned acc = sad_list_cclm(c, q.tx, q.ty, 3, &call_);
     const unsigned lt = (unsigned)__builtin_amdgcn_readlane((int)acc, 0), t = (unsigned)__builtin_amdgcn_readlane((int)acc, 1),
                    l = (unsigned)__builtin_amdgcn_readlane((int)acc, 2);
     if (c.trace && lane < 3)
@@ -895,13 +901,10 @@ __device__ __forceinline__ Res leafc4_search(const Ctx& c, const Req& q, int* ov
     const int cm = (lt <= t && lt <= l) ? LT_CCLM : (t <= l ? T_CCLM : L_CCLM);
     if (q.refs1) build_refs(c, 1, q.tx, q.ty, 3);
     PROF_MARK(t0_);
-    // model parameters of both planes: odd lanes derive Cr, even lanes Cb (as predict())
-    const CclmParams cpv = cclm_params(c, 1 + (lane & 1), q.tx, q.ty, 3, cm);
-    const int a0 = __builtin_amdgcn_readlane(cpv.a, 0), a1 = __builtin_amdgcn_readlane(cpv.a, 1);
-    const int k0 = __builtin_amdgcn_readlane(cpv.k, 0), k1 = __builtin_amdgcn_readlane(cpv.k, 1);
-    const int b0 = __builtin_amdgcn_readlane(cpv.b, 0), b1 = __builtin_amdgcn_readlane(cpv.b, 1);
-    const bool flat128 = __builtin_amdgcn_readlane((int)cpv.flat128, 0) != 0;
-    const bool avail_l = __builtin_amdgcn_readlane((int)cpv.avail_l, 0) != 0;
+    // model parameters of both planes of the picked mode: derived with the SAD list's
+    const CclmPick cpk_ = cclm_pick(call_, 2 * cclm_mode_index(cm));
+    const int a0 = cpk_.a0, a1 = cpk_.a1, k0 = cpk_.k0, k1 = cpk_.k1, b0 = cpk_.b0, b1 = cpk_.b1;
+    const bool flat128 = cpk_.flat128, avail_l = cpk_.avail_l;
     const int row = lane >> 4, i = lane & 15, x = i & 3, y = i >> 2;
     const int pl = row & 1;
     int v = predict4_lane(c, row >= 2 ? dm : kNoMode, pl); // rows 2, 3: the DM candidate (every lane passes the WSYNC inside)
@@ -1152,16 +1155,22 @@ __device__ __forceinline__ Res leaf8_search(const Ctx& c, const Req& q, int* ove
         lv_word_add(&SHT.lvb.job_posted);
     } else if (q.n & 1) {
         // pack A: planar and DC (:887-898)
+        PROF_MARK(la0_);
         const Pack8Out a = pack8_eval(c, q, 2, PLANAR, DC, kNoMode, overflow);
         int win_ = -1;
         LEAF8_CANDIDATE(a, 0, PLANAR);
         LEAF8_CANDIDATE(a, 1, DC);
         pack8_to_tile(q, 2, win_);
+        PROF_MARK(la1_);
+        PROF_ADD2(PH_LEAF + 0, la0_, la1_);
     }
     if (q.n & 2) {
         int cm;
         unsigned smin;
+        PROF_MARK(ls0_);
         sad_search(c, q, cm, smin);
+        PROF_MARK(ls1_);
+        PROF_ADD2(PH_LEAF + 1, ls0_, ls1_);
         cm = uni(cm);
         // pack B: step_search(mode, 1, _, aux = false) on {cm, cm - 1, cm + 1} (:974)
         const int lo = !(cm < 3) ? cm - 1 : kNoMode, hi = !(cm + 1 > 66) ? cm + 1 : kNoMode;
@@ -1171,6 +1180,8 @@ __device__ __forceinline__ Res leaf8_search(const Ctx& c, const Req& q, int* ove
         if (lo != kNoMode) LEAF8_CANDIDATE(b, 1, lo);
         if (hi != kNoMode) LEAF8_CANDIDATE(b, 2, hi);
         if (win_ >= 0) pack8_to_tile(q, 3, win_);
+        PROF_MARK(lb1_);
+        PROF_ADD2(PH_LEAF + 2, ls1_, lb1_);
     }
     if (served) {
         // the server's pack A: first minimum of [planar, DC] against the first minimum of pack B found above; the
@@ -1229,7 +1240,9 @@ __device__ __forceinline__ Res leaf8_search(const Ctx& c, const Req& q, int* ove
     } else {
         cur = q.fcur; // (team schedule: the team decided the winner, every member assembled this cost)
     }
-    const unsigned acc = sad_list_cclm(c, q.tx, q.ty, 3);
+    PROF_MARK(lc0_);
+    CclmParams call_;
+    const unsigned acc = sad_list_cclm(c, q.tx, q.ty, 3, &call_);
     const unsigned lt = (unsigned)__builtin_amdgcn_readlane((int)acc, 0), t = (unsigned)__builtin_amdgcn_readlane((int)acc, 1),
                    l = (unsigned)__builtin_amdgcn_readlane((int)acc, 2);
     if (c.trace && lane < 3)
@@ -1237,12 +1250,10 @@ __device__ __forceinline__ Res leaf8_search(const Ctx& c, const Req& q, int* ove
                   __float_as_int((float)acc));
     const int cm = (lt <= t && lt <= l) ? LT_CCLM : (t <= l ? T_CCLM : L_CCLM);
     PROF_MARK(t0_);
-    const CclmParams cpv = cclm_params(c, 1 + (lane & 1), q.tx, q.ty, 3, cm);
-    const int a0 = __builtin_amdgcn_readlane(cpv.a, 0), a1 = __builtin_amdgcn_readlane(cpv.a, 1);
-    const int k0 = __builtin_amdgcn_readlane(cpv.k, 0), k1 = __builtin_amdgcn_readlane(cpv.k, 1);
-    const int b0 = __builtin_amdgcn_readlane(cpv.b, 0), b1 = __builtin_amdgcn_readlane(cpv.b, 1);
-    const bool flat128 = __builtin_amdgcn_readlane((int)cpv.flat128, 0) != 0;
-    const bool avail_l = __builtin_amdgcn_readlane((int)cpv.avail_l, 0) != 0;
+    PROF_ADD2(PH_LEAF + 11, lc0_, t0_);
+    const CclmPick cpk_ = cclm_pick(call_, 2 * cclm_mode_index(cm)); // (derived with the SAD list's)
+    const int a0 = cpk_.a0, a1 = cpk_.a1, k0 = cpk_.k0, k1 = cpk_.k1, b0 = cpk_.b0, b1 = cpk_.b1;
+    const bool flat128 = cpk_.flat128, avail_l = cpk_.avail_l;
     const int row = lane >> 4, i = lane & 15, x = i & 3, y = i >> 2;
     const int pl = row & 1;
     const bool mine = row < 2; // rows 0 / 1 = Cb / Cr
@@ -1278,6 +1289,8 @@ __device__ __forceinline__ Res leaf8_search(const Ctx& c, const Req& q, int* ove
     // :1062-1072 final get_intra_pred_cost: the winner's luma with the DM chroma (still in the tile) or the CCLM chroma
     if (!dm_wins && mine) rec_put(1 + pl, (q.tx >> 1) + x, (q.ty >> 1) + y, rec);
     WSYNC();
+    PROF_MARK(lc9_);
+    PROF_ADD2(PH_LEAF + 3, lc0_, lc9_);
     if (q.n & 3) {
         r.vmin = dm_wins ? uni_f(assemble_cost(c, TREE_SINGLE, best_cls, best_mode, eb))
                          : uni_f(assemble_cost(c, TREE_SINGLE, best_cls, cm, e));
@@ -1434,15 +1447,21 @@ __device__ __forceinline__ Res leaf16_search(const Ctx& c, const Req& q, int* ov
     } while (0)
     {
         // planar and DC (:887-898)
+        PROF_MARK(la0_);
         const Pack16Out a = pack16_eval(c, q, 2, PLANAR, DC, overflow);
         int win_ = -1;
         LEAF16_CANDIDATE(a, 0, PLANAR);
         LEAF16_CANDIDATE(a, 1, DC);
         pack16_to_tile(c, q, 2, win_);
+        PROF_MARK(la1_);
+        PROF_ADD2(PH_LEAF + 4, la0_, la1_);
     }
     int cm;
     unsigned smin;
+    PROF_MARK(ls0_);
     sad_search(c, q, cm, smin);
+    PROF_MARK(ls1_);
+    PROF_ADD2(PH_LEAF + 5, ls0_, ls1_);
     cm = uni(cm);
     // step_search(mode, 1, _, aux = false) on {cm, cm - 1, cm + 1} (:974): {cm, cm - 1}, then cm + 1
     const int lo = !(cm < 3) ? cm - 1 : kNoMode, hi = !(cm + 1 > 66) ? cm + 1 : kNoMode;
@@ -1453,12 +1472,16 @@ __device__ __forceinline__ Res leaf16_search(const Ctx& c, const Req& q, int* ov
         if (lo != kNoMode) LEAF16_CANDIDATE(b, 1, lo);
         if (win_ >= 0) pack16_to_tile(c, q, 2, win_);
     }
+    PROF_MARK(lb1_);
+    PROF_ADD2(PH_LEAF + 6, ls1_, lb1_);
     if (hi != kNoMode) {
         const Pack16Out b = pack16_eval(c, q, 1, hi, kNoMode, overflow);
         int win_ = -1;
         LEAF16_CANDIDATE(b, 0, hi);
         if (win_ >= 0) pack16_to_tile(c, q, 1, win_);
     }
+    PROF_MARK(lc1_);
+    PROF_ADD2(PH_LEAF + 7, lb1_, lc1_);
 #undef LEAF16_CANDIDATE
     r.vmin = best;
     r.imin = best_mode;
