@@ -140,36 +140,41 @@ __device__ __forceinline__ int cclm_ds6(Ctx c, int tx, int ty, int sy, int sx, b
             cclm_w(c, tx, ty, sy, sx + 1, avail_l) + cclm_w(c, tx, ty, sy + 1, sx + 1, avail_l) + 4) >> 3;
 }
 
-// the parameters of one mode and both planes as scalars (lanes l0: Cb, l0 + 1: Cr of a cclm_params result)
+// the parameters of one mode and both planes as scalars: sets s0 (Cb) and s0 + 1 (Cr) of a cclm_params result
 struct CclmPick {
     int a0, a1, k0, k1, b0, b1;
     bool flat128, avail_l;
 };
-__device__ __forceinline__ CclmPick cclm_pick(const CclmParams& v, int l0) {
+__device__ __forceinline__ CclmPick cclm_pick(const CclmParams& v, int s0) {
     CclmPick p;
-    p.a0 = __builtin_amdgcn_readlane(v.a, l0);
-    p.a1 = __builtin_amdgcn_readlane(v.a, l0 + 1);
-    p.k0 = __builtin_amdgcn_readlane(v.k, l0);
-    p.k1 = __builtin_amdgcn_readlane(v.k, l0 + 1);
-    p.b0 = __builtin_amdgcn_readlane(v.b, l0);
-    p.b1 = __builtin_amdgcn_readlane(v.b, l0 + 1);
-    p.flat128 = __builtin_amdgcn_readlane((int)v.flat128, l0) != 0;
-    p.avail_l = __builtin_amdgcn_readlane((int)v.avail_l, l0) != 0;
+    p.a0 = __builtin_amdgcn_readlane(v.a, 8 * s0);
+    p.a1 = __builtin_amdgcn_readlane(v.a, 8 * s0 + 8);
+    p.k0 = __builtin_amdgcn_readlane(v.k, 8 * s0);
+    p.k1 = __builtin_amdgcn_readlane(v.k, 8 * s0 + 8);
+    p.b0 = __builtin_amdgcn_readlane(v.b, 8 * s0);
+    p.b1 = __builtin_amdgcn_readlane(v.b, 8 * s0 + 8);
+    p.flat128 = __builtin_amdgcn_readlane((int)v.flat128, 8 * s0) != 0;
+    p.avail_l = __builtin_amdgcn_readlane((int)v.avail_l, 8 * s0) != 0;
     return p;
 }
-// the lanes of the three modes in a cclm_params call that derives them side by side (cclm_params_all): mode index m
-// (0 LT_CCLM, 1 T_CCLM, 2 L_CCLM) = lanes 2 m (Cb) and 2 m + 1 (Cr)
+// the sets of the three modes in a call that derives them side by side (cclm_params_all): mode index m (0 LT_CCLM,
+// 1 T_CCLM, 2 L_CCLM) = sets 2 m (Cb) and 2 m + 1 (Cr)
 __device__ __forceinline__ int cclm_mode_index(int mode) { return mode == LT_CCLM ? 0 : (mode == T_CCLM ? 1 : 2); }
 
-// `comp` (plane 1 or 2) and `mode` may differ per lane: everything that depends on them is per-lane data.  (The three
-// modes of a block used to be derived one call after the other, and the picked one once more for its evaluation: four
-// times this serial code per leaf, 7 % of the kernel's time at max-split-depth 2.)
-__device__ __forceinline__ CclmParams cclm_params(Ctx c, int comp, int tx, int ty, int tlg, int mode) {
+// CCLM model parameters (intra_predictor.rs:1604-2031) of up to eight SETS at once: set s = lanes 8 s .. 8 s + 7 derives
+// plane 1 + (s & 1) for the mode its lanes pass (constant inside a set); every lane of a set returns the set's result.
+// The (at most four) neighbour positions a model is fitted to are taken one per lane -- lanes 0..3 of a set the
+// positions above the block, 4..7 the ones to its left, each with its six (or three) luma taps and its chroma sample --
+// and gathered in the reference's order (above first) with ds_bpermute.  (Until round 3 a call derived one mode, every
+// lane walking the positions one after the other: some fifty dependent LDS reads, and four calls per leaf -- the three
+// modes of the SAD list, then the picked one again for its evaluation: 7 % of the kernel's time at max-split-depth 2.)
+__device__ __forceinline__ CclmParams cclm_params(Ctx c, int tx, int ty, int tlg, int mode) {
     c = uni(c);
     tx = uni(tx);
     ty = uni(ty);
     tlg = uni(tlg);
     CclmParams r;
+    const int comp = 1 + ((LANE >> 3) & 1);
     const int tn = 1 << tlg;
     const int tw = tn >> 1, th = tw;
     const int cx = tx >> 1, cy = ty >> 1;
@@ -191,65 +196,39 @@ __device__ __forceinline__ CclmParams cclm_params(Ctx c, int comp, int tx, int t
         const bool a = LANE < th && nb_avail(c, gx, gy, tn, gx - 1, gy + (th + LANE) * 2, ar, bl);
         num_below_left = min((int)__ffsll(~__ballot(a)) - 1, th);
     }
-    int num_samp_t, num_samp_l;
-    if (mode == LT_CCLM) {
-        num_samp_t = avail_t ? tw : 0;
-        num_samp_l = avail_l ? th : 0;
-    } else {
-        num_samp_t = (avail_t && mode == T_CCLM) ? tw + min(num_top_right, th) : 0;
-        num_samp_l = (avail_l && mode == L_CCLM) ? th + min(num_below_left, tw) : 0;
-    }
-    r.flat128 = (num_samp_l == 0 && num_samp_t == 0); // (such a lane runs along with counts of 0 and is overruled at the end)
+    const int num_samp_t = mode == LT_CCLM ? (avail_t ? tw : 0) : ((avail_t && mode == T_CCLM) ? tw + min(num_top_right, th) : 0);
+    const int num_samp_l = mode == LT_CCLM ? (avail_l ? th : 0) : ((avail_l && mode == L_CCLM) ? th + min(num_below_left, tw) : 0);
+    r.flat128 = (num_samp_l == 0 && num_samp_t == 0); // (such a set runs along with counts of 0 and is overruled at the end)
     const bool b_ctu_boundary = ((c.ctu_y + ty) & 31) == 0;
     const int num_is_4 = !(avail_t && avail_l && mode == LT_CCLM) ? 1 : 0;
-    int cnt_t = 0, cnt_l = 0;
-    int y0 = 0, y1 = 0, y2 = 0, y3 = 0, c0 = 0, c1 = 0, c2 = 0, c3 = 0; // p_sel_ds_y / p_sel_c
-    // selects, not an indexed array: the four slots stay in registers
-#define CCLM_PUT(I, YY, CC)            \
-    do {                               \
-        const int i_ = (I);            \
-        const int yv_ = (YY), cv_ = (CC); \
-        y0 = i_ == 0 ? yv_ : y0;       \
-        c0 = i_ == 0 ? cv_ : c0;       \
-        y1 = i_ == 1 ? yv_ : y1;       \
-        c1 = i_ == 1 ? cv_ : c1;       \
-        y2 = i_ == 2 ? yv_ : y2;       \
-        c2 = i_ == 2 ? cv_ : c2;       \
-        y3 = i_ == 3 ? yv_ : y3;       \
-        c3 = i_ == 3 ? cv_ : c3;       \
-    } while (0)
-    if (avail_t && (mode == LT_CCLM || mode == T_CCLM)) {
-        const int start = num_samp_t >> (2 + num_is_4);
-        const int step = max(num_samp_t >> (1 + num_is_4), 1);
-        cnt_t = min((1 + num_is_4) << 1, num_samp_t);
-        for (int i = 0; i < cnt_t; ++i) {
-            const int pos = start + i * step;
-            const int sc = rec_get(comp, cx + pos, cy - 1);
-            const int sx = 2 * pos;
-            int sy;
-            if (!b_ctu_boundary)
-                sy = (cclm_w(c, tx, ty, -1, sx - 1, avail_l) + cclm_w(c, tx, ty, -2, sx - 1, avail_l) +
-                      cclm_w(c, tx, ty, -1, sx, avail_l) * 2 + cclm_w(c, tx, ty, -2, sx, avail_l) * 2 +
-                      cclm_w(c, tx, ty, -1, sx + 1, avail_l) + cclm_w(c, tx, ty, -2, sx + 1, avail_l) + 4) >> 3;
-            else
-                sy = (cclm_w(c, tx, ty, -1, sx - 1, avail_l) + cclm_w(c, tx, ty, -1, sx, avail_l) * 2 +
-                      cclm_w(c, tx, ty, -1, sx + 1, avail_l) + 2) >> 2;
-            CCLM_PUT(i, sy, sc);
-        }
+    const int cnt_t = (avail_t && (mode == LT_CCLM || mode == T_CCLM)) ? min((1 + num_is_4) << 1, num_samp_t) : 0;
+    const int cnt_l = (avail_l && (mode == LT_CCLM || mode == L_CCLM)) ? min((1 + num_is_4) << 1, num_samp_l) : 0;
+    // this lane's position: i-th above (:1920-1945) or i-th to the left (:1946-1960); no branches: a lane without a
+    // position reads some sample nearby and contributes nothing
+    const int j = LANE & 7, i = j & 3;
+    const bool top = j < 4;
+    const int ns = top ? num_samp_t : num_samp_l;
+    const int pos = (ns >> (2 + num_is_4)) + i * max(ns >> (1 + num_is_4), 1);
+    const bool act = i < (top ? cnt_t : cnt_l);
+    const int ra = top ? -1 : 2 * pos, rb = top ? -2 : 2 * pos + 1, cc = top ? 2 * pos : -2; // two luma rows, centre column
+    const int row_a = cclm_w(c, tx, ty, ra, cc - 1, avail_l) + cclm_w(c, tx, ty, ra, cc, avail_l) * 2 + cclm_w(c, tx, ty, ra, cc + 1, avail_l);
+    const int row_b = cclm_w(c, tx, ty, rb, cc - 1, avail_l) + cclm_w(c, tx, ty, rb, cc, avail_l) * 2 + cclm_w(c, tx, ty, rb, cc + 1, avail_l);
+    const int sy = (top && b_ctu_boundary) ? (row_a + 2) >> 2 : (row_a + row_b + 4) >> 3; // (:1893-1918: one row at a CTU's top)
+    const int sc = rec_get(comp, top ? cx + pos : cx - 1, top ? cy - 1 : cy + pos);
+    const int mine = act ? (sy | (sc << 16)) : 0;
+    // p_sel_ds_y / p_sel_c: slots 0 .. cnt_t - 1 from above, then the ones from the left; unused slots stay 0
+    const int sbase = (int)LANE & ~7;
+    int ysel[4], csel[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int src = sbase + (q < cnt_t ? q : 4 + q - cnt_t);
+        const int v = __builtin_amdgcn_ds_bpermute(src << 2, mine);
+        ysel[q] = v & 0xFFFF;
+        csel[q] = v >> 16;
     }
-    if (avail_l && (mode == LT_CCLM || mode == L_CCLM)) {
-        const int start = num_samp_l >> (2 + num_is_4);
-        const int step = max(num_samp_l >> (1 + num_is_4), 1);
-        cnt_l = min((1 + num_is_4) << 1, num_samp_l);
-        for (int i = 0; i < cnt_l; ++i) {
-            const int pos = start + i * step;
-            CCLM_PUT(cnt_t + i, cclm_ds6(c, tx, ty, 2 * pos, -2, avail_l), rec_get(comp, cx - 1, cy + pos));
-        }
-    }
-#undef CCLM_PUT
     // min group {0,2}, max group {1,3} and the four compare-exchanges of :1973-1986,
     // carried out on (luma, chroma) value pairs instead of indices
-    int mnAy = y0, mnAc = c0, mnBy = y2, mnBc = c2, mxAy = y1, mxAc = c1, mxBy = y3, mxBc = c3, t;
+    int mnAy = ysel[0], mnAc = csel[0], mnBy = ysel[2], mnBc = csel[2], mxAy = ysel[1], mxAc = csel[1], mxBy = ysel[3], mxBc = csel[3], t;
     if (mnAy > mnBy) { t = mnAy; mnAy = mnBy; mnBy = t; t = mnAc; mnAc = mnBc; mnBc = t; }
     if (mxAy > mxBy) { t = mxAy; mxAy = mxBy; mxBy = t; t = mxAc; mxAc = mxBc; mxBc = t; }
     if (mnAy > mxBy) {
@@ -293,10 +272,10 @@ __device__ __forceinline__ CclmParams cclm_params(Ctx c, int comp, int tx, int t
     }
     return r;
 }
-// the three modes of a block, both planes, in one pass: lane 2 m + pl (cclm_mode_index)
+// the three modes of a block, both planes, in one pass: sets 2 m + pl (cclm_mode_index)
 __device__ __forceinline__ CclmParams cclm_params_all(const Ctx& c, int tx, int ty, int tlg) {
-    const int m = (LANE >> 1) & 3;
-    return cclm_params(c, 1 + (LANE & 1), tx, ty, tlg, m == 1 ? T_CCLM : (m == 2 ? L_CCLM : LT_CCLM));
+    const int m = (LANE >> 4) & 3;
+    return cclm_params(c, tx, ty, tlg, m == 1 ? T_CCLM : (m == 2 ? L_CCLM : LT_CCLM));
 }
 
 // Original sample for prediction index i (plane pc, component coordinates x, y).  A full
@@ -422,7 +401,7 @@ __device__ __forceinline__ int predict(Ctx c, int comp, int tx, int ty, int tlg,
     if (mode >= LT_CCLM) {
         // model parameters of both planes in one pass: odd lanes derive Cr, even lanes Cb
         // (pick: the parameters are at hand from the block's CCLM SAD list, sad_list_cclm)
-        const CclmPick cp = pick ? *pick : cclm_pick(cclm_params(c, 1 + (LANE & 1), tx, ty, tlg, mode), 0);
+        const CclmPick cp = pick ? *pick : cclm_pick(cclm_params(c, tx, ty, tlg, mode), 0);
         const int a0 = cp.a0, a1 = cp.a1, k0 = cp.k0, k1 = cp.k1, b0 = cp.b0, b1 = cp.b1;
         const bool flat128 = cp.flat128, avail_l = cp.avail_l;
         for (int i = LANE; i < nb * nn; i += 64) {
@@ -686,11 +665,11 @@ __device__ __forceinline__ unsigned sad_list_cclm(const Ctx& c, int tx, int ty, 
     for (int m = 0; m < 3; ++m) {
 #pragma unroll
         for (int pl = 0; pl < 2; ++pl) {
-            a[m][pl] = __builtin_amdgcn_readlane(cp.a, 2 * m + pl);
-            k[m][pl] = __builtin_amdgcn_readlane(cp.k, 2 * m + pl);
-            b[m][pl] = __builtin_amdgcn_readlane(cp.b, 2 * m + pl);
+            a[m][pl] = __builtin_amdgcn_readlane(cp.a, 8 * (2 * m + pl));
+            k[m][pl] = __builtin_amdgcn_readlane(cp.k, 8 * (2 * m + pl));
+            b[m][pl] = __builtin_amdgcn_readlane(cp.b, 8 * (2 * m + pl));
         }
-        flat[m] = __builtin_amdgcn_readlane((int)cp.flat128, 2 * m) != 0;
+        flat[m] = __builtin_amdgcn_readlane((int)cp.flat128, 16 * m) != 0;
         avail_l = __builtin_amdgcn_readlane((int)cp.avail_l, 0) != 0; // the same for the three modes
     }
     int s0 = 0, s1 = 0, s2 = 0;
