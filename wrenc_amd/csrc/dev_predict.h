@@ -771,25 +771,33 @@ __device__ __forceinline__ unsigned sad_list_angular(const Ctx& c, int comps, in
         {
             const int oL0 = comp == 0 ? R_L0 : R_LC0, oA0 = comp == 0 ? R_A0 : R_AC0; // (filtered refs: modes 2, 34, 66 below)
             const int total = nmodes << (lgs + cs);
-            for (int e = LANE; e < total; e += 64) {
+            // four table bytes per lane and iteration: they belong to one entry and lie on one side of index 0 (the
+            // table of a block starts n entries below it, n a multiple of 4)
+            for (int e = 4 * LANE; e < total; e += 256) {
                 const int mi = e >> (lgs + cs);
                 const int blk = cs ? ((e >> lgs) & 1) : 0;
                 const int ee = e & ((1 << lgs) - 1);
                 const uint32_t pw = ptab[mi];
                 const int inv_angle = (int)(int16_t)(pw & 0xFFFF);
                 const bool vertical = (pw >> 16) & 1;
-                const int idx = ee - n;
+                const int idx0 = ee - n;
                 int oL = blk ? R_LC1 : oL0, oA = blk ? R_AC1 : oA0;
                 if (comp == 0 && nn > 32) { // luma blocks of more than 32 samples: modes 2, 34, 66 use the filtered references
-                    const int m = (int)(((mi < 8 ? modes_lo : modes_hi) >> (8 * (mi & 7))) & 255u);
+                    const int m = (int)(ptab2[mi] >> 24);
                     if (m == 2 || m == 34 || m == 66) {
                         oL = R_LF;
                         oA = R_AF;
                     }
                 }
-                const int k = idx >= 0 ? min(idx, 2 * n) : max(min((M24(idx, inv_angle) + 256) >> 9, n), 0);
-                const bool from_above = (idx >= 0) == vertical;
-                tab[e] = (uint8_t)(SH.refs[k == 0 ? oL : (from_above ? oA + k - 1 : oL + k)] ^ 0x80);
+                const bool from_above = (idx0 >= 0) == vertical;
+                uint32_t four = 0;
+#pragma unroll
+                for (int b4 = 0; b4 < 4; ++b4) {
+                    const int idx = idx0 + b4;
+                    const int k = idx0 >= 0 ? min(idx, 2 * n) : max(min((M24(idx, inv_angle) + 256) >> 9, n), 0);
+                    four |= (uint32_t)SH.refs[k == 0 ? oL : (from_above ? oA + k - 1 : oL + k)] << (8 * b4);
+                }
+                *(uint32_t*)&tab[e] = four ^ 0x80808080u;
             }
         }
         WSYNC();

@@ -2898,7 +2898,7 @@ __device__ __forceinline__ bool ctu_step(Ctx& c, const Res& r, Req& q) {
         // CU is emitted at its top-left unit (luma TB, then the chroma TBs) ----
         case T_FINAL_Z: {
             const int z = t.z;
-            if (z == t.zend) {
+            if (z >= t.zend) {
                 t.cont = T_START;
                 return false;
             }
@@ -2929,10 +2929,12 @@ __device__ __forceinline__ bool ctu_step(Ctx& c, const Res& r, Req& q) {
             cont = T_FZ_NEXT;
             break;
         }
-        default: // T_FZ_NEXT
-            t.z = (uint8_t)(t.z + 1);
+        default: { // T_FZ_NEXT: on to the next CU (a CU of 2^lg samples a side covers 4^(lg - 2) units of the z-order)
+            const int lgz = t.lg;
+            t.z = (uint8_t)(t.z + (lgz <= 2 ? 1 : (1 << (2 * (lgz - 2)))));
             cont = T_FINAL_Z;
             break;
+        }
         }
     }
 }
