@@ -144,6 +144,8 @@ __device__ __forceinline__ int cclm_ds6(Ctx c, int tx, int ty, int sy, int sx, b
 struct CclmPick {
     int a0, a1, k0, k1, b0, b1;
     bool flat128, avail_l;
+    bool have; // (false: nothing at hand, predict() derives the parameters itself.  Passed BY VALUE: a pointer to a pick
+               // that is only sometimes there kept the struct in scratch memory, 1.6 KB stored and re-read per request)
 };
 __device__ __forceinline__ CclmPick cclm_pick(const CclmParams& v, int s0) {
     CclmPick p;
@@ -155,6 +157,7 @@ __device__ __forceinline__ CclmPick cclm_pick(const CclmParams& v, int s0) {
     p.b1 = __builtin_amdgcn_readlane(v.b, 8 * s0 + 8);
     p.flat128 = __builtin_amdgcn_readlane((int)v.flat128, 8 * s0) != 0;
     p.avail_l = __builtin_amdgcn_readlane((int)v.avail_l, 8 * s0) != 0;
+    p.have = true;
     return p;
 }
 // the sets of the three modes in a call that derives them side by side (cclm_params_all): mode index m (0 LT_CCLM,
@@ -379,7 +382,7 @@ __device__ __forceinline__ int emit_sample(const Ctx& c, int o, int i, int v, in
 // Returns the lane's partial sum of |org - pred| (the SAD of block_splitter.rs:96-104).
 template <bool full>
 __device__ __forceinline__ int predict(Ctx c, int comp, int tx, int ty, int tlg, int mode, int rbase = 0,
-                                       int to_tile = PRED_TILE, int nl = 0, const CclmPick* pick = nullptr) {
+                                       int to_tile = PRED_TILE, int nl = 0, CclmPick pick = CclmPick{}) {
     c = uni(c);
     rbase = uni(rbase);
     to_tile = uni(to_tile);
@@ -401,7 +404,8 @@ __device__ __forceinline__ int predict(Ctx c, int comp, int tx, int ty, int tlg,
     if (mode >= LT_CCLM) {
         // model parameters of both planes in one pass: odd lanes derive Cr, even lanes Cb
         // (pick: the parameters are at hand from the block's CCLM SAD list, sad_list_cclm)
-        const CclmPick cp = pick ? *pick : cclm_pick(cclm_params(c, tx, ty, tlg, mode), 0);
+        CclmPick cp = pick;
+        if (!pick.have) cp = cclm_pick(cclm_params(c, tx, ty, tlg, mode), 0);
         const int a0 = cp.a0, a1 = cp.a1, k0 = cp.k0, k1 = cp.k1, b0 = cp.b0, b1 = cp.b1;
         const bool flat128 = cp.flat128, avail_l = cp.avail_l;
         for (int i = LANE; i < nb * nn; i += 64) {

@@ -101,7 +101,7 @@ __device__ __forceinline__ unsigned tile_checksum(int comp, int cx, int cy, int 
 // samples, prediction, forward transform.  Residual / coefficients at r1[rbase ..], prediction bytes
 // in the tile (the final pass first takes the checksum of what the search left there).
 __device__ __forceinline__ void full_front(const Ctx& c, const Req& q, int comp, int mode, int rbase,
-                                           const CclmPick* pick = nullptr) {
+                                           CclmPick pick = CclmPick{}) {
     const int cs = comp ? 1 : 0;
     const int nb = comp ? 2 : 1;
     const int lg = q.tlg - cs;
@@ -363,8 +363,7 @@ __device__ __forceinline__ Res evaluate(const Ctx& c, const PicBufs& pb, const R
         return r;
     }
     int mc = q.mc;
-    CclmPick cpick_;
-    const bool have_pick = q.kind == K_CCLMSEARCH;
+    CclmPick cpick_ = CclmPick{};
     if (q.kind == K_CCLMSEARCH) {
         // get_chroma_intra_pred_aux_cost of LT, T, L_CCLM in one sample pass, then the pick of :847-854 (SADs are
         // integers < 2^20: comparing them is comparing the reference's f32 values); the evaluation follows below
@@ -405,7 +404,7 @@ __device__ __forceinline__ Res evaluate(const Ctx& c, const PicBufs& pb, const R
                 for (int comp = 0; comp < 2; ++comp)
                     if ((cset >> comp) & 1) {
                         PROF_MARK(tf0_);
-                        full_front(c, q, comp, comp ? mc : q.ml, (merged && comp) ? p0 : 0, (comp && have_pick) ? &cpick_ : nullptr);
+                        full_front(c, q, comp, comp ? mc : q.ml, (merged && comp) ? p0 : 0, cpick_);
                         PROF_MARK(tf1_);
                         PROF_ADD2(PH_PSZ + ((q.tlg - 2) * 2 + comp), tf0_, tf1_); // stage passes by block size and component
                         PROF_ADD2(PH_PCNT + ((q.tlg - 2) * 2 + comp), 0, 1);
