@@ -288,6 +288,9 @@ __device__ __forceinline__ ListOut angular_list(const Ctx& c, const Req& q, int 
     return o;
 }
 
+#ifndef WRENC_STEP_ONE_LIST
+#define WRENC_STEP_ONE_LIST 1
+#endif
 // The SAD part of a luma / single-tree leaf search: the 13 directional candidates, their first minimum and the two
 // step-search rounds around it (block_splitter.rs:899-973).  cm: the mode found, smin: its SAD.
 __device__ __forceinline__ void sad_search(const Ctx& c, const Req& q, int& cm_out, unsigned& smin_out) {
@@ -301,6 +304,61 @@ __device__ __forceinline__ void sad_search(const Ctx& c, const Req& q, int& cm_o
     // step_search(mode, 2, cost, aux = true) (:905-973): rounds with step 2 and 1; keep the current mode on ties,
     // then the lower probe (Q12).  The SADs are integers < 2^20, so comparing them as integers is comparing the
     // reference's f32 values; a probe outside 2..66 is kNoSad = f32::MAX.
+    if (WRENC_STEP_ONE_LIST && q.tlg <= 3) {
+        // Small blocks (8x8 single-tree and 4x4 luma leaves): a list of two entries costs nearly what a list of six does
+        // (parameters, tables, reductions: two thirds of it), so BOTH rounds' probes come from ONE list -- round 1's
+        // cm -+ 2 and the four modes round 2 can ask for around cm - 2, cm or cm + 2: cm - 3, cm - 1, cm + 1, cm + 3.  A
+        // mode's SAD does not depend on the list it is in; the decisions below are the two rounds' in their order, an
+        // entry the reference would not evaluate (Q12) is kNoMode here as there, and only the probes the reference makes
+        // are traced.
+        constexpr unsigned kNoSad = 0xFFFFFFFFu;
+        const int e0 = !(cm < 4) ? cm - 2 : kNoMode, e1 = !(cm + 2 > 66) ? cm + 2 : kNoMode;
+        const int e2 = !(cm < 5) ? cm - 3 : kNoMode, e3 = !(cm < 3) ? cm - 1 : kNoMode;
+        const int e4 = !(cm + 1 > 66) ? cm + 1 : kNoMode, e5 = !(cm + 3 > 66) ? cm + 3 : kNoMode;
+        const unsigned long long lo6 = (unsigned long long)e0 | ((unsigned long long)e1 << 8) | ((unsigned long long)e2 << 16) |
+                                       ((unsigned long long)e3 << 24) | ((unsigned long long)e4 << 32) | ((unsigned long long)e5 << 40);
+        const unsigned acc = sad_list_angular(c, q.comps, q.tx, q.ty, q.tlg, 6, lo6, 0);
+        const unsigned s0 = (unsigned)__builtin_amdgcn_readlane((int)acc, 0), s1 = (unsigned)__builtin_amdgcn_readlane((int)acc, 1);
+        const unsigned s2 = (unsigned)__builtin_amdgcn_readlane((int)acc, 2), s3 = (unsigned)__builtin_amdgcn_readlane((int)acc, 3);
+        const unsigned s4 = (unsigned)__builtin_amdgcn_readlane((int)acc, 4), s5 = (unsigned)__builtin_amdgcn_readlane((int)acc, 5);
+        // round 1, step 2
+        const unsigned c0 = e0 != kNoMode ? s0 : kNoSad, c1 = e1 != kNoMode ? s1 : kNoSad;
+        const unsigned mn = min(min(cur, c0), c1);
+        int d = 0; // cm' - cm
+        if (cur == mn) {
+        } else if (c0 == mn) {
+            d = -2;
+            cur = c0;
+        } else {
+            d = 2;
+            cur = c1;
+        }
+        // round 2, step 1, around cm' = cm + d: its probes are entries 2 + (d + 2) / 2 and 3 + (d + 2) / 2
+        const int elo = d < 0 ? e2 : (d == 0 ? e3 : e4), ehi = d < 0 ? e3 : (d == 0 ? e4 : e5);
+        const unsigned slo = d < 0 ? s2 : (d == 0 ? s3 : s4), shi = d < 0 ? s3 : (d == 0 ? s4 : s5);
+        const unsigned p0 = elo != kNoMode ? slo : kNoSad, p1 = ehi != kNoMode ? shi : kNoSad;
+        int cm2 = cm + d;
+        const unsigned mn2 = min(min(cur, p0), p1);
+        if (cur == mn2) {
+        } else if (p0 == mn2) {
+            cm2 -= 1;
+            cur = p0;
+        } else {
+            cm2 += 1;
+            cur = p1;
+        }
+        if (c.trace) {
+            const int ilo = d < 0 ? 2 : (d == 0 ? 3 : 4);
+            const int my = LANE < 6 ? (int)((lo6 >> (8 * (LANE & 7))) & 255u) : kNoMode;
+            const bool used = LANE < 2 || LANE == ilo || LANE == ilo + 1;
+            if (my != kNoMode && used)
+                TRACE_REC(c.ctu_x + q.tx, c.ctu_y + q.ty, q.tlg, q.tree, (q.comps & 1) ? 0 : 2, (q.comps & 1) ? my : 0, my,
+                          __float_as_int((float)acc));
+        }
+        cm_out = cm2;
+        smin_out = cur;
+        return;
+    }
 #pragma unroll 1
     for (int st = 2; st > 0; st >>= 1) {
         const int lo = !(cm < 2 + st) ? cm - st : kNoMode;
