@@ -249,7 +249,13 @@ int wrenc_gpu_test_dequantize(wrenc_gpu_ctx* ctx, const int16_t* levels, int log
  * coordinates, multiples of the size), log2 luma size 2..5, comp (0 = luma block, 1 = Cb+Cr pair of the block,
  * log2 size >= 3, 2 = the 4x4 luma block through the row-parallel predictor of the packed 4x4 leaf search, log2 size 2),
  * mode (0..66, or 81..83 for comp 1)}.  out: the predicted samples, item after item (luma
- * n x n; pair: Cb (n/2)^2 then Cr (n/2)^2); out_bytes must equal their total. */
+ * n x n; pair: Cb (n/2)^2 then Cr (n/2)^2); out_bytes must equal their total.
+ * comp 4 / 5 / 6: not a prediction but a SAD LIST of the search (get_intra_pred_aux_cost, block_splitter.rs:64-108, of each
+ * entry) over the luma block / the chroma pair (log2 size >= 3) / both, against the block's own samples in the planes as
+ * originals: mode = first mode (2..66) | entries (1..13) << 8 | stride (1..64) << 16, entry j = first mode + j * stride (an
+ * entry beyond 66 is not evaluated and reads 0).  comp 7 (log2 size >= 3, mode 0): the CCLM SAD list of the chroma pair,
+ * entries LT_CCLM, T_CCLM, L_CCLM (get_chroma_intra_pred_aux_cost, :476-522).  A list item's output is 16 uint32 (64 bytes):
+ * the SAD of entry j at index j. */
 int wrenc_gpu_test_predict(wrenc_gpu_ctx* ctx, const uint8_t* rec_y, const uint8_t* rec_cb,
                            const uint8_t* rec_cr, int n_items, const int32_t* items, uint8_t* out,
                            size_t out_bytes);

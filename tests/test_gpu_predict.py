@@ -82,3 +82,82 @@ def test_predict_dual_tree_chroma_matches_single(built):
     for i, g in enumerate(got):
         assert np.array_equal(a[2 * i], b[2 * i]) and np.array_equal(a[2 * i + 1], b[2 * i + 1]), gi[i]
         assert np.array_equal(g, np.stack(a[2 * i:2 * i + 2])), gi[i]
+
+
+@pytest.mark.parametrize("kind", ["smooth", "noise", "extreme"])
+@pytest.mark.parametrize("lg", [5, 4, 3, 2])
+def test_sad_lists_of_every_mode_against_the_oracles_predictions(built, kind, lg):
+    """The SAD lists of the search (sad_list_angular: one sample per lane, or a 4x4 block of samples per lane with the
+    taps of a row shared and packed v_sad_u8) for EVERY angular mode 2..66, in lists of 13 entries (the block-per-lane
+    code from 8x8 up), of 2 entries (a step-search round: block-per-lane only for 32x32 luma and 16x16 chroma) and of 6
+    (both rounds of a small block at once), luma block and chroma pair, at picture corners, edges and inside: each
+    entry's SAD against the block's own samples equals the one computed from the ORACLE's prediction of that mode."""
+    from wrenc_amd import gpu
+    from oracle import pyoracle as po
+    planes = _planes(kind, 300 + lg)
+    n = 1 << lg
+    comps = 3 if lg >= 3 else 1
+    rng = np.random.default_rng(17 * lg)
+    blocks = [(x, y) for y in range(0, H, n) for x in range(0, W, n)]
+    if len(blocks) > 36:
+        corners = [(0, 0), (W - n, 0), (0, H - n), (W - n, H - n), (32, 0), (0, 32), (32, 32), (64, 32 + n)]
+        pick = rng.choice(len(blocks), 28, replace=False)
+        blocks = corners + [blocks[i] for i in pick]
+    lists = [(m0, 13, 5) for m0 in range(2, 7)] + [(m0, 2, 2) for m0 in (2, 17, 33, 34, 49, 64, 65)] + [(9, 6, 1), (30, 6, 1), (61, 6, 1)]
+    items = [(x, y, lg, comps, m0, nm, st) for (x, y) in blocks for (m0, nm, st) in lists]
+    enc = gpu.Encoder(W, H, qp=32, max_split_depth=3)
+    got = enc.sad_lists(*planes, np.array(items, np.int32))
+    enc.close()
+    # the oracle's predictions of every mode of every block
+    ora = []
+    for (x, y) in blocks:
+        for m in range(2, 67):
+            ora.append((x, y, lg, 1 if lg == 2 else 0, 0, m))
+            if comps & 2:
+                ora.append((x, y, lg, 0, 1, m))
+                ora.append((x, y, lg, 0, 2, m))
+    preds = po.predict_blocks(*planes, np.array(ora, np.int32))
+    per = 3 if comps & 2 else 1
+    sad = {}
+    for bi, (x, y) in enumerate(blocks):
+        oy = planes[0][y:y + n, x:x + n].astype(np.int64)
+        ocb = planes[1][y // 2:(y + n) // 2, x // 2:(x + n) // 2].astype(np.int64)
+        ocr = planes[2][y // 2:(y + n) // 2, x // 2:(x + n) // 2].astype(np.int64)
+        for mi, m in enumerate(range(2, 67)):
+            at = (bi * 65 + mi) * per
+            v = int(np.abs(oy - preds[at].astype(np.int64)).sum())
+            if comps & 2:
+                v += int(np.abs(ocb - preds[at + 1].astype(np.int64)).sum()) + int(np.abs(ocr - preds[at + 2].astype(np.int64)).sum())
+            sad[(x, y, m)] = v
+    for item, row in zip(items, got):
+        x, y, _, _, m0, nm, st = item
+        for j in range(nm):
+            m = m0 + j * st
+            want = sad[(x, y, m)] if m <= 66 else 0
+            assert int(row[j]) == want, (kind, item, j, m, int(row[j]), want)
+
+
+@pytest.mark.parametrize("kind", ["smooth", "noise", "extreme"])
+@pytest.mark.parametrize("lg", [5, 4, 3])
+def test_cclm_sad_lists_against_the_oracles_predictions(built, kind, lg):
+    """sad_list_cclm (the three CCLM models' parameters derived side by side, one neighbour position per lane) at every
+    block position of a 3x3-CTU picture: the SADs of LT_CCLM / T_CCLM / L_CCLM against the block's own chroma samples
+    equal the ones computed from the oracle's CCLM predictions."""
+    from wrenc_amd import gpu
+    from oracle import pyoracle as po
+    planes = _planes(kind, 400 + lg)
+    n = 1 << lg
+    blocks = [(x, y) for y in range(0, H, n) for x in range(0, W, n)]
+    items = [(x, y, lg, 4, 0, 0, 0) for (x, y) in blocks]
+    enc = gpu.Encoder(W, H, qp=32, max_split_depth=3)
+    got = enc.sad_lists(*planes, np.array(items, np.int32))
+    enc.close()
+    ora = [(x, y, lg, 0, pc, m) for (x, y) in blocks for m in (81, 83, 82) for pc in (1, 2)]   # LT, T, L
+    preds = po.predict_blocks(*planes, np.array(ora, np.int32))
+    for bi, ((x, y), row) in enumerate(zip(blocks, got)):
+        ocb = planes[1][y // 2:(y + n) // 2, x // 2:(x + n) // 2].astype(np.int64)
+        ocr = planes[2][y // 2:(y + n) // 2, x // 2:(x + n) // 2].astype(np.int64)
+        for mi in range(3):
+            at = (bi * 3 + mi) * 2
+            want = int(np.abs(ocb - preds[at].astype(np.int64)).sum()) + int(np.abs(ocr - preds[at + 1].astype(np.int64)).sum())
+            assert int(row[mi]) == want, (kind, (x, y, lg), mi, int(row[mi]), want)

@@ -389,6 +389,9 @@ __global__ __launch_bounds__(64) void test_dequantize_kernel(const DevConst* __r
 // the CTU's reconstruction tile and border are loaded from the planes, then reference samples +
 // prediction run exactly as in a full evaluation of the final pass (prediction bytes to scratch).
 // item = {x, y (luma, picture), log2 luma size, comp (0 luma block, 1 Cb+Cr pair), mode, output offset}
+// comp 3 + comps (comps: bit 0 luma, bit 1 the chroma pair): a SAD LIST (sad_list_angular) of the block against its own samples
+// in the planes as "originals"; mode = m0 | entries << 8 | stride << 16, entry j = m0 + j * stride (kNoMode beyond 66); the
+// output is the 16 accumulators of lanes 0..15 (u32 each); comp 7: the CCLM SAD list of the chroma pair (mode 0), same output
 __global__ __launch_bounds__(64) void test_predict_kernel(const DevConst* __restrict__ k, const uint8_t* planes,
                                                           const int* items, uint8_t* scratch, uint8_t* out) {
     const int* it = items + 6 * blockIdx.x;
@@ -433,6 +436,43 @@ __global__ __launch_bounds__(64) void test_predict_kernel(const DevConst* __rest
         const int row = LANE >> 4;
         const int v = predict4_lane(c, row == 0 ? mode : (mode + 1 + 22 * row) % 67);
         if (LANE < 16) out[it[5] + LANE] = (uint8_t)v;
+        return;
+    }
+    if (comp == 7) { // the CCLM SAD list of the chroma pair (sad_list_cclm): lanes 0..2 = LT_CCLM, T_CCLM, L_CCLM
+        uint8_t* oc = (uint8_t*)SH.r2 + org_byte(1, tlg);
+        const int nc = 1 << (tlg - 1);
+        for (int i = LANE; i < 2 * nc * nc; i += 64) {
+            const int pl = i >= nc * nc ? 1 : 0, ii = i - pl * nc * nc;
+            oc[i] = rec[plane_off(c, 1 + pl) + (size_t)((y >> 1) + ii / nc) * Wc + (x >> 1) + ii % nc];
+        }
+        WSYNC();
+        const unsigned acc = sad_list_cclm(c, tx, ty, tlg);
+        if (LANE < 16) ((uint32_t*)(out + it[5]))[LANE] = acc;
+        return;
+    }
+    if (comp >= 4) {
+        const int comps = comp - 3, m0 = mode & 255, nm = (mode >> 8) & 255, stride = mode >> 16;
+        // the originals where a SAD list reads them (stage_org / stage_org_leaf's layout): luma, then Cb | Cr
+        uint8_t* ol = (uint8_t*)SH.r2 + org_byte(0, tlg);
+        uint8_t* oc = (uint8_t*)SH.r2 + org_byte(1, tlg);
+        const int n = 1 << tlg, nc = n >> 1;
+        for (int i = LANE; i < n * n; i += 64) ol[i] = rec[(size_t)(y + (i >> tlg)) * W + x + (i & (n - 1))];
+        if (comps & 2)
+            for (int i = LANE; i < 2 * nc * nc; i += 64) {
+                const int pl = i >= nc * nc ? 1 : 0, ii = i - pl * nc * nc;
+                oc[i] = rec[plane_off(c, 1 + pl) + (size_t)((y >> 1) + ii / nc) * Wc + (x >> 1) + ii % nc];
+            }
+        WSYNC();
+        if (comps & 1) build_refs(c, 0, tx, ty, tlg);
+        if (comps & 2) build_refs(c, 1, tx, ty, tlg);
+        unsigned long long lo = 0, hi = 0;
+        for (int j = 0; j < nm; ++j) {
+            const int m = m0 + j * stride;
+            const unsigned long long e = (unsigned long long)(m <= 66 ? m : kNoMode) << (8 * (j & 7));
+            if (j < 8) lo |= e; else hi |= e;
+        }
+        const unsigned acc = sad_list_angular(c, comps, tx, ty, tlg, nm, lo, hi);
+        if (LANE < 16) ((uint32_t*)(out + it[5]))[LANE] = acc;
         return;
     }
     if (mode < LT_CCLM) build_refs(c, comp, tx, ty, tlg);
@@ -1534,13 +1574,17 @@ int wrenc_gpu_test_predict(wrenc_gpu_ctx* ctx, const uint8_t* rec_y, const uint8
         const int32_t* q = items + 5 * i;
         const int x = q[0], y = q[1], lg = q[2], comp = q[3], mode = q[4];
         const int n = 1 << lg;
+        const bool list = comp >= 4 && comp <= 6; // a SAD list: mode = m0 | entries << 8 | stride << 16
+        const int m0 = mode & 255, nm = (mode >> 8) & 255, stride = mode >> 16;
         const bool ok = lg >= 2 && lg <= 5 && x >= 0 && y >= 0 && x + n <= W && y + n <= H && !(x & (n - 1)) && !(y & (n - 1)) &&
-                        (comp == 0 || (comp == 1 && lg >= 3) || (comp == 2 && lg == 2)) &&
-                        ((mode >= 0 && mode <= 66) || (comp == 1 && mode >= LT_CCLM && mode <= T_CCLM));
+                        (comp == 0 || (comp == 1 && lg >= 3) || (comp == 2 && lg == 2) || (comp == 4) || (list && lg >= 3) ||
+                         (comp == 7 && lg >= 3)) &&
+                        (comp == 7 ? mode == 0 : list ? (mode >= 0 && m0 >= 2 && m0 <= 66 && nm >= 1 && nm <= 13 && stride >= 1 && stride <= 64)
+                              : ((mode >= 0 && mode <= 66) || (comp == 1 && mode >= LT_CCLM && mode <= T_CCLM)));
         if (!ok) return fail(ctx, WRENC_GPU_EINVAL, "wrenc_gpu_test_predict: bad item");
         int* d = &dev_items[(size_t)i * 6];
         d[0] = x; d[1] = y; d[2] = lg; d[3] = comp; d[4] = mode; d[5] = (int)total;
-        total += comp == 1 ? (size_t)n * n / 2 : (size_t)n * n;
+        total += (list || comp == 7) ? 64 : (comp == 1 ? (size_t)n * n / 2 : (size_t)n * n);
     }
     if (total != out_bytes) return fail(ctx, WRENC_GPU_EINVAL, "wrenc_gpu_test_predict: output size does not match the items");
     HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));

@@ -371,6 +371,24 @@ class Encoder:
             at += sz
         return res
 
+    def sad_lists(self, rec_y, rec_cb, rec_cr, items):
+        """SAD lists (the search's sad_list_angular) of blocks against their own samples in the planes as originals.
+        items: (n, 7) {x, y, log2 luma size, comps (1 luma, 2 chroma pair, 3 both), first mode, entries (<= 13), stride};
+        entry j = first mode + j * stride (not evaluated beyond 66: its SAD stays 0).  Returns (n, 16) uint32."""
+        it = np.ascontiguousarray(items, np.int32).reshape(-1, 7)
+        dev = np.zeros((len(it), 5), np.int32)
+        dev[:, :3] = it[:, :3]
+        dev[:, 3] = np.where(it[:, 3] == 4, 7, 3 + it[:, 3])   # comps 4: the CCLM list of the chroma pair (lanes 0..2: LT, T, L)
+        dev[:, 4] = np.where(it[:, 3] == 4, 0, it[:, 4] | (it[:, 5] << 8) | (it[:, 6] << 16))
+        out = np.zeros(64 * len(it), np.uint8)
+        planes = [np.ascontiguousarray(a, np.uint8) for a in (rec_y, rec_cb, rec_cr)]
+        assert planes[0].shape == (self.height, self.width)
+        self.lib.wrenc_gpu_test_predict.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
+                                                    C.c_void_p, C.c_size_t]
+        self._check(self.lib.wrenc_gpu_test_predict(self.ctx, _p(planes[0]), _p(planes[1]), _p(planes[2]), len(dev),
+                                                    _p(dev), _p(out), out.size))
+        return out.view(np.uint32).reshape(len(it), 16)
+
     def quantize_p16(self, blocks):
         """4x4 blocks through the packed quantiser of the 4x4 leaf search (four blocks per wavefront)."""
         arr = np.ascontiguousarray(blocks, np.int16)
