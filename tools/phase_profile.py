@@ -30,7 +30,8 @@ names = (["predict", "fdct", "q_pre", "q_back", "q_trace", "deq", "idct", "recon
          + ["st%d_m%d" % (k, m) for k in range(12) for m in range(4)] + ["y4"] + ["stn%d" % k for k in range(12)] + ["y5"]
          + ["ev%d" % i for i in range(64)] + ["y6"] + ["evn%d" % i for i in range(64)] + ["y7"] + ["quant_t%d" % (4 << i) for i in range(4)] + ["y8"]
          + ["leaf8_packA", "leaf8_sad", "leaf8_packB", "leaf8_cclm", "leaf16_packA", "leaf16_sad", "leaf16_packB", "leaf16_packC",
-            "sad_tables", "sad_blocks", "sad_samples", "leaf8_cclm_sad"])
+            "sad_tables", "sad_blocks", "sad_samples", "leaf8_cclm_sad"] + ["y9"]
+         + ["leaf4_stage", "leaf4_packA", "leaf4_sad", "leaf4_packB", "leafc4", "split8_other"])
 KINDS = ["sadlist", "full", "nop/copy", "sadsearch", "cclmsearch", "leaf4", "leafc4", "leaf8", "leaf16", "split8"] + ["?"] * 6
 N = len(names)
 out = (C.c_ulonglong * N)()

@@ -861,17 +861,23 @@ __device__ __forceinline__ Res leaf4_search(const Ctx& c, const Req& q, int* ove
         lv_word_add(&SHT.lvb.job4_posted);
     } else if (q.n & 1) {
         // pack A: planar and DC (:887-898)
+        PROF_MARK(l4a0_);
         const Pack4Out a = pack4_eval(c, q, 2, PLANAR, DC, kNoMode, overflow);
         int win_ = -1;
         LEAF4_CANDIDATE(a, 0, PLANAR);
         LEAF4_CANDIDATE(a, 1, DC);
         if (row == win_) rec_put(0, q.tx + x, q.ty + y, a.rec);
         WSYNC();
+        PROF_MARK(l4a1_);
+        PROF_ADD2(PH_L4 + 1, l4a0_, l4a1_);
     }
     if (q.n & 2) {
         int cm;
         unsigned smin;
+        PROF_MARK(l4s0_);
         sad_search(c, q, cm, smin);
+        PROF_MARK(l4s1_);
+        PROF_ADD2(PH_L4 + 2, l4s0_, l4s1_);
         cm = uni(cm);
         // pack B: step_search(mode, 1, _, aux = false) on {cm, cm - 1, cm + 1} (:974)
         const int lo = !(cm < 3) ? cm - 1 : kNoMode, hi = !(cm + 1 > 66) ? cm + 1 : kNoMode;
@@ -882,6 +888,8 @@ __device__ __forceinline__ Res leaf4_search(const Ctx& c, const Req& q, int* ove
         if (hi != kNoMode) LEAF4_CANDIDATE(b, 2, hi);
         if (row == win_) rec_put(0, q.tx + x, q.ty + y, b.rec);
         WSYNC();
+        PROF_MARK(l4b1_);
+        PROF_ADD2(PH_L4 + 3, l4s1_, l4b1_);
     }
     if (served) {
         // [planar, DC] from the server against pack B's first minimum, which wins only if strictly cheaper
@@ -1597,7 +1605,10 @@ __device__ __forceinline__ Res split8_search(const Ctx& c, const Req& q, int* ov
         ql.refs1 = false;
         ql.n = 3;
         ql.tree = TREE_DUAL_LUMA;
+        PROF_MARK(l4g0_);
         stage_org_leaf(c, 1, ql.tx, ql.ty, 2);
+        PROF_MARK(l4g1_);
+        PROF_ADD2(PH_L4 + 0, l4g0_, l4g1_);
         const Res rl = leaf4_search(c, ql, overflow);
         fill_maps(ql.tx, ql.ty, 2, rl.imin, 0, true, false);
         split8 = uni_f(split8 + rl.vmin);
@@ -1613,9 +1624,12 @@ __device__ __forceinline__ Res split8_search(const Ctx& c, const Req& q, int* ov
     qc.refs0 = false;
     qc.refs1 = true;
     qc.tree = TREE_DUAL_CHROMA;
+    PROF_MARK(l4c0_);
     stage_org_leaf(c, 2, q.tx, q.ty, 3);
     const Res rc = leafc4_search(c, qc, overflow);
     fill_maps(q.tx, q.ty, 3, 0, rc.imin, false, true);
+    PROF_MARK(l4c1_);
+    PROF_ADD2(PH_L4 + 4, l4c0_, l4c1_);
     r.vmin = uni_f(split8 + rc.vmin);
     return r;
 }
