@@ -493,7 +493,10 @@ thread_local std::string g_create_error;
 // An encode call splits its pictures over this many HIP streams.  Pictures are independent, so the
 // streams' anti-diagonal launches overlap and one lane's tail (partially filled GPU) is filled by
 // the other lanes' work.
-constexpr int kEncodeLanes = 4;
+#ifndef WRENC_ENCODE_LANES
+#define WRENC_ENCODE_LANES 4
+#endif
+constexpr int kEncodeLanes = WRENC_ENCODE_LANES;
 
 
 // AUTO picks the team schedule for an anti-diagonal while one wave per CTU would leave more than half of the
