@@ -76,8 +76,10 @@ def test_auto_schedule_mixing_team_and_wave_diagonals(built, n_pictures, w, h, q
     from oracle import pyoracle as po
     frames = [_frame(i, w, h) for i in range(n_pictures)]
     enc = gpu.Encoder(w, h, qp=qp, max_split_depth=depth, n_slots=n_pictures, schedule=0)
-    # diagonals hold 1 .. min(cols, rows-ish) CTUs: team while pictures x count x 100 <= slots x 50
-    enc.test_set_wave_slots(2 * n_pictures * 2 - 1)          # count = 1 -> team, count >= 2 -> wave
+    # diagonals hold 1 .. min(cols, rows-ish) CTUs: team while pictures x count x 100 <= slots x pct (pct: 65 at
+    # max-split-depth 3, 50 below: wrenc_gpu.hip, kTeamBelowSlotsPct)
+    pct = 65 if depth == 3 else 50
+    enc.test_set_wave_slots((200 * n_pictures - 1) // pct)   # count = 1 -> team, count >= 2 -> wave
     for s, f in enumerate(frames):
         enc.upload(s, *f)
     enc.encode(0, n_pictures)

@@ -503,7 +503,11 @@ constexpr int kEncodeLanes = WRENC_ENCODE_LANES;
 // GPU's wave slots empty (slots: CUs x kWorkgroupsPerCU x WPB = 5120 on an MI355X).  Measured (DESIGN.md section 5,
 // gpurun_out/r3b): threshold at 25 / 50 / 75 / 100 % of the slots gives 282 / 306 / 270 / 269 frames/s at 1080p depth 2
 // with 128 pictures, 54.4 / 55.9 / 53.8 / 48.9 at 3840x2176 depth 3 with 128; 50 % is best at every batch size tried.
-constexpr int kTeamBelowSlotsPct = 50;
+// End of round 3 (level schedule at every depth, leaf searches a third faster): at max-split-depth 3, where all four
+// members of a team have a tree level of their own, 65 % is better at every batch size between 30 and 240 pictures of
+// 3840x2176 (60 pictures: 89.0 against 86.1 frames/s; 90: 102.6 / 100.9; 128: 115.8 / 114.5; 7680x4320, 32 pictures:
+// 23.2 / 22.5; gpurun_out/s69, s70); at depth 2 it is 50 % still (128 pictures of 1080p: 459 against 454 at 65 %).
+constexpr int kTeamBelowSlotsPct = 50, kTeamBelowSlotsPctDepth3 = 65;
 
 // DCT-2 integer cosines c[j] ~ 64*sqrt(2)*cos(j*pi/128), H.266 8.7.4.5
 // (the reference's 64-point matrix, transformer.rs:934-1191, is row k = c[(2n+1)k])
@@ -1092,7 +1096,7 @@ int wrenc_gpu_encode(wrenc_gpu_ctx* ctx, int first_slot, int n_pictures) {
         if (count <= 0) continue;
         const bool team = ctx->schedule == WRENC_GPU_SCHEDULE_TEAM ||
                           (ctx->schedule == WRENC_GPU_SCHEDULE_AUTO &&
-                           (long long)n_pictures * count * 100 <= ctx->wave_slots * kTeamBelowSlotsPct);
+                           (long long)n_pictures * count * 100 <= ctx->wave_slots * (d3 ? kTeamBelowSlotsPctDepth3 : kTeamBelowSlotsPct));
         ++(team ? n_team_diags : n_wave_diags);
         for (int l = 0; l < n_lanes; ++l) {
             const int g0 = (int)((long long)total_groups * l / n_lanes), g1 = (int)((long long)total_groups * (l + 1) / n_lanes);
