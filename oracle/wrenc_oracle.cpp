@@ -638,6 +638,256 @@ static void quantize_viterbi(const RdConst& rd, const int16_t* coef, int log2n, 
     }
 }
 
+// ---------------------------------------------------------------------------
+// MODEL of the device quantiser's shortcuts (round 4), kept here so that they are proven against the literal DFS on the
+// CPU before the kernel relies on them (tests/test_oracle.py).  Same backward Viterbi as above, plus two exits that
+// skip the serial walk where its outcome can be PROVEN without it:
+//
+//  (H) the head.  Positions i < 16 * SB (SB = the 4x4 sub-block that holds istar, or the DC sub-block) all have
+//      a0(state 0) == 0.  The forward trace starts in state 0 at i = 0 and stays there while state 0 decides "zero", so
+//      only state 0's decisions matter in the head.  With V_i[s] the exact cost-to-go, G_i = min_{s != 0} V_i[s] - V_i[0],
+//      alpha_i = c1(i) - c0tz(i) (state 0's margin; +inf for a zero coefficient) and beta_i = min over the branches of
+//      states 1..3 that do not lead to state 0 of (cost - c0tz(i)):
+//          state 0 decides zero at i      <=>  V_{i+1}[2] - V_{i+1}[0] >= -alpha_i   <=  G_{i+1} >= -alpha_i
+//          G_i >= min(alpha_i, beta_i + G_{i+1}) + rebate_i        (state 1's odd branch is the only way into state 0,
+//                                                                   and it costs c1(i), the same as state 0's)
+//      so with beta_i >= 0 everywhere, alpha_min = min alpha_i >= 0 and G_{16 SB} >= -alpha_min (exact, from the walk so
+//      far) induction gives G_i >= min(alpha_min, G_{16 SB}) >= -alpha_min for the whole head: all its levels are zero.
+//  (Z) a sub-block strictly behind the head (every node non-trailing), not the DC one, whose 16 quotients are all zero:
+//      c0 is the same in all four states, c1 depends on delta only.  If every decision is "zero" the state permutation
+//      [0,2,1,3] is applied 16 times (identity) and V_top[s] = V_bottom[s] + sum c0.  The decisions at step j compare
+//      m_j(delta) = c1 - c0 with V[t0(s)] - V[t1(s)], which under the hypothesis alternate between two patterns of the
+//      bottom values: even j: |V0 - V2| <= m_j(0), |V1 - V3| <= m_j(1); odd j: |V0 - V1| <= m_j(0), |V2 - V3| <= m_j(1)
+//      (tie rule cost0 <= cost1 -> zero, hence <=).  All 16 x 4 checks hold <=> the hypothesis is exact.
+// ---------------------------------------------------------------------------
+struct DqScStats {
+    long long blocks, nz_blocks, sub_blocks, head_sb_skipped, head_tests, head_fail, z_eligible, z_pass, walked;
+};
+static DqScStats g_sc_stats[6]; // by log2n
+static bool g_sc_stats_on = false;
+static long long g_sc_mismatch = 0;
+
+static void quantize_viterbi_sc(const RdConst& rd, const int16_t* coef, int log2n, int qp, int16_t* levels,
+                                bool use_head, bool use_z) {
+    ScanGeom g(log2n);
+    const int N = g.n * g.n;
+    const int32_t lsc = level_scale(qp);
+    const int bd_shift = quant_bd_shift(log2n);
+    const int32_t bd_offset = (1 << bd_shift) >> 1;
+    const int64_t lambda = rd.lambda_q;
+    std::vector<int32_t> tc(N), qd(N);
+    std::vector<int> px(N), py(N);
+    bool any = false;
+    {
+        int i = 0;
+        for (int sb = g.num_sb - 1; sb >= 0; --sb)
+            for (int sp = 15; sp >= 0; --sp, ++i) {
+                int xc, yc;
+                g.pos(sb, sp, xc, yc);
+                px[i] = xc;
+                py[i] = yc;
+                tc[i] = coef[yc * g.n + xc];
+                any = any || tc[i] != 0;
+            }
+    }
+    auto sval = [&](int32_t t) {
+        int32_t s = (int32_t)((uint32_t)t << bd_shift) - bd_offset;
+        return t < 0 ? -s : s;
+    };
+    int istar = N;
+    for (int i = 0; i < N; ++i) {
+        qd[i] = tc[i] == 0 ? 0 : sval(tc[i]) / lsc;
+        if (istar == N && tc[i] != 0 && qd[i] / 2 > 0) istar = i;
+    }
+    DqScStats& st = g_sc_stats[log2n];
+    if (g_sc_stats_on) {
+        st.blocks++;
+        if (any) {
+            st.nz_blocks++;
+            st.sub_blocks += N / 16;
+        }
+    }
+    auto dqc = [&](int64_t dist, int64_t bits) { return 128 * dist + lambda * rd.dq[tbl((size_t)bits)]; };
+    // branch costs of node (i, s): level a0 -> (c0, parity), a0 + 1 -> c1; has1 = false for a zero coefficient
+    struct Br {
+        int64_t c0, c1;
+        size_t a0;
+        int16_t q0, q1;
+        bool has1;
+    };
+    auto branches = [&](int i, int s) {
+        Br b;
+        const bool tz = (s == 0 && i <= istar);
+        const int32_t t = tc[i];
+        if (t == 0) {
+            b.c0 = dqc(0, 1 - (int64_t)tz);
+            b.c1 = 0;
+            b.a0 = 0;
+            b.q0 = b.q1 = 0;
+            b.has1 = false;
+            return b;
+        }
+        b.has1 = true;
+        if (i == N - 1) {
+            const size_t delta = s > 1;
+            const size_t a0 = (size_t)(sval(t) / lsc / 2);
+            int16_t q0 = (int16_t)(2 * a0 - delta);
+            if (t < 0) q0 = (int16_t)-q0;
+            const int32_t d0 = std::abs(t - (((int32_t)q0 * lsc + bd_offset) >> bd_shift));
+            b.c0 = dqc(d0, (int64_t)(a0 + 1) * (int64_t)(a0 != 0 || !tz));
+            int16_t q1 = (int16_t)(2 * (a0 + 1) - delta);
+            if (t < 0) q1 = (int16_t)-q1;
+            const int32_t d1 = std::abs(t - (((int32_t)q1 * lsc + bd_offset) >> bd_shift));
+            b.c1 = dqc(d1, (int64_t)(a0 + 2));
+            b.a0 = a0;
+            b.q0 = q0;
+            b.q1 = q1;
+        } else {
+            const int32_t delta = s > 1;
+            const size_t a0 = (size_t)((sval(t) / lsc + delta) / 2);
+            int32_t q0 = a0 > 0 ? 2 * (int32_t)a0 - delta : 0;
+            if (t < 0) q0 = -q0;
+            const int32_t d0 = std::abs(t - ((q0 * lsc + bd_offset) >> bd_shift));
+            b.c0 = (a0 == 0 && tz) ? dqc(d0, 0) : dqc(d0, (int64_t)(a0 + 1));
+            int32_t q1 = 2 * (int32_t)(a0 + 1) - delta;
+            if (t < 0) q1 = -q1;
+            const int32_t d1 = std::abs(t - ((q1 * lsc + bd_offset) >> bd_shift));
+            b.c1 = dqc(d1, (int64_t)(a0 + 2));
+            b.a0 = a0;
+            b.q0 = (int16_t)q0;
+            b.q1 = (int16_t)q1;
+        }
+        return b;
+    };
+    std::vector<int64_t> C((size_t)(N + 1) * 4, 0);
+    std::vector<uint32_t> A((size_t)N * 4, 0);
+    std::vector<int16_t> Q((size_t)N * 4, 0);
+    if (!any) { // (the device leaves at once too)
+        for (int i = 0; i < N; ++i) levels[py[i] * g.n + px[i]] = 0;
+        return;
+    }
+    // alpha_i / beta_i of every position (see (H) above); the proof region is [0, 16 sb_star): the sub-blocks above the
+    // first position that cannot be part of it (a0(state 0) > 0, alpha < 0 or beta < 0)
+    std::vector<int64_t> alpha(N, INT64_MAX), beta(N, INT64_MAX);
+    int kstar = N;
+    for (int i = 0; i < N && i <= istar && kstar == N; ++i) {
+        const Br b0 = branches(i, 0);
+        const int64_t c0tz = b0.c0;
+        int64_t am = INT64_MAX, bm = INT64_MAX;
+        if (b0.has1) am = std::min(am, b0.c1 - c0tz);
+        for (int s = 1; s < 4; ++s) {
+            const Br b = branches(i, s);
+            const int* trans = kQStateTrans[s];
+            if (!b.has1) {
+                bm = std::min(bm, b.c0 - c0tz); // (its target trans[s][0] is never 0 for s != 0)
+            } else {
+                if (trans[b.a0 & 1] != 0)
+                    bm = std::min(bm, b.c0 - c0tz);
+                else
+                    am = std::min(am, b.c0 - c0tz); // a way into state 0
+                if (trans[(b.a0 + 1) & 1] != 0)
+                    bm = std::min(bm, b.c1 - c0tz);
+                else
+                    am = std::min(am, b.c1 - c0tz); // a way into state 0 (state 1, odd level)
+            }
+        }
+        alpha[i] = am;
+        beta[i] = bm;
+        if (i == istar || i == N - 1 || am < 0 || bm < 0) kstar = i;
+    }
+    const int sb_star = std::min(kstar, N - 1) >> 4;
+    auto step = [&](int i) {
+        for (int s = 0; s < 4; ++s) {
+            const bool tz = (s == 0 && i <= istar);
+            const Br b = branches(i, s);
+            const int* trans = kQStateTrans[s];
+            size_t a;
+            int16_t q;
+            int64_t cost;
+            if (!b.has1) {
+                cost = b.c0 + (i == N - 1 ? 0 : C[(size_t)(i + 1) * 4 + trans[0]]);
+                a = 0;
+                q = 0;
+            } else {
+                const int64_t k0 = b.c0 + (i == N - 1 ? 0 : C[(size_t)(i + 1) * 4 + trans[b.a0 & 1]]);
+                const int64_t k1 = b.c1 + (i == N - 1 ? 0 : C[(size_t)(i + 1) * 4 + trans[(b.a0 + 1) & 1]]);
+                if (k0 <= k1) {
+                    a = b.a0;
+                    q = b.q0;
+                    cost = k0;
+                } else {
+                    a = b.a0 + 1;
+                    q = b.q1;
+                    cost = k1;
+                }
+            }
+            if ((i & 15) == 15 && tz && a == 0) cost -= lambda * rd.dq[1];
+            C[(size_t)i * 4 + s] = cost;
+            A[(size_t)i * 4 + s] = (uint32_t)a;
+            Q[(size_t)i * 4 + s] = q;
+        }
+    };
+    int start = 0; // the forward trace starts here in state 0; everything before it is zero
+    for (int sb = N / 16 - 1; sb >= 0; --sb) {
+        const int base = 16 * sb;
+        if (use_head && sb < sb_star) {
+            // (H): the exact costs at 16 (sb + 1) are known; try to prove the rest of the head, [0, 16 (sb + 1)), zero
+            // (first at the end of the head; after a failure again one sub-block further up, with the minima of what is left)
+            const int head_end = 16 * (sb + 1);
+            if (g_sc_stats_on) st.head_tests++;
+            int64_t amin = INT64_MAX;
+            for (int i = 0; i < head_end; ++i) amin = std::min(amin, alpha[i]);
+            const int64_t* Cb = &C[(size_t)head_end * 4];
+            const int64_t G = std::min(std::min(Cb[1], Cb[2]), Cb[3]) - Cb[0];
+            const bool ok = lambda * rd.dq[1] >= 0 && (amin == INT64_MAX || G >= -amin); // (alpha, beta >= 0 in the region)
+            if (ok) {
+                if (g_sc_stats_on) st.head_sb_skipped += sb + 1;
+                start = head_end;
+                break;
+            }
+            if (g_sc_stats_on) st.head_fail++;
+        }
+        bool done = false;
+        if (use_z && sb > sb_star && sb < N / 16 - 1) {
+            bool elig = true;
+            for (int j = 0; j < 16; ++j) elig = elig && qd[base + j] == 0;
+            if (elig) {
+                if (g_sc_stats_on) st.z_eligible++;
+                const int64_t* Cb = &C[(size_t)(base + 16) * 4];
+                int64_t sum = 0;
+                bool pass = true;
+                for (int i = base + 15, j = 0; i >= base; --i, ++j) {
+                    const Br b0 = branches(i, 1), b1 = branches(i, 2);
+                    sum += b0.c0;
+                    if (!b0.has1) continue;
+                    const int64_t m0 = b0.c1 - b0.c0, m1 = b1.c1 - b1.c0;
+                    const int64_t x = (j & 1) ? Cb[1] : Cb[2], y = (j & 1) ? Cb[2] : Cb[1];
+                    pass = pass && std::llabs(Cb[0] - x) <= m0 && std::llabs(y - Cb[3]) <= m1;
+                }
+                if (pass) {
+                    if (g_sc_stats_on) st.z_pass++;
+                    for (int s = 0; s < 4; ++s) C[(size_t)base * 4 + s] = Cb[s] + sum;
+                    // (the costs inside the sub-block are not needed: A and Q stay zero, the state maps are [0,2,1,3])
+                    done = true;
+                }
+            }
+        }
+        if (!done) {
+            if (g_sc_stats_on) st.walked++;
+            for (int i = base + 15; i >= base; --i) step(i);
+        }
+    }
+    int s = 0;
+    for (int i = 0; i < N; ++i) {
+        if (i < start) {
+            levels[py[i] * g.n + px[i]] = 0;
+            continue;
+        }
+        levels[py[i] * g.n + px[i]] = Q[(size_t)i * 4 + s];
+        s = kQStateTrans[s][A[(size_t)i * 4 + s] & 1];
+    }
+}
+
 // quantizer.rs:1068-1077
 static void dequantize(const int16_t* levels, int log2n, int qp, int16_t* deq) {
     const int n = 1 << log2n;
@@ -1491,6 +1741,11 @@ struct Splitter {
         ip.predict(tu, c);
         fwd_dct(tu->resid[c].data(), log2n, tu->coef[c].data());
         quantize(p.rd, tu->coef[c].data(), log2n, p.qp, tu->lev[c].data());
+        if (g_sc_stats_on) { // round-4 model check on the search's own blocks (tests / tools only)
+            std::vector<int16_t> alt(tu->lev[c].size());
+            quantize_viterbi_sc(p.rd, tu->coef[c].data(), log2n, p.qp, alt.data(), true, true);
+            if (alt != tu->lev[c]) ++g_sc_mismatch;
+        }
         dequantize(tu->lev[c].data(), log2n, p.qp, tu->deq[c].data());
         inv_dct(tu->deq[c].data(), log2n, tu->itr[c].data());
     }
@@ -2163,6 +2418,28 @@ void wro_quantize_viterbi(const int16_t* coef, int log2n, int qp, int16_t* level
         rd_gen = g_extra_gen;
     }
     quantize_viterbi(rd, coef, log2n, qp, levels);
+}
+void wro_quantize_viterbi_sc(const int16_t* coef, int log2n, int qp, int16_t* levels, int use_head, int use_z) {
+    init_tables();
+    static thread_local RdConst rd;
+    static thread_local int rd_qp = -1, rd_gen = -1;
+    if (rd_qp != qp || rd_gen != g_extra_gen) {
+        init_rd(rd, qp);
+        rd_qp = qp;
+        rd_gen = g_extra_gen;
+    }
+    quantize_viterbi_sc(rd, coef, log2n, qp, levels, use_head != 0, use_z != 0);
+}
+void wro_dq_sc_stats_enable(int on) {
+    g_sc_stats_on = on != 0;
+    if (on) {
+        memset(g_sc_stats, 0, sizeof(g_sc_stats));
+        g_sc_mismatch = 0;
+    }
+}
+long long wro_dq_sc_stats_read(long long* out54) {
+    for (int l = 0; l < 6; ++l) memcpy(out54 + 9 * l, &g_sc_stats[l], 9 * sizeof(long long));
+    return g_sc_mismatch;
 }
 void wro_dequantize(const int16_t* levels, int log2n, int qp, int16_t* deq) {
     dequantize(levels, log2n, qp, deq);

@@ -110,6 +110,53 @@ def test_trellis_dfs_equals_viterbi():
         assert np.array_equal(po.quantize(c, qp), po.quantize(c, qp, viterbi=True)), it
 
 
+def _trellis_block(rng, it):
+    n = [4, 8, 16, 32][it % 4]
+    scale = [3, 30, 200, 1500][(it // 4) % 4]
+    decay = np.exp(-np.add.outer(np.arange(n), np.arange(n)) / (n / [3.0, 1.5, 6.0][(it // 16) % 3]))
+    c = (rng.standard_normal((n, n)) * scale * decay).astype(np.int16)
+    if it % 7 == 0:
+        c[:] = 0
+    if it % 11 == 0:
+        c = rng.integers(-3, 4, (n, n)).astype(np.int16)
+    if it % 13 == 0:  # one stray coefficient at a high frequency: the head ends early
+        c[rng.integers(n // 2, n), rng.integers(n // 2, n)] = rng.integers(-400, 400)
+    if it % 17 == 0:  # only DC and its neighbours
+        c[2:, :] = 0
+        c[:, 2:] = 0
+    return c
+
+
+@pytest.mark.parametrize("qp", [18, 22, 27, 30, 32, 33, 34, 35, 37, 41, 45, 51])
+def test_trellis_shortcuts_equal_the_literal_dfs(qp):
+    """The device quantiser's exits (round 4) -- the head proven zero without walking it, an all-quotient-zero sub-block
+    in closed form -- modelled on the CPU (oracle: quantize_viterbi_sc) give the literal memoised DFS's levels
+    (quantizer.rs:338-517) at every QP class ((qp + 1) % 6 = 0..5), each exit alone and both together."""
+    rng = np.random.default_rng(100 + qp)
+    for it in range(240):
+        c = _trellis_block(rng, it)
+        want = po.quantize(c, qp)
+        for head, z in ((True, False), (False, True), (True, True)):
+            got = po.quantize_sc(c, qp, head, z)
+            assert np.array_equal(got, want), (qp, it, head, z)
+
+
+def test_trellis_shortcuts_on_the_search_own_blocks():
+    """... and on every block the search itself quantises (smooth and textured content, two QPs); the exits do fire."""
+    from wrenc_amd import synth
+    for qp, fn in ((32, synth.synth_frame), (37, synth.synth_textured_frame), (24, synth.synth_textured_frame)):
+        y, cb, cr = fn(1920, 1088, 3)
+        y, cb, cr = y[64:128, 128:256].copy(), cb[32:64, 64:128].copy(), cr[32:64, 64:128].copy()
+        po.dq_sc_stats_enable(True)
+        po.encode_picture(y, cb, cr, qp, 2)
+        mism, st = po.dq_sc_stats_read()
+        po.dq_sc_stats_enable(False)
+        assert mism == 0
+        assert st[4]["blocks"] > 0 and st[5]["blocks"] > 0
+        if qp == 32:
+            assert st[5]["head_sb_skipped"] > st[5]["sub_blocks"] // 2
+
+
 def _diag(n):
     out, x, y = [], 0, 0
     while len(out) < n * n:
