@@ -412,6 +412,279 @@ __device__ __forceinline__ long long quantize(Ctx c, int lg, int nb, bool shared
     return sum;
 }
 
+// ---------------------------------------------------------------------------
+// The head of a chain, proven zero without walking it (round 4).
+//
+// Proof and CPU model: oracle/wrenc_oracle.cpp, quantize_viterbi_sc (tests/test_oracle.py runs it against the literal DFS,
+// quantizer.rs:338-517, at QP 18..51).  In short: the forward trace starts in state 0 at p = 0 (the last scan position)
+// and stays there while state 0 decides "zero", so above the first significant coefficient only state 0's decisions
+// matter.  Per position p with a0(state 0) = 0 (quotient 0 or 1), in undoubled costs:
+//     alpha_p = c1(delta 0) - c0tz        what state 0 -- and state 1, whose odd level is the only other way INTO state 0 --
+//                                          pays more for level 1 than state 0 pays for its free zero
+//     beta_p  = min over the branches of states 1..3 that do not lead to state 0 of (cost - c0tz)
+// With G_p = min_{s != 0} V_p[s] - V_p[0] (V = exact cost-to-go):  state 0 decides zero at p  <=  G_{p+1} >= -alpha_p,  and
+// G_p >= min(alpha_p, beta_p + G_{p+1}) + rebate_p.  So if alpha, beta >= 0 on the REGION [0, 16 sb) and the exact path
+// costs at 16 sb (the walker has them after sub-block sb) satisfy G >= -min alpha, every level of the region is zero
+// and the trace reaches 16 sb in state 0: the walk ends there.  The region is cut at the first position that cannot be
+// part of it (quotient >= 2, alpha < 0, beta < 0, or the DC position with its own formula); on the bench content it
+// covers 93 % of the sub-blocks of a 32x32 or 16x16 block and the test behind it does not fail once
+// (tools/dq_shortcut_stats.py).  A failed test only means the walk goes on as before.
+// ---------------------------------------------------------------------------
+constexpr int kAlphaInf = 1 << 28;
+struct HeadK {
+    int ldq1, ldq2, ldq3;          // lambda_q * dq_table[1..3]
+    int dp1, dp2, dp3, dn1, dn2, dn3; // dequantised levels +-1, +-2, +-3 at this block size: (q * lsc + off) >> sh
+};
+__device__ __forceinline__ HeadK head_consts(int sh, int off, int lsc) {
+    HeadK h;
+    h.ldq1 = uni(SHT.ldq[1]);
+    h.ldq2 = uni(SHT.ldq[2]);
+    h.ldq3 = uni(SHT.ldq[3]);
+    h.dp1 = (lsc + off) >> sh;
+    h.dp2 = (2 * lsc + off) >> sh;
+    h.dp3 = (3 * lsc + off) >> sh;
+    h.dn1 = (-lsc + off) >> sh;
+    h.dn2 = (-2 * lsc + off) >> sh;
+    h.dn3 = (-3 * lsc + off) >> sh;
+    return h;
+}
+// alpha of one position and whether it ends the region (same arithmetic as chunk_entry for quotients 0 and 1:
+// delta 0: a0 = 0, a1 = 1 (q1 = 2); delta 1: quotient 0: a0 = 0, a1 = 1 (q1 = 1), quotient 1: a0 = 1 (q0 = 1), a1 = 2 (q1 = 3))
+__device__ __forceinline__ int head_alpha(int tc, int qd, bool last, const HeadK& h, bool* bad) {
+    const bool neg = tc < 0;
+    const int d1 = abs(tc - (neg ? h.dn1 : h.dp1));
+    const int d2 = abs(tc - (neg ? h.dn2 : h.dp2));
+    const int d3 = abs(tc - (neg ? h.dn3 : h.dp3));
+    const int c0tz = 128 * abs(tc); // state 0's zero inside the trailing run costs no bits (:449-453)
+    const int c0d0 = c0tz + h.ldq1;
+    const int c1d0 = 128 * d2 + h.ldq2;
+    const int c0d1 = qd ? 128 * d1 + h.ldq2 : c0d0;
+    const int c1d1 = qd ? 128 * d3 + h.ldq3 : 128 * d1 + h.ldq2;
+    int alpha = c1d0 - c0tz;
+    int beta = min(min(c0d0, c0d1), c1d1) - c0tz;
+    if (tc == 0) { // no second branch; the zero costs dq_table[1] outside the trailing run, nothing inside
+        alpha = kAlphaInf;
+        beta = h.ldq1;
+    }
+    *bad = last || qd >= 2 || alpha < 0 || beta < 0 || h.ldq1 < 0;
+    return min(alpha, kAlphaInf);
+}
+// One batch of 64 positions (lane = position p0 + LANE of a chain of P) of the region search: `open` while no position has
+// ended the region; arun = this lane's minimum of alpha over the region so far; sb = the sub-block the walk must reach
+__device__ __forceinline__ void head_batch(int tc, int qd, int p, int P, bool valid, const HeadK& h, bool& open, int& arun, int& sb) {
+    if (!open) return;
+    bool bad;
+    const int alpha = head_alpha(tc, qd, p == P - 1, h, &bad);
+    const unsigned long long B = __ballot(valid && bad);
+    if (B == 0ULL) {
+        if (valid) arun = min(arun, alpha);
+    } else {
+        const int fb = (int)__builtin_ctzll(B);
+        sb = (p - LANE + fb) >> 4; // (p - LANE = the batch's first position)
+        if (valid && LANE < (fb & ~15)) arun = min(arun, alpha);
+        open = false;
+    }
+}
+// After the walk of sub-block sb (path costs C of the quad's four states, doubled): is G >= -alpha_min ?
+__device__ __forceinline__ bool head_test(int C, int st, int amin) {
+    const int c0 = dpp_quad<0x00>(C);                  // state 0's cost in every lane of the quad
+    int m = st == 0 ? 0x7FFFFFFF : C;
+    m = min(m, dpp_quad<0xB1>(m));
+    m = min(m, dpp_quad<0x4E>(m));
+    return (m - c0) + 2 * amin >= 0;                   // |m - c0| < 2^30 (see kNoBranch), amin <= 2^28
+}
+
+// quantize() for ONE wave on its own blocks (no pooling), with the head exit: same results.
+__device__ __forceinline__ long long quantize_solo(Ctx c, int lg, int nb, int* overflow, bool* any_level) {
+    c = uni(c);
+    lg = uni(lg);
+    nb = uni(nb);
+    const CONST_AS DevConst* k = c.k;
+    const int n = 1 << lg;
+    const int P = n * n;
+    const int lgP = 2 * lg;
+    const int sh = 8 + lg - 5 + 1; // quantizer.rs:558-569
+    const int off = (1 << sh) >> 1;
+    const int lsc = k->lsc;
+    const CONST_AS uint16_t* scan = k->scan_idx[lg - 2];
+    int16_t* tcs = (int16_t*)SH.r2;          // [blk][p]: coefficient in reverse-scan order (all of r2 for a 32x32 block)
+    int32_t* cc = (int32_t*)SH.r1;           // chunk: [blk][CH][6] ints (coefficients are dead after the gather)
+    uint16_t* dec16 = (uint16_t*)SH.decw;    // decisions: [blk][sub-block][state] 16-bit masks
+    PROF_MARK(q0_);
+    *any_level = false;
+    const HeadK hk = head_consts(sh, off, lsc);
+    const int nsb = P >> 4;
+    int istar0 = P, istar1 = P, sbs0 = nsb - 1, sbs1 = nsb - 1, amin0 = kAlphaInf, amin1 = kAlphaInf;
+    int nzl = 0;
+#pragma unroll 1
+    for (int blk = 0; blk < nb; ++blk) {
+        int first = P, arun = kAlphaInf, sb = nsb - 1;
+        bool open = true;
+#pragma unroll 1
+        for (int p0 = 0; p0 < P; p0 += 64) {
+            const int p = p0 + LANE;
+            const bool valid = p < P;
+            const int tc = valid ? (int)SH.r1[blk * P + scan[valid ? p : 0]] : 0;
+            nzl |= tc;
+            const int qd = quotient(k, tc, sh, off);
+            if (valid) tcs[blk * P + p] = (int16_t)tc;
+            if (tc != 0 && (qd >> 1) > 0) first = min(first, p);
+            head_batch(tc, qd, p, P, valid, hk, open, arun, sb);
+        }
+        first = wave_min_i32(first);
+        arun = wave_min_i32(arun);
+        if (blk) {
+            istar1 = first;
+            sbs1 = sb;
+            amin1 = arun;
+        } else {
+            istar0 = first;
+            sbs0 = sb;
+            amin0 = arun;
+        }
+    }
+    if (__ballot(nzl != 0) == 0ULL) return 0; // zero blocks: nothing to walk, the levels are the zeros already in r1
+    WSYNC();
+    // decisions of the sub-blocks the walk may never reach: zero in every state (the trace then stays in state 0 there)
+    if (LANE < sbs0) *(uint2*)(dec16 + LANE * 4) = make_uint2(0u, 0u);
+    if (nb == 2 && LANE < sbs1) *(uint2*)(dec16 + (P >> 2) + LANE * 4) = make_uint2(0u, 0u);
+    PROF_MARK(q1_);
+    PROF_ADD2(PH_QPRE, q0_, q1_);
+    const int ldq1 = hk.ldq1;
+    const int st = LANE & 3;
+    const int CH = min(P, nb == 2 ? 32 : 64); // chunk positions per block
+    const int quad = LANE >> 2;
+    const bool walker = quad < nb;
+    const int wblk = walker ? quad : 0;
+    const int32_t* wcc = (const int32_t*)SH.r1 + wblk * CH * 6;
+    const int cls = st == 0 ? 0 : (st == 1 ? 1 : 2);
+    uint16_t* wdec = dec16 + wblk * (P >> 2);
+    int wsb = wblk ? sbs1 : sbs0;            // the walker's block: walk down to this sub-block, then test
+    const int wamin = wblk ? amin1 : amin0;
+    int lowest = nb == 2 ? min(sbs0, sbs1) : sbs0;
+    int C = 0;
+    int ovf = 0;
+    for (int base = P - CH; base >= 0 && base + CH > 16 * lowest; base -= CH) {
+        PROF_MARK(qb0_);
+        WSYNC();
+        {
+            const bool mine = LANE < nb * CH;
+            const int blk = LANE >= CH ? 1 : 0;
+            const int i = LANE - blk * CH;
+            const int p = base + i;
+            int par0 = 0, par1 = 0, adj = 0;
+            if (mine) {
+                const int tc = tcs[blk * P + p];
+                chunk_entry(c, cc + LANE * 6, tc, quotient(k, tc, sh, off), p == P - 1, p <= (blk ? istar1 : istar0),
+                            sh, off, lsc, ldq1, &par0, &par1, &adj, &ovf);
+            }
+            const unsigned long long b0 = __ballot(mine && par0), b1 = __ballot(mine && par1), ba = __ballot(mine && adj);
+            if (mine && (LANE & 15) == 0) {
+                uint16_t* pm = SH.q_pm[blk][i >> 4];
+                pm[0] = (uint16_t)(b0 >> LANE);
+                pm[1] = (uint16_t)(b1 >> LANE);
+                pm[2] = (uint16_t)((ba >> (LANE + 15)) & 1);
+            }
+        }
+        WSYNC();
+        PROF_MARK(qb1_);
+        if (walker) {
+            for (int g16 = CH - 16; g16 >= 0; g16 -= 16) { // one 4x4 sub-block per iteration
+                const int sb = (base + g16) >> 4;
+                if (sb < lowest) break;                     // (uniform) every block's head is proven zero from here on
+                const uint16_t* pm = SH.q_pm[wblk][g16 >> 4];
+                const unsigned parmask = pm[st > 1 ? 1 : 0];
+                const bool adj = st == 0 && pm[2] != 0;
+                int2 cur[16];
+#pragma unroll
+                for (int kk = 0; kk < 16; ++kk) cur[kk] = *(const int2*)&wcc[(g16 + kk) * 6 + 2 * cls];
+                unsigned bits = 0;
+#pragma unroll
+                for (int kk = 15; kk >= 0; --kk) {
+                    const int2 e = cur[kk];
+                    const int KA = e.x + dpp_quad<0xD8>(C); // C[trans[s][0]]: quad_perm [0,2,1,3]
+                    const int KB = e.y + dpp_quad<0x72>(C); // C[trans[s][1]]: quad_perm [2,0,3,1]
+                    C = min(KA, KB) & ~1;
+                    bits = shift_in_less(bits, KB, KA);
+                    if (kk == 15) { // first position of a sub-block in coding order (:512-514)
+                        const bool choseB = KB < KA;
+                        const bool pick1 = choseB != (((parmask >> 15) & 1) != 0);
+                        if (!pick1 && adj) C -= 2 * ldq1;
+                    }
+                }
+                bits ^= parmask; // choseB -> pick1
+                int m = min(C, dpp_quad<0xB1>(C));  // renormalise (see quantize())
+                m = min(m, dpp_quad<0x4E>(m));
+                C -= m;
+                wdec[sb * 4 + st] = (uint16_t)bits;
+                // the end of this block's region: proven?  (A quad whose block is done walks on while the other block
+                // needs it: what it writes are the true decisions of those sub-blocks, the trace is the same.)
+                const bool proven = head_test(C, st, wamin);
+                if (sb == wsb && sb > 0 && !proven) wsb = 0; // no: walk the whole chain
+                lowest = __builtin_amdgcn_readlane(wsb, 0);
+                if (nb == 2) lowest = min(lowest, __builtin_amdgcn_readlane(wsb, 4));
+            }
+        }
+        lowest = __builtin_amdgcn_readlane(wsb, 0);
+        if (nb == 2) lowest = min(lowest, __builtin_amdgcn_readlane(wsb, 4));
+        PROF_MARK(qb3_);
+        PROF_ADD2(PH_QB_PRE, qb0_, qb1_);
+        PROF_ADD2(PH_QB_WALK, qb1_, qb3_);
+    }
+    WSYNC();
+    PROF_MARK(q2_);
+    PROF_ADD2(PH_QBACK, q1_, q2_);
+    // ---- forward trace from state 0 (quantizer.rs:686-721) + level-cost walk, as in quantize() ----
+    const int half = nb == 2 ? 32 : 64;
+    const int blk = nb == 2 ? (LANE >> 5) : 0;
+    const int lane_in = LANE & (half - 1);
+    const int per = P >= half ? P / half : 1;
+    const int p0 = lane_in * per;
+    const bool act = p0 < P;
+    const int16_t* btcs = tcs + blk * P;
+    const uint16_t* bdec = dec16 + blk * (P >> 2);
+    int fmap = kMapId;
+    const DecMasks dm = dec_masks(bdec, act ? p0 : 0); // a lane's positions lie in one sub-block (per divides 16)
+    if (act) {
+        for (int j = 0; j < per; ++j) {
+            const int p = p0 + j;
+            const int tc = btcs[p];
+            fmap = compose_map(position_map(tc, quotient(k, tc, sh, off), p == P - 1, dec_nib(dm, p)), fmap);
+        }
+    }
+    int pre = fmap;
+    pre = compose_map(pre, __builtin_amdgcn_update_dpp(kMapId, pre, 0x111, 0xF, 0xF, false)); // row_shr:1
+    pre = compose_map(pre, __builtin_amdgcn_update_dpp(kMapId, pre, 0x112, 0xF, 0xF, false)); // row_shr:2
+    pre = compose_map(pre, __builtin_amdgcn_update_dpp(kMapId, pre, 0x114, 0xF, 0xF, false)); // row_shr:4
+    pre = compose_map(pre, __builtin_amdgcn_update_dpp(kMapId, pre, 0x118, 0xF, 0xF, false)); // row_shr:8
+    pre = compose_map(pre, __builtin_amdgcn_update_dpp(kMapId, pre, 0x142, 0xA, 0xF, false)); // row_bcast:15 -> rows 1, 3
+    if (nb == 1) pre = compose_map(pre, __builtin_amdgcn_update_dpp(kMapId, pre, 0x143, 0xC, 0xF, false)); // row_bcast:31 -> rows 2, 3
+    int entry = __builtin_amdgcn_update_dpp(0, pre, 0x138, 0xF, 0xF, false) & 3; // wave_shr:1
+    if (lane_in == 0) entry = 0;
+    long long sum_nz = 0;
+    unsigned zmask = 0;
+    int fnz = P;
+    if (act) {
+        int state = entry;
+        for (int j = 0; j < per; ++j) {
+            const int p = p0 + j;
+            const int tc = btcs[p];
+            SH.r1[blk * P + scan[p]] = (int16_t)emit_level(c, tc, quotient(k, tc, sh, off), p == P - 1, dec_nib(dm, p), p, j,
+                                                           state, zmask, sum_nz, fnz, ovf);
+        }
+    }
+    const int pf = group_min_i32(fnz, half); // zeros before a block's first non-zero level cost nothing
+    if (act) // zeros after the first non-zero position: positions j > pf - p0 of this lane
+        sum_nz += (long long)__popc(zmask >> min(max(pf - p0 + 1, 0), 16)) * SHT.lv[0];
+    *any_level = __ballot(pf < P) != 0ULL;
+    const long long sum = wave_sum_i64(sum_nz);
+    if (__ballot(ovf != 0) != 0ULL) *overflow = 1;
+    WSYNC();
+    PROF_MARK(q3_);
+    PROF_ADD2(PH_QTRACE, q2_, q3_);
+    return sum;
+}
+
 // Dependent quantisation of the three transform blocks of one candidate in ONE pooled pass: luma
 // n0 x n0 at r1[0, P0), Cb and Cr (n0/2)^2 at r1[P0, P0 + Pc) and r1[P0 + Pc, P0 + 2 Pc), n0 = 8 or
 // 16 (search only: every wave of the workgroup is in this call with the same block size).  Same
@@ -952,24 +1225,35 @@ __device__ __forceinline__ void quantize_pk(Ctx c, int nc, int* overflow, long l
     lvl_c[0] = lvl_c[1] = lvl_c[2] = 0;
     *any_y = false;
     *any_c = false;
-    // ---- coefficients into scan order, the first significant position of every chain ----
+    // ---- coefficients into scan order, the first significant position of every chain, and how far down its head is
+    //      provably zero (head_batch): lane i of v_low / v_amin = chain i (luma candidate i; 4 + b: chroma chain b) ----
     int nzl = 0;
+    int v_low = 0, v_amin = kAlphaInf;
+    const HeadK hkl = head_consts(shl, offl, lsc);
 #pragma unroll 1
     for (int cd = 0; cd < nc; ++cd) {
-        int first = PL;
+        int first = PL, arun = kAlphaInf, sb = SBL - 1;
+        bool open = true;
 #pragma unroll
         for (int p = lane; p < PL; p += 64) {
             const int tc = SH.r1[cd * PL + scanl[p]];
             nzl |= tc;
             tcs[cd * PL + p] = (int16_t)tc;
-            if (tc != 0 && (quotient(k, tc, shl, offl) >> 1) > 0) first = min(first, p);
+            const int qd = quotient(k, tc, shl, offl);
+            if (tc != 0 && (qd >> 1) > 0) first = min(first, p);
+            head_batch(tc, qd, p, PL, true, hkl, open, arun, sb);
         }
         first = wave_min_i32(first);
+        arun = wave_min_i32(arun);
         if (lane == 0) ist[cd] = (uint16_t)first;
+        if (lane == cd) {
+            v_low = sb;
+            v_amin = arun;
+        }
     }
     if constexpr (LGL == 3) {
 #pragma unroll
-        for (int ps = 0; ps < 2; ++ps) {
+        for (int ps = 0; ps < 2; ++ps) { // (4x4 chroma blocks: one sub-block, the DC one: no head)
             const int blk = 4 * ps + row;
             const bool mine = blk < nch;
             int tc = 0, qd = 0;
@@ -983,16 +1267,33 @@ __device__ __forceinline__ void quantize_pk(Ctx c, int nc, int* overflow, long l
             if (mine && i16 == 0) ist[4 + blk] = (uint16_t)first;
         }
     } else {
+        const HeadK hkc = head_consts(shc, offc, lsc);
 #pragma unroll 1
         for (int b = 0; b < nch; ++b) {
             const int tc = SH.r1[nL + b * PC + scanc[lane]];
             nzl |= tc;
             tcs[nL + b * PC + lane] = (int16_t)tc;
-            const int first = wave_min_i32((tc != 0 && (quotient(k, tc, shc, offc) >> 1) > 0) ? lane : PC);
+            const int qd = quotient(k, tc, shc, offc);
+            const int first = wave_min_i32((tc != 0 && (qd >> 1) > 0) ? lane : PC);
+            int arun = kAlphaInf, sb = SBC - 1;
+            bool open = true;
+            head_batch(tc, qd, lane, PC, true, hkc, open, arun, sb);
+            arun = wave_min_i32(arun);
             if (lane == 0) ist[4 + b] = (uint16_t)first;
+            if (lane == 4 + b) {
+                v_low = sb;
+                v_amin = arun;
+            }
         }
     }
     if (__ballot(nzl != 0) == 0ULL) return; // every block of the pack is zero: the levels are the zeros already in r1
+    // the decisions of sub-blocks the walk never reaches are zero in every state (the trace stays in state 0 there)
+    {
+        constexpr int kMaxNc = LGL == 3 ? 3 : 2;
+        constexpr int kDecWords = (4 * SBL * kMaxNc + 4 * SBC * 2 * kMaxNc + 3) / 4; // 8-byte words of the largest pack
+        static_assert(kDecWords <= 64 && 8 * kDecWords <= 512, "decw");
+        if (lane < (4 * SBL * nc + 4 * SBC * nch + 3) / 4) *(uint2*)(dec16 + 4 * lane) = make_uint2(0u, 0u);
+    }
     WSYNC();
     PROF_MARK(q1_);
     PROF_ADD2(PH_QPRE, q0_, q1_);
@@ -1001,44 +1302,46 @@ __device__ __forceinline__ void quantize_pk(Ctx c, int nc, int* overflow, long l
     const int cls = st == 0 ? 0 : (st == 1 ? 1 : 2);
     int C = 0;
     int ovf = 0;
-    // the rows' chroma chains (uniform): chain in the row (-1: none), its sub-blocks still to walk
-    int rchain[4] = {-1, -1, -1, -1}, rleft[4] = {0, 0, 0, 0};
+    // The rows' chains (uniform).  A ROUND gives each row the next sub-block of its chain; a row whose chain is done
+    // takes the next chain of the pack: the luma chains first, then the chroma chains.  rleft = sub-blocks still to
+    // walk, rlow = the sub-block its walk stops at if the head test passes there (0: walk to the end, no test).
+    int rid[4] = {-1, -1, -1, -1}, rleft[4] = {0, 0, 0, 0}, rlow[4] = {0, 0, 0, 0}, ramin[4] = {0, 0, 0, 0};
     int next_chain = 0;
+    const int nct = nc + nch;
 #pragma unroll 1
-    for (int r = 0;; ++r) {
-        const int nlum = r < SBL ? nc : 0;              // rows 0 .. nlum - 1: the luma candidates' sub-block SBL - 1 - r
-        bool fresh[4];                                  // the row starts a chain in this round (its path costs start at 0)
-        bool any_row = nlum > 0;
+    for (;;) {
+        bool fresh[4];
+        bool any_row = false;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             fresh[j] = false;
-            if (j < nlum) continue;
             if (rleft[j] == 0) {
-                rchain[j] = -1;
-                if (next_chain < nch) {
-                    rchain[j] = next_chain++;
-                    rleft[j] = SBC;
+                rid[j] = -1;
+                if (next_chain < nct) {
+                    const int id = next_chain < nc ? next_chain : 4 + (next_chain - nc); // lane of v_low / v_amin, index of ist
+                    ++next_chain;
+                    rid[j] = id;
+                    rlow[j] = __builtin_amdgcn_readlane(v_low, id);
+                    ramin[j] = __builtin_amdgcn_readlane(v_amin, id);
+                    rleft[j] = (id < 4 ? SBL : SBC) - rlow[j];
                     fresh[j] = true;
                 }
             }
-            any_row = any_row || rchain[j] >= 0;
+            any_row = any_row || rid[j] >= 0;
         }
         if (!any_row) break;
-        const int base0 = PL - 16 * (r + 1);            // the luma chains' positions of the round
-        // this lane's row: luma candidate, or chroma chain + sub-block
-        const bool is_l = row < nlum;
-        const int mychain = row == 0 ? rchain[0] : (row == 1 ? rchain[1] : (row == 2 ? rchain[2] : rchain[3]));
-        const int myleft = row == 0 ? rleft[0] : (row == 1 ? rleft[1] : (row == 2 ? rleft[2] : rleft[3]));
-        const bool is_c = !is_l && mychain >= 0;
-        const int cbase = 16 * (myleft - 1);            // the chroma chain's positions of the round
+        // this lane's row: chain, sub-block of the round
+        const int myid = row == 0 ? rid[0] : (row == 1 ? rid[1] : (row == 2 ? rid[2] : rid[3]));
+        const int mysb = (row == 0 ? rlow[0] + rleft[0] : (row == 1 ? rlow[1] + rleft[1] : (row == 2 ? rlow[2] + rleft[2] : rlow[3] + rleft[3]))) - 1;
         {
-            const bool mine = is_l || is_c;
-            const int p = (is_l ? base0 : cbase) + i16;
+            const bool mine = myid >= 0;
+            const bool is_l = myid < 4;
+            const int p = 16 * mysb + i16;
             const int sh = is_l ? shl : shc, off = is_l ? offl : offc;
             int par0 = 0, par1 = 0, adj = 0;
             if (mine) {
-                const int tc = tcs[is_l ? row * PL + p : nL + mychain * PC + p];
-                const int first = ist[is_l ? row : 4 + mychain];
+                const int tc = tcs[is_l ? myid * PL + p : nL + (myid - 4) * PC + p];
+                const int first = ist[myid];
                 chunk_entry(c, cc + lane * 6, tc, quotient(k, tc, sh, off), p == (is_l ? PL - 1 : PC - 1), p <= first, sh, off, lsc, ldq1,
                             &par0, &par1, &adj, &ovf);
             }
@@ -1052,14 +1355,17 @@ __device__ __forceinline__ void quantize_pk(Ctx c, int nc, int* overflow, long l
         }
         WSYNC();
         PROF_MARK(qb1_);
+        bool unproven = false;
         if (quad < 4) {
             // (quad q walks row q: the same selects with the quad number)
-            const bool wl = quad < nlum;
-            const int wchain = quad == 0 ? rchain[0] : (quad == 1 ? rchain[1] : (quad == 2 ? rchain[2] : rchain[3]));
+            const int wid = quad == 0 ? rid[0] : (quad == 1 ? rid[1] : (quad == 2 ? rid[2] : rid[3]));
             const int wleft = quad == 0 ? rleft[0] : (quad == 1 ? rleft[1] : (quad == 2 ? rleft[2] : rleft[3]));
+            const int wlow = quad == 0 ? rlow[0] : (quad == 1 ? rlow[1] : (quad == 2 ? rlow[2] : rlow[3]));
+            const int wamin = quad == 0 ? ramin[0] : (quad == 1 ? ramin[1] : (quad == 2 ? ramin[2] : ramin[3]));
             const bool wfresh = quad == 0 ? fresh[0] : (quad == 1 ? fresh[1] : (quad == 2 ? fresh[2] : fresh[3]));
-            if (wl || wchain >= 0) {
-                if (!wl && wfresh) C = 0; // a new chain
+            if (wid >= 0) {
+                if (wfresh) C = 0; // a new chain
+                const int wsb = wlow + wleft - 1;
                 const int32_t* wcc = cc + quad * 16 * 6;
                 const uint16_t* pm = SH.q_pm[0][quad];
                 const unsigned parmask = pm[st > 1 ? 1 : 0];
@@ -1085,15 +1391,25 @@ __device__ __forceinline__ void quantize_pk(Ctx c, int nc, int* overflow, long l
                 int m = min(C, dpp_quad<0xB1>(C)); // renormalise (see quantize())
                 m = min(m, dpp_quad<0x4E>(m));
                 C -= m;
-                dec16[(wl ? 4 * SBL * quad + 4 * (SBL - 1 - r) : 4 * SBL * nc + 4 * SBC * wchain + 4 * (wleft - 1)) + st] = (uint16_t)bits;
+                dec16[(wid < 4 ? 4 * SBL * wid : 4 * SBL * nc + 4 * SBC * (wid - 4)) + 4 * wsb + st] = (uint16_t)bits;
+                // the last sub-block of the chain's planned walk: is the head above it proven zero?
+                const bool proven = head_test(C, st, wamin);
+                unproven = wleft == 1 && wlow > 0 && !proven;
             }
         }
+        const unsigned long long ub = __ballot(unproven);
         WSYNC();
         PROF_MARK(qb2_);
         PROF_ADD2(PH_QB_WALK, qb1_, qb2_);
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-            if (j >= nlum && rchain[j] >= 0) --rleft[j];
+            if (rid[j] >= 0) {
+                --rleft[j];
+                if ((ub >> (4 * j)) & 1ULL) { // not proven: the chain walks on to its end
+                    rleft[j] = rlow[j];
+                    rlow[j] = 0;
+                }
+            }
     }
     PROF_MARK(q2_);
     PROF_ADD2(PH_QBACK, q1_, q2_);

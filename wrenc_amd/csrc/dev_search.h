@@ -11,7 +11,7 @@ namespace wrenc {
 // ---------------------------------------------------------------------------
 enum { K_SADLIST = 0, K_FULL = 1, K_NOP = 2, K_SADSEARCH = 3, K_CCLMSEARCH = 4, K_LEAF4 = 5, K_LEAFC4 = 6, K_LEAF8 = 7, K_LEAF16 = 8, K_SPLIT8 = 9, K_SERVE4 = 10 };
 #ifndef WRENC_POOL_MIN_TLG
-#define WRENC_POOL_MIN_TLG 3
+#define WRENC_POOL_MIN_TLG 6
 #endif
 enum { COPY_NONE = 0, COPY_SAVE = 1, COPY_RESTORE = 2, COPY_PULL = 3 };
 // build knobs (tools/README.md): the level schedule of the team kernel at max-split-depth 3; an 8x8 CU's split as one request
@@ -474,7 +474,11 @@ __device__ __forceinline__ Res evaluate(const Ctx& c, const PicBufs& pb, const R
                 quantize3(c, q.tlg, pooled, q.active, overflow, &r.lvl_y, &r.lvl_c, &any_y, &any_c);
             } else {
                 bool any = false;
-                const long long lvl = quantize(c, q.tlg - round, round ? 2 : 1, pooled, q.active, overflow, &any);
+                long long lvl = 0;
+                if (pooled)
+                    lvl = quantize(c, q.tlg - round, round ? 2 : 1, true, q.active, overflow, &any);
+                else if (q.active)
+                    lvl = quantize_solo(c, q.tlg - round, round ? 2 : 1, overflow, &any);
                 if (round) {
                     r.lvl_c = lvl;
                     any_c = any;

@@ -319,7 +319,7 @@ __global__ __launch_bounds__(64) void test_quantize_kernel(const DevConst* __res
     WSYNC();
     int ovf = 0;
     bool any = false;
-    const long long lc = quantize(c, lg, 1, false, true, &ovf, &any);
+    const long long lc = quantize_solo(c, lg, 1, &ovf, &any);
     for (int i = threadIdx.x; i < nn; i += 64) out[(size_t)blockIdx.x * nn + i] = SH.r1[i];
     if (threadIdx.x == 0) {
         cost[blockIdx.x] = lc;
