@@ -1,5 +1,5 @@
 """frames/s of one encode call against pictures in flight: fill_probe.py WxH DEPTH B1,B2,... [QP] [textured]
-(WRENC_GPU_LIB selects the library: experiment builds live under build/exp/).  Best of 2 per point; one JSON line."""
+(WRENC_GPU_LIB selects the library: experiment builds live under xbuild/).  Best of 2 per point; one JSON line."""
 import json
 import os
 import sys

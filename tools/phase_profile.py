@@ -1,6 +1,6 @@
 """Phase shares of a CTU-wave from the diagnostic build (never the product library):
   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -shared -mllvm -sink-insts-to-avoid-spills=1 -DWRENC_PROFILE \
-        -o build/exp/libwrenc_gpu_prof.so wrenc_amd/csrc/wrenc_gpu.hip
+        -o xbuild/libwrenc_gpu_prof.so wrenc_amd/csrc/wrenc_gpu.hip
   python tools/phase_profile.py WxH DEPTH B SCHEDULE
 The counters are s_memtime differences of thread 0 of each workgroup (wave 0 = member 0 of its team in the team
 schedule), summed over all CTUs."""
@@ -10,7 +10,7 @@ import sys
 import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-os.environ["WRENC_GPU_LIB"] = os.path.join(ROOT, "build", "exp", "libwrenc_gpu_prof.so")
+os.environ["WRENC_GPU_LIB"] = os.path.join(ROOT, "xbuild", "libwrenc_gpu_prof.so")
 sys.path.insert(0, ROOT)
 from wrenc_amd import gpu, synth  # noqa: E402
 

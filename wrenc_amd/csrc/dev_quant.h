@@ -634,12 +634,19 @@ __device__ __forceinline__ long long quantize_solo(Ctx c, int lg, int nb, int* o
     WSYNC();
     PROF_MARK(q2_);
     PROF_ADD2(PH_QBACK, q1_, q2_);
-    // ---- forward trace from state 0 (quantizer.rs:686-721) + level-cost walk, as in quantize() ----
+    // ---- forward trace from state 0 (quantizer.rs:686-721) + level-cost walk, as in quantize(), from where each block's
+    //      walk ended: the levels before that are zero (r1's chunk entries are dead: zero all levels first), the trace
+    //      reaches that position in state 0, and the block's lanes share what is left ----
+    const int start0 = 16 * __builtin_amdgcn_readlane(wsb, 0), start1 = nb == 2 ? 16 * __builtin_amdgcn_readlane(wsb, 4) : 0;
+    for (int i = LANE; i < (nb * P) / 8; i += 64) *(uint4*)&SH.r1[8 * i] = make_uint4(0u, 0u, 0u, 0u);
+    WSYNC();
     const int half = nb == 2 ? 32 : 64;
     const int blk = nb == 2 ? (LANE >> 5) : 0;
     const int lane_in = LANE & (half - 1);
-    const int per = P >= half ? P / half : 1;
-    const int p0 = lane_in * per;
+    const int start = blk ? start1 : start0;
+    int per = 1;
+    while (per * half < P - start) per *= 2;   // (uniform per block; per divides 16: P - start <= 1024 = 16 * 64)
+    const int p0 = start + lane_in * per;
     const bool act = p0 < P;
     const int16_t* btcs = tcs + blk * P;
     const uint16_t* bdec = dec16 + blk * (P >> 2);
@@ -1064,19 +1071,22 @@ __device__ __forceinline__ void quantize_p16(Ctx c, int nb, int* overflow, long 
 // positions per lane: they lie in one sub-block); levels to r1[rbase + 64 b + scan[p]]; per block the level cost and
 // "has a non-zero level"
 __device__ __forceinline__ void trace_rows64(const Ctx& c, int nblk, const int16_t* tcs, const uint16_t* dec16, int rbase,
-                                             const CONST_AS uint16_t* scan, int sh, int off, long long lvl[4], bool any[4], int& ovf) {
+                                             const CONST_AS uint16_t* scan, int sh, int off, long long lvl[4], bool any[4], int& ovf,
+                                             int start = 0) {
+    // start (per row: a multiple of 16): the positions before it are proven zero (their levels are zero already, the
+    // trace reaches `start` in state 0); the row's lanes share what is left, 1, 2 or 4 consecutive positions each
     const int lane = lane_fresh();
     const int row = lane >> 4, i16 = lane & 15;
     const CONST_AS DevConst* k = c.k;
-    const bool act = row < nblk;
-    const int b = act ? row : 0;
-    const int p0 = i16 * 4;
+    const int per = start >= 48 ? 1 : (start >= 32 ? 2 : 4);
+    const int p0 = start + i16 * per;
+    const bool act = row < nblk && p0 < 64;
+    const int b = row < nblk ? row : 0;
     const int16_t* btcs = tcs + b * 64;
-    const DecMasks dm = dec_masks(dec16 + b * 16, p0);
+    const DecMasks dm = dec_masks(dec16 + b * 16, act ? p0 : 0);
     int fmap = kMapId;
     if (act) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < per; ++j) {
             const int p = p0 + j;
             const int tc = btcs[p];
             fmap = compose_map(position_map(tc, quotient(k, tc, sh, off), p == 63, dec_nib(dm, p)), fmap);
@@ -1094,8 +1104,7 @@ __device__ __forceinline__ void trace_rows64(const Ctx& c, int nblk, const int16
     int fnz = 64;
     if (act) {
         int state = entry;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < per; ++j) {
             const int p = p0 + j;
             const int tc = btcs[p];
             SH.r1[rbase + b * 64 + scan[p]] = (int16_t)emit_level(c, tc, quotient(k, tc, sh, off), p == 63, dec_nib(dm, p), p, j, state,
@@ -1158,17 +1167,22 @@ __device__ __forceinline__ void trace_rows16(const Ctx& c, int nblk, const int16
 
 // the same for ONE block of 256 positions over the whole wave (four consecutive positions per lane), as quantize()
 __device__ __forceinline__ void trace_wave256(const Ctx& c, const int16_t* tcs, const uint16_t* dec16, int rbase,
-                                              const CONST_AS uint16_t* scan, int sh, int off, long long* lvl, bool* any, int& ovf) {
+                                              const CONST_AS uint16_t* scan, int sh, int off, long long* lvl, bool* any, int& ovf,
+                                              int start = 0) {
+    // start (uniform, a multiple of 16): see trace_rows64; the wave's lanes share the positions from there on
     const int lane = lane_fresh();
     const CONST_AS DevConst* k = c.k;
-    const int p0 = lane * 4;
-    const DecMasks dm = dec_masks(dec16, p0);
+    const int per = start >= 192 ? 1 : (start >= 128 ? 2 : 4);
+    const int p0 = start + lane * per;
+    const bool act = p0 < 256;
+    const DecMasks dm = dec_masks(dec16, act ? p0 : 0);
     int fmap = kMapId;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int p = p0 + j;
-        const int tc = tcs[p];
-        fmap = compose_map(position_map(tc, quotient(k, tc, sh, off), p == 255, dec_nib(dm, p)), fmap);
+    if (act) {
+        for (int j = 0; j < per; ++j) {
+            const int p = p0 + j;
+            const int tc = tcs[p];
+            fmap = compose_map(position_map(tc, quotient(k, tc, sh, off), p == 255, dec_nib(dm, p)), fmap);
+        }
     }
     int pre = fmap;
     pre = compose_map(pre, __builtin_amdgcn_update_dpp(kMapId, pre, 0x111, 0xF, 0xF, false)); // row_shr:1
@@ -1182,10 +1196,9 @@ __device__ __forceinline__ void trace_wave256(const Ctx& c, const int16_t* tcs, 
     long long sum_nz = 0;
     unsigned zmask = 0;
     int fnz = 256;
-    {
+    if (act) {
         int state = entry;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < per; ++j) {
             const int p = p0 + j;
             const int tc = tcs[p];
             SH.r1[rbase + scan[p]] = (int16_t)emit_level(c, tc, quotient(k, tc, sh, off), p == 255, dec_nib(dm, p), p, j, state, zmask,
@@ -1193,7 +1206,7 @@ __device__ __forceinline__ void trace_wave256(const Ctx& c, const int16_t* tcs, 
         }
     }
     const int pf = wave_min_i32(fnz);
-    sum_nz += (long long)__popc(zmask >> min(max(pf - p0 + 1, 0), 16)) * SHT.lv[0];
+    if (act) sum_nz += (long long)__popc(zmask >> min(max(pf - p0 + 1, 0), 16)) * SHT.lv[0];
     *any = pf < 256;
     *lvl = wave_sum_i64(sum_nz);
 }
@@ -1408,16 +1421,22 @@ __device__ __forceinline__ void quantize_pk(Ctx c, int nc, int* overflow, long l
                 if ((ub >> (4 * j)) & 1ULL) { // not proven: the chain walks on to its end
                     rleft[j] = rlow[j];
                     rlow[j] = 0;
+                    if (lane == rid[j]) v_low = 0;
                 }
             }
     }
     PROF_MARK(q2_);
     PROF_ADD2(PH_QBACK, q1_, q2_);
-    // ---- forward trace from state 0 (quantizer.rs:686-721) + level cost ----
+    // ---- forward trace from state 0 (quantizer.rs:686-721) + level cost, from where each chain's walk ended (v_low);
+    //      the levels before that are zero: the chunk entries in r1 are dead, zero all of the pack's levels first ----
+    for (int i = lane; i < (nL + nch * PC) / 8; i += 64) *(uint4*)&SH.r1[8 * i] = make_uint4(0u, 0u, 0u, 0u);
+    WSYNC();
     if constexpr (LGL == 3) {
         long long l4[4];
         bool a4[4];
-        trace_rows64(c, nc, tcs, dec16, 0, scanl, shl, offl, l4, a4, ovf);
+        const int s0_ = 16 * __builtin_amdgcn_readlane(v_low, 0), s1_ = 16 * __builtin_amdgcn_readlane(v_low, 1),
+                  s2_ = 16 * __builtin_amdgcn_readlane(v_low, 2);
+        trace_rows64(c, nc, tcs, dec16, 0, scanl, shl, offl, l4, a4, ovf, row == 0 ? s0_ : (row == 1 ? s1_ : (row == 2 ? s2_ : 0)));
 #pragma unroll
         for (int b = 0; b < 3; ++b)
             if (b < nc) {
@@ -1440,7 +1459,8 @@ __device__ __forceinline__ void quantize_pk(Ctx c, int nc, int* overflow, long l
         for (int cd = 0; cd < nc; ++cd) {
             long long l1;
             bool a1;
-            trace_wave256(c, tcs + cd * PL, dec16 + 4 * SBL * cd, cd * PL, scanl, shl, offl, &l1, &a1, ovf);
+            trace_wave256(c, tcs + cd * PL, dec16 + 4 * SBL * cd, cd * PL, scanl, shl, offl, &l1, &a1, ovf,
+                          16 * __builtin_amdgcn_readlane(v_low, cd));
             if (cd == 0)
                 lvl_y[0] = l1;
             else
@@ -1449,7 +1469,10 @@ __device__ __forceinline__ void quantize_pk(Ctx c, int nc, int* overflow, long l
         }
         long long l4[4];
         bool a4[4];
-        trace_rows64(c, nch, tcs + nL, dec16 + 4 * SBL * nc, nL, scanc, shc, offc, l4, a4, ovf); // four 8x8 chroma blocks at most
+        const int s4_ = 16 * __builtin_amdgcn_readlane(v_low, 4), s5_ = 16 * __builtin_amdgcn_readlane(v_low, 5),
+                  s6_ = 16 * __builtin_amdgcn_readlane(v_low, 6), s7_ = 16 * __builtin_amdgcn_readlane(v_low, 7);
+        trace_rows64(c, nch, tcs + nL, dec16 + 4 * SBL * nc, nL, scanc, shc, offc, l4, a4, ovf,
+                     row == 0 ? s4_ : (row == 1 ? s5_ : (row == 2 ? s6_ : s7_))); // four 8x8 chroma blocks at most
 #pragma unroll
         for (int b = 0; b < 4; ++b)
             if (b < nch) {
