@@ -40,6 +40,12 @@ enum wrenc_gpu_status {
     WRENC_GPU_ELEVEL = -6    /* a quantised level reached 1024 (reference would panic,
                                 block_splitter.rs:453) */
 };
+/* WRENC_GPU_ELEVEL and the internal WRENC_GPU_EHIP "a team member never reached a meeting point" are reported by sync /
+ * download / download_compact and are STICKY, like the reference's panic: the pictures of the call that raised them --
+ * and of every call in flight next to it -- are undefined (a team that times out stops storing, its CTU and everything
+ * that depends on it are garbage; the slots' zero-block bookkeeping no longer matches their level planes), every later
+ * sync / download of the context fails the same way, and the context must be destroyed.  The wrenc_gpu_test_* entries
+ * keep a word of their own and never poison a context. */
 
 /* Resolved configuration.  The RD-model constants are resolved on the host
  * (libm pow/powf, exactly as block_splitter.rs:29-53,187-375 and

@@ -1,7 +1,7 @@
 """Phase shares of a CTU-wave from the diagnostic build (never the product library):
   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -shared -mllvm -sink-insts-to-avoid-spills=1 -DWRENC_PROFILE \
         -o xbuild/libwrenc_gpu_prof.so wrenc_amd/csrc/wrenc_gpu.hip
-  python tools/phase_profile.py WxH DEPTH B SCHEDULE
+  python tools/phase_profile.py WxH DEPTH B SCHEDULE [1 = textured content]
 The counters are s_memtime differences of thread 0 of each workgroup (wave 0 = member 0 of its team in the team
 schedule), summed over all CTUs."""
 import ctypes as C
@@ -18,7 +18,8 @@ w, h = [int(v) for v in (sys.argv[1] if len(sys.argv) > 1 else "1920x1088").spli
 depth = int(sys.argv[2]) if len(sys.argv) > 2 else 2
 B = int(sys.argv[3]) if len(sys.argv) > 3 else 16
 schedule = int(sys.argv[4]) if len(sys.argv) > 4 else 1
-frames = [synth.synth_frame(w, h, f) for f in range(4)]
+make = synth.synth_textured_frame if len(sys.argv) > 5 and sys.argv[5] == "1" else synth.synth_frame
+frames = [make(w, h, f) for f in range(4)]
 enc = gpu.Encoder(w, h, qp=32, max_split_depth=depth, n_slots=B, schedule=schedule)
 for s in range(B):
     enc.upload(s, *frames[s % 4])

@@ -312,7 +312,20 @@ struct __attribute__((aligned(16))) Lds {
     uint8_t recY[32 * 36];     // x = -4..31 (index x+4), stride 36
     uint8_t recCtop[2][40];    // y = -1, x = -4..35
     uint8_t recC[2][16 * 20];  // x = -4..15, stride 20
-    uint32_t decw[128];        // trellis decisions: 4 bits per position, 8 positions per word
+    // 512 bytes with SIX users; who holds which bytes, and for how long (profiles/r04_wrong_sads.md: an overlap here is what
+    // round 3's wrong-SAD builds had):
+    //   [0, nb P / 2)   trellis decisions of a quantiser call, one u16 mask per sub-block and state: 512 B for a 32x32 block,
+    //                   144 B for a pack of three 8x8 candidates, 384 B for a pack of two 16x16 ones, 32 B for four 4x4
+    //                   blocks; dead when the call returns
+    //   [128, 256)      SAD lists: ptab, ptab2 (16 entries each); [4 WRENC_SAD_SUMS_AT, + 64): sums.  Live inside one
+    //                   sad_list_angular call
+    //   [160, 448)      PRED_PARK (kParkByte): predictions, then reconstructions, of an 8x8 pack; live from pack8_eval's
+    //                   predictions to pack8_to_tile -- a pack's winner is in the tile BEFORE the leaf's SAD search runs
+    //                   (the server's pack A: until the owner has taken the winner, job_ack)
+    //   [384, 512)      PRED_PARK16: the last 128 bytes of a 16x16 pack's park, behind its 384 bytes of decisions; same
+    //                   lifetime as PRED_PARK
+    //   [448, 504)      team kernel, member 0 as pack-A server of 4x4 leaves (kSrv4Byte): results until the owner's job4_ack
+    uint32_t decw[128];
     int32_t q_istar[2];        // shared-Viterbi hand-off, per block: first position with a non-zero state-0 level
     int32_t q_active;          // this wave's TB takes part in the shared Viterbi
     uint32_t fsum;             // final pass: checksum of the search's reconstruction of the block being re-made

@@ -346,6 +346,7 @@ __device__ __forceinline__ void stage_org_leaf(const Ctx& c, int comps, int tx, 
 // instead: PRED_PARK, byte kParkByte + i of decw (behind the pack's trellis decisions).
 enum { PRED_SCRATCH = 0, PRED_TILE = 1, PRED_PARK = 2, PRED_PARK16 = 3 };
 constexpr int kParkByte = 160; // 144 bytes of decisions in front, 288 bytes of predictions (3 x (64 + 16 + 16)) behind
+static_assert(kParkByte >= 144 && kParkByte % 16 == 0 && kParkByte + 288 <= 448, "Lds::decw: decisions of an 8x8 pack | its park | the server's results");
 // PRED_PARK16: a pack of TWO 16x16 candidates (K_LEAF16) has no one free region for its 768 bytes of predictions, but
 // three that add up to exactly that: the last 512 bytes of r1 (two candidates' residuals fill the first 1536; chunk
 // entries, levels and the inverse transform stay inside them) for the luma predictions, 128 bytes of r2 between the
@@ -839,6 +840,7 @@ __device__ __forceinline__ unsigned sad_list_angular(const Ctx& c, int comps, in
 #ifndef WRENC_SAD_SUMS_AT
 #define WRENC_SAD_SUMS_AT 64
 #endif
+            static_assert(WRENC_SAD_SUMS_AT >= 64 && WRENC_SAD_SUMS_AT + 16 <= 128, "Lds::decw: sums behind ptab2, inside decw");
             uint32_t* sums = (uint32_t*)SH.decw + WRENC_SAD_SUMS_AT; // [entry]: the SAD of this component
 #pragma unroll 1
             for (int base = 0; base < nmodes; base += 64 >> lgG) {
@@ -894,10 +896,28 @@ __device__ __forceinline__ unsigned sad_list_angular(const Ctx& c, int comps, in
                         else
                             v[k] = __builtin_amdgcn_sdot4(wgt, taps, 4096 + 16, false) >> 5;
                     }
+#ifdef WRENC_EXP_OLD_PDPC // experiment only (profiles/r04_wrong_sads.md): round 3's first version, PDPC under a lane-divergent branch
+                    if (any_pdpc && pdpc) {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            const int w_ = pdpc_w(n_scale, c0 + k);
+                            int rs_;
+                            if (kind == 1)
+                                rs_ = (int)(int16_t)(side[along] - alrs + v[k]);
+                            else
+                                rs_ = side[along + ((M24(c0 + k + 1, inv_angle) + 256) >> 9)];
+                            const int pv_ = (int16_t)(M24(rs_, w_) + M24(64 - w_, v[k]) + 32) >> 6;
+                            v[k] = min(max(pv_, 0), 255);
+                        }
+                    }
+                    if (false) {
+                        for (int k = 0; k < 4; ++k) {
+#else
                     if (any_pdpc) { // (wave-uniform; inside it every lane runs the same code: a lane without PDPC weighs by 0,
                                     // as does a sample beyond 3 << n_scale, so what is read for those does not matter)
 #pragma unroll
                         for (int k = 0; k < 4; ++k) {
+#endif
                             const int sv = side[pdpc ? along + dk[k] : 0];
                             const int rs = kind == 1 ? (int)(int16_t)(sv - alrs + v[k]) : sv;
                             const int pv = (int16_t)(M24(rs, wp[k]) + M24(64 - wp[k], v[k]) + 32) >> 6;

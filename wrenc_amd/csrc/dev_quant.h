@@ -473,6 +473,8 @@ __device__ __forceinline__ int head_alpha(int tc, int qd, bool last, const HeadK
 // ended the region; arun = this lane's minimum of alpha over the region so far; sb = the sub-block the walk must reach
 __device__ __forceinline__ void head_batch(int tc, int qd, int p, int P, bool valid, const HeadK& h, bool& open, int& arun, int& sb) {
     if (!open) return;
+    // a batch of zero coefficients that does not hold the DC position: alpha = inf, beta = ldq1 everywhere
+    if (__ballot(valid && (tc != 0 || p == P - 1)) == 0ULL && h.ldq1 >= 0) return;
     bool bad;
     const int alpha = head_alpha(tc, qd, p == P - 1, h, &bad);
     const unsigned long long B = __ballot(valid && bad);
@@ -518,7 +520,7 @@ __device__ __forceinline__ long long quantize_solo(Ctx c, int lg, int nb, int* o
     int nzl = 0;
 #pragma unroll 1
     for (int blk = 0; blk < nb; ++blk) {
-        int first = P, arun = kAlphaInf, sb = nsb - 1;
+        int first = P, arun = kAlphaInf, sb = nsb - 1; // (first: uniform)
         bool open = true;
 #pragma unroll 1
         for (int p0 = 0; p0 < P; p0 += 64) {
@@ -528,11 +530,13 @@ __device__ __forceinline__ long long quantize_solo(Ctx c, int lg, int nb, int* o
             nzl |= tc;
             const int qd = quotient(k, tc, sh, off);
             if (valid) tcs[blk * P + p] = (int16_t)tc;
-            if (tc != 0 && (qd >> 1) > 0) first = min(first, p);
+            if (first == P) {
+                const unsigned long long sig = __ballot(tc != 0 && (qd >> 1) > 0);
+                if (sig != 0ULL) first = p0 + (int)__builtin_ctzll(sig);
+            }
             head_batch(tc, qd, p, P, valid, hk, open, arun, sb);
         }
-        first = wave_min_i32(first);
-        arun = wave_min_i32(arun);
+        if (sb > 0) arun = wave_min_i32(arun);
         if (blk) {
             istar1 = first;
             sbs1 = sb;
@@ -1245,7 +1249,7 @@ __device__ __forceinline__ void quantize_pk(Ctx c, int nc, int* overflow, long l
     const HeadK hkl = head_consts(shl, offl, lsc);
 #pragma unroll 1
     for (int cd = 0; cd < nc; ++cd) {
-        int first = PL, arun = kAlphaInf, sb = SBL - 1;
+        int first = PL, arun = kAlphaInf, sb = SBL - 1; // (first: uniform)
         bool open = true;
 #pragma unroll
         for (int p = lane; p < PL; p += 64) {
@@ -1253,11 +1257,13 @@ __device__ __forceinline__ void quantize_pk(Ctx c, int nc, int* overflow, long l
             nzl |= tc;
             tcs[cd * PL + p] = (int16_t)tc;
             const int qd = quotient(k, tc, shl, offl);
-            if (tc != 0 && (qd >> 1) > 0) first = min(first, p);
+            if (first == PL) {
+                const unsigned long long sig = __ballot(tc != 0 && (qd >> 1) > 0);
+                if (sig != 0ULL) first = (p - lane) + (int)__builtin_ctzll(sig);
+            }
             head_batch(tc, qd, p, PL, true, hkl, open, arun, sb);
         }
-        first = wave_min_i32(first);
-        arun = wave_min_i32(arun);
+        if (sb > 0) arun = wave_min_i32(arun);
         if (lane == 0) ist[cd] = (uint16_t)first;
         if (lane == cd) {
             v_low = sb;
@@ -1287,11 +1293,12 @@ __device__ __forceinline__ void quantize_pk(Ctx c, int nc, int* overflow, long l
             nzl |= tc;
             tcs[nL + b * PC + lane] = (int16_t)tc;
             const int qd = quotient(k, tc, shc, offc);
-            const int first = wave_min_i32((tc != 0 && (qd >> 1) > 0) ? lane : PC);
+            const unsigned long long sig = __ballot(tc != 0 && (qd >> 1) > 0);
+            const int first = sig != 0ULL ? (int)__builtin_ctzll(sig) : PC;
             int arun = kAlphaInf, sb = SBC - 1;
             bool open = true;
             head_batch(tc, qd, lane, PC, true, hkc, open, arun, sb);
-            arun = wave_min_i32(arun);
+            if (sb > 0) arun = wave_min_i32(arun);
             if (lane == 0) ist[4 + b] = (uint16_t)first;
             if (lane == 4 + b) {
                 v_low = sb;

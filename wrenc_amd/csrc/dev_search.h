@@ -3154,14 +3154,17 @@ __device__ __forceinline__ void encode_ctu(Ctx& c, const PicBufs& pb, int ctu_co
     const float cost = SH.st.ctu_cost;
     // which blocks of levels this encode left non-zero: the words of the quadrants whose CUs this wave emitted (wave
     // schedule: all four; a team member: its own, member 0 all four when the CTU is one 32x32 CU)
-    if (c.store && SH.st.fz_on) {
+    // a team whose meeting point timed out (lv_meet) has made its decisions from half-posted costs: it stores nothing more
+    // (the host reports WRENC_GPU_EHIP at the next sync / download and the context is to be destroyed, wrenc_gpu.h)
+    const bool dead = TEAM && uni((int)SHT.lvb.pad_) != 0;
+    if (c.store && SH.st.fz_on && !dead) {
         WSYNC();
         const bool all4 = !TEAM || uni((int)SH.cu_log2[0]) == 5;
         if (LANE < 4 && (all4 || LANE == c.member))
             AS_GLOBAL(uint32_t, pb.lev_dirty)[(size_t)(ctu_row * k->ctu_cols + ctu_col) * 4 + LANE] = SH.lev_now[LANE];
     }
     // store recon + decisions
-    if (c.write) {
+    if (c.write && !dead) {
         for (int i = LANE; i < 1024 / 4; i += 64) {
             const int y = i >> 3, x4 = (i & 7) * 4;
             *(GLOBAL_AS uint32_t*)&rec[(size_t)(c.ctu_y + y) * W + c.ctu_x + x4] = *(const uint32_t*)&SH.recY[y * 36 + x4 + 4];

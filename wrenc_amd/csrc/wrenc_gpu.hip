@@ -972,8 +972,8 @@ int wrenc_gpu_create(const wrenc_gpu_config* cfg, wrenc_gpu_ctx** out) {
     }
     CREATE_TRY(hipMalloc((void**)&ctx->d_mismatch, sizeof(unsigned long long)));
     CREATE_TRY(hipMemset(ctx->d_mismatch, 0, sizeof(unsigned long long)));
-    CREATE_TRY(hipMalloc((void**)&ctx->d_overflow, sizeof(int)));
-    CREATE_TRY(hipMemset(ctx->d_overflow, 0, sizeof(int)));
+    CREATE_TRY(hipMalloc((void**)&ctx->d_overflow, 2 * sizeof(int))); // [0]: encode calls (sticky), [1]: the building-block test entries
+    CREATE_TRY(hipMemset(ctx->d_overflow, 0, 2 * sizeof(int)));
     ctx->slots.assign(cfg->n_slots, PicBufs{});
     ctx->state.assign(cfg->n_slots, 0);
     for (int s = 0; s < cfg->n_slots; ++s) {
@@ -1514,7 +1514,7 @@ int wrenc_gpu_test_quantize(wrenc_gpu_ctx* ctx, const int16_t* coef, int log2n, 
     HIP_TRY(ctx, hipMalloc((void**)&d_cost, sizeof(long long) * count));
     int rc = run_block_test(ctx, coef, log2n, count, levels, [&](int16_t* i, int16_t* o) {
         hipLaunchKernelGGL(test_quantize_kernel, dim3(count), dim3(64), 0, ctx->stream, ctx->d_const, i, log2n, o,
-                           d_cost, ctx->d_overflow);
+                           d_cost, ctx->d_overflow + 1);
     });
     if (rc == WRENC_GPU_OK) {
         hipError_t e = hipMemcpy(level_cost, d_cost, sizeof(long long) * count, hipMemcpyDeviceToHost);
@@ -1532,7 +1532,7 @@ int wrenc_gpu_test_quantize_p16(wrenc_gpu_ctx* ctx, const int16_t* coef, int cou
     HIP_TRY(ctx, hipMalloc((void**)&d_cost, sizeof(long long) * count));
     int rc = run_block_test(ctx, coef, 2, count, levels, [&](int16_t* i, int16_t* o) {
         hipLaunchKernelGGL(test_quantize_p16_kernel, dim3((count + 3) / 4), dim3(64), 0, ctx->stream, ctx->d_const, i, count, o,
-                           d_cost, ctx->d_overflow);
+                           d_cost, ctx->d_overflow + 1);
     });
     if (rc == WRENC_GPU_OK) {
         hipError_t e = hipMemcpy(level_cost, d_cost, sizeof(long long) * count, hipMemcpyDeviceToHost);
@@ -1557,7 +1557,7 @@ int wrenc_gpu_test_quantize_pk(wrenc_gpu_ctx* ctx, const int16_t* coef, int log2
     if (e == hipSuccess) e = hipMemcpy(d_in, coef, total * sizeof(int16_t), hipMemcpyHostToDevice);
     if (e == hipSuccess) {
         hipLaunchKernelGGL(test_quantize_pk_kernel, dim3(n_packs), dim3(64), 0, ctx->stream, ctx->d_const, d_in, log2n, nc, d_out,
-                           d_cost, ctx->d_overflow);
+                           d_cost, ctx->d_overflow + 1);
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
