@@ -23,6 +23,8 @@ CASES = [
     ("tex96x64_qp27_d2", 96, 64, 27, 2, 1, 2),
     ("smooth64_qp37_d1", 64, 64, 37, 1, 0, 0),
     ("tex64_qp22_d0", 64, 64, 22, 0, 1, 5),
+    # the reference's own test geometry (scripts/intergration_test.sh:6: CIF, QP 20, default depth 3), synthetic content
+    ("cif_qp20_d3", 352, 288, 20, 3, 1, 7),
 ]
 
 if __name__ == "__main__":

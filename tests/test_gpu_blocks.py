@@ -13,6 +13,49 @@ def enc(built):
     e.close()
 
 
+# the quantiser's constants depend on the QP (level scale 16 * LEVEL_SCALE[(qp + 1) % 6] << ((qp + 1) / 6), its 32-bit
+# reciprocal, lambda_q): one context per QP, every class of (qp + 1) % 6 and both ends of the range the tables allow
+QPS = [18, 22, 27, 30, 31, 33, 34, 35, 37, 45, 51]
+
+
+@pytest.fixture(scope="module")
+def enc_at(built):
+    from wrenc_amd import gpu
+    made = {}
+
+    def get(qp):
+        if qp not in made:
+            made[qp] = gpu.Encoder(64, 64, qp=qp, max_split_depth=0)
+        return made[qp]
+    yield get
+    for e in made.values():
+        e.close()
+
+
+def _trellis_blocks(rng, n, count, big):
+    """Decaying spectra at four scales, zero blocks, +-3 noise, a lone DC, a lone last coefficient; `big`: coefficients up
+    to the i16 range (levels beyond the 1024-entry tables are the caller's to avoid: QP >= 30 keeps them inside)."""
+    decay = np.exp(-np.add.outer(np.arange(n), np.arange(n)) / (n / 3.0))
+    blocks = []
+    for it in range(count):
+        scale = [3, 30, 200, 1500][it % 4]
+        b = (rng.standard_normal((n, n)) * scale * decay).clip(-32768, 32767).astype(np.int16)
+        if it % 7 == 0:
+            b[:] = 0
+        if it % 11 == 0:
+            b = rng.integers(-3, 4, (n, n)).astype(np.int16)
+        if it % 13 == 0:
+            b[0, 0] = [1, -1, 40, -40][it % 4]
+        if it % 17 == 5:
+            b[:] = 0
+            b[n - 1, n - 1] = [2, -700][it % 2]
+        if big and it % 19 == 3:
+            b[0, 0] = [32767, -32768][it % 2]
+            b[n - 1, 0] = [-32768, 32767][it % 2]
+        blocks.append(b)
+    return np.stack(blocks)
+
+
 def _rand_blocks(rng, count, n, scale):
     return (rng.standard_normal((count, n, n)) * scale).clip(-32768, 32767).astype(np.int16)
 
@@ -75,6 +118,65 @@ def test_quantize_trellis(enc, n):
         ref = po.quantize(blocks[i], 32)
         assert np.array_equal(got[i], ref), (n, i)
         assert int(cost[i]) == po.level_cost(ref), (n, i)
+
+
+@pytest.mark.parametrize("qp", QPS)
+def test_quantize_trellis_at_every_qp_class(enc_at, qp):
+    """The lane Viterbi with its head exit, the 32-bit reciprocal quotient (exact for n < 2^26: |tc << sh| <= 2^24 + 256 at
+    every size) and the dequantiser at QPs other than the bench's: levels and level cost equal the literal DFS's
+    (quantizer.rs:338-517, block_splitter.rs:436-458), coefficients of +-32767 included where the level tables allow."""
+    from oracle import pyoracle as po
+    e = enc_at(qp)
+    rng = np.random.default_rng(4000 + qp)
+    for n in (4, 8, 16, 32):
+        blocks = _trellis_blocks(rng, n, 24, big=False)
+        if qp >= 37:  # 32767 / step stays below 1024 levels from here on (step = lsc / 2^sh grows with the QP)
+            blocks[3, 0, 0] = 32767
+            blocks[4, n - 1, n - 1] = -32768
+        got, cost = e.quantize(blocks)
+        deq = e.dequantize(got)
+        for i in range(blocks.shape[0]):
+            ref = po.quantize(blocks[i], qp)
+            assert np.array_equal(got[i], ref), (qp, n, i)
+            assert int(cost[i]) == po.level_cost(ref), (qp, n, i)
+            assert np.array_equal(deq[i], po.dequantize(ref, qp)), (qp, n, i)
+
+
+@pytest.mark.parametrize("qp", [18, 27, 34, 45, 51])
+def test_packed_quantisers_at_other_qps(enc_at, qp):
+    """quantize_p16 and quantize_pk<3 / 4> at other QPs: every block of every pack equals the literal DFS."""
+    from oracle import pyoracle as po
+    e = enc_at(qp)
+    rng = np.random.default_rng(5000 + qp)
+    b4 = _trellis_blocks(rng, 4, 41, big=False)
+    got, cost = e.quantize_p16(b4)
+    for i in range(b4.shape[0]):
+        ref = po.quantize(b4[i], qp)
+        assert np.array_equal(got[i], ref), (qp, i)
+        assert int(cost[i]) == po.level_cost(ref), (qp, i)
+    for log2n, nc in ((3, 3), (3, 2), (4, 2), (4, 1)):
+        n, nch = 1 << log2n, 1 << (log2n - 1)
+        n_packs = 12
+        luma = _trellis_blocks(rng, n, n_packs * nc, big=False)
+        chroma = _trellis_blocks(rng, nch, n_packs * 2 * nc, big=False)
+        packs = [np.concatenate([b.ravel() for b in list(luma[p * nc:(p + 1) * nc]) + list(chroma[p * 2 * nc:(p + 1) * 2 * nc])])
+                 for p in range(n_packs)]
+        levels, cost = e.quantize_pk(np.stack(packs), log2n, nc)
+        for p in range(n_packs):
+            at = 0
+            for c in range(nc):
+                ref = po.quantize(luma[p * nc + c], qp)
+                assert np.array_equal(levels[p, at:at + n * n].reshape(n, n), ref), (qp, log2n, nc, p, c)
+                assert int(cost[p, c, 0]) == po.level_cost(ref), (qp, log2n, nc, p, c)
+                at += n * n
+            for c in range(nc):
+                want = 0
+                for pl in range(2):
+                    ref = po.quantize(chroma[p * 2 * nc + 2 * c + pl], qp)
+                    assert np.array_equal(levels[p, at:at + nch * nch].reshape(nch, nch), ref), (qp, log2n, nc, p, c, pl)
+                    want += po.level_cost(ref)
+                    at += nch * nch
+                assert int(cost[p, c, 1]) == want, (qp, log2n, nc, p, c)
 
 
 @pytest.mark.parametrize("count", [1, 2, 3, 4, 5, 203])

@@ -38,6 +38,32 @@ def test_picture_matches_oracle(built, w, h, qp, depth, tex, schedule):
     _compare(got, ref, "%dx%d qp%d d%d" % (w, h, qp, depth))
 
 
+@pytest.mark.parametrize("schedule", [0, 1, 2])    # AUTO / wave / team
+def test_the_reference_own_test_geometry(built, schedule):
+    """wrenc's only end-to-end test encodes CIF 352x288 at QP 20 with the default max-split-depth 3
+    (scripts/intergration_test.sh:6 of the reference): two 11 x 9-CTU pictures of that geometry (one textured, one
+    smooth; synthetic: the bus clip is not in the image) in one encode call, every array of the record against the
+    oracle, and the stream written from it decodes -- parser + the independent spec decoder -- to the reconstruction."""
+    from wrenc_amd import bitstream as bs, gpu, synth
+    from oracle import pyoracle as po
+    w, h, qp, depth = 352, 288, 20, 3
+    frames = [synth.synth_textured_frame(w, h, 7), synth.synth_frame(w, h, 2)]
+    enc = gpu.Encoder(w, h, qp=qp, max_split_depth=depth, n_slots=2, schedule=schedule)
+    for s, (y, cb, cr) in enumerate(frames):
+        enc.upload(s, y, cb, cr)
+    enc.encode(0, 2)
+    enc.sync()
+    assert enc.final_pass_mismatches() == 0
+    for s, (y, cb, cr) in enumerate(frames):
+        got = enc.download(s)
+        _compare(got, po.encode_picture(y, cb, cr, qp, depth), "CIF picture %d" % s)
+        stream = bs.write_parameter_sets(w, h, qp) + bs.write_picture(w, h, qp, s, got)
+        back = po.parse_picture(stream, 0)
+        for a, k in zip(po.spec_decode_record(back, qp), ("rec_y", "rec_cb", "rec_cr")):
+            assert np.array_equal(a, got[k]), (s, k)
+    enc.close()
+
+
 @pytest.mark.parametrize("schedule", [1, 2])
 def test_batch_of_pictures(built, schedule):
     """Several pictures in flight in one encode call give the same result as one by one."""

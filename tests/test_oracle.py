@@ -245,3 +245,26 @@ def test_extreme_content():
     assert 1024 < np.abs(out["lev_y"]).max() < 2046
     with pytest.raises(ValueError):
         po.encode_picture(y, cb, cb, 0, 2)
+
+
+def test_reciprocal_quotient_is_exact_at_every_qp():
+    """The device divides by the level scale with one 32-bit multiply-high (wrenc_gpu.hip fill_dev_const: m = floor(2^k /
+    lsc) + 1, k = 26 + ceil(log2 lsc), q = mulhi(n, m) >> (k - 32)).  n = |(tc << sh) - off| <= (32768 << 9) + 256 < 2^26 at
+    every block size whatever the QP; the quotient is exact there for every level scale QP 0..63 gives: checked at every
+    multiple of lsc +- 1 below 2^26 (where a reciprocal first fails) and at random n."""
+    scale = [40, 45, 51, 57, 64, 72]
+    rng = np.random.default_rng(5)
+    for qp in range(64):
+        lsc = (16 * scale[(qp + 1) % 6]) << ((qp + 1) // 6)
+        lg = 0
+        while (1 << lg) < lsc:
+            lg += 1
+        k = 26 + lg
+        m = (1 << k) // lsc + 1
+        assert m < 1 << 32 and k >= 32
+        q = np.arange(1, (1 << 26) // lsc + 1, dtype=np.uint64) * np.uint64(lsc)
+        n = np.concatenate([q - np.uint64(1), q, q + np.uint64(1), rng.integers(0, 1 << 26, 20000).astype(np.uint64),
+                            np.array([0, 1, (1 << 26) - 1, (32768 << 9) + 256], np.uint64)])
+        n = n[n < (1 << 26)]
+        got = ((n * np.uint64(m)) >> np.uint64(32)) >> np.uint64(k - 32)
+        assert np.array_equal(got, n // np.uint64(lsc)), qp
