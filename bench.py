@@ -24,7 +24,8 @@ Objects next to it on the same JSON line (rank 0 prints ONE line), each measured
   config3       BASELINE.json configs[3] as written: 240 pictures of 3840x2176 IN TOTAL, picture p on rank p mod N
                 (strong scaling); at N = 1 it is the headline itself
   textured      the headline workload on textured content; fill_curve: frames/s against pictures in flight;
-                e2e: file to stream with the native program (upload + search + read-back + host CABAC); N = 1
+                e2e / e2e_4k: file to stream with the native program (upload + search + read-back + host CABAC), 1080p
+                depth 2 and the headline workload itself; N = 1
 The process exits with status 1 (after printing the line) if any parity check or final-pass check fails.
 """
 import argparse
@@ -410,6 +411,12 @@ def main():
             result["e2e"] = {"smooth": e2e_native(1920, 1088, 32, 2, 2048, 512, threads, False),
                              "textured": e2e_native(1920, 1088, 32, 2, 2048, 512, threads, True),
                              "workload": "1920x1088 QP32 max-split-depth 2 (configs[1]), 2048 pictures in 4 batches of 512"}
+            # ... and the headline workload itself, file to stream (missing 1): BASELINE's metric is encoded
+            # frames/s; `value` is the search alone.  480 pictures in 2 batches of 240
+            result["e2e_4k"] = {"smooth": e2e_native(3840, 2176, 32, 3, 480, 240, threads, False),
+                                "textured": e2e_native(3840, 2176, 32, 3, 480, 240, threads, True),
+                                "workload": "3840x2176 QP32 max-split-depth 3 (configs[2]/[3]), 480 pictures in 2 batches of 240",
+                                "search_rate_smooth": head["value"], "search_rate_textured": result["textured"]["value"]}
             for k in ("textured",):
                 if result[k].get("final_pass_mismatches"):
                     failed.append("final pass mismatches (%s)" % k)

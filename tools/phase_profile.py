@@ -32,7 +32,7 @@ names = (["predict", "fdct", "q_pre", "q_back", "q_trace", "deq", "idct", "recon
          + ["ev%d" % i for i in range(64)] + ["y6"] + ["evn%d" % i for i in range(64)] + ["y7"] + ["quant_t%d" % (4 << i) for i in range(4)] + ["y8"]
          + ["leaf8_packA", "leaf8_sad", "leaf8_packB", "leaf8_cclm", "leaf16_packA", "leaf16_sad", "leaf16_packB", "leaf16_packC",
             "sad_tables", "sad_blocks", "sad_samples", "leaf8_cclm_sad"] + ["y9"]
-         + ["leaf4_stage", "leaf4_packA", "leaf4_sad", "leaf4_packB", "leafc4", "split8_other"])
+         + ["leaf4_stage", "leaf4_packA", "leaf4_sad", "leaf4_packB", "leafc4", "split8_other"] + ["hist%d" % i for i in range(64)])
 KINDS = ["sadlist", "full", "nop/copy", "sadsearch", "cclmsearch", "leaf4", "leafc4", "leaf8", "leaf16", "split8"] + ["?"] * 6
 N = len(names)
 out = (C.c_ulonglong * N)()
@@ -51,7 +51,7 @@ print("%dx%d depth %d B %d schedule %d: wall %.3f s, fps %.2f, ticks per profile
 for i, n in enumerate(names):
     if i == 8 or n.startswith("x") or n.startswith("y") or n.startswith("cbn") or out[i] == 0:
         continue
-    if n.startswith("stn") or n.startswith("evn"):
+    if n.startswith("stn") or n.startswith("evn") or n.startswith("hist"):
         continue
     if n.startswith("ev"):
         k = int(n[2:])
@@ -75,4 +75,21 @@ for i, n in enumerate(names):
         print("%-10s %10.1f per CTU (count)" % (n, out[i] / nctu))
     else:
         print("%-10s %6.2f%%  %10.0f ticks per CTU" % (n, 100.0 * out[i] / tot, out[i] / nctu))
+# how long a CTU (wave schedule) / a CTU-team takes: the launch of an anti-diagonal waits for the slowest
+hist = [out[names.index("hist%d" % i)] for i in range(64)]
+n_h = sum(hist)
+if n_h:
+    mean = sum((i + 0.5) * c for i, c in enumerate(hist)) / n_h
+    lo = next(i for i, c in enumerate(hist) if c)
+    hi = max(i for i, c in enumerate(hist) if c)
+    cum, p50, p99 = 0, None, None
+    for i, c in enumerate(hist):
+        cum += c
+        if p50 is None and cum >= 0.5 * n_h:
+            p50 = i
+        if p99 is None and cum >= 0.99 * n_h:
+            p99 = i
+    unit = (1 << 17) / 1e6
+    print("CTU durations (M ticks, buckets of %.3f): min %.2f  median %.2f  mean %.2f  99 %% %.2f  max %.2f  (max / mean %.2f)"
+          % (unit, lo * unit, (p50 + 0.5) * unit, mean * unit, (p99 + 1) * unit, (hi + 1) * unit, (hi + 1) / mean))
 enc.close()

@@ -5,7 +5,7 @@
 # pictures), 8kd3 (7680x4320 QP32 depth 3, 32 pictures: BASELINE.json configs[4]), 4kd3b30 (30 pictures: what one GPU of
 # an 8-GPU configs[3] run holds).  One kernel-trace + stats pass, then counter passes of the SAME command (SQ counters in
 # groups of 8, FETCH_SIZE and WRITE_SIZE in passes of their own; --pmc is never combined with a trace domain other than
-# --kernel-trace).  Output: gpurun_out/prof/r03_WORKLOAD_COMMIT_{kernel_stats.csv,pmc.txt,summary.json}; copy what is
+# --kernel-trace).  Output: gpurun_out/prof/r04_WORKLOAD_COMMIT_{kernel_stats.csv,pmc.txt,summary.json}; copy what is
 # to be judged into profiles/.  A failing pass leaves its log next to the outputs and is named on stderr.
 set -o pipefail
 COMMIT=${1:?commit id}; WL=${2:?workload}; LIB=${3:-}
@@ -16,7 +16,7 @@ case "$WL" in
   8kd3)    ARGS="7680x4320 3 32 32 1";  UNITS=$((32 * 240 * 135));;
   *) echo "unknown workload $WL" >&2; exit 2;;
 esac
-R=$(pwd); O=$R/gpurun_out/prof; P=r03_${WL}_${COMMIT}; W=$O/$P.work
+R=$(pwd); O=$R/gpurun_out/prof; P=${ROUND:-r04}_${WL}_${COMMIT}; W=$O/$P.work
 mkdir -p "$W"
 [ -n "$LIB" ] && export WRENC_GPU_LIB="$R/$LIB"
 cd /tmp && export TMPDIR=/tmp

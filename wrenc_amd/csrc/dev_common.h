@@ -450,7 +450,7 @@ __device__ __forceinline__ Ctx uni(Ctx c) {
 // Diagnostic build only (-DWRENC_PROFILE): per-phase cycle counters, summed per wave and
 // added to a global table at CTU end.  Never compiled into the product library.
 #ifdef WRENC_PROFILE
-enum { PH_PREDICT, PH_FDCT, PH_QPRE, PH_QBACK, PH_QTRACE, PH_DEQ, PH_IDCT, PH_RECON, PH_TOTAL, PH_CTRL, PH_REFS, PH_SKIP, PH_NSTEP, PH_NFULL, PH_PSZ, PH_PSZ_END = PH_PSZ + 8, PH_PCNT, PH_PCNT_END = PH_PCNT + 8, PH_QB_PRE, PH_QB_WAIT1, PH_QB_WALK, PH_QB_WAIT2, PH_XCHG, PH_COPY, PH_CB, PH_CB_END = PH_CB + 32, PH_CBN, PH_CBN_END = PH_CBN + 32, PH_MEM, PH_MEM_END = PH_MEM + 16, PH_ST, PH_ST_END = PH_ST + 48, PH_STN, PH_STN_END = PH_STN + 12, PH_EV, PH_EV_END = PH_EV + 64, PH_EVN, PH_EVN_END = PH_EVN + 64, PH_QZ, PH_QZ_END = PH_QZ + 4, PH_LEAF, PH_LEAF_END = PH_LEAF + 12, PH_L4, PH_L4_END = PH_L4 + 6, PH_COUNT };
+enum { PH_PREDICT, PH_FDCT, PH_QPRE, PH_QBACK, PH_QTRACE, PH_DEQ, PH_IDCT, PH_RECON, PH_TOTAL, PH_CTRL, PH_REFS, PH_SKIP, PH_NSTEP, PH_NFULL, PH_PSZ, PH_PSZ_END = PH_PSZ + 8, PH_PCNT, PH_PCNT_END = PH_PCNT + 8, PH_QB_PRE, PH_QB_WAIT1, PH_QB_WALK, PH_QB_WAIT2, PH_XCHG, PH_COPY, PH_CB, PH_CB_END = PH_CB + 32, PH_CBN, PH_CBN_END = PH_CBN + 32, PH_MEM, PH_MEM_END = PH_MEM + 16, PH_ST, PH_ST_END = PH_ST + 48, PH_STN, PH_STN_END = PH_STN + 12, PH_EV, PH_EV_END = PH_EV + 64, PH_EVN, PH_EVN_END = PH_EVN + 64, PH_QZ, PH_QZ_END = PH_QZ + 4, PH_LEAF, PH_LEAF_END = PH_LEAF + 12, PH_L4, PH_L4_END = PH_L4 + 6, PH_HIST, PH_HIST_END = PH_HIST + 64, PH_COUNT }; // PH_HIST: CTU durations, buckets of 2^17 ticks
 __device__ unsigned long long g_prof[PH_COUNT];
 __shared__ unsigned long long s_prof[PH_COUNT];
 #define PROF_T0() const unsigned long long prof_t0_ = __builtin_readcyclecounter()

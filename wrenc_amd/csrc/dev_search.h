@@ -3205,6 +3205,7 @@ __device__ __forceinline__ void encode_ctu(Ctx& c, const PicBufs& pb, int ctu_co
 #ifdef WRENC_PROFILE
     PROF_MARK(tt1_);
     PROF_ADD2(PH_TOTAL, tt0_, tt1_);
+    if (threadIdx.x == 0) s_prof[PH_HIST + (int)min((unsigned long long)63, (tt1_ - tt0_) >> 17)] += 1; // how long this CTU took (the launch waits for the slowest)
     __syncthreads();
     for (int i = threadIdx.x; i < PH_COUNT; i += blockDim.x) atomicAdd(&g_prof[i], s_prof[i]);
 #endif
