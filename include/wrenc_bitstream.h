@@ -58,6 +58,22 @@ int wrenc_bs_write_parameter_sets(int width, int height, int qp, uint8_t* out, s
 int wrenc_bs_write_picture(int width, int height, int qp, int poc, const wrenc_bs_record* rec,
                            uint8_t* out, size_t cap, size_t* len);
 
+/* The same picture from the device's TOKEN record (include/wrenc_gpu.h, wrenc_gpu_download_tokens: residual_coding done
+ * on the device): the maps, the page pool the call filled, and this picture's table of first pages.  Writes the bytes
+ * wrenc_bs_write_picture writes from the level planes of the same search result; the host then runs the CU-level syntax
+ * and the arithmetic coder only.  WRENC_BS_EDATA on a token stream that ends early or names a context that does not exist. */
+#define WRENC_BS_TOKEN_PAGE 64
+typedef struct wrenc_bs_tokens {
+    const uint8_t* cu_log2_size;
+    const uint8_t* luma_mode;
+    const uint8_t* chroma_mode;
+    const uint32_t* pool;        /* the pages of the download call */
+    size_t pool_words;           /* words of `pool` that are valid */
+    const uint32_t* first_page;  /* (width / 32) * (height / 32): where each CTU's tokens start */
+} wrenc_bs_tokens;
+int wrenc_bs_write_picture_tokens(int width, int height, int qp, int poc, const wrenc_bs_tokens* tok, uint8_t* out,
+                                  size_t cap, size_t* len);
+
 /* Bits the CABAC engine produced for the CTU data of the last wrenc_bs_write_picture call made by
  * this thread (slice data without headers and framing): the true rate the search's estimate models. */
 long long wrenc_bs_last_slice_data_bits(void);

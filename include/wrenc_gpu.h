@@ -155,6 +155,38 @@ int wrenc_gpu_download_compact(wrenc_gpu_ctx* ctx, int first_slot, int n, wrenc_
 void wrenc_gpu_expand_levels(int width, int height, const uint32_t* mask, const int16_t* payload, int16_t* lev_y,
                              int16_t* lev_cb, int16_t* lev_cr);
 
+/* Token read-back (round 4): residual_coding done on the device.  Behind the search a device pass walks every CTU's
+ * transform blocks in coding order and turns their levels into the tokens the host's arithmetic coder consumes as they
+ * come (ctu_encoder.rs:1786-2269, context selection bool_coder.rs:2053-2400, binarisations :1133-1465):
+ *     context-coded bin   (ctx << 1) | bin                      ctx: index into the flat context array of wrenc_amd/csrc/host/cabac.h
+ *     bypass group        1 << 31 | (nbits - 1) << 25 | value   nbits <= 25
+ * Per transform unit (CU luma + Cb + Cr; a 4x4 luma block of a split 8x8 CU; the 4x4 Cb + Cr pair of such a CU) one header
+ * word per component -- bit 31: coded, bits 0..23: tokens of the component that follow, bit 30 (luma): the last
+ * significant position is not the DC position (MtsDcOnly = 0), bit 29 (luma): a level outside the 16x16 low-frequency
+ * corner (MtsZeroOutSigCoeffFlag = 0) -- then the components' tokens in order.  Tokens live in PAGES of
+ * WRENC_GPU_TOKEN_PAGE words (the last word of a page is the index of the CTU's next page, 0xFFFFFFFF at its end) taken
+ * from `pool`; first_page[ctu] (CTUs in raster order) is where a CTU starts.  The CU-level syntax stays on the host: it
+ * needs only the maps.  wrenc_bs_write_picture_tokens (wrenc_bitstream.h) writes the same bytes from this record as
+ * wrenc_bs_write_picture writes from the level planes, with the residual syntax walk gone from the host.
+ * wrenc_gpu_download_tokens reads back `n` slots in one call: pool_cap_words of room in `pool` for all of them together
+ * (WRENC_GPU_ENOMEM with *pool_words_used = the need of what was produced so far if it does not suffice: fall back to
+ * wrenc_gpu_download_compact), every picture's first_page table and maps, its reconstruction when asked for. */
+#define WRENC_GPU_TOKEN_PAGE 64
+typedef struct wrenc_gpu_tokens {
+    uint32_t* first_page;   /* (width / 32) * (height / 32) entries */
+    uint8_t* cu_log2_size;  /* as in wrenc_gpu_picture; any may be NULL */
+    uint8_t* luma_mode;
+    uint8_t* chroma_mode;
+    uint8_t* rec_y;
+    uint8_t* rec_cb;
+    uint8_t* rec_cr;
+} wrenc_gpu_tokens;
+int wrenc_gpu_download_tokens(wrenc_gpu_ctx* ctx, int first_slot, int n, wrenc_gpu_tokens* out, uint32_t* pool,
+                              size_t pool_cap_words, size_t* pool_words_used);
+/* Test entry: put an arbitrary record (maps + level planes, as wrenc_gpu_download fills them) into a slot as if a search
+ * had produced it, so that the token pass can be compared with the host-only writer on records no search emits. */
+int wrenc_gpu_test_load_record(wrenc_gpu_ctx* ctx, int slot, const wrenc_gpu_picture* rec);
+
 /* Page-locked host memory for the planes handed to wrenc_gpu_upload / wrenc_gpu_download: transfers from
  * and to it run at PCIe rate and truly asynchronously (pageable buffers are staged by the runtime at a
  * fraction of that).  Optional: any host memory works.  Free with wrenc_gpu_free_host before destroy. */

@@ -12,7 +12,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "host", "libwrenc_host.so")
 EXPORTED_SYMBOLS = ("wrenc_bs_picture_bound", "wrenc_bs_write_parameter_sets", "wrenc_bs_write_picture",
-                    "wrenc_bs_last_slice_data_bits")
+                    "wrenc_bs_write_picture_tokens", "wrenc_bs_last_slice_data_bits")
 
 OK, EINVAL, ENOSPC, EDATA = 0, -1, -2, -3
 
@@ -27,6 +27,11 @@ class BitstreamError(RuntimeError):
 class _Record(C.Structure):
     _fields_ = [("cu_log2_size", C.c_void_p), ("luma_mode", C.c_void_p), ("chroma_mode", C.c_void_p),
                 ("lev_y", C.c_void_p), ("lev_cb", C.c_void_p), ("lev_cr", C.c_void_p)]
+
+
+class _Tokens(C.Structure):
+    _fields_ = [("cu_log2_size", C.c_void_p), ("luma_mode", C.c_void_p), ("chroma_mode", C.c_void_p),
+                ("pool", C.c_void_p), ("pool_words", C.c_size_t), ("first_page", C.c_void_p)]
 
 
 _lib = None
@@ -91,6 +96,32 @@ def write_picture(width, height, qp, poc, rec):
         rc = lib.wrenc_bs_write_picture(w, h, int(qp), int(poc), C.byref(r), buf.ctypes.data, cap, C.byref(n))
     if rc != OK:
         raise BitstreamError(rc, "wrenc_bs_write_picture")
+    return buf[:n.value].tobytes()
+
+
+def write_picture_tokens(width, height, qp, poc, pool, pic):
+    """The same NAL units from the device's token record (gpu.Encoder.download_tokens: `pool` and one of its per-picture
+    dicts): the host runs the CU-level syntax and the arithmetic coder only."""
+    lib = load_library()
+    w, h = int(width), int(height)
+    pool = np.ascontiguousarray(pool, np.uint32)
+    arrs = [_plane(pic, "cu_log2_size", (h // 4, w // 4), np.uint8), _plane(pic, "luma_mode", (h // 4, w // 4), np.uint8),
+            _plane(pic, "chroma_mode", (h // 8, w // 8), np.uint8)]
+    first = np.ascontiguousarray(pic["first_page"], np.uint32)
+    t = _Tokens(arrs[0].ctypes.data, arrs[1].ctypes.data, arrs[2].ctypes.data, pool.ctypes.data, pool.size, first.ctypes.data)
+    lib.wrenc_bs_write_picture_tokens.restype = C.c_int
+    lib.wrenc_bs_write_picture_tokens.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(_Tokens), C.c_void_p, C.c_size_t,
+                                                  C.POINTER(C.c_size_t)]
+    cap = min(lib.wrenc_bs_picture_bound(w, h), w * h // 2 + 65536)
+    buf = np.empty(cap, np.uint8)
+    n = C.c_size_t()
+    rc = lib.wrenc_bs_write_picture_tokens(w, h, int(qp), int(poc), C.byref(t), buf.ctypes.data, cap, C.byref(n))
+    if rc == ENOSPC:
+        cap = n.value
+        buf = np.empty(cap, np.uint8)
+        rc = lib.wrenc_bs_write_picture_tokens(w, h, int(qp), int(poc), C.byref(t), buf.ctypes.data, cap, C.byref(n))
+    if rc != OK:
+        raise BitstreamError(rc, "wrenc_bs_write_picture_tokens")
     return buf[:n.value].tobytes()
 
 

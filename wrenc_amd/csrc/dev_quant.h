@@ -471,7 +471,14 @@ __device__ __forceinline__ int head_alpha(int tc, int qd, bool last, const HeadK
 }
 // One batch of 64 positions (lane = position p0 + LANE of a chain of P) of the region search: `open` while no position has
 // ended the region; arun = this lane's minimum of alpha over the region so far; sb = the sub-block the walk must reach
+#ifndef WRENC_HEAD_EXIT
+#define WRENC_HEAD_EXIT 1 // 0: every chain is walked to its end (round 3's behaviour; for A/B runs)
+#endif
 __device__ __forceinline__ void head_batch(int tc, int qd, int p, int P, bool valid, const HeadK& h, bool& open, int& arun, int& sb) {
+    if (!WRENC_HEAD_EXIT) {
+        sb = 0;
+        open = false;
+    }
     if (!open) return;
     // a batch of zero coefficients that does not hold the DC position: alpha = inf, beta = ldq1 everywhere
     if (__ballot(valid && (tc != 0 || p == P - 1)) == 0ULL && h.ldq1 >= 0) return;

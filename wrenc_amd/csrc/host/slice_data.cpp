@@ -60,10 +60,18 @@ class PictureCoder {
 public:
     PictureCoder(int width, int height, int qp, const wrenc_bs_record& rec, BitWriter& bw)
         : W_(width), H_(height), qp_(qp), r_(rec), cabac_(bw) {}
+    // the residual syntax as device-made tokens (include/wrenc_gpu.h, wrenc_gpu_download_tokens): the record then
+    // carries the maps only
+    PictureCoder(int width, int height, int qp, const wrenc_bs_record& maps, const wrenc_bs_tokens& tok, BitWriter& bw)
+        : W_(width), H_(height), qp_(qp), r_(maps), cabac_(bw), tok_(&tok) {}
 
     // ctu_encoder.rs:38-47 (CABAC initialised at the picture's first CTU) + :172-201 (the CTU's coding tree)
     int encode_ctu(int x, int y) {
         if (x == 0 && y == 0) cabac_.start(qp_);
+        if (tok_) { // this CTU's run of tokens
+            tk_page_ = tok_->first_page[(size_t)(y >> 5) * (W_ >> 5) + (x >> 5)];
+            tk_pos_ = 0;
+        }
         return coding_tree(x, y, 5);
     }
     // slice_encoder.rs:388-394: end_of_slice_one_bit behind the last CTU
@@ -246,8 +254,76 @@ private:
         return mask;
     }
 
+    // ---- the device's token stream: pages of WRENC_BS_TOKEN_PAGE words, the last one the index of the next page ----
+    enum { kPage = WRENC_BS_TOKEN_PAGE, kPayload = kPage - 1 };
+    bool next_word(uint32_t& w) {
+        if (tk_pos_ == kPayload) {
+            if (tk_page_ == 0xFFFFFFFFu) return false;
+            tk_page_ = tok_->pool[(size_t)tk_page_ * kPage + kPayload];
+            tk_pos_ = 0;
+        }
+        if (tk_page_ == 0xFFFFFFFFu || ((size_t)tk_page_ + 1) * kPage > tok_->pool_words) return false;
+        w = tok_->pool[(size_t)tk_page_ * kPage + tk_pos_++];
+        return true;
+    }
+    // `count` tokens straight into the arithmetic coder
+    int splice(uint32_t count) {
+        while (count) {
+            if (tk_pos_ == kPayload) {
+                if (tk_page_ == 0xFFFFFFFFu) return WRENC_BS_EDATA;
+                tk_page_ = tok_->pool[(size_t)tk_page_ * kPage + kPayload];
+                tk_pos_ = 0;
+            }
+            if (tk_page_ == 0xFFFFFFFFu || ((size_t)tk_page_ + 1) * kPage > tok_->pool_words) return WRENC_BS_EDATA;
+            const uint32_t* p = tok_->pool + (size_t)tk_page_ * kPage + tk_pos_;
+            uint32_t run = (uint32_t)(kPayload - tk_pos_);
+            run = run < count ? run : count;
+            for (uint32_t i = 0; i < run; ++i) {
+                const uint32_t t = p[i];
+                if ((int32_t)t >= 0) {
+                    if ((t >> 1) >= (uint32_t)CTX_COUNT) return WRENC_BS_EDATA;
+                    cabac_.encode((int)(t >> 1), (int)(t & 1));
+                } else {
+                    cabac_.bypass_bits(t & 0x1FFFFFFu, (int)((t >> 25) & 63) + 1);
+                }
+            }
+            tk_pos_ += (int)run;
+            count -= run;
+        }
+        return WRENC_BS_OK;
+    }
+    // transform_unit with the residuals as tokens: header words of the components present, then their tokens
+    int transform_unit_tokens(Tree tree) {
+        const bool chroma = tree != DUAL_TREE_LUMA, luma = tree != DUAL_TREE_CHROMA;
+        uint32_t h[3] = {0, 0, 0};
+        if (luma && !next_word(h[0])) return WRENC_BS_EDATA;
+        if (chroma && (!next_word(h[1]) || !next_word(h[2]))) return WRENC_BS_EDATA;
+        const bool cbf_y = h[0] >> 31, cbf_cb = h[1] >> 31, cbf_cr = h[2] >> 31;
+        if (chroma) {
+            cabac_.encode(CTX_CB_CBF, cbf_cb);
+            cabac_.encode(CTX_CR_CBF + cbf_cb, cbf_cr);
+        }
+        if (luma) cabac_.encode(CTX_Y_CBF, cbf_y);
+        if ((cbf_y || cbf_cb || cbf_cr) && luma && !qp_delta_coded_) {
+            cabac_.encode(CTX_QP_DELTA_ABS, 0);
+            qp_delta_coded_ = true;
+        }
+        for (int c = 0; c < 3; ++c) {
+            if (!(h[c] >> 31)) continue;
+            cabac_.encode(CTX_TS_FLAG + (c != 0), 0);
+            if (c == 0) {
+                if (h[0] & (1u << 30)) mts_dc_only_ = false;
+                if (h[0] & (1u << 29)) mts_zero_out_ = false;
+            }
+            const int rc = splice(h[c] & 0xFFFFFFu);
+            if (rc) return rc;
+        }
+        return WRENC_BS_OK;
+    }
+
     // ctu_encoder.rs:1463-1784
     int transform_unit(int x0, int y0, int lg, Tree tree) {
+        if (tok_) return transform_unit_tokens(tree);
         const bool chroma = tree != DUAL_TREE_LUMA, luma = tree != DUAL_TREE_CHROMA;
         const uint64_t m_y = luma ? sb_mask(0, x0, y0, lg) : 0;
         const uint64_t m_cb = chroma ? sb_mask(1, x0 >> 1, y0 >> 1, lg - 1) : 0;
@@ -506,6 +582,9 @@ private:
     bool mts_dc_only_ = true, mts_zero_out_ = true;
     int abs_[34 * kS]; // AbsLevel of the current TB
     int tpl_[34 * kS]; // AbsLevelPass1 | significant << 8
+    const wrenc_bs_tokens* tok_ = nullptr; // residuals as device-made tokens (else: from the level planes of r_)
+    uint32_t tk_page_ = 0xFFFFFFFFu;
+    int tk_pos_ = 0;
 };
 
 int CtuEncoder::encode(Bins& bins, const Ctu& ctu, const SliceHeader& sh) {
@@ -537,6 +616,19 @@ Bins SliceEncoder::encode(const Slice& slice, const SliceHeader& sh, int* status
     if (status) *status = rc;
     bins.align(); // slice_encoder.rs:418
     return bins;
+}
+
+// the same picture loop with the residual syntax read from the device's tokens
+int write_slice_data_tokens(int width, int height, int qp, const wrenc_bs_tokens& tok, BitWriter& bw) {
+    const wrenc_bs_record maps = {tok.cu_log2_size, tok.luma_mode, tok.chroma_mode, nullptr, nullptr, nullptr};
+    PictureCoder coder(width, height, qp, maps, tok, bw);
+    for (int y = 0; y < height; y += 32)
+        for (int x = 0; x < width; x += 32) {
+            const int rc = coder.encode_ctu(x, y);
+            if (rc) return rc;
+        }
+    coder.end_of_slice();
+    return WRENC_BS_OK;
 }
 
 int write_slice_data(int width, int height, int qp, const wrenc_bs_record& rec, BitWriter& bw) {

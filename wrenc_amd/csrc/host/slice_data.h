@@ -49,6 +49,7 @@ private:
 
 // CABAC-coded CTUs of the whole picture followed by end_of_slice_one_bit; bw must be byte aligned.
 int write_slice_data(int width, int height, int qp, const wrenc_bs_record& rec, BitWriter& bw);
+int write_slice_data_tokens(int width, int height, int qp, const wrenc_bs_tokens& tok, BitWriter& bw);
 
 // Raw byte sequence payloads (headers.cpp)
 void write_vps(BitWriter& bw, int width, int height);

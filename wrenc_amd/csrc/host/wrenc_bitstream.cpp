@@ -78,6 +78,30 @@ int wrenc_bs_write_picture(int width, int height, int qp, int poc, const wrenc_b
     return hand_over(stream, out, cap, len);
 }
 
+int wrenc_bs_write_picture_tokens(int width, int height, int qp, int poc, const wrenc_bs_tokens* tok, uint8_t* out, size_t cap,
+                                  size_t* len) {
+    if (!size_ok(width, height, qp) || poc < 0 || !tok || !tok->cu_log2_size || !tok->luma_mode || !tok->chroma_mode ||
+        !tok->pool || !tok->first_page)
+        return WRENC_BS_EINVAL;
+    std::vector<uint8_t> stream;
+    {
+        BitWriter bw;
+        write_picture_header(bw, poc);
+        append_nal(stream, 9, NAL_PH, 0, bw.bytes());
+    }
+    {
+        Bins bins;
+        write_slice_header(bins, qp);
+        const size_t header_bits = bins.bit_count();
+        const int rc = write_slice_data_tokens(width, height, qp, *tok, bins);
+        if (rc) return rc;
+        g_last_slice_data_bits = (long long)(bins.bit_count() - header_bits);
+        bins.align();
+        append_nal(stream, 9, NAL_IDR_W_RADL, 0, bins.bytes());
+    }
+    return hand_over(stream, out, cap, len);
+}
+
 long long wrenc_bs_last_slice_data_bits(void) { return g_last_slice_data_bits; }
 
 } // extern "C"

@@ -17,6 +17,7 @@
 //   dev_transform.h  transformer.rs:2040-2737       lane = basis row, v_dot2 / v_mad_i24
 //   dev_quant.h      quantizer.rs:338-759           backward 4-state Viterbi, one lane per state, DPP
 //   dev_search.h     block_splitter.rs:64-1154, ctu_encoder.rs:1421-1461
+//   dev_bins.h       ctu_encoder.rs:1786-2269       residual_coding as a token stream for the host's arithmetic coder
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -26,3 +27,5 @@
 #include "dev_transform.h"
 #include "dev_quant.h"
 #include "dev_search.h"
+#define WRENC_TOKENS_KERNEL_TU
+#include "dev_bins.h"

@@ -592,6 +592,12 @@ struct wrenc_gpu_ctx {
     int16_t* d_cpayload = nullptr;
     unsigned* d_ccount = nullptr;
     int compact_cap = 0; // pictures the scratch holds
+    // token read-back: the page pool of one call, its allocation counter, the CTUs' first pages
+    uint32_t* d_tok_pool = nullptr;
+    size_t tok_pool_words = 0;
+    unsigned* d_tok_counter = nullptr;
+    uint32_t* d_tok_first = nullptr;
+    int tok_first_cap = 0;
     int schedule = WRENC_GPU_SCHEDULE_AUTO;
     int last_schedule = WRENC_GPU_SCHEDULE_WAVE; // what the most recent encode call ran
     bool stats_valid = false;
@@ -883,6 +889,9 @@ void wrenc_gpu_destroy(wrenc_gpu_ctx* ctx) {
     if (ctx->d_slots) (void)hipFree(ctx->d_slots);
     if (ctx->d_mismatch) (void)hipFree(ctx->d_mismatch);
     if (ctx->d_overflow) (void)hipFree(ctx->d_overflow);
+    if (ctx->d_tok_pool) (void)hipFree(ctx->d_tok_pool);
+    if (ctx->d_tok_counter) (void)hipFree(ctx->d_tok_counter);
+    if (ctx->d_tok_first) (void)hipFree(ctx->d_tok_first);
     if (ctx->d_pred_scratch) (void)hipFree(ctx->d_pred_scratch);
     if (ctx->d_slot_map) (void)hipFree(ctx->d_slot_map);
     if (ctx->d_cmask) (void)hipFree(ctx->d_cmask);
@@ -1258,6 +1267,90 @@ int wrenc_gpu_download_compact(wrenc_gpu_ctx* ctx, int first_slot, int n, wrenc_
     }
     HIP_TRY(ctx, hipStreamSynchronize(cs));
     if (short_buf) return fail(ctx, WRENC_GPU_ENOMEM, "wrenc_gpu_download_compact: payload_cap is smaller than n_blocks of a picture");
+    return WRENC_GPU_OK;
+}
+
+int wrenc_gpu_download_tokens(wrenc_gpu_ctx* ctx, int first_slot, int n, wrenc_gpu_tokens* out, uint32_t* pool, size_t pool_cap_words,
+                              size_t* pool_words_used) {
+    if (!ctx || !out || !pool || !pool_words_used || n < 1) return WRENC_GPU_EINVAL;
+    if (first_slot < 0 || first_slot + n > ctx->cfg.n_slots) return fail(ctx, WRENC_GPU_EINVAL, "bad slot range");
+    for (int s = first_slot; s < first_slot + n; ++s)
+        if (ctx->state[s] != 2) return fail(ctx, WRENC_GPU_ESTATE, "slot has not been encoded");
+    HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
+    const wrenc_gpu_config& c = ctx->cfg;
+    const int ctus = ctx->ctu_cols * ctx->ctu_rows;
+    const size_t pages = pool_cap_words / kTokPage;
+    if (pages < 1 || pages > 0xFFFFFFF0u) return fail(ctx, WRENC_GPU_EINVAL, "wrenc_gpu_download_tokens: pool_cap_words");
+    if (ctx->tok_pool_words < pages * kTokPage) {
+        if (ctx->d_tok_pool) (void)hipFree(ctx->d_tok_pool);
+        ctx->d_tok_pool = nullptr;
+        ctx->tok_pool_words = 0;
+        HIP_TRY(ctx, hipMalloc((void**)&ctx->d_tok_pool, pages * kTokPage * sizeof(uint32_t)));
+        ctx->tok_pool_words = pages * kTokPage;
+    }
+    if (!ctx->d_tok_counter) HIP_TRY(ctx, hipMalloc((void**)&ctx->d_tok_counter, 2 * sizeof(unsigned)));
+    if (ctx->tok_first_cap < n) {
+        if (ctx->d_tok_first) (void)hipFree(ctx->d_tok_first);
+        ctx->d_tok_first = nullptr;
+        ctx->tok_first_cap = 0;
+        HIP_TRY(ctx, hipMalloc((void**)&ctx->d_tok_first, (size_t)n * ctus * sizeof(uint32_t)));
+        ctx->tok_first_cap = n;
+    }
+    hipStream_t cs = ctx->copy_stream;
+    hipEvent_t last = nullptr;
+    for (int s = first_slot; s < first_slot + n; ++s)
+        if (ctx->slot_event[s] && ctx->slot_event[s] != last) {
+            last = ctx->slot_event[s];
+            HIP_TRY(ctx, hipStreamWaitEvent(cs, last, 0));
+        }
+    HIP_TRY(ctx, hipMemsetAsync(ctx->d_tok_counter, 0, 2 * sizeof(unsigned), cs));
+    const int waves = n * ctus;
+    hipLaunchKernelGGL(residual_tokens_kernel, dim3((waves + 3) / 4), dim3(256), 0, cs, ctx->d_const, ctx->d_slots, first_slot, n,
+                       ctx->d_tok_pool, (unsigned)pages, ctx->d_tok_counter, ctx->d_tok_first, (int*)(ctx->d_tok_counter + 1));
+    HIP_TRY(ctx, hipGetLastError());
+    unsigned cnt[2] = {0, 0};
+    int ovf = 0;
+    HIP_TRY(ctx, hipMemcpyAsync(cnt, ctx->d_tok_counter, sizeof(cnt), hipMemcpyDeviceToHost, cs));
+    HIP_TRY(ctx, hipMemcpyAsync(&ovf, ctx->d_overflow, sizeof(int), hipMemcpyDeviceToHost, cs));
+    HIP_TRY(ctx, hipStreamSynchronize(cs));
+    if (ovf & 2) return fail(ctx, WRENC_GPU_EHIP, "internal: a team member never reached a meeting point of the level schedule");
+    if (ovf) return fail(ctx, WRENC_GPU_ELEVEL, "a quantised level reached 1024 (reference panics: block_splitter.rs:453)");
+    *pool_words_used = (size_t)cnt[0] * kTokPage;
+    if (cnt[1] || cnt[0] > pages) return fail(ctx, WRENC_GPU_ENOMEM, "wrenc_gpu_download_tokens: the token pool is too small for these pictures");
+    HIP_TRY(ctx, hipMemcpyAsync(pool, ctx->d_tok_pool, (size_t)cnt[0] * kTokPage * sizeof(uint32_t), hipMemcpyDeviceToHost, cs));
+    const size_t n4 = (size_t)(c.width / 4) * (c.height / 4), n8 = (size_t)(c.width / 8) * (c.height / 8);
+    for (int k = 0; k < n; ++k) {
+        wrenc_gpu_tokens& o = out[k];
+        const PicBufs& b = ctx->slots[first_slot + k];
+        if (o.first_page) HIP_TRY(ctx, hipMemcpyAsync(o.first_page, ctx->d_tok_first + (size_t)k * ctus, (size_t)ctus * sizeof(uint32_t), hipMemcpyDeviceToHost, cs));
+        if (o.cu_log2_size) HIP_TRY(ctx, hipMemcpyAsync(o.cu_log2_size, b.cu_log2, n4, hipMemcpyDeviceToHost, cs));
+        if (o.luma_mode) HIP_TRY(ctx, hipMemcpyAsync(o.luma_mode, b.luma_mode, n4, hipMemcpyDeviceToHost, cs));
+        if (o.chroma_mode) HIP_TRY(ctx, hipMemcpyAsync(o.chroma_mode, b.chroma_mode, n8, hipMemcpyDeviceToHost, cs));
+        uint8_t* rec[3] = {o.rec_y, o.rec_cb, o.rec_cr};
+        for (int p = 0; p < 3; ++p)
+            if (rec[p]) HIP_TRY(ctx, hipMemcpyAsync(rec[p], b.rec[p], plane_bytes(c, p, 1), hipMemcpyDeviceToHost, cs));
+    }
+    HIP_TRY(ctx, hipStreamSynchronize(cs));
+    return WRENC_GPU_OK;
+}
+
+int wrenc_gpu_test_load_record(wrenc_gpu_ctx* ctx, int slot, const wrenc_gpu_picture* rec) {
+    if (!ctx || !rec || !rec->cu_log2_size || !rec->luma_mode || !rec->chroma_mode || !rec->lev_y || !rec->lev_cb || !rec->lev_cr)
+        return WRENC_GPU_EINVAL;
+    if (slot < 0 || slot >= ctx->cfg.n_slots) return fail(ctx, WRENC_GPU_EINVAL, "bad slot");
+    HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
+    HIP_TRY(ctx, hipDeviceSynchronize());
+    const wrenc_gpu_config& c = ctx->cfg;
+    const PicBufs& b = ctx->slots[slot];
+    const size_t n4 = (size_t)(c.width / 4) * (c.height / 4), n8 = (size_t)(c.width / 8) * (c.height / 8);
+    const int16_t* lev[3] = {rec->lev_y, rec->lev_cb, rec->lev_cr};
+    for (int k = 0; k < 3; ++k) HIP_TRY(ctx, hipMemcpy(b.lev[k], lev[k], plane_bytes(c, k, 2), hipMemcpyHostToDevice));
+    HIP_TRY(ctx, hipMemcpy(b.cu_log2, rec->cu_log2_size, n4, hipMemcpyHostToDevice));
+    HIP_TRY(ctx, hipMemcpy(b.luma_mode, rec->luma_mode, n4, hipMemcpyHostToDevice));
+    HIP_TRY(ctx, hipMemcpy(b.chroma_mode, rec->chroma_mode, n8, hipMemcpyHostToDevice));
+    // (the slot's "these 4x4 blocks may be non-zero" bookkeeping no longer matches its planes: every block may be)
+    HIP_TRY(ctx, hipMemset(b.lev_dirty, 0xFF, (size_t)ctx->ctu_cols * ctx->ctu_rows * 4 * sizeof(uint32_t)));
+    ctx->state[slot] = 2;
     return WRENC_GPU_OK;
 }
 

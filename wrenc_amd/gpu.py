@@ -19,7 +19,7 @@ LIB_PATH = os.environ.get("WRENC_GPU_LIB", os.path.join(_HERE, "csrc", "libwrenc
 
 EXPORTED_SYMBOLS = [
     "wrenc_gpu_default_config", "wrenc_gpu_config_extra_params", "wrenc_gpu_create", "wrenc_gpu_destroy", "wrenc_gpu_last_error",
-    "wrenc_gpu_upload", "wrenc_gpu_encode", "wrenc_gpu_sync", "wrenc_gpu_download", "wrenc_gpu_download_compact", "wrenc_gpu_compact_mask_words", "wrenc_gpu_expand_levels",
+    "wrenc_gpu_upload", "wrenc_gpu_encode", "wrenc_gpu_sync", "wrenc_gpu_download", "wrenc_gpu_download_compact", "wrenc_gpu_compact_mask_words", "wrenc_gpu_expand_levels", "wrenc_gpu_download_tokens", "wrenc_gpu_test_load_record",
     "wrenc_gpu_alloc_host", "wrenc_gpu_free_host", "wrenc_gpu_encode_picture", "wrenc_gpu_set_schedule", "wrenc_gpu_last_schedule", "wrenc_gpu_stats_enable", "wrenc_gpu_last_encode_stats", "wrenc_gpu_last_encode_kernel_stats", "wrenc_gpu_final_pass_mismatches",
     "wrenc_gpu_test_fwd_dct", "wrenc_gpu_test_inv_dct", "wrenc_gpu_test_quantize",
     "wrenc_gpu_test_dequantize", "wrenc_gpu_test_predict", "wrenc_gpu_test_fwd_dct32", "wrenc_gpu_test_inv_dct32", "wrenc_gpu_test_quantize_p16", "wrenc_gpu_test_quantize_pk", "wrenc_gpu_test_set_wave_slots", "wrenc_gpu_test_scratch_overflows",
@@ -50,6 +50,14 @@ class Compact(C.Structure):
     _fields_ = [("mask", C.c_void_p), ("payload", C.c_void_p), ("payload_cap", C.c_size_t), ("n_blocks", C.c_size_t),
                 ("cu_log2_size", C.c_void_p), ("luma_mode", C.c_void_p), ("chroma_mode", C.c_void_p),
                 ("rec_y", C.c_void_p), ("rec_cb", C.c_void_p), ("rec_cr", C.c_void_p)]
+
+
+class Tokens(C.Structure):
+    _fields_ = [("first_page", C.c_void_p), ("cu_log2_size", C.c_void_p), ("luma_mode", C.c_void_p), ("chroma_mode", C.c_void_p),
+                ("rec_y", C.c_void_p), ("rec_cb", C.c_void_p), ("rec_cr", C.c_void_p)]
+
+
+TOKEN_PAGE = 64  # WRENC_GPU_TOKEN_PAGE
 
 
 class WrencGpuError(RuntimeError):
@@ -206,6 +214,39 @@ class Encoder:
         self.lib.wrenc_gpu_download_compact.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         self._check(self.lib.wrenc_gpu_download_compact(self.ctx, first_slot, n, outs))
         return [(m, p[:outs[k].n_blocks], maps) for k, (m, p, maps) in enumerate(keep)]
+
+    def download_tokens(self, first_slot, n, pool_words=None):
+        """The token read-back of n slots (include/wrenc_gpu.h: residual_coding done on the device): (pool, [per picture a
+        dict with first_page and the maps]); feed both to bitstream.write_picture_tokens."""
+        w, h = self.width, self.height
+        grow = pool_words is None
+        if pool_words is None:
+            pool_words = max(n * w * h * 3 // 2, 1 << 16)   # 6 bytes per luma sample: plenty at QP 27 and above
+        pool = np.zeros(pool_words, np.uint32)
+        outs = (Tokens * n)()
+        pics = []
+        for k in range(n):
+            d = {"first_page": np.zeros((h // 32) * (w // 32), np.uint32), "cu_log2_size": np.zeros((h // 4, w // 4), np.uint8),
+                 "luma_mode": np.zeros((h // 4, w // 4), np.uint8), "chroma_mode": np.zeros((h // 8, w // 8), np.uint8)}
+            for name, arr in d.items():
+                setattr(outs[k], name, _p(arr).value)
+            pics.append(d)
+        used = C.c_size_t()
+        self.lib.wrenc_gpu_download_tokens.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+        rc = self.lib.wrenc_gpu_download_tokens(self.ctx, first_slot, n, outs, _p(pool), pool_words, C.byref(used))
+        while rc == -3 and grow and pool_words < (1 << 31):     # WRENC_GPU_ENOMEM: a bigger pool (the pass is cheap)
+            pool_words *= 4
+            pool = np.zeros(pool_words, np.uint32)
+            rc = self.lib.wrenc_gpu_download_tokens(self.ctx, first_slot, n, outs, _p(pool), pool_words, C.byref(used))
+        self._check(rc)
+        return pool[:used.value], pics
+
+    def test_load_record(self, slot, rec):
+        """Test entry: put a record (maps + level planes) into a slot as if a search had produced it."""
+        keep = {k: np.ascontiguousarray(rec[k]) for k in ("lev_y", "lev_cb", "lev_cr", "cu_log2_size", "luma_mode", "chroma_mode")}
+        pic = Picture(*[_p(keep[k]) if k in keep else None for k in _PIC_KEYS])
+        self.lib.wrenc_gpu_test_load_record.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        self._check(self.lib.wrenc_gpu_test_load_record(self.ctx, slot, C.byref(pic)))
 
     def expand_levels(self, mask, payload):
         """Dense level planes from a compact record (host only)."""
