@@ -203,12 +203,16 @@ def measure(grp, rank, world, local_rank, wl, steps, warmup, with_cpu):
     if rank == 0:
         from wrenc_amd import bitstream
         rec0 = enc.download(0)
-        best = None
+        pool0, pics0 = enc.download_tokens(0, 1)     # the same picture as residual tokens made on the device (dev_bins.h)
+        best = best_tok = None
         for _ in range(2):      # what follows the hot path on the host, one core; not part of `value`
             t1 = time.perf_counter()
             nal = bitstream.write_picture(w, h, wl["qp"], 0, rec0)
             t2 = time.perf_counter()
+            nal_tok = bitstream.write_picture_tokens(w, h, wl["qp"], 0, pool0, pics0[0])
+            t3 = time.perf_counter()
             best = t2 - t1 if best is None else min(best, t2 - t1)
+            best_tok = t3 - t2 if best_tok is None else min(best_tok, t3 - t2)
         fps = world * B * steps / dt
         ctus = B * steps * (w // 32) * (h // 32)
         out = {"value": fps, "unit": "frames/s", "mpix_per_s": fps * w * h / 1e6, "ms_per_step": dt * 1e3 / steps,
@@ -216,7 +220,13 @@ def measure(grp, rank, world, local_rank, wl, steps, warmup, with_cpu):
                "pictures_per_step_per_gpu": B, "final_pass_mismatches": mism,
                "roofline": kernel_roofline(ks, dt, ctus, wl["name"]),
                "host_bitstream": {"ms_per_picture_one_core": best * 1e3, "bytes_per_picture": len(nal),
-                                  "note": "host CABAC + syntax of one searched picture; pictures are independent, one host thread each"}}
+                                  "ms_per_picture_one_core_from_device_tokens": best_tok * 1e3, "token_bytes_per_picture": int(pool0.size) * 4,
+                                  "same_bytes_from_tokens": nal == nal_tok,
+                                  "note": "host CABAC + syntax of one searched picture from its level planes, and from the residual "
+                                          "tokens the device makes of it (the host then runs the CU-level syntax and the arithmetic "
+                                          "coder only); pictures are independent, one host thread each"}}
+        if nal != nal_tok:
+            out["host_bitstream"]["error"] = "the token path wrote other bytes"
         if with_cpu:
             base, ref0 = cpu_baseline(wl)
             out["cpu_baseline"] = base
@@ -320,7 +330,8 @@ def e2e_native(w, h, qp, depth, n_pictures, batch, threads, textured):
                 f.write(frames[i % 8])
         r = subprocess.run([exe, "-i", src, "-o", dst, "--input-size", "%dx%d" % (w, h), "--output-size", "%dx%d" % (w, h),
                             "--num-pictures", str(n_pictures), "--qp", str(qp), "--max-split-depth", str(depth),
-                            "--batch", str(batch), "--threads", str(threads), "--verbose"],
+                            "--batch", str(batch), "--threads", str(threads), "--verbose"]
+                           + (["--no-tokens"] if os.environ.get("WRENC_E2E_NO_TOKENS") else []),   # (A/B: residual syntax on the host)
                            capture_output=True, timeout=900)
         m = re.search(rb"(\d+) pictures, (\d+) bytes, ([\d.]+) s, ([\d.]+) pictures/s", r.stderr)
         if r.returncode != 0 or not m:
@@ -382,6 +393,8 @@ def main():
             "roofline": head["roofline"], "host_bitstream": head["host_bitstream"]}
         if head["final_pass_mismatches"]:
             failed.append("final pass mismatches (headline)")
+        if not head["host_bitstream"]["same_bytes_from_tokens"]:
+            failed.append("token path bytes (headline)")
         if "cpu_baseline" in head:
             result["cpu_baseline"] = head["cpu_baseline"]
             result["parity"] = head["parity"]
@@ -413,9 +426,9 @@ def main():
                              "workload": "1920x1088 QP32 max-split-depth 2 (configs[1]), 2048 pictures in 4 batches of 512"}
             # ... and the headline workload itself, file to stream (missing 1): BASELINE's metric is encoded
             # frames/s; `value` is the search alone.  480 pictures in 2 batches of 240
-            result["e2e_4k"] = {"smooth": e2e_native(3840, 2176, 32, 3, 480, 240, threads, False),
-                                "textured": e2e_native(3840, 2176, 32, 3, 480, 240, threads, True),
-                                "workload": "3840x2176 QP32 max-split-depth 3 (configs[2]/[3]), 480 pictures in 2 batches of 240",
+            result["e2e_4k"] = {"smooth": e2e_native(3840, 2176, 32, 3, 960, 240, threads, False),
+                                "textured": e2e_native(3840, 2176, 32, 3, 960, 240, threads, True),
+                                "workload": "3840x2176 QP32 max-split-depth 3 (configs[2]/[3]), 960 pictures in 4 batches of 240",
                                 "search_rate_smooth": head["value"], "search_rate_textured": result["textured"]["value"]}
             for k in ("textured",):
                 if result[k].get("final_pass_mismatches"):

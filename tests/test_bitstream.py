@@ -38,7 +38,7 @@ def test_library_exports_every_declared_symbol(built):
     txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
     declared = sorted(set(re.findall(r"\b(wrenc_bs_[a-z0-9_]+)\s*\(", txt)))
     lib = C.CDLL(bs.LIB_PATH)
-    assert len(declared) == 4
+    assert len(declared) == 5
     for name in declared:
         assert hasattr(lib, name), name
     assert sorted(bs.EXPORTED_SYMBOLS) == declared

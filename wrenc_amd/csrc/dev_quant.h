@@ -415,7 +415,7 @@ __device__ __forceinline__ long long quantize(Ctx c, int lg, int nb, bool shared
 // ---------------------------------------------------------------------------
 // The head of a chain, proven zero without walking it (round 4).
 //
-// Proof and CPU model: oracle/wrenc_oracle.cpp, quantize_viterbi_sc (tests/test_oracle.py runs it against the literal DFS,
+// Proof and CPU model: quantize_viterbi_sc in the CPU checker under oracle/ (tests/test_oracle.py runs it against the literal DFS,
 // quantizer.rs:338-517, at QP 18..51).  In short: the forward trace starts in state 0 at p = 0 (the last scan position)
 // and stays there while state 0 decides "zero", so above the first significant coefficient only state 0's decisions
 // matter.  Per position p with a0(state 0) = 0 (quotient 0 or 1), in undoubled costs:

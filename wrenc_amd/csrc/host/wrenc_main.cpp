@@ -13,7 +13,11 @@
 // reference does (main.rs:127-133); a failure inside the search or the stream writer (a HIP error, a level
 // that overflows the rate tables, ...) is where the reference panics (block_splitter.rs:453): status 101,
 // Rust's panic status, so that a truncated stream never comes with a success status.  Options the reference does not have: --batch, --threads, --device,
-// --devices (several GPUs of the node, batches in turn), --verbose.  Links only against the two C ABIs: no HIP, no Python.
+// --devices (several GPUs of the node, batches in turn), --verbose, --tokens auto|on|off (how a batch comes back: as the
+// residual tokens the device makes of it, wrenc_gpu_download_tokens -- the host then runs the CU-level syntax and the
+// arithmetic coder only, 1.8x less host time per picture, 20x the bytes over PCIe -- or as the compact level record with
+// residual_coding on the host as until round 3; same bytes either way; auto = tokens while the host threads are what the
+// run waits for).  Links only against the two C ABIs: no HIP, no Python.
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
@@ -134,6 +138,12 @@ struct HostSet { // one (device, slot set) unit: page-locked planes of one batch
     int16_t* lev = nullptr;     // batch x room for every 4x4 block of levels; the compact read-back fills the coded ones
     uint32_t* mask = nullptr;   // batch x mask of coded 4x4 blocks (wrenc_gpu_download_compact)
     std::vector<wrenc_gpu_compact> cps;
+    uint32_t* tok_pool = nullptr;   // token read-back (wrenc_gpu_download_tokens): the pages of the batch
+    size_t tok_cap = 0, tok_used = 0;
+    uint32_t* tok_first = nullptr;  // batch x CTUs: first page of every CTU
+    std::vector<wrenc_gpu_tokens> tks;
+    bool bs_tokens = false; // the batch being written was read back as tokens
+    std::atomic<long long> busy_ns{0}; // worker time spent on the batch being written
     uint8_t* maps = nullptr;    // batch x (cu_log2_size | luma_mode | chroma_mode)
     std::vector<std::vector<uint8_t>> nal; // per picture
     std::vector<int> status;
@@ -153,7 +163,8 @@ int main(int argc, char** argv) {
     long num_pictures = -1;
     int qp = 26; // ctu.rs:382 when --qp is absent
     int depth = 3, batch = 64, n_threads = 8, device = 0;
-    bool verbose = false;
+    bool verbose = false, use_tokens = true;
+    int tokens_mode = 0; // --tokens auto (0) | on (1) | off (2)
     const char* device_list = nullptr;
     for (int i = 1; i < argc; ++i) {
         const std::string a = argv[i];
@@ -175,6 +186,12 @@ int main(int argc, char** argv) {
         else if (a == "--device") device = atoi(val());
         else if (a == "--devices") device_list = val();
         else if (a == "--verbose") verbose = true;
+        else if (a == "--no-tokens") tokens_mode = 2;
+        else if (a == "--tokens") {
+            const std::string v = val();
+            tokens_mode = v == "on" ? 1 : (v == "off" ? 2 : (v == "auto" ? 0 : -1));
+            if (tokens_mode < 0) die("Invalid tokens: %s (auto, on, off)", v.c_str());
+        }
         else die("unknown option %s", a.c_str());
     }
     if (!input || !output || !in_size || !out_size || num_pictures < 0)
@@ -193,6 +210,7 @@ int main(int argc, char** argv) {
             pos = end + 1;
         }
     }
+    use_tokens = tokens_mode != 2;
     if (w % 32 || h % 32) die("output-size must be a multiple of the 32x32 CTU (picture.rs:178-181): %dx%d", w, h);
     if (qp < 0 || qp > 63 || depth < 0 || depth > 3) die("qp must be 0..63, max-split-depth 0..3");
     if (batch < 1) batch = 1;
@@ -239,18 +257,31 @@ int main(int argc, char** argv) {
     const size_t ysz = (size_t)w * h, csz = ysz / 4, pic = ysz + 2 * csz;
     const size_t n4 = ysz / 16, n8 = ysz / 64, maps = 2 * n4 + n8;
     const size_t mask_words = wrenc_gpu_compact_mask_words(w, h), level_blocks = pic / 16;
+    const size_t n_ctus = (size_t)(w / 32) * (h / 32);
     std::vector<HostSet> units((size_t)(per_dev * n_dev));
     for (size_t u = 0; u < units.size(); ++u) {
         HostSet& s = units[u];
         s.ctx = ctxs[u % (size_t)n_dev];
         s.base = (int)(u / (size_t)n_dev) * batch;
         s.in = (uint8_t*)wrenc_gpu_alloc_host(s.ctx, pic * batch);
-        s.lev = (int16_t*)wrenc_gpu_alloc_host(s.ctx, pic * batch * sizeof(int16_t));
         s.maps = (uint8_t*)wrenc_gpu_alloc_host(s.ctx, maps * batch);
-        s.mask = (uint32_t*)wrenc_gpu_alloc_host(s.ctx, mask_words * sizeof(uint32_t) * batch);
+        if (use_tokens) {
+            // room for the batch's tokens: what textured content takes at this QP (4-byte tokens per luma sample: ~1 at QP 32,
+            // ~3 at QP 22) with a margin; a batch that needs more is read back as the compact level record instead
+            const double per_sample = qp >= 30 ? 1.5 : (qp >= 25 ? 2.5 : 4.5);
+            s.tok_cap = (size_t)((double)ysz * batch * per_sample) / WRENC_GPU_TOKEN_PAGE * WRENC_GPU_TOKEN_PAGE + WRENC_GPU_TOKEN_PAGE * 1024;
+            s.tok_pool = (uint32_t*)wrenc_gpu_alloc_host(s.ctx, s.tok_cap * sizeof(uint32_t));
+            s.tok_first = (uint32_t*)wrenc_gpu_alloc_host(s.ctx, n_ctus * sizeof(uint32_t) * batch);
+            s.tks.resize((size_t)batch);
+            if (!s.tok_pool || !s.tok_first) fatal("%s", wrenc_gpu_last_error(s.ctx));
+        } else {
+            s.lev = (int16_t*)wrenc_gpu_alloc_host(s.ctx, pic * batch * sizeof(int16_t));
+            s.mask = (uint32_t*)wrenc_gpu_alloc_host(s.ctx, mask_words * sizeof(uint32_t) * batch);
+            if (!s.lev || !s.mask) fatal("%s", wrenc_gpu_last_error(s.ctx));
+        }
         s.cps.resize((size_t)batch);
         if (frec) s.rec = (uint8_t*)wrenc_gpu_alloc_host(s.ctx, pic * batch);
-        if (!s.in || !s.lev || !s.maps || !s.mask || (frec && !s.rec)) fatal("%s", wrenc_gpu_last_error(s.ctx));
+        if (!s.in || !s.maps || (frec && !s.rec)) fatal("%s", wrenc_gpu_last_error(s.ctx));
         s.nal.resize((size_t)batch);
         s.status.assign((size_t)batch, 0);
         s.len.assign((size_t)batch, 0);
@@ -331,8 +362,29 @@ int main(int argc, char** argv) {
     const auto start_slices = [&](HostSet& s) {
         s.bs_count = s.count;
         s.bs_first_poc = s.first_poc;
-        pool.start(0, [&s, w, h, qp, pic, ysz, csz, maps, n4, first_guess, mask_words](int k) {
+        s.busy_ns.store(0);
+        pool.start(0, [&s, w, h, qp, pic, ysz, csz, maps, n4, first_guess, mask_words, n_ctus](int k) {
+            struct Busy { // (every exit of the function adds its time)
+                HostSet& s;
+                std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+                ~Busy() { s.busy_ns += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count(); }
+            } busy{s};
             const uint8_t* m = s.maps + maps * k;
+            if (s.bs_tokens) {
+                // the device made the residual tokens: CU-level syntax + arithmetic coder here
+                const wrenc_bs_tokens tk = {m, m + n4, m + 2 * n4, s.tok_pool, s.tok_used, s.tok_first + n_ctus * k};
+                std::vector<uint8_t>& out = s.nal[(size_t)k];
+                if (out.size() < first_guess) out.resize(first_guess);
+                size_t n = 0;
+                int rc = wrenc_bs_write_picture_tokens(w, h, qp, s.bs_first_poc + k, &tk, out.data(), out.size(), &n);
+                if (rc == WRENC_BS_ENOSPC) {
+                    out.resize(n);
+                    rc = wrenc_bs_write_picture_tokens(w, h, qp, s.bs_first_poc + k, &tk, out.data(), out.size(), &n);
+                }
+                s.status[(size_t)k] = rc;
+                s.len[(size_t)k] = rc ? 0 : n;
+                return;
+            }
             // the level planes the stream writer reads, rebuilt from the compact record in this thread's own buffer
             static thread_local std::vector<int16_t> dense;
             if (dense.size() < pic) dense.resize(pic);
@@ -370,20 +422,70 @@ int main(int argc, char** argv) {
     for (HostSet& s : units)
         if (poc < num_pictures) submit(s);
     HostSet* pending = nullptr;
+    // --verbose: where the main thread spends the run (waiting for slices, for the search + read-back, reading + uploading)
+    double t_flush = 0, t_readback = 0, t_submit = 0;
+    bool host_bound = false;
+    int n_token_batches = 0;
+    auto t_turn = std::chrono::steady_clock::now();
+    const auto now = [] { return std::chrono::steady_clock::now(); };
+    const auto since = [](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t).count(); };
+    if (verbose) fprintf(stderr, "first batches submitted after %.3f s\n", since(t_start));
     for (size_t head = 0; units[head].count > 0; head = (head + 1) % units.size()) {
         HostSet& s = units[head];
-        // the previous batch's slices have been written while this batch was searched; then this batch is read back
-        // in ONE compact call (waits for its search): per picture the mask of coded 4x4 blocks of levels, those blocks,
-        // and the maps -- a few per cent of the 6 bytes per luma sample the level planes take
-        if (pending) flush(*pending);
-        start_slices(s);
-        for (int k = 0; k < s.count; ++k) {
-            uint8_t* m = s.maps + maps * k;
-            uint8_t* r = frec ? s.rec + pic * k : nullptr;
-            s.cps[(size_t)k] = wrenc_gpu_compact{s.mask + mask_words * k, s.lev + pic * k, level_blocks, 0, m, m + n4, m + 2 * n4,
-                                                 r, r ? r + ysz : nullptr, r ? r + ysz + csz : nullptr};
+        auto tp = now();
+        // This batch is read back in ONE call (waits for its search) while the pool still writes the previous batch's
+        // slices (other buffers): the residual tokens the device made of it, or -- when they do not fit, or with
+        // --no-tokens -- the compact level record (mask of coded 4x4 blocks + those blocks); either way with the maps.
+        bool tokens_done = false;
+        // --tokens auto: the token record is many times the compact one (7 MB against 0.3 MB per textured 1080p picture at
+        // QP 32), so it pays exactly when the host threads could not keep up with the search otherwise.  Decided per batch
+        // from the last one's worker time: tokens when writing it from the compact record takes (or, from tokens at 1 / 1.8
+        // of the time, would take) more than 0.8 of the threads for the whole turn of a batch
+        const bool want_tokens = use_tokens && (tokens_mode == 1 || host_bound);
+        if (want_tokens) {
+            for (int k = 0; k < s.count; ++k) {
+                uint8_t* m = s.maps + maps * k;
+                uint8_t* r = frec ? s.rec + pic * k : nullptr;
+                s.tks[(size_t)k] = wrenc_gpu_tokens{s.tok_first + n_ctus * k, m, m + n4, m + 2 * n4, r, r ? r + ysz : nullptr, r ? r + ysz + csz : nullptr};
+            }
+            const int rc = wrenc_gpu_download_tokens(s.ctx, s.base, s.count, s.tks.data(), s.tok_pool, s.tok_cap, &s.tok_used);
+            if (rc == WRENC_GPU_OK)
+                tokens_done = true;
+            else if (rc != WRENC_GPU_ENOMEM)
+                gpu_check(s, rc);
+            else if (verbose)
+                fprintf(stderr, "batch at picture %d: more tokens than the pool holds, read back as the compact level record\n", s.first_poc);
         }
-        gpu_check(s, wrenc_gpu_download_compact(s.ctx, s.base, s.count, s.cps.data()));
+        if (!tokens_done) {
+            if (!s.lev) { // (first fallback of this set)
+                s.lev = (int16_t*)wrenc_gpu_alloc_host(s.ctx, pic * batch * sizeof(int16_t));
+                s.mask = (uint32_t*)wrenc_gpu_alloc_host(s.ctx, mask_words * sizeof(uint32_t) * batch);
+                if (!s.lev || !s.mask) fatal("%s", wrenc_gpu_last_error(s.ctx));
+            }
+            for (int k = 0; k < s.count; ++k) {
+                uint8_t* m = s.maps + maps * k;
+                uint8_t* r = frec ? s.rec + pic * k : nullptr;
+                s.cps[(size_t)k] = wrenc_gpu_compact{s.mask + mask_words * k, s.lev + pic * k, level_blocks, 0, m, m + n4, m + 2 * n4,
+                                                     r, r ? r + ysz : nullptr, r ? r + ysz + csz : nullptr};
+            }
+            gpu_check(s, wrenc_gpu_download_compact(s.ctx, s.base, s.count, s.cps.data()));
+        }
+        t_readback += since(tp);
+        tp = now();
+        if (pending) flush(*pending); // the previous batch's slices, in picture order, to the output
+        {
+            const double waited = since(tp), turn = since(t_turn);
+            t_flush += waited;
+            if (pending && pending->bs_count > 0 && turn > 0) {
+                const double busy = (double)pending->busy_ns.load() * 1e-9 * (pending->bs_tokens ? 1.8 : 1.0); // as if from the compact record
+                host_bound = busy > 0.8 * n_threads * turn;
+            }
+            n_token_batches += tokens_done ? 1 : 0;
+            t_turn = now();
+        }
+        tp = now();
+        s.bs_tokens = tokens_done;
+        start_slices(s);
         pool.extend(s.count);
         pending = &s;
         s.count = 0;
@@ -394,8 +496,16 @@ int main(int argc, char** argv) {
             }
             submit(s);
         }
+        t_submit += since(tp);
     }
-    if (pending) flush(*pending);
+    {
+        const auto tp = now();
+        if (pending) flush(*pending);
+        t_flush += since(tp);
+    }
+    if (verbose)
+        fprintf(stderr, "main thread: %.3f s waiting for slices, %.3f s for search + read-back, %.3f s reading + uploading; %d batch(es) read back as tokens\n",
+                t_flush, t_readback, t_submit, n_token_batches);
     fflush(fout);
     if (frec) fclose(frec);
     if (fout != stdout) fclose(fout);
@@ -409,6 +519,8 @@ int main(int argc, char** argv) {
         wrenc_gpu_free_host(s.ctx, s.lev);
         wrenc_gpu_free_host(s.ctx, s.maps);
         wrenc_gpu_free_host(s.ctx, s.mask);
+        wrenc_gpu_free_host(s.ctx, s.tok_pool);
+        wrenc_gpu_free_host(s.ctx, s.tok_first);
         wrenc_gpu_free_host(s.ctx, s.rec);
     }
     for (wrenc_gpu_ctx* ctx : ctxs) wrenc_gpu_destroy(ctx);
