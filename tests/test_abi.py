@@ -179,3 +179,29 @@ def test_expand_levels_is_the_inverse_of_the_compact_layout(built):
         lib.wrenc_gpu_expand_levels(w, h, ptr(mask), ptr(pay), ptr(out[0]), ptr(out[1]), ptr(out[2]))
         for got, want in zip(out, planes):
             assert np.array_equal(got, want)
+
+
+def test_device_token_contexts_match_the_host_context_array():
+    """The residual tokens the device emits (wrenc_amd/csrc/dev_bins.h) name contexts by their index in the host coder's flat
+    array (wrenc_amd/csrc/host/cabac.h, CtxBase): the six bases the device uses are the host's, and the page size of the
+    token pool is one constant in the three places that know it."""
+    import re
+    host = open(os.path.join(ROOT, "wrenc_amd", "csrc", "host", "cabac.h")).read()
+    vals = {}
+    for name, expr in re.findall(r"\b(CTX_[A-Z_]+) = ([A-Z_0-9 +]+?)\s*(?:,|//|\n)", host):
+        expr = expr.strip()
+        m = re.match(r"(CTX_[A-Z_]+) \+ (\d+)$", expr)
+        vals[name] = int(expr) if expr.isdigit() else vals[m.group(1)] + int(m.group(2))
+    dev = open(os.path.join(ROOT, "wrenc_amd", "csrc", "dev_bins.h")).read()
+    m = re.search(r"CTXD_LAST_X = (\d+), CTXD_LAST_Y = CTXD_LAST_X \+ (\d+), CTXD_SB_CODED = CTXD_LAST_Y \+ (\d+), CTXD_SIG = CTXD_SB_CODED \+ (\d+),\s*"
+                  r"CTXD_PAR = CTXD_SIG \+ (\d+), CTXD_GTX = CTXD_PAR \+ (\d+);", dev)
+    a = [int(g) for g in m.groups()]
+    got = {"CTX_LAST_X": a[0], "CTX_LAST_Y": a[0] + a[1], "CTX_SB_CODED": a[0] + a[1] + a[2], "CTX_SIG": a[0] + a[1] + a[2] + a[3],
+           "CTX_PAR": a[0] + a[1] + a[2] + a[3] + a[4], "CTX_GTX": a[0] + a[1] + a[2] + a[3] + a[4] + a[5]}
+    for k, v in got.items():
+        assert vals[k] == v, (k, vals[k], v)
+    assert vals["CTX_COUNT"] == 253
+    page = int(re.search(r"constexpr int kTokPage = (\d+);", dev).group(1))
+    gh = open(os.path.join(ROOT, "include", "wrenc_gpu.h")).read()
+    bh = open(os.path.join(ROOT, "include", "wrenc_bitstream.h")).read()
+    assert page == int(re.search(r"#define WRENC_GPU_TOKEN_PAGE (\d+)", gh).group(1)) == int(re.search(r"#define WRENC_BS_TOKEN_PAGE (\d+)", bh).group(1))
