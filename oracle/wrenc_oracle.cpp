@@ -661,14 +661,14 @@ static void quantize_viterbi(const RdConst& rd, const int16_t* coef, int log2n, 
 //      (tie rule cost0 <= cost1 -> zero, hence <=).  All 16 x 4 checks hold <=> the hypothesis is exact.
 // ---------------------------------------------------------------------------
 struct DqScStats {
-    long long blocks, nz_blocks, sub_blocks, head_sb_skipped, head_tests, head_fail, z_eligible, z_pass, walked;
+    long long blocks, nz_blocks, sub_blocks, head_sb_skipped, head_tests, head_fail, z_eligible, z_pass, walked, seg_sb, seg_kept;
 };
 static DqScStats g_sc_stats[6]; // by log2n
 static bool g_sc_stats_on = false;
 static long long g_sc_mismatch = 0;
 
 static void quantize_viterbi_sc(const RdConst& rd, const int16_t* coef, int log2n, int qp, int16_t* levels,
-                                bool use_head, bool use_z) {
+                                bool use_head, bool use_z, bool use_seg = false) {
     ScanGeom g(log2n);
     const int N = g.n * g.n;
     const int32_t lsc = level_scale(qp);
@@ -796,6 +796,39 @@ static void quantize_viterbi_sc(const RdConst& rd, const int16_t* coef, int log2
         if (i == istar || i == N - 1 || am < 0 || bm < 0) kstar = i;
     }
     const int sb_star = std::min(kstar, N - 1) >> 4;
+    // one position of a walk whose costs live in Cw (4 values: the costs at i + 1 on entry, at i on return)
+    auto step_on = [&](int i, int64_t* Cw, uint32_t* Aw, int16_t* Qw) {
+        int64_t nc[4];
+        for (int s = 0; s < 4; ++s) {
+            const bool tz = (s == 0 && i <= istar);
+            const Br b = branches(i, s);
+            const int* trans = kQStateTrans[s];
+            size_t a;
+            int16_t q;
+            int64_t cost;
+            if (!b.has1) {
+                cost = b.c0 + Cw[trans[0]];
+                a = 0;
+                q = 0;
+            } else {
+                const int64_t k0 = b.c0 + Cw[trans[b.a0 & 1]], k1 = b.c1 + Cw[trans[(b.a0 + 1) & 1]];
+                if (k0 <= k1) {
+                    a = b.a0;
+                    q = b.q0;
+                    cost = k0;
+                } else {
+                    a = b.a0 + 1;
+                    q = b.q1;
+                    cost = k1;
+                }
+            }
+            if ((i & 15) == 15 && tz && a == 0) cost -= lambda * rd.dq[1];
+            nc[s] = cost;
+            Aw[s] = (uint32_t)a;
+            Qw[s] = q;
+        }
+        for (int s = 0; s < 4; ++s) Cw[s] = nc[s];
+    };
     auto step = [&](int i) {
         for (int s = 0; s < 4; ++s) {
             const bool tz = (s == 0 && i <= istar);
@@ -828,8 +861,83 @@ static void quantize_viterbi_sc(const RdConst& rd, const int16_t* coef, int log2
         }
     };
     int start = 0; // the forward trace starts here in state 0; everything before it is zero
+    // (S) the long non-trailing part of a chain in FOUR SEGMENTS walked side by side.  Behind istar's sub-block the
+    // recursion is (min, +)-linear in the costs it starts from (the rebate of :512-514 only touches trailing state-0
+    // nodes).  The bottom segment starts from the true costs; each of the others is walked from the four vectors e_t = (0
+    // for state t, BIG elsewhere) at once.  Every cost vector v with differences below BIG is min_t (v[t] + e_t), so the true
+    // walk is the same combination of the four -- and where the four have MERGED (equal costs up to a constant at a
+    // sub-block boundary) they are one walk: its decisions are the true ones from there on, and its costs (up to a
+    // constant) the true costs the next segment starts from.  Only the sub-blocks between a segment's bottom and its
+    // merge point are walked again, from the true costs.
+    int seg_done_above = N / 16; // sub-blocks >= this index are decided already
+    if (use_seg) {
+        const int sb_tz = std::min(istar, N - 1) >> 4;         // sub-blocks <= sb_tz hold trailing nodes: not linear
+        const int n_lin = N / 16 - 1 - sb_tz;
+        if (n_lin >= 8) {
+            const int64_t BIG = (int64_t)1 << 40;
+            int bound[5]; // segment k = sub-blocks [bound[k], bound[k + 1]), k = 3 at the DC end
+            for (int k = 0; k <= 4; ++k) bound[k] = sb_tz + 1 + (n_lin * k) / 4;
+            std::vector<int64_t> Cw(16 * 4);                   // [seg * 4 + basis][state]
+            std::vector<uint32_t> Ab((size_t)N * 4 * 4);       // basis walks' decisions [basis][i][s]
+            std::vector<int16_t> Qb((size_t)N * 4 * 4);
+            int merged_at[4] = {-1, -1, -1, -1};               // sub-block whose walk ended with the four merged
+            int64_t top[4][4];                                 // a segment's costs at its top (differences matter)
+            for (int k = 0; k < 4; ++k) {
+                const int nb_ = k == 3 ? 1 : 4;
+                for (int t = 0; t < nb_; ++t)
+                    for (int s2 = 0; s2 < 4; ++s2) Cw[(k * 4 + t) * 4 + s2] = k == 3 ? 0 : (s2 == t ? 0 : BIG);
+                for (int sb = bound[k + 1] - 1; sb >= bound[k]; --sb) {
+                    for (int i = 16 * sb + 15; i >= 16 * sb; --i)
+                        for (int t = 0; t < nb_; ++t)
+                            step_on(i, &Cw[(k * 4 + t) * 4], &Ab[((size_t)t * N + i) * 4], &Qb[((size_t)t * N + i) * 4]);
+                    for (int t = 0; t < nb_; ++t) { // renormalise, as the device does
+                        int64_t* c4 = &Cw[(k * 4 + t) * 4];
+                        const int64_t m = std::min(std::min(c4[0], c4[1]), std::min(c4[2], c4[3]));
+                        for (int s2 = 0; s2 < 4; ++s2) c4[s2] -= m;
+                    }
+                    if (k < 3 && merged_at[k] < 0) {
+                        bool same = true;
+                        for (int t = 1; t < 4; ++t)
+                            for (int s2 = 0; s2 < 4; ++s2) same = same && Cw[(k * 4 + t) * 4 + s2] == Cw[(k * 4) * 4 + s2];
+                        if (same) merged_at[k] = sb;
+                    }
+                }
+                for (int s2 = 0; s2 < 4; ++s2) top[k][s2] = Cw[(k * 4) * 4 + s2];
+            }
+            // true walks: segment 3 is one already; the others from the true costs at their bottom up to their merge point
+            for (int i = 16 * bound[3]; i < N; ++i)
+                for (int s2 = 0; s2 < 4; ++s2) {
+                    A[(size_t)i * 4 + s2] = Ab[((size_t)0 * N + i) * 4 + s2];
+                    Q[(size_t)i * 4 + s2] = Qb[((size_t)0 * N + i) * 4 + s2];
+                }
+            for (int k = 2; k >= 0; --k) {
+                int64_t c4[4];
+                for (int s2 = 0; s2 < 4; ++s2) c4[s2] = top[k + 1][s2];
+                const int redo_to = merged_at[k] < 0 ? bound[k] : merged_at[k]; // sub-blocks [redo_to, bound[k + 1]) again
+                for (int sb = bound[k + 1] - 1; sb >= redo_to; --sb) {
+                    for (int i = 16 * sb + 15; i >= 16 * sb; --i) step_on(i, c4, &A[(size_t)i * 4], &Q[(size_t)i * 4]);
+                    const int64_t m = std::min(std::min(c4[0], c4[1]), std::min(c4[2], c4[3]));
+                    for (int s2 = 0; s2 < 4; ++s2) c4[s2] -= m;
+                }
+                for (int i = 16 * bound[k]; i < 16 * redo_to; ++i) // beyond the merge point: the merged walk's decisions
+                    for (int s2 = 0; s2 < 4; ++s2) {
+                        A[(size_t)i * 4 + s2] = Ab[((size_t)0 * N + i) * 4 + s2];
+                        Q[(size_t)i * 4 + s2] = Qb[((size_t)0 * N + i) * 4 + s2];
+                    }
+                if (merged_at[k] < 0)
+                    for (int s2 = 0; s2 < 4; ++s2) top[k][s2] = c4[s2]; // never merged: the true walk went all the way
+                if (g_sc_stats_on) {
+                    st.seg_sb += bound[k + 1] - bound[k];              // (statistics: sub-blocks of segments 0..2 ...
+                    st.seg_kept += redo_to - bound[k];                 //  ... and how many were not walked again)
+                }
+            }
+            for (int s2 = 0; s2 < 4; ++s2) C[(size_t)(16 * bound[0]) * 4 + s2] = top[0][s2];
+            seg_done_above = bound[0];
+        }
+    }
     for (int sb = N / 16 - 1; sb >= 0; --sb) {
         const int base = 16 * sb;
+        if (sb >= seg_done_above) continue;
         if (use_head && sb < sb_star) {
             // (H): the exact costs at 16 (sb + 1) are known; try to prove the rest of the head, [0, 16 (sb + 1)), zero
             // (first at the end of the head; after a failure again one sub-block further up, with the minima of what is left)
@@ -1743,8 +1851,18 @@ struct Splitter {
         quantize(p.rd, tu->coef[c].data(), log2n, p.qp, tu->lev[c].data());
         if (g_sc_stats_on) { // round-4 model check on the search's own blocks (tests / tools only)
             std::vector<int16_t> alt(tu->lev[c].size());
-            quantize_viterbi_sc(p.rd, tu->coef[c].data(), log2n, p.qp, alt.data(), true, true);
+            quantize_viterbi_sc(p.rd, tu->coef[c].data(), log2n, p.qp, alt.data(), true, true, false);
             if (alt != tu->lev[c]) ++g_sc_mismatch;
+            g_sc_stats_on = false; // (the segmented walk's statistics are its own two counters; the others count once)
+            DqScStats& st_ = g_sc_stats[log2n];
+            const DqScStats keep = st_;
+            g_sc_stats_on = true;
+            quantize_viterbi_sc(p.rd, tu->coef[c].data(), log2n, p.qp, alt.data(), false, false, true);
+            if (alt != tu->lev[c]) ++g_sc_mismatch;
+            const long long sb_ = st_.seg_sb, kept_ = st_.seg_kept;
+            st_ = keep;
+            st_.seg_sb = sb_;
+            st_.seg_kept = kept_;
         }
         dequantize(tu->lev[c].data(), log2n, p.qp, tu->deq[c].data());
         inv_dct(tu->deq[c].data(), log2n, tu->itr[c].data());
@@ -2428,7 +2546,7 @@ void wro_quantize_viterbi_sc(const int16_t* coef, int log2n, int qp, int16_t* le
         rd_qp = qp;
         rd_gen = g_extra_gen;
     }
-    quantize_viterbi_sc(rd, coef, log2n, qp, levels, use_head != 0, use_z != 0);
+    quantize_viterbi_sc(rd, coef, log2n, qp, levels, use_head != 0, (use_z & 1) != 0, (use_z & 2) != 0);
 }
 void wro_dq_sc_stats_enable(int on) {
     g_sc_stats_on = on != 0;
@@ -2437,8 +2555,8 @@ void wro_dq_sc_stats_enable(int on) {
         g_sc_mismatch = 0;
     }
 }
-long long wro_dq_sc_stats_read(long long* out54) {
-    for (int l = 0; l < 6; ++l) memcpy(out54 + 9 * l, &g_sc_stats[l], 9 * sizeof(long long));
+long long wro_dq_sc_stats_read(long long* out66) {
+    for (int l = 0; l < 6; ++l) memcpy(out66 + 11 * l, &g_sc_stats[l], 11 * sizeof(long long));
     return g_sc_mismatch;
 }
 void wro_dequantize(const int16_t* levels, int log2n, int qp, int16_t* deq) {

@@ -81,13 +81,15 @@ void wro_quantize(const int16_t* coef, int log2n, int qp, int16_t* levels);
 // equivalence the GPU kernel relies on
 void wro_quantize_viterbi(const int16_t* coef, int log2n, int qp, int16_t* levels);
 // MODEL of the device quantiser's shortcuts (round 4; see quantize_viterbi_sc in the .cpp): the same Viterbi with the
-// "head proven zero" (use_head) and "all-quotient-zero sub-block in closed form" (use_z) exits.  Must equal wro_quantize.
+// "head proven zero" (use_head) and "all-quotient-zero sub-block in closed form" (use_z bit 0) exits and the long linear part
+// of a chain walked as four segments side by side (use_z bit 1).  Must equal wro_quantize.
 void wro_quantize_viterbi_sc(const int16_t* coef, int log2n, int qp, int16_t* levels, int use_head, int use_z);
 // while enabled, every quantiser call of wro_encode_picture also runs the model on the same coefficients; read returns
-// the number of blocks whose levels differed (expected 0) and 6 x 9 counters by log2n: blocks, non-zero blocks, their
-// sub-blocks, head sub-blocks skipped, head tests, head tests failed, (Z)-eligible sub-blocks, (Z) passed, walked
+// the number of blocks whose levels differed (expected 0) and 6 x 11 counters by log2n: blocks, non-zero blocks, their
+// sub-blocks, head sub-blocks skipped, head tests, head tests failed, (Z)-eligible sub-blocks, (Z) passed, walked; and of a
+// second run with the segmented walk alone: sub-blocks of its segments 0..2, those of them not walked a second time
 void wro_dq_sc_stats_enable(int on);
-long long wro_dq_sc_stats_read(long long* out54);
+long long wro_dq_sc_stats_read(long long* out66);
 // quantizer.rs:761-1079
 void wro_dequantize(const int16_t* levels, int log2n, int qp, int16_t* deq);
 // block_splitter.rs:415-460 level-cost walk of one TB (no header bits)

@@ -131,7 +131,8 @@ def _trellis_block(rng, it):
 def test_trellis_shortcuts_equal_the_literal_dfs(qp):
     """The device quantiser's exits (round 4) -- the head proven zero without walking it, an all-quotient-zero sub-block
     in closed form -- modelled on the CPU (oracle: quantize_viterbi_sc) give the literal memoised DFS's levels
-    (quantizer.rs:338-517) at every QP class ((qp + 1) % 6 = 0..5), each exit alone and both together."""
+    (quantizer.rs:338-517) at every QP class ((qp + 1) % 6 = 0..5), each exit alone and both together; so does the
+    walk of the long linear part of a chain as four segments from (min, +) basis vectors (proven here for a later round)."""
     rng = np.random.default_rng(100 + qp)
     for it in range(240):
         c = _trellis_block(rng, it)
@@ -139,6 +140,9 @@ def test_trellis_shortcuts_equal_the_literal_dfs(qp):
         for head, z in ((True, False), (False, True), (True, True)):
             got = po.quantize_sc(c, qp, head, z)
             assert np.array_equal(got, want), (qp, it, head, z)
+        if c.shape[0] >= 16:    # the long linear part of a chain as four segments side by side (not in the kernel yet)
+            for head in (False, True):
+                assert np.array_equal(po.quantize_sc(c, qp, head, False, True), want), (qp, it, head, "segments")
 
 
 def test_trellis_shortcuts_on_the_search_own_blocks():
