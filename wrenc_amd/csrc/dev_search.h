@@ -3045,52 +3045,31 @@ __device__ __forceinline__ void encode_ctu(Ctx& c, const PicBufs& pb, int ctu_co
     PROF_MARK(tt0_);
     load_tables(c);
     GLOBAL_AS uint8_t* const rec = AS_GLOBAL(uint8_t, pb.rec[0]);
+    // neighbour border of the reconstruction: row -1 (x = -4..67) and columns -4..-1
+    for (int i = LANE; i < 72; i += 64) {
+        const int gx = c.ctu_x - 4 + i, gy = c.ctu_y - 1;
+        SH.recYtop[i] = (gx >= 0 && gx < W && gy >= 0) ? rec[(size_t)gy * W + gx] : 0;
+    }
+    // columns -4..-1 and the left CTU's modes: two cache lines of the left CTU's border record instead of 64
+    // row pieces of the planes (lane = dword: 32 luma rows, 16 + 16 chroma rows, 2 dwords of modes)
     GLOBAL_AS uint8_t* const my_border =
         AS_GLOBAL(uint8_t, pb.border) + (size_t)(ctu_row * k->ctu_cols + ctu_col) * kBorderBytes;
-    // The CTU's neighbourhood.  In the team kernel member 0 fetches it and the others copy it LDS to LDS (round 4: the rows
-    // above and the border record were written by other workgroups, mostly on other XCDs, so every member's own loads
-    // were misses of whole 128-byte lines past L2: half of the team kernel's FETCH_SIZE).
-    if (!TEAM || c.member == 0) {
-        // neighbour border of the reconstruction: row -1 (x = -4..67) and columns -4..-1
-        for (int i = LANE; i < 72; i += 64) {
-            const int gx = c.ctu_x - 4 + i, gy = c.ctu_y - 1;
-            SH.recYtop[i] = (gx >= 0 && gx < W && gy >= 0) ? rec[(size_t)gy * W + gx] : 0;
-        }
-        // columns -4..-1 and the left CTU's modes: two cache lines of the left CTU's border record instead of 64
-        // row pieces of the planes (lane = dword: 32 luma rows, 16 + 16 chroma rows, 2 dwords of modes)
-        {
-            const uint32_t v = (c.ctu_x > 0 && LANE < 66) ? ((const GLOBAL_AS uint32_t*)(my_border - kBorderBytes))[LANE] : 0u;
-            const uint32_t v2 = (c.ctu_x > 0 && LANE < 2) ? ((const GLOBAL_AS uint32_t*)(my_border - kBorderBytes))[64 + LANE] : 0u;
-            if (LANE < 32)
-                *(uint32_t*)&SH.recY[LANE * 36] = v;
-            else if (LANE < 48)
-                *(uint32_t*)&SH.recC[0][(LANE - 32) * 20] = v;
-            else
-                *(uint32_t*)&SH.recC[1][(LANE - 48) * 20] = v;
-            if (LANE < 2) *(uint32_t*)&SH.left_mode[4 * LANE] = v2;
-        }
-        for (int comp = 1; comp < 3; ++comp)
-            for (int i = LANE; i < 40; i += 64) {
-                const int gx = (c.ctu_x >> 1) - 4 + i, gy = (c.ctu_y >> 1) - 1;
-                SH.recCtop[comp - 1][i] = (gx >= 0 && gx < Wc && gy >= 0) ? rec[plane_off(c, comp) + (size_t)gy * Wc + gx] : 0;
-            }
+    {
+        const uint32_t v = (c.ctu_x > 0 && LANE < 66) ? ((const GLOBAL_AS uint32_t*)(my_border - kBorderBytes))[LANE] : 0u;
+        const uint32_t v2 = (c.ctu_x > 0 && LANE < 2) ? ((const GLOBAL_AS uint32_t*)(my_border - kBorderBytes))[64 + LANE] : 0u;
+        if (LANE < 32)
+            *(uint32_t*)&SH.recY[LANE * 36] = v;
+        else if (LANE < 48)
+            *(uint32_t*)&SH.recC[0][(LANE - 32) * 20] = v;
+        else
+            *(uint32_t*)&SH.recC[1][(LANE - 48) * 20] = v;
+        if (LANE < 2) *(uint32_t*)&SH.left_mode[4 * LANE] = v2;
     }
-    if (TEAM) {
-        __syncthreads();
-        if (c.member != 0) {
-            const Lds& m0 = team_lds(c, 0);
-            if (LANE < 18) ((uint32_t*)SH.recYtop)[LANE] = ((const uint32_t*)m0.recYtop)[LANE];
-            if (LANE < 20) ((uint32_t*)SH.recCtop)[LANE] = ((const uint32_t*)m0.recCtop)[LANE];
-            if (LANE < 32)
-                *(uint32_t*)&SH.recY[LANE * 36] = *(const uint32_t*)&m0.recY[LANE * 36];
-            else if (LANE < 48)
-                *(uint32_t*)&SH.recC[0][(LANE - 32) * 20] = *(const uint32_t*)&m0.recC[0][(LANE - 32) * 20];
-            else
-                *(uint32_t*)&SH.recC[1][(LANE - 48) * 20] = *(const uint32_t*)&m0.recC[1][(LANE - 48) * 20];
-            if (LANE < 2) *(uint32_t*)&SH.left_mode[4 * LANE] = *(const uint32_t*)&m0.left_mode[4 * LANE];
+    for (int comp = 1; comp < 3; ++comp)
+        for (int i = LANE; i < 40; i += 64) {
+            const int gx = (c.ctu_x >> 1) - 4 + i, gy = (c.ctu_y >> 1) - 1;
+            SH.recCtop[comp - 1][i] = (gx >= 0 && gx < Wc && gy >= 0) ? rec[plane_off(c, comp) + (size_t)gy * Wc + gx] : 0;
         }
-        __syncthreads(); // (member 0 zeroes its tile next: the copies above read its border columns only, but keep it simple)
-    }
     // tile.rs:49-58: planes start at zero
     for (int i = LANE; i < 32 * 32; i += 64) SH.recY[(i >> 5) * 36 + (i & 31) + 4] = 0;
     for (int comp = 1; comp < 3; ++comp)
