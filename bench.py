@@ -144,7 +144,7 @@ def run_resident(enc, grp, first, count, steps, warmup, timed_stats=False):
     return dt, ks
 
 
-def kernel_roofline(ks, dt, total_ctu_pictures, name):
+def kernel_roofline(ks, dt, total_ctu_pictures, name, lanes=4):
     """The roofline object of one workload from the per-launch HIP events of the timed steps.  A CTU-picture is 1024
     luma pixels = 6144 algorithmic bytes."""
     bytes_per_ctu = ALGO_BYTES_PER_PIXEL * 1024.0
@@ -168,8 +168,8 @@ def kernel_roofline(ks, dt, total_ctu_pictures, name):
            "ctu_search_kernel": wave, "ctu_search_team_kernel": team,
            # an encode call keeps 4 HIP streams of launches co-resident: the GPU as a whole moves the step's algorithmic
            # bytes over its wall time
-           "achieved_device": device_gbs, "frac_device": device_gbs / HBM_PEAK_GBS, "concurrent_streams": 4,
-           "traffic": None, "limiter": "per-wave latency at 5 waves per SIMD (not hbm): DESIGN.md section 4"}
+           "achieved_device": device_gbs, "frac_device": device_gbs / HBM_PEAK_GBS, "concurrent_streams": lanes,
+           "traffic": None, "limiter": "per-wave latency at 5 waves per SIMD, both issue pipes ~60 % busy (not hbm): DESIGN.md section 4, profiles/r04_issue_model.md"}
     if prof and "traffic_bytes_per_launch" in prof:
         out["traffic"] = prof["traffic_bytes_per_launch"]
         out["traffic_source"] = "committed profile of %s (profiles/traffic.json; FETCH_SIZE x 2 + WRITE_SIZE per launch), NOT measured in this run" % prof.get("commit")
@@ -218,7 +218,7 @@ def measure(grp, rank, world, local_rank, wl, steps, warmup, with_cpu):
         out = {"value": fps, "unit": "frames/s", "mpix_per_s": fps * w * h / 1e6, "ms_per_step": dt * 1e3 / steps,
                "workload": "%dx%d synthetic YUV420 QP%d max-split-depth %d" % (w, h, wl["qp"], wl["depth"]),
                "pictures_per_step_per_gpu": B, "final_pass_mismatches": mism,
-               "roofline": kernel_roofline(ks, dt, ctus, wl["name"]),
+               "roofline": kernel_roofline(ks, dt, ctus, wl["name"], lanes=enc.device_info()[1]),
                "host_bitstream": {"ms_per_picture_one_core": best * 1e3, "bytes_per_picture": len(nal),
                                   "ms_per_picture_one_core_from_device_tokens": best_tok * 1e3, "token_bytes_per_picture": int(pool0.size) * 4,
                                   "same_bytes_from_tokens": nal == nal_tok,

@@ -209,6 +209,9 @@ int wrenc_gpu_encode_picture(wrenc_gpu_ctx* ctx, const uint8_t* y, const uint8_t
 enum wrenc_gpu_schedule { WRENC_GPU_SCHEDULE_AUTO = 0, WRENC_GPU_SCHEDULE_WAVE = 1, WRENC_GPU_SCHEDULE_TEAM = 2 };
 int wrenc_gpu_set_schedule(wrenc_gpu_ctx* ctx, int schedule);
 int wrenc_gpu_last_schedule(const wrenc_gpu_ctx* ctx); /* what the most recent encode call used (AUTO = both) */
+/* What the library found and how it was built: wavefronts of the search kernel the device holds at once (CUs x 20) and
+ * the HIP streams an encode call deals its pictures to.  For measurement tools (bench.py, tools/fill_probe.py). */
+int wrenc_gpu_device_info(const wrenc_gpu_ctx* ctx, long long* wave_slots, int* encode_lanes);
 /* Test entry: overrides the number of wave slots AUTO compares a diagonal's CTUs x pictures with (default: what the
  * device holds, CUs x waves per CU), so that a SMALL encode call mixes TEAM and WAVE diagonals as a big one does on
  * the real figure (tests/test_gpu_groups.py).  slots <= 0 restores the device's value.  Results do not depend on it. */

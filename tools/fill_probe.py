@@ -19,7 +19,7 @@ enc = gpu.Encoder(w, h, qp=qp, max_split_depth=depth, n_slots=max(points))
 if len(sys.argv) > 6:
     enc.set_schedule(int(sys.argv[6]))
 if os.environ.get("WRENC_TEAM_PCT"):    # experiment: AUTO's team / wave crossover at this share of the wave slots (library: 65 at depth 3, 50 below)
-    enc.test_set_wave_slots(int(5120 * float(os.environ["WRENC_TEAM_PCT"]) / (65.0 if depth == 3 else 50.0)))
+    enc.test_set_wave_slots(int(enc.device_info()[0] * float(os.environ["WRENC_TEAM_PCT"]) / (65.0 if depth == 3 else 50.0)))
 for s in range(max(points)):
     enc.upload(s, *frames[s % 4])
 enc.sync()

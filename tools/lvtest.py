@@ -1,5 +1,5 @@
 import sys, numpy as np
-sys.path.insert(0, '/root/repo')
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 from wrenc_amd import gpu, synth
 from oracle import pyoracle as po
 for (w, h, qp, depth) in [(64, 64, 32, 3), (96, 64, 27, 3), (64, 64, 32, 2), (96, 96, 37, 1), (64, 32, 22, 0), (128, 96, 30, 2)]:

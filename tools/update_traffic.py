@@ -1,6 +1,6 @@
 """Merges tools/profile_kernel.sh summaries into profiles/traffic.json (one entry per workload; what bench.py's
 `roofline.traffic` / `issue_bound` quote, labelled with the commit they were taken on) and copies the per-workload
-files into profiles/:  python tools/update_traffic.py gpurun_out/prof/r03_WORKLOAD_COMMIT_summary.json ..."""
+files into profiles/:  python tools/update_traffic.py gpurun_out/prof/r04_WORKLOAD_COMMIT_summary.json ..."""
 import json
 import os
 import shutil

@@ -1461,6 +1461,13 @@ int wrenc_gpu_set_schedule(wrenc_gpu_ctx* ctx, int schedule) {
 
 int wrenc_gpu_last_schedule(const wrenc_gpu_ctx* ctx) { return ctx ? ctx->last_schedule : WRENC_GPU_EINVAL; }
 
+int wrenc_gpu_device_info(const wrenc_gpu_ctx* ctx, long long* wave_slots, int* encode_lanes) {
+    if (!ctx) return WRENC_GPU_EINVAL;
+    if (wave_slots) *wave_slots = ctx->device_wave_slots;
+    if (encode_lanes) *encode_lanes = kEncodeLanes;
+    return WRENC_GPU_OK;
+}
+
 int wrenc_gpu_test_set_wave_slots(wrenc_gpu_ctx* ctx, long long slots) {
     if (!ctx) return WRENC_GPU_EINVAL;
     ctx->wave_slots = slots > 0 ? slots : ctx->device_wave_slots;

@@ -19,7 +19,7 @@ LIB_PATH = os.environ.get("WRENC_GPU_LIB", os.path.join(_HERE, "csrc", "libwrenc
 
 EXPORTED_SYMBOLS = [
     "wrenc_gpu_default_config", "wrenc_gpu_config_extra_params", "wrenc_gpu_create", "wrenc_gpu_destroy", "wrenc_gpu_last_error",
-    "wrenc_gpu_upload", "wrenc_gpu_encode", "wrenc_gpu_sync", "wrenc_gpu_download", "wrenc_gpu_download_compact", "wrenc_gpu_compact_mask_words", "wrenc_gpu_expand_levels", "wrenc_gpu_download_tokens", "wrenc_gpu_test_load_record",
+    "wrenc_gpu_upload", "wrenc_gpu_encode", "wrenc_gpu_sync", "wrenc_gpu_download", "wrenc_gpu_download_compact", "wrenc_gpu_compact_mask_words", "wrenc_gpu_expand_levels", "wrenc_gpu_download_tokens", "wrenc_gpu_test_load_record", "wrenc_gpu_device_info",
     "wrenc_gpu_alloc_host", "wrenc_gpu_free_host", "wrenc_gpu_encode_picture", "wrenc_gpu_set_schedule", "wrenc_gpu_last_schedule", "wrenc_gpu_stats_enable", "wrenc_gpu_last_encode_stats", "wrenc_gpu_last_encode_kernel_stats", "wrenc_gpu_final_pass_mismatches",
     "wrenc_gpu_test_fwd_dct", "wrenc_gpu_test_inv_dct", "wrenc_gpu_test_quantize",
     "wrenc_gpu_test_dequantize", "wrenc_gpu_test_predict", "wrenc_gpu_test_fwd_dct32", "wrenc_gpu_test_inv_dct32", "wrenc_gpu_test_quantize_p16", "wrenc_gpu_test_quantize_pk", "wrenc_gpu_test_set_wave_slots", "wrenc_gpu_test_scratch_overflows",
@@ -240,6 +240,13 @@ class Encoder:
             rc = self.lib.wrenc_gpu_download_tokens(self.ctx, first_slot, n, outs, _p(pool), pool_words, C.byref(used))
         self._check(rc)
         return pool[:used.value], pics
+
+    def device_info(self):
+        """(wavefronts of the search kernel the device holds at once, HIP streams an encode call uses)."""
+        slots, lanes = C.c_longlong(), C.c_int()
+        self.lib.wrenc_gpu_device_info.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        self._check(self.lib.wrenc_gpu_device_info(self.ctx, C.byref(slots), C.byref(lanes)))
+        return int(slots.value), int(lanes.value)
 
     def test_load_record(self, slot, rec):
         """Test entry: put a record (maps + level planes) into a slot as if a search had produced it."""
