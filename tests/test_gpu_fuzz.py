@@ -58,6 +58,7 @@ def test_random_case_matches_oracle(built, seed):
         return
     got = enc.encode_picture(y, cb, cr)
     assert enc.final_pass_mismatches() == 0
+    pool, pics = enc.download_tokens(0, 1)      # the same picture as residual tokens made on the device (dev_bins.h)
     enc.close()
     for k in KEYS:
         if not np.array_equal(got[k], ref[k]):
@@ -66,7 +67,9 @@ def test_random_case_matches_oracle(built, seed):
                 seed, w, h, qp, depth, k, len(bad), bad[0]))
     # and through the host bitstream writer: the stream decodes to the same record and reconstruction
     from wrenc_amd import bitstream as bs
-    stream = bs.write_parameter_sets(w, h, qp) + bs.write_picture(w, h, qp, seed, got)
+    nal = bs.write_picture(w, h, qp, seed, got)
+    assert bs.write_picture_tokens(w, h, qp, seed, pool, pics[0]) == nal, "seed %d: the token path writes other bytes" % seed
+    stream = bs.write_parameter_sets(w, h, qp) + nal
     back = po.parse_picture(stream, 0)
     for k in ("cu_log2_size", "luma_mode", "chroma_mode", "lev_y", "lev_cb", "lev_cr"):
         assert np.array_equal(back[k], got[k]), (seed, k)
