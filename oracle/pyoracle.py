@@ -202,12 +202,12 @@ def quantize(coef, qp, viterbi=False):
     return out
 
 
-def quantize_sc(coef, qp, use_head=True, use_z=True, use_seg=False):
+def quantize_sc(coef, qp, use_head=True, use_z=True, use_seg=False, use_whole=True):
     """Model of the device quantiser's shortcuts (wro_quantize_viterbi_sc); must equal quantize()."""
     n = coef.shape[0]
     coef = np.ascontiguousarray(coef, np.int16)
     out = np.zeros_like(coef)
-    lib().wro_quantize_viterbi_sc(_p(coef), int(n).bit_length() - 1, int(qp), _p(out), int(use_head), int(use_z) | (2 if use_seg else 0))
+    lib().wro_quantize_viterbi_sc(_p(coef), int(n).bit_length() - 1, int(qp), _p(out), int(use_head), int(use_z) | (2 if use_seg else 0) | (0 if use_whole else 4))
     return out
 
 
@@ -217,12 +217,12 @@ def dq_sc_stats_enable(on):
 
 def dq_sc_stats_read():
     """(mismatching blocks, {log2n: dict of counters}) gathered since dq_sc_stats_enable(True)."""
-    buf = (C.c_longlong * 66)()
+    buf = (C.c_longlong * 72)()
     lib().wro_dq_sc_stats_read.restype = C.c_longlong
     mism = lib().wro_dq_sc_stats_read(buf)
     names = ("blocks", "nz_blocks", "sub_blocks", "head_sb_skipped", "head_tests", "head_fail", "z_eligible", "z_pass", "walked", "seg_sb",
-             "seg_kept")
-    return int(mism), {l: dict(zip(names, [int(buf[11 * l + i]) for i in range(11)])) for l in range(2, 6)}
+             "seg_kept", "whole_zero")
+    return int(mism), {l: dict(zip(names, [int(buf[12 * l + i]) for i in range(12)])) for l in range(2, 6)}
 
 
 def dequantize(levels, qp):

@@ -661,14 +661,14 @@ static void quantize_viterbi(const RdConst& rd, const int16_t* coef, int log2n, 
 //      (tie rule cost0 <= cost1 -> zero, hence <=).  All 16 x 4 checks hold <=> the hypothesis is exact.
 // ---------------------------------------------------------------------------
 struct DqScStats {
-    long long blocks, nz_blocks, sub_blocks, head_sb_skipped, head_tests, head_fail, z_eligible, z_pass, walked, seg_sb, seg_kept;
+    long long blocks, nz_blocks, sub_blocks, head_sb_skipped, head_tests, head_fail, z_eligible, z_pass, walked, seg_sb, seg_kept, whole_zero;
 };
 static DqScStats g_sc_stats[6]; // by log2n
 static bool g_sc_stats_on = false;
 static long long g_sc_mismatch = 0;
 
 static void quantize_viterbi_sc(const RdConst& rd, const int16_t* coef, int log2n, int qp, int16_t* levels,
-                                bool use_head, bool use_z, bool use_seg = false) {
+                                bool use_head, bool use_z, bool use_seg = false, bool use_whole = true) {
     ScanGeom g(log2n);
     const int N = g.n * g.n;
     const int32_t lsc = level_scale(qp);
@@ -793,7 +793,16 @@ static void quantize_viterbi_sc(const RdConst& rd, const int16_t* coef, int log2
         }
         alpha[i] = am;
         beta[i] = bm;
-        if (i == istar || i == N - 1 || am < 0 || bm < 0) kstar = i;
+        // (the DC position, with its own level formula and no successor, can be part of the region like any other: then
+        // the region is the whole block)
+        if (i == istar || (i == N - 1 && !use_whole) || am < 0 || bm < 0) kstar = i;
+    }
+    if (use_head && use_whole && kstar == N && lambda * rd.dq[1] >= 0) {
+        // (W) nothing ends the region: with G = 0 behind the DC position the induction of (H) runs over the WHOLE block
+        // -- every level is zero, nothing is walked
+        if (g_sc_stats_on) st.whole_zero++;
+        for (int i = 0; i < N; ++i) levels[py[i] * g.n + px[i]] = 0;
+        return;
     }
     const int sb_star = std::min(kstar, N - 1) >> 4;
     // one position of a walk whose costs live in Cw (4 values: the costs at i + 1 on entry, at i on return)
@@ -2546,7 +2555,7 @@ void wro_quantize_viterbi_sc(const int16_t* coef, int log2n, int qp, int16_t* le
         rd_qp = qp;
         rd_gen = g_extra_gen;
     }
-    quantize_viterbi_sc(rd, coef, log2n, qp, levels, use_head != 0, (use_z & 1) != 0, (use_z & 2) != 0);
+    quantize_viterbi_sc(rd, coef, log2n, qp, levels, use_head != 0, (use_z & 1) != 0, (use_z & 2) != 0, (use_z & 4) == 0);
 }
 void wro_dq_sc_stats_enable(int on) {
     g_sc_stats_on = on != 0;
@@ -2555,8 +2564,8 @@ void wro_dq_sc_stats_enable(int on) {
         g_sc_mismatch = 0;
     }
 }
-long long wro_dq_sc_stats_read(long long* out66) {
-    for (int l = 0; l < 6; ++l) memcpy(out66 + 11 * l, &g_sc_stats[l], 11 * sizeof(long long));
+long long wro_dq_sc_stats_read(long long* out72) {
+    for (int l = 0; l < 6; ++l) memcpy(out72 + 12 * l, &g_sc_stats[l], 12 * sizeof(long long));
     return g_sc_mismatch;
 }
 void wro_dequantize(const int16_t* levels, int log2n, int qp, int16_t* deq) {

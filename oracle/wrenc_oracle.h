@@ -87,9 +87,10 @@ void wro_quantize_viterbi_sc(const int16_t* coef, int log2n, int qp, int16_t* le
 // while enabled, every quantiser call of wro_encode_picture also runs the model on the same coefficients; read returns
 // the number of blocks whose levels differed (expected 0) and 6 x 11 counters by log2n: blocks, non-zero blocks, their
 // sub-blocks, head sub-blocks skipped, head tests, head tests failed, (Z)-eligible sub-blocks, (Z) passed, walked; and of a
-// second run with the segmented walk alone: sub-blocks of its segments 0..2, those of them not walked a second time
+// second run with the segmented walk alone: sub-blocks of its segments 0..2, those of them not walked a second time; blocks
+// proven all zero without any walk (the head proof over the whole block; use_z bit 2 switches that off)
 void wro_dq_sc_stats_enable(int on);
-long long wro_dq_sc_stats_read(long long* out66);
+long long wro_dq_sc_stats_read(long long* out72);
 // quantizer.rs:761-1079
 void wro_dequantize(const int16_t* levels, int log2n, int qp, int16_t* deq);
 // block_splitter.rs:415-460 level-cost walk of one TB (no header bits)

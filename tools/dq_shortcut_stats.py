@@ -32,10 +32,11 @@ def main():
                 if not s["blocks"]:
                     continue
                 sb = max(s["sub_blocks"], 1)
-                print("  %2dx%-2d blocks %7d non-zero %5.1f %% | sub-blocks of those: head-skipped %5.1f %%, closed form %5.1f %% "
+                print("  %2dx%-2d blocks %7d non-zero %5.1f %%, proven all zero without a walk %5.1f %% of those | sub-blocks of those: head-skipped %5.1f %%, closed form %5.1f %% "
                       "(eligible %5.1f %%), walked %5.1f %% | head tests %d failed %d | four segments: %5.1f %% of the sub-blocks in "
                       "segments 0..2, %5.1f %% of those not walked again"
-                      % (1 << l, 1 << l, s["blocks"], 100.0 * s["nz_blocks"] / s["blocks"], 100.0 * s["head_sb_skipped"] / sb,
+                      % (1 << l, 1 << l, s["blocks"], 100.0 * s["nz_blocks"] / s["blocks"], 100.0 * s["whole_zero"] / max(s["nz_blocks"], 1),
+                         100.0 * s["head_sb_skipped"] / sb,
                          100.0 * s["z_pass"] / sb, 100.0 * s["z_eligible"] / sb, 100.0 * s["walked"] / sb, s["head_tests"],
                          s["head_fail"], 100.0 * s["seg_sb"] / sb, 100.0 * s["seg_kept"] / max(s["seg_sb"], 1)))
 

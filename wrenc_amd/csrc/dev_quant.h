@@ -449,28 +449,34 @@ __device__ __forceinline__ HeadK head_consts(int sh, int off, int lsc) {
     return h;
 }
 // alpha of one position and whether it ends the region (same arithmetic as chunk_entry for quotients 0 and 1:
-// delta 0: a0 = 0, a1 = 1 (q1 = 2); delta 1: quotient 0: a0 = 0, a1 = 1 (q1 = 1), quotient 1: a0 = 1 (q0 = 1), a1 = 2 (q1 = 3))
-__device__ __forceinline__ int head_alpha(int tc, int qd, bool last, const HeadK& h, bool* bad) {
+// delta 0: a0 = 0, a1 = 1 (q1 = 2); delta 1: quotient 0: a0 = 0, a1 = 1 (q1 = 1), quotient 1: a0 = 1 (q0 = 1), a1 = 2 (q1 = 3);
+// at the DC position (dcn; quantizer.rs:378-391) delta is not added to the quotient and delta 1's "zero" is the level -1
+// of the usize wrap: a0 = 0 with q0 of the OPPOSITE sign, a1 = 1 (q1 = 1)).  The DC position can be part of the region like
+// any other -- with nothing behind it G is 0 there, which is all the induction needs -- and then the region is the whole
+// block: every level zero, nothing to walk (round 4, (W) in the CPU model).
+__device__ __forceinline__ int head_alpha(int tc, int qd, bool dcn, const HeadK& h, bool* bad) {
     const bool neg = tc < 0;
     const int d1 = abs(tc - (neg ? h.dn1 : h.dp1));
     const int d2 = abs(tc - (neg ? h.dn2 : h.dp2));
     const int d3 = abs(tc - (neg ? h.dn3 : h.dp3));
+    const int d1o = abs(tc - (neg ? h.dp1 : h.dn1)); // level 1 of the opposite sign (DC position, delta 1)
     const int c0tz = 128 * abs(tc); // state 0's zero inside the trailing run costs no bits (:449-453)
     const int c0d0 = c0tz + h.ldq1;
     const int c1d0 = 128 * d2 + h.ldq2;
-    const int c0d1 = qd ? 128 * d1 + h.ldq2 : c0d0;
-    const int c1d1 = qd ? 128 * d3 + h.ldq3 : 128 * d1 + h.ldq2;
+    const int c0d1 = dcn ? 128 * d1o + h.ldq1 : (qd ? 128 * d1 + h.ldq2 : c0d0);
+    const int c1d1 = (qd && !dcn) ? 128 * d3 + h.ldq3 : 128 * d1 + h.ldq2;
     int alpha = c1d0 - c0tz;
     int beta = min(min(c0d0, c0d1), c1d1) - c0tz;
     if (tc == 0) { // no second branch; the zero costs dq_table[1] outside the trailing run, nothing inside
         alpha = kAlphaInf;
         beta = h.ldq1;
     }
-    *bad = last || qd >= 2 || alpha < 0 || beta < 0 || h.ldq1 < 0;
+    *bad = qd >= 2 || alpha < 0 || beta < 0 || h.ldq1 < 0;
     return min(alpha, kAlphaInf);
 }
 // One batch of 64 positions (lane = position p0 + LANE of a chain of P) of the region search: `open` while no position has
-// ended the region; arun = this lane's minimum of alpha over the region so far; sb = the sub-block the walk must reach
+// ended the region (still open behind the last batch: the whole block is zero, head_sb gives P / 16); arun = this lane's
+// minimum of alpha over the region so far; sb = the sub-block the walk must reach
 #ifndef WRENC_HEAD_EXIT
 #define WRENC_HEAD_EXIT 1 // 0: every chain is walked to its end (round 3's behaviour; for A/B runs)
 #endif
@@ -480,8 +486,8 @@ __device__ __forceinline__ void head_batch(int tc, int qd, int p, int P, bool va
         open = false;
     }
     if (!open) return;
-    // a batch of zero coefficients that does not hold the DC position: alpha = inf, beta = ldq1 everywhere
-    if (__ballot(valid && (tc != 0 || p == P - 1)) == 0ULL && h.ldq1 >= 0) return;
+    // a batch of zero coefficients: alpha = inf, beta = ldq1 everywhere
+    if (__ballot(valid && tc != 0) == 0ULL && h.ldq1 >= 0) return;
     bool bad;
     const int alpha = head_alpha(tc, qd, p == P - 1, h, &bad);
     const unsigned long long B = __ballot(valid && bad);
@@ -494,6 +500,8 @@ __device__ __forceinline__ void head_batch(int tc, int qd, int p, int P, bool va
         open = false;
     }
 }
+// the sub-block the walk must reach, once every batch of the chain has been seen: nsb (= nothing to walk) if none ended the region
+__device__ __forceinline__ int head_sb(bool open, int sb, int nsb) { return (open && WRENC_HEAD_EXIT) ? nsb : sb; }
 // After the walk of sub-block sb (path costs C of the quad's four states, doubled): is G >= -alpha_min ?
 __device__ __forceinline__ bool head_test(int C, int st, int amin) {
     const int c0 = dpp_quad<0x00>(C);                  // state 0's cost in every lane of the quad
@@ -543,7 +551,8 @@ __device__ __forceinline__ long long quantize_solo(Ctx c, int lg, int nb, int* o
             }
             head_batch(tc, qd, p, P, valid, hk, open, arun, sb);
         }
-        if (sb > 0) arun = wave_min_i32(arun);
+        sb = head_sb(open, sb, nsb);
+        if (sb > 0 && sb < nsb) arun = wave_min_i32(arun);
         if (blk) {
             istar1 = first;
             sbs1 = sb;
@@ -556,6 +565,14 @@ __device__ __forceinline__ long long quantize_solo(Ctx c, int lg, int nb, int* o
     }
     if (__ballot(nzl != 0) == 0ULL) return 0; // zero blocks: nothing to walk, the levels are the zeros already in r1
     WSYNC();
+    if (sbs0 == nsb && (nb == 1 || sbs1 == nsb)) {
+        // every level of the call is proven zero: nothing to walk, nothing to trace (the coefficients in r1 make way for them)
+        for (int i = LANE; i < (nb * P) / 8; i += 64) *(uint4*)&SH.r1[8 * i] = make_uint4(0u, 0u, 0u, 0u);
+        WSYNC();
+        PROF_MARK(qz_);
+        PROF_ADD2(PH_QPRE, q0_, qz_);
+        return 0;
+    }
     // decisions of the sub-blocks the walk may never reach: zero in every state (the trace then stays in state 0 there)
     if (LANE < sbs0) *(uint2*)(dec16 + LANE * 4) = make_uint2(0u, 0u);
     if (nb == 2 && LANE < sbs1) *(uint2*)(dec16 + (P >> 2) + LANE * 4) = make_uint2(0u, 0u);
@@ -970,6 +987,18 @@ __device__ __forceinline__ void quantize_p16(Ctx c, int nb, int* overflow, long 
     lvl[0] = lvl[1] = lvl[2] = lvl[3] = 0;
     *any_mask = 0;
     if (nzb == 0ULL) return; // every block is zero: the levels are the zero coefficients already in r1
+    if (WRENC_HEAD_EXIT) {
+        // every block's levels proven zero (the head proof over the whole block, head_alpha): nothing to walk or trace
+        const HeadK hk = head_consts(sh, off, lsc);
+        bool bad;
+        (void)head_alpha(tc, qd, p == P - 1, hk, &bad);
+        if (__ballot(mine && bad) == 0ULL) {
+            WSYNC();
+            if (mine) SH.r1[blk * P + scan[p]] = 0;
+            WSYNC();
+            return;
+        }
+    }
     PROF_MARK(q1_);
     PROF_ADD2(PH_QPRE, q0_, q1_);
     WSYNC(); // every lane has its coefficient before the chunk entries overwrite r1
@@ -1270,7 +1299,8 @@ __device__ __forceinline__ void quantize_pk(Ctx c, int nc, int* overflow, long l
             }
             head_batch(tc, qd, p, PL, true, hkl, open, arun, sb);
         }
-        if (sb > 0) arun = wave_min_i32(arun);
+        sb = head_sb(open, sb, SBL);
+        if (sb > 0 && sb < SBL) arun = wave_min_i32(arun);
         if (lane == 0) ist[cd] = (uint16_t)first;
         if (lane == cd) {
             v_low = sb;
@@ -1278,8 +1308,9 @@ __device__ __forceinline__ void quantize_pk(Ctx c, int nc, int* overflow, long l
         }
     }
     if constexpr (LGL == 3) {
+        const HeadK hkc = head_consts(shc, offc, lsc);
 #pragma unroll
-        for (int ps = 0; ps < 2; ++ps) { // (4x4 chroma blocks: one sub-block, the DC one: no head)
+        for (int ps = 0; ps < 2; ++ps) { // (4x4 chroma blocks: one sub-block; all of it proven zero, or all of it walked)
             const int blk = 4 * ps + row;
             const bool mine = blk < nch;
             int tc = 0, qd = 0;
@@ -1291,6 +1322,12 @@ __device__ __forceinline__ void quantize_pk(Ctx c, int nc, int* overflow, long l
             }
             const int first = row_min_i32((tc != 0 && (qd >> 1) > 0) ? i16 : 16);
             if (mine && i16 == 0) ist[4 + blk] = (uint16_t)first;
+            bool bad;
+            (void)head_alpha(tc, qd, i16 == 15, hkc, &bad);
+            const unsigned long long B = __ballot(mine && bad);
+#pragma unroll
+            for (int rw = 0; rw < 4; ++rw) // (lane 4 + block of v_low: 1 = nothing to walk)
+                if (lane == 4 + 4 * ps + rw) v_low = (WRENC_HEAD_EXIT && ((B >> (16 * rw)) & 0xFFFFULL) == 0ULL) ? 1 : 0;
         }
     } else {
         const HeadK hkc = head_consts(shc, offc, lsc);
@@ -1305,7 +1342,8 @@ __device__ __forceinline__ void quantize_pk(Ctx c, int nc, int* overflow, long l
             int arun = kAlphaInf, sb = SBC - 1;
             bool open = true;
             head_batch(tc, qd, lane, PC, true, hkc, open, arun, sb);
-            if (sb > 0) arun = wave_min_i32(arun);
+            sb = head_sb(open, sb, SBC);
+            if (sb > 0 && sb < SBC) arun = wave_min_i32(arun);
             if (lane == 0) ist[4 + b] = (uint16_t)first;
             if (lane == 4 + b) {
                 v_low = sb;
@@ -1314,6 +1352,18 @@ __device__ __forceinline__ void quantize_pk(Ctx c, int nc, int* overflow, long l
         }
     }
     if (__ballot(nzl != 0) == 0ULL) return; // every block of the pack is zero: the levels are the zeros already in r1
+    {
+        // every chain proven zero from end to end: no walk, no trace; the coefficients in r1 make way for the zero levels
+        const bool todo = lane < 12 && (lane < nc || (lane >= 4 && lane < 4 + nch)) && v_low < (lane < 4 ? SBL : SBC);
+        if (__ballot(todo) == 0ULL) {
+            WSYNC();
+            for (int i = lane; i < (nL + nch * PC) / 8; i += 64) *(uint4*)&SH.r1[8 * i] = make_uint4(0u, 0u, 0u, 0u);
+            WSYNC();
+            PROF_MARK(qz_);
+            PROF_ADD2(PH_QPRE, q0_, qz_);
+            return;
+        }
+    }
     // the decisions of sub-blocks the walk never reaches are zero in every state (the trace stays in state 0 there)
     {
         constexpr int kMaxNc = LGL == 3 ? 3 : 2;
@@ -1344,14 +1394,18 @@ __device__ __forceinline__ void quantize_pk(Ctx c, int nc, int* overflow, long l
             fresh[j] = false;
             if (rleft[j] == 0) {
                 rid[j] = -1;
-                if (next_chain < nct) {
+                while (next_chain < nct) {
                     const int id = next_chain < nc ? next_chain : 4 + (next_chain - nc); // lane of v_low / v_amin, index of ist
                     ++next_chain;
+                    const int low = __builtin_amdgcn_readlane(v_low, id);
+                    const int len = (id < 4 ? SBL : SBC) - low;
+                    if (len <= 0) continue; // proven zero from end to end: nothing to walk
                     rid[j] = id;
-                    rlow[j] = __builtin_amdgcn_readlane(v_low, id);
+                    rlow[j] = low;
                     ramin[j] = __builtin_amdgcn_readlane(v_amin, id);
-                    rleft[j] = (id < 4 ? SBL : SBC) - rlow[j];
+                    rleft[j] = len;
                     fresh[j] = true;
+                    break;
                 }
             }
             any_row = any_row || rid[j] >= 0;
