@@ -220,6 +220,13 @@ int wrenc_gpu_test_set_wave_slots(wrenc_gpu_ctx* ctx, long long slots);
  * region of the shared overflow partition instead (wrenc_gpu.hip, acquire_scratch).  0 on MI355X: the saved
  * reconstructions of the search then stay behind the L2 of the XCD that wrote them.  Waits for the device. */
 int wrenc_gpu_test_scratch_overflows(wrenc_gpu_ctx* ctx, long long* count);
+/* Test entry: the dependent quantiser's head proof decides "this coefficient ends the region" and "quotient >= 2" by range
+ * tests whose bounds the host derives per context (QP) and block size; this holds them against the device's own
+ * formulas over every 16-bit coefficient, 4 block sizes, DC and other positions.  counts[0]: coefficients a range admits
+ * that the formula does not (must be 0: results depend on it); counts[1]: the opposite (allowed, costs speed; 0
+ * expected); counts[2]: quotient differences (must be 0); counts[3]: differences of the two alpha formulas (must be 0).
+ * ranges (may be NULL): the 4 x 6 bounds.  Waits for the device. */
+int wrenc_gpu_test_head_ranges(wrenc_gpu_ctx* ctx, int counts[4], int ranges[24]);
 
 /* Per-launch timing (two HIP events around every kernel launch) is OFF by default: the product path
  * (CLI, native program) never reads it.  bench.py / profiling switch it on.  While it is on, an encode

@@ -142,6 +142,21 @@ def test_quantize_trellis_at_every_qp_class(enc_at, qp):
             assert np.array_equal(deq[i], po.dequantize(ref, qp)), (qp, n, i)
 
 
+def test_head_proof_ranges_equal_the_formulas_at_every_qp(built):
+    """The head proof reads "ends the region" and "quotient >= 2" off range tests whose bounds the host derives per QP and
+    block size (DevConst::head_rng): at every QP 0..63 they say what the device's formulas (head_alpha, quotient) say for
+    every 16-bit coefficient, 4 block sizes, the DC position and the others; so does the quotient-free alpha."""
+    from wrenc_amd import gpu
+    for qp in range(64):
+        e = gpu.Encoder(64, 64, qp=qp, max_split_depth=0)
+        try:
+            counts, ranges = e.test_head_ranges()
+        finally:
+            e.close()
+        assert counts == [0, 0, 0, 0], (qp, counts, ranges.tolist())
+        assert (ranges[:, 5] > 0).all(), (qp, ranges.tolist())  # a zero coefficient has quotient 0
+
+
 @pytest.mark.parametrize("qp", [18, 27, 34, 45, 51])
 def test_packed_quantisers_at_other_qps(enc_at, qp):
     """quantize_p16 and quantize_pk<3 / 4> at other QPs: every block of every pack equals the literal DFS."""

@@ -42,6 +42,11 @@ struct DevConst {
     int8_t idct32_p[32][2][16];
     int32_t idct32_k1[32];
     int32_t idct32_k2[2][16];
+    // The head proof's per-coefficient conditions (dev_quant.h, head_alpha) as range tests, per block size lg - 2: a coefficient tc
+    // (a) does not end the region  <=>  (unsigned)(tc + r[0]) < (unsigned)r[1];  (b) the same at the DC position with r[2], r[3];
+    // (c) has a quotient below 2  <=>  (unsigned)(tc + r[4]) < (unsigned)r[5].  Filled by the host from the same formulas
+    // (fill_head_ranges; test_head_ranges_kernel compares them with the device functions over every 16-bit coefficient).
+    int32_t head_rng[4][6];
 };
 
 // Pointers that are loaded from memory (PicBufs) lose their address space; these casts tell the

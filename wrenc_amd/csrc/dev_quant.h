@@ -474,23 +474,47 @@ __device__ __forceinline__ int head_alpha(int tc, int qd, bool dcn, const HeadK&
     *bad = qd >= 2 || alpha < 0 || beta < 0 || h.ldq1 < 0;
     return min(alpha, kAlphaInf);
 }
+// The same conditions as range tests (round 4, after (W)): `bad` and "quotient >= 2" depend on nothing but the coefficient and
+// the block size, and each is false exactly on one interval around zero (the costs are piecewise linear in |tc|), which the
+// host finds by running the formulas above over every 16-bit coefficient (DevConst::head_rng).  A coefficient outside the
+// interval is taken as ending the region: if the true set were not an interval, that would only shorten regions, never
+// admit a position the proof does not cover.  alpha needs no quotient either: c1(delta 0) is level 2's cost at both quotients.
+struct HeadT {
+    int tn, cnt, tnd, cntd, tnq, cntq;
+};
+__device__ __forceinline__ HeadT head_ranges(const CONST_AS DevConst* k, int lg) {
+    const CONST_AS int32_t* r = k->head_rng[lg - 2];
+    HeadT t;
+    t.tn = r[0];
+    t.cnt = r[1];
+    t.tnd = r[2];
+    t.cntd = r[3];
+    t.tnq = r[4];
+    t.cntq = r[5];
+    return t;
+}
+__device__ __forceinline__ bool head_bad(int tc, bool dcn, const HeadT& t) {
+    return (unsigned)(tc + (dcn ? t.tnd : t.tn)) >= (unsigned)(dcn ? t.cntd : t.cnt);
+}
+__device__ __forceinline__ bool head_sig(int tc, const HeadT& t) { return (unsigned)(tc + t.tnq) >= (unsigned)t.cntq; } // quotient >= 2
+__device__ __forceinline__ int head_alpha1(int tc, const HeadK& h) {
+    const int d2 = abs(tc - (tc < 0 ? h.dn2 : h.dp2));
+    return tc == 0 ? kAlphaInf : min(128 * d2 + h.ldq2 - 128 * abs(tc), kAlphaInf);
+}
 // One batch of 64 positions (lane = position p0 + LANE of a chain of P) of the region search: `open` while no position has
 // ended the region (still open behind the last batch: the whole block is zero, head_sb gives P / 16); arun = this lane's
 // minimum of alpha over the region so far; sb = the sub-block the walk must reach
 #ifndef WRENC_HEAD_EXIT
 #define WRENC_HEAD_EXIT 1 // 0: every chain is walked to its end (round 3's behaviour; for A/B runs)
 #endif
-__device__ __forceinline__ void head_batch(int tc, int qd, int p, int P, bool valid, const HeadK& h, bool& open, int& arun, int& sb) {
+__device__ __forceinline__ void head_batch(int tc, int p, int P, bool valid, const HeadK& h, const HeadT& t, bool& open, int& arun, int& sb) {
     if (!WRENC_HEAD_EXIT) {
         sb = 0;
         open = false;
     }
     if (!open) return;
-    // a batch of zero coefficients: alpha = inf, beta = ldq1 everywhere
-    if (__ballot(valid && tc != 0) == 0ULL && h.ldq1 >= 0) return;
-    bool bad;
-    const int alpha = head_alpha(tc, qd, p == P - 1, h, &bad);
-    const unsigned long long B = __ballot(valid && bad);
+    const int alpha = head_alpha1(tc, h);
+    const unsigned long long B = __ballot(valid && head_bad(tc, p == P - 1, t));
     if (B == 0ULL) {
         if (valid) arun = min(arun, alpha);
     } else {
@@ -530,6 +554,7 @@ __device__ __forceinline__ long long quantize_solo(Ctx c, int lg, int nb, int* o
     PROF_MARK(q0_);
     *any_level = false;
     const HeadK hk = head_consts(sh, off, lsc);
+    const HeadT ht = head_ranges(k, lg);
     const int nsb = P >> 4;
     int istar0 = P, istar1 = P, sbs0 = nsb - 1, sbs1 = nsb - 1, amin0 = kAlphaInf, amin1 = kAlphaInf;
     int nzl = 0;
@@ -543,13 +568,12 @@ __device__ __forceinline__ long long quantize_solo(Ctx c, int lg, int nb, int* o
             const bool valid = p < P;
             const int tc = valid ? (int)SH.r1[blk * P + scan[valid ? p : 0]] : 0;
             nzl |= tc;
-            const int qd = quotient(k, tc, sh, off);
             if (valid) tcs[blk * P + p] = (int16_t)tc;
             if (first == P) {
-                const unsigned long long sig = __ballot(tc != 0 && (qd >> 1) > 0);
+                const unsigned long long sig = __ballot(head_sig(tc, ht));
                 if (sig != 0ULL) first = p0 + (int)__builtin_ctzll(sig);
             }
-            head_batch(tc, qd, p, P, valid, hk, open, arun, sb);
+            head_batch(tc, p, P, valid, hk, ht, open, arun, sb);
         }
         sb = head_sb(open, sb, nsb);
         if (sb > 0 && sb < nsb) arun = wave_min_i32(arun);
@@ -977,22 +1001,16 @@ __device__ __forceinline__ void quantize_p16(Ctx c, int nb, int* overflow, long 
     PROF_MARK(q0_);
     const int blk = lane >> 4, p = lane & 15;
     const bool mine = blk < nb;
-    int tc = 0, qd = 0;
-    if (mine) {
-        tc = SH.r1[blk * P + scan[p]];
-        qd = quotient(k, tc, sh, off);
-    }
-    const int istar = row_min_i32((tc != 0 && (qd >> 1) > 0) ? p : P); // of this lane's block
+    const HeadT ht = head_ranges(k, 2);
+    const int tc = mine ? (int)SH.r1[blk * P + scan[p]] : 0;
+    const int istar = row_min_i32(head_sig(tc, ht) ? p : P); // of this lane's block
     const unsigned long long nzb = __ballot(tc != 0);
     lvl[0] = lvl[1] = lvl[2] = lvl[3] = 0;
     *any_mask = 0;
     if (nzb == 0ULL) return; // every block is zero: the levels are the zero coefficients already in r1
     if (WRENC_HEAD_EXIT) {
         // every block's levels proven zero (the head proof over the whole block, head_alpha): nothing to walk or trace
-        const HeadK hk = head_consts(sh, off, lsc);
-        bool bad;
-        (void)head_alpha(tc, qd, p == P - 1, hk, &bad);
-        if (__ballot(mine && bad) == 0ULL) {
+        if (__ballot(mine && head_bad(tc, p == P - 1, ht)) == 0ULL) {
             WSYNC();
             if (mine) SH.r1[blk * P + scan[p]] = 0;
             WSYNC();
@@ -1002,6 +1020,7 @@ __device__ __forceinline__ void quantize_p16(Ctx c, int nb, int* overflow, long 
     PROF_MARK(q1_);
     PROF_ADD2(PH_QPRE, q0_, q1_);
     WSYNC(); // every lane has its coefficient before the chunk entries overwrite r1
+    const int qd = quotient(k, tc, sh, off); // (0 for a lane without a block)
     const int ldq1 = (int)ldq_at(c, 1);
     int ovf = 0;
     {
@@ -1283,6 +1302,7 @@ __device__ __forceinline__ void quantize_pk(Ctx c, int nc, int* overflow, long l
     int nzl = 0;
     int v_low = 0, v_amin = kAlphaInf;
     const HeadK hkl = head_consts(shl, offl, lsc);
+    const HeadT htl = head_ranges(k, LGL), htc = head_ranges(k, LGL - 1);
 #pragma unroll 1
     for (int cd = 0; cd < nc; ++cd) {
         int first = PL, arun = kAlphaInf, sb = SBL - 1; // (first: uniform)
@@ -1292,12 +1312,11 @@ __device__ __forceinline__ void quantize_pk(Ctx c, int nc, int* overflow, long l
             const int tc = SH.r1[cd * PL + scanl[p]];
             nzl |= tc;
             tcs[cd * PL + p] = (int16_t)tc;
-            const int qd = quotient(k, tc, shl, offl);
             if (first == PL) {
-                const unsigned long long sig = __ballot(tc != 0 && (qd >> 1) > 0);
+                const unsigned long long sig = __ballot(head_sig(tc, htl));
                 if (sig != 0ULL) first = (p - lane) + (int)__builtin_ctzll(sig);
             }
-            head_batch(tc, qd, p, PL, true, hkl, open, arun, sb);
+            head_batch(tc, p, PL, true, hkl, htl, open, arun, sb);
         }
         sb = head_sb(open, sb, SBL);
         if (sb > 0 && sb < SBL) arun = wave_min_i32(arun);
@@ -1308,23 +1327,19 @@ __device__ __forceinline__ void quantize_pk(Ctx c, int nc, int* overflow, long l
         }
     }
     if constexpr (LGL == 3) {
-        const HeadK hkc = head_consts(shc, offc, lsc);
 #pragma unroll
         for (int ps = 0; ps < 2; ++ps) { // (4x4 chroma blocks: one sub-block; all of it proven zero, or all of it walked)
             const int blk = 4 * ps + row;
             const bool mine = blk < nch;
-            int tc = 0, qd = 0;
+            int tc = 0;
             if (mine) {
                 tc = SH.r1[nL + blk * 16 + scanc[i16]];
                 nzl |= tc;
                 tcs[nL + blk * 16 + i16] = (int16_t)tc;
-                qd = quotient(k, tc, shc, offc);
             }
-            const int first = row_min_i32((tc != 0 && (qd >> 1) > 0) ? i16 : 16);
+            const int first = row_min_i32(head_sig(tc, htc) ? i16 : 16);
             if (mine && i16 == 0) ist[4 + blk] = (uint16_t)first;
-            bool bad;
-            (void)head_alpha(tc, qd, i16 == 15, hkc, &bad);
-            const unsigned long long B = __ballot(mine && bad);
+            const unsigned long long B = __ballot(mine && head_bad(tc, i16 == 15, htc));
 #pragma unroll
             for (int rw = 0; rw < 4; ++rw) // (lane 4 + block of v_low: 1 = nothing to walk)
                 if (lane == 4 + 4 * ps + rw) v_low = (WRENC_HEAD_EXIT && ((B >> (16 * rw)) & 0xFFFFULL) == 0ULL) ? 1 : 0;
@@ -1336,12 +1351,11 @@ __device__ __forceinline__ void quantize_pk(Ctx c, int nc, int* overflow, long l
             const int tc = SH.r1[nL + b * PC + scanc[lane]];
             nzl |= tc;
             tcs[nL + b * PC + lane] = (int16_t)tc;
-            const int qd = quotient(k, tc, shc, offc);
-            const unsigned long long sig = __ballot(tc != 0 && (qd >> 1) > 0);
+            const unsigned long long sig = __ballot(head_sig(tc, htc));
             const int first = sig != 0ULL ? (int)__builtin_ctzll(sig) : PC;
             int arun = kAlphaInf, sb = SBC - 1;
             bool open = true;
-            head_batch(tc, qd, lane, PC, true, hkc, open, arun, sb);
+            head_batch(tc, lane, PC, true, hkc, htc, open, arun, sb);
             sb = head_sb(open, sb, SBC);
             if (sb > 0 && sb < SBC) arun = wave_min_i32(arun);
             if (lane == 0) ist[4 + b] = (uint16_t)first;

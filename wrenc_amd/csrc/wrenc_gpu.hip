@@ -327,6 +327,31 @@ __global__ __launch_bounds__(64) void test_quantize_kernel(const DevConst* __res
     }
 }
 
+// DevConst::head_rng against the functions it stands for, over every 16-bit coefficient (grid: 1024 blocks of 64 lanes;
+// block size and DC flag in blockIdx.y): out[0] += coefficients the range lets into the region that head_alpha ends it
+// at (never allowed), out[1] += coefficients the range ends the region at that head_alpha would let in (allowed, not
+// expected), out[2] += coefficients whose "quotient >= 2" differs from the range's, out[3] += alpha differences
+__global__ __launch_bounds__(64) void test_head_ranges_kernel(const DevConst* __restrict__ kk, int* out) {
+    Ctx c = {};
+    c.k = (const CONST_AS DevConst*)kk;
+    load_tables(c);
+    const CONST_AS DevConst* k = c.k;
+    const int lg = 2 + (int)(blockIdx.y >> 1);
+    const bool dcn = blockIdx.y & 1;
+    const int tc = (int)(blockIdx.x * 64 + threadIdx.x) - 32768;
+    const int sh = lg + 4, off = (1 << sh) >> 1;
+    const HeadK hk = head_consts(sh, off, k->lsc);
+    const HeadT ht = head_ranges(k, lg);
+    const int qd = quotient(k, tc, sh, off);
+    bool bad;
+    const int alpha = head_alpha(tc, qd, dcn, hk, &bad);
+    const bool rbad = head_bad(tc, dcn, ht);
+    if (bad && !rbad) atomicAdd(out + 0, 1);
+    if (!bad && rbad) atomicAdd(out + 1, 1);
+    if ((qd >= 2) != head_sig(tc, ht)) atomicAdd(out + 2, 1);
+    if (alpha != head_alpha1(tc, hk)) atomicAdd(out + 3, 1);
+}
+
 // quantize_p16 (the packed 4x4 leaf search's quantiser): each wave takes up to four consecutive 4x4 blocks
 __global__ __launch_bounds__(64) void test_quantize_p16_kernel(const DevConst* __restrict__ k, const int16_t* in, int count,
                                                                int16_t* out, long long* cost, int* overflow) {
@@ -627,6 +652,54 @@ size_t plane_bytes(const wrenc_gpu_config& c, int comp, size_t elem) {
     return w * h * elem;
 }
 
+// DevConst::head_rng: the coefficients that do not end the head proof's region, and those with a quotient below 2, as one
+// interval around zero each (dev_quant.h: head_alpha, quotient -- the same integer arithmetic here on the host, over
+// every 16-bit coefficient; test_head_ranges_kernel holds the result against the device functions).  An interval that
+// stops at the first coefficient that fails can only be too narrow, which costs a longer walk, never a wrong level.
+void fill_head_ranges(DevConst& k) {
+    const int ldq1 = (int32_t)k.ldq[1], ldq2 = (int32_t)k.ldq[2], ldq3 = (int32_t)k.ldq[3]; // (the 32-bit table of the kernels' LDS)
+    for (int idx = 0; idx < 4; ++idx) {
+        const int sh = idx + 2 + 4, off = (1 << sh) >> 1, lsc = k.lsc;
+        const int dp[4] = {0, (lsc + off) >> sh, (2 * lsc + off) >> sh, (3 * lsc + off) >> sh};
+        const int dn[4] = {0, (-lsc + off) >> sh, (-2 * lsc + off) >> sh, (-3 * lsc + off) >> sh};
+        const auto quot = [&](int tc) {
+            int S = (int)((unsigned)tc << sh) - off;
+            if (tc < 0) S = -S;
+            return tc == 0 ? 0 : (int)((uint32_t)(((uint64_t)(uint32_t)S * k.div_magic) >> 32) >> k.div_shift);
+        };
+        const auto bad = [&](int tc, bool dcn) {
+            const int qd = quot(tc);
+            const bool neg = tc < 0;
+            const int d1 = abs(tc - (neg ? dn[1] : dp[1])), d2 = abs(tc - (neg ? dn[2] : dp[2])), d3 = abs(tc - (neg ? dn[3] : dp[3]));
+            const int d1o = abs(tc - (neg ? dp[1] : dn[1]));
+            const int c0tz = 128 * abs(tc);
+            const int c0d0 = c0tz + ldq1;
+            const int c1d0 = 128 * d2 + ldq2;
+            const int c0d1 = dcn ? 128 * d1o + ldq1 : (qd ? 128 * d1 + ldq2 : c0d0);
+            const int c1d1 = (qd && !dcn) ? 128 * d3 + ldq3 : 128 * d1 + ldq2;
+            int alpha = c1d0 - c0tz;
+            int beta = std::min(std::min(c0d0, c0d1), c1d1) - c0tz;
+            if (tc == 0) {
+                alpha = 1 << 28;
+                beta = ldq1;
+            }
+            return qd >= 2 || alpha < 0 || beta < 0 || ldq1 < 0;
+        };
+        const auto interval = [&](int32_t* r, auto&& fails) { // r[0] = -lowest, r[1] = how many: the run of passing coefficients around 0
+            r[0] = r[1] = 0;
+            if (fails(0)) return;
+            int tp = 0, tn = 0;
+            while (tp < 32767 && !fails(tp + 1)) ++tp;
+            while (tn < 32768 && !fails(-(tn + 1))) ++tn;
+            r[0] = tn;
+            r[1] = tp + tn + 1;
+        };
+        interval(&k.head_rng[idx][0], [&](int tc) { return bad(tc, false); });
+        interval(&k.head_rng[idx][2], [&](int tc) { return bad(tc, true); });
+        interval(&k.head_rng[idx][4], [&](int tc) { return quot(tc) >= 2; });
+    }
+}
+
 void fill_dev_const(const wrenc_gpu_config& cfg, DevConst& k) {
     memset(&k, 0, sizeof(k));
     k.W = cfg.width;
@@ -705,6 +778,7 @@ void fill_dev_const(const wrenc_gpu_config& cfg, DevConst& k) {
             for (int j = 0; j < 16; ++j) k.idct32_p[x][h][j] = (int8_t)dct64((8 * (j / 4) + 4 * h + j % 4) * 2, x);
     for (int h = 0; h < 2; ++h)
         for (int w = 0; w < 16; ++w) k.idct32_k2[h][w] = 128 * colsum[8 * (w / 4) + 4 * h + w % 4] + 2048;
+    fill_head_ranges(k);
 }
 
 } // namespace
@@ -1471,6 +1545,29 @@ int wrenc_gpu_device_info(const wrenc_gpu_ctx* ctx, long long* wave_slots, int* 
 int wrenc_gpu_test_set_wave_slots(wrenc_gpu_ctx* ctx, long long slots) {
     if (!ctx) return WRENC_GPU_EINVAL;
     ctx->wave_slots = slots > 0 ? slots : ctx->device_wave_slots;
+    return WRENC_GPU_OK;
+}
+
+int wrenc_gpu_test_head_ranges(wrenc_gpu_ctx* ctx, int counts[4], int ranges[24]) {
+    if (!ctx || !counts) return WRENC_GPU_EINVAL;
+    HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
+    int* d = nullptr;
+    HIP_TRY(ctx, hipMalloc((void**)&d, 4 * sizeof(int)));
+    hipError_t e = hipMemset(d, 0, 4 * sizeof(int));
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(test_head_ranges_kernel, dim3(1024, 8), dim3(64), 0, 0, ctx->d_const, d);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e == hipSuccess) e = hipMemcpy(counts, d, 4 * sizeof(int), hipMemcpyDeviceToHost);
+    (void)hipFree(d);
+    HIP_TRY(ctx, e);
+    if (ranges) {
+        DevConst* hk = new DevConst;
+        fill_dev_const(ctx->cfg, *hk);
+        memcpy(ranges, hk->head_rng, sizeof(hk->head_rng));
+        delete hk;
+    }
     return WRENC_GPU_OK;
 }
 
