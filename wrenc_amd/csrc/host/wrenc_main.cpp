@@ -424,7 +424,7 @@ int main(int argc, char** argv) {
     HostSet* pending = nullptr;
     // --verbose: where the main thread spends the run (waiting for slices, for the search + read-back, reading + uploading)
     double t_flush = 0, t_readback = 0, t_submit = 0;
-    bool host_bound = false;
+    bool host_bound = true; // (--tokens auto starts with tokens: nothing is known yet, and they are never much worse)
     int n_token_batches = 0;
     auto t_turn = std::chrono::steady_clock::now();
     const auto now = [] { return std::chrono::steady_clock::now(); };
@@ -437,10 +437,12 @@ int main(int argc, char** argv) {
         // slices (other buffers): the residual tokens the device made of it, or -- when they do not fit, or with
         // --no-tokens -- the compact level record (mask of coded 4x4 blocks + those blocks); either way with the maps.
         bool tokens_done = false;
-        // --tokens auto: the token record is many times the compact one (7 MB against 0.3 MB per textured 1080p picture at
-        // QP 32), so it pays exactly when the host threads could not keep up with the search otherwise.  Decided per batch
-        // from the last one's worker time: tokens when writing it from the compact record takes (or, from tokens at 1 / 1.8
-        // of the time, would take) more than 0.8 of the threads for the whole turn of a batch
+        // --tokens auto: the token pass costs device time and bus bytes in proportion to the tokens (textured 1080p at QP 32:
+        // 7 MB per picture and a fifth of the search's time; smooth content: next to nothing), so the compact level record
+        // is the better read-back exactly when there are many tokens AND the host threads have time to spare.  Decided per
+        // batch from the last one written: compact when its tokens exceed 2 bytes per luma sample and writing it from the
+        // compact record takes (or, from tokens at 1 / 1.8 of the time, would take) less than 0.6 of the threads for the
+        // whole turn of a batch; back to tokens above 0.8
         const bool want_tokens = use_tokens && (tokens_mode == 1 || host_bound);
         if (want_tokens) {
             for (int k = 0; k < s.count; ++k) {
@@ -471,14 +473,20 @@ int main(int argc, char** argv) {
             gpu_check(s, wrenc_gpu_download_compact(s.ctx, s.base, s.count, s.cps.data()));
         }
         t_readback += since(tp);
+        if (verbose) fprintf(stderr, "  %.3f s: batch at picture %d read back (%s)", since(t_start), s.first_poc, tokens_done ? "tokens" : "compact");
         tp = now();
         if (pending) flush(*pending); // the previous batch's slices, in picture order, to the output
+        if (verbose) fprintf(stderr, ", %.3f s: previous batch's slices out", since(t_start));
         {
             const double waited = since(tp), turn = since(t_turn);
             t_flush += waited;
             if (pending && pending->bs_count > 0 && turn > 0) {
                 const double busy = (double)pending->busy_ns.load() * 1e-9 * (pending->bs_tokens ? 1.8 : 1.0); // as if from the compact record
-                host_bound = busy > 0.8 * n_threads * turn;
+                const bool many_tokens = !pending->bs_tokens || (double)pending->tok_used * 4.0 > 2.0 * (double)ysz * pending->bs_count;
+                if (host_bound)
+                    host_bound = !(many_tokens && busy < 0.6 * n_threads * turn);
+                else
+                    host_bound = busy > 0.8 * n_threads * turn;
             }
             n_token_batches += tokens_done ? 1 : 0;
             t_turn = now();
@@ -497,6 +505,7 @@ int main(int argc, char** argv) {
             submit(s);
         }
         t_submit += since(tp);
+        if (verbose) fprintf(stderr, ", %.3f s: next batch submitted\n", since(t_start));
     }
     {
         const auto tp = now();
