@@ -220,7 +220,7 @@ def measure(grp, rank, world, local_rank, wl, steps, warmup, with_cpu):
                "pictures_per_step_per_gpu": B, "final_pass_mismatches": mism,
                "roofline": kernel_roofline(ks, dt, ctus, wl["name"], lanes=enc.device_info()[1]),
                "host_bitstream": {"ms_per_picture_one_core": best * 1e3, "bytes_per_picture": len(nal),
-                                  "ms_per_picture_one_core_from_device_tokens": best_tok * 1e3, "token_bytes_per_picture": int(pool0.size) * 4,
+                                  "ms_per_picture_one_core_from_device_tokens": best_tok * 1e3, "token_bytes_per_picture": enc.last_token_words * 4,
                                   "same_bytes_from_tokens": nal == nal_tok,
                                   "note": "host CABAC + syntax of one searched picture from its level planes, and from the residual "
                                           "tokens the device makes of it (the host then runs the CU-level syntax and the arithmetic "

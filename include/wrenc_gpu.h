@@ -169,8 +169,11 @@ void wrenc_gpu_expand_levels(int width, int height, const uint32_t* mask, const 
  * needs only the maps.  wrenc_bs_write_picture_tokens (wrenc_bitstream.h) writes the same bytes from this record as
  * wrenc_bs_write_picture writes from the level planes, with the residual syntax walk gone from the host.
  * wrenc_gpu_download_tokens reads back `n` slots in one call: pool_cap_words of room in `pool` for all of them together
- * (WRENC_GPU_ENOMEM with *pool_words_used = the need of what was produced so far if it does not suffice: fall back to
- * wrenc_gpu_download_compact), every picture's first_page table and maps, its reconstruction when asked for. */
+ * (WRENC_GPU_ENOMEM if it does not suffice: fall back to wrenc_gpu_download_compact), every picture's first_page table
+ * and maps, its reconstruction when asked for.  The pages in use are spread over the WHOLE pool (it is cut into up to 64
+ * sub-pools that fill side by side, each needing room for its share of the CTUs): page indices are valid up to
+ * pool_cap_words -- that is wrenc_bs_tokens::pool_words -- and *pool_words_used is the words of the pages in use, i.e.
+ * what crossed the bus (with WRENC_GPU_ENOMEM: of the pages asked for until the pass gave up). */
 #define WRENC_GPU_TOKEN_PAGE 64
 typedef struct wrenc_gpu_tokens {
     uint32_t* first_page;   /* (width / 32) * (height / 32) entries */

@@ -22,5 +22,5 @@ for rep in range(2):
     comp = enc.download_compact(0, B)
     dc = time.perf_counter() - t0
     print("%dx%d QP %d %s, %d pictures: tokens %.1f MB in %.3f s (%.2f ms per picture); compact record in %.3f s"
-          % (w, h, qp, "textured" if tex else "smooth", B, pool.size * 4 / 1e6, dt, dt * 1e3 / B, dc), flush=True)
+          % (w, h, qp, "textured" if tex else "smooth", B, enc.last_token_words * 4 / 1e6, dt, dt * 1e3 / B, dc), flush=True)
 enc.close()

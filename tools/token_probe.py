@@ -26,5 +26,5 @@ for _ in range(5):
     b = bs.write_picture_tokens(w, h, qp, 0, pool, pics[0])
     best_b = min(best_b, time.perf_counter() - t0)
 print("%dx%d depth %d QP %d %s: %d bytes; from the planes %.2f ms, from %d token words (%.1f MB, read back in %.1f ms) %.2f ms; same bytes: %s"
-      % (w, h, depth, qp, "textured" if tex else "smooth", len(a), best_a * 1e3, pool.size, pool.size * 4 / 1e6, t_dl * 1e3, best_b * 1e3, a == b))
+      % (w, h, depth, qp, "textured" if tex else "smooth", len(a), best_a * 1e3, enc.last_token_words, enc.last_token_words * 4 / 1e6, t_dl * 1e3, best_b * 1e3, a == b))
 enc.close()

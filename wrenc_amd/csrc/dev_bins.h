@@ -16,7 +16,9 @@
 //
 // Token storage: pages of kTokPage words, taken from a pool with an atomic counter as a CTU needs them; the last word of
 // a page links to the next one, a table holds every CTU's first page.  (A CTU of the bench content needs one page; a
-// CTU of noise at QP 22 about a hundred.)
+// CTU of noise at QP 22 about a hundred.)  The pool is kTokPools sub-pools with a counter (in a cache line of its own)
+// each, CTU g taking its pages from sub-pool g mod their number: with ONE counter the pass ran at the rate of atomics on
+// one address -- 11 ns per page, 83 ms for the 7.4 M pages of 256 textured 1080p pictures, whatever the code around them.
 //
 // Same bytes as the host-only writer: tests/test_gpu_tokens.py compares the two streams on searched pictures and on
 // random records no search would emit (escape codes, exhausted bin budgets, every block size).
@@ -28,11 +30,16 @@ constexpr int kTokPage = 64;               // words per page: kTokPage - 1 token
 constexpr int kTokPayload = kTokPage - 1;
 constexpr int kTokMaxPages = 160;          // pages one CTU can need: < (1.75 + 2) * 1536 + 96 * 24 tokens
 constexpr uint32_t kTokNone = 0xFFFFFFFFu;
+constexpr int kTokPools = 64;              // sub-pools at most (a power of two; a call with few CTUs uses fewer, see wrenc_gpu_download_tokens)
+constexpr int kTokCounterStride = 32;      // words from one sub-pool's counter to the next
 
 // first context of each syntax element of residual_coding in the host's flat model array (host/cabac.h CtxBase)
 constexpr int CTXD_LAST_X = 32, CTXD_LAST_Y = CTXD_LAST_X + 23, CTXD_SB_CODED = CTXD_LAST_Y + 23, CTXD_SIG = CTXD_SB_CODED + 7,
               CTXD_PAR = CTXD_SIG + 63, CTXD_GTX = CTXD_PAR + 33;
 
+#ifndef WRENC_TOKENS_4X4_ROWS
+#define WRENC_TOKENS_4X4_ROWS 1 // 0: every 4x4 block a step of its own (as first built; for A/B runs)
+#endif
 struct TokLds {
     int16_t lv[1024];                 // the transform block's levels, raster
     uint16_t tpl[34 * 34 + 2];        // AbsLevelPass1 | significant << 8, two zero columns / rows behind the block
@@ -45,8 +52,9 @@ __shared__ TokLds TOKW[4];
 
 struct TokOut {
     GLOBAL_AS uint32_t* pool;
-    unsigned* page_counter;
-    unsigned pool_pages;
+    unsigned* page_counter;   // of this CTU's sub-pool
+    unsigned pool_first;      // the sub-pool's first page
+    unsigned pool_pages;      // pages per sub-pool
     int n_tok;        // tokens of this CTU so far (virtual index of the next one)
     int n_pages;      // pages it holds
     int* overflow;
@@ -68,6 +76,7 @@ __device__ __forceinline__ void tok_reserve(TokOut& o, int count) {
             if (LANE == 0) atomicOr(o.overflow, 1);
             break;
         }
+        pg += o.pool_first;
         if (LANE == 0) {
             o.pool[(size_t)pg * kTokPage + kTokPayload] = kTokNone;
             if (o.n_pages > 0) o.pool[(size_t)TK.pt[o.n_pages - 1] * kTokPage + kTokPayload] = pg;
@@ -366,10 +375,152 @@ __device__ __forceinline__ uint32_t tb_tokens(const CONST_AS DevConst* k, TokOut
     return 0x80000000u | flags | (uint32_t)(o.n_tok - start);
 }
 
+// residual_coding of up to FOUR 4x4 transform blocks in one step: block r = lanes 16 r .. 16 r + 15, one lane per coefficient
+// (a 4x4 block is one sub-block, and tb_tokens above spends a whole 64-lane step on its 16 coefficients: the four luma
+// blocks of a split 8x8 CU and its chroma pair were six steps, an unsplit 8x8 CU's chroma pair two).  Same tokens in the
+// same order as tb_tokens block after block: everything that runs along the scan -- the dependent-quantisation state, the
+// bin budget (28 per block), the first coded position, the token offsets -- is a prefix INSIDE a row of 16 lanes here.
+// comp / lev / stride of block r: cs[r], l[r], st[r].  own_headers: every block's header word goes right in front of its
+// tokens (the four luma transform units of a split CU); otherwise the caller has made room for the headers and gets
+// them back in hdr[] (the chroma pair of one transform unit).
+__device__ __forceinline__ void tb4_tokens(const CONST_AS DevConst* k, TokOut& o, int ntu, const int cs[4], const GLOBAL_AS int16_t* const l[4],
+                                           const int st[4], bool own_headers, uint32_t hdr[4]) {
+    const int lane = lane_fresh();
+    const int row = lane >> 4, i16 = lane & 15;
+    const bool mine = row < ntu;
+    const CONST_AS uint16_t* scan = k->scan_idx[0];
+    const int r = scan[i16];
+    const int xc = r & 3, yc = r >> 2;
+    const int c = row == 0 ? cs[0] : (row == 1 ? cs[1] : (row == 2 ? cs[2] : cs[3]));
+    const GLOBAL_AS int16_t* lp = row == 0 ? l[0] : (row == 1 ? l[1] : (row == 2 ? l[2] : l[3]));
+    const int stride = row == 0 ? st[0] : (row == 1 ? st[1] : (row == 2 ? st[2] : st[3]));
+    const int lvl = mine ? (int)lp[(size_t)yc * stride + xc] : 0;
+    hdr[0] = hdr[1] = hdr[2] = hdr[3] = 0u;
+    const unsigned long long nzb = __ballot(lvl != 0);
+    if (nzb == 0ULL && !own_headers) return;
+    // neighbourhood arrays: block r at 40 r, 6 entries a row (two zero columns / rows behind the block)
+    for (int i = lane; i < 80; i += 64) ((uint32_t*)TK.tpl)[i] = 0u;
+    if (lane < 40) ((uint32_t*)TK.ab)[lane] = 0u;
+    WSYNC();
+    const unsigned rowm = (unsigned)((nzb >> (lane & 48)) & 0xFFFFULL);
+    const bool has = rowm != 0u;                       // the block has a level
+    const int p_last = has ? (int)__builtin_ctz(rowm) : 16;
+    const bool valid = mine && i16 >= p_last;
+    const int v = valid ? lvl : 0;
+    const int av = abs(v);
+    // last_sig_coeff_{x,y}_prefix of the block (log2 size 2: no suffixes, one context per bin)
+    const int rl = scan[has ? p_last : 0];
+    const int px = rl & 3, py = rl >> 2;
+    const int nx = px + (px < 3 ? 1 : 0), ny = py + (py < 3 ? 1 : 0);
+    const int last_n = nx + ny;
+    const int loff = c == 0 ? 0 : 20;
+    // dependent-quantisation state in front of every coefficient: prefix composition inside the row, from state 0
+    int pre = valid ? position_map(v, av, false, 0) : kMapId;
+    pre = compose_map(pre, __builtin_amdgcn_update_dpp(kMapId, pre, 0x111, 0xF, 0xF, false)); // row_shr:1
+    pre = compose_map(pre, __builtin_amdgcn_update_dpp(kMapId, pre, 0x112, 0xF, 0xF, false)); // row_shr:2
+    pre = compose_map(pre, __builtin_amdgcn_update_dpp(kMapId, pre, 0x114, 0xF, 0xF, false)); // row_shr:4
+    pre = compose_map(pre, __builtin_amdgcn_update_dpp(kMapId, pre, 0x118, 0xF, 0xF, false)); // row_shr:8
+    const int before = __builtin_amdgcn_update_dpp(kMapId, pre, 0x111, 0xF, 0xF, false);      // row_shr:1 (lane 0 of a row: identity)
+    const int q_in = before & 3;
+    const int a = v ? (av + (q_in > 1 ? 1 : 0)) >> 1 : 0;   // AbsLevel (:1968-1985)
+    const bool sig = a > 0, gt1 = a > 1, gt3 = a > 3;
+    const bool is_last = i16 == p_last;
+    const bool act = valid;
+    const bool sigcoded = act && !is_last;
+    const int nb1 = act ? (sigcoded ? 1 : 0) + (sig ? (gt1 ? 3 : 1) : 0) : 0;
+    int used;
+    const int ex = row_excl_sum(nb1, &used);
+    const bool covered = act && 28 - ex >= 4;               // pass 1 reaches the coefficient (:2014-2016)
+    const int p1 = covered && sig ? (gt1 ? 2 + (a & 1) + (gt3 ? 2 : 0) : 1) : 0;
+    const int cell = 40 * row + 6 * yc + xc;
+    if (act) {
+        TK.tpl[cell] = (uint16_t)(p1 ? (256 | p1) : 0);
+        TK.ab[cell] = (uint8_t)min(a, 255);
+    }
+    WSYNC();
+    int c1 = 0, c2 = 0;
+    uint32_t t1[4] = {0, 0, 0, 0}, t2[2] = {0, 0};
+    if (act) {
+        const uint16_t* tp = &TK.tpl[cell];
+        const uint8_t* ap = &TK.ab[cell];
+        const int tsum = tp[1] + tp[2] + tp[6] + tp[7] + tp[12];
+        const int asum = ap[1] + ap[2] + ap[6] + ap[7] + ap[12];
+        const int d = xc + yc;
+        if (covered) {
+            const int sum_p1 = tsum & 255, num_sig = tsum >> 8;
+            if (sigcoded) {
+                const int s_ = (sum_p1 + 1) >> 1;
+                const int qs = q_in > 1 ? q_in - 1 : 0;
+                const int inc = c == 0 ? 12 * qs + min(s_, 3) + (d < 2 ? 8 : (d < 5 ? 4 : 0)) : 36 + 8 * qs + min(s_, 3) + (d < 2 ? 4 : 0);
+                t1[c1++] = tok_ctx(CTXD_SIG + inc, sig);
+            }
+            if (sig) {
+                const int off = min(sum_p1 - num_sig, 4);
+                int inc;
+                if (is_last)
+                    inc = c == 0 ? 0 : 21;
+                else if (c == 0)
+                    inc = 1 + off + (d == 0 ? 15 : (d < 3 ? 10 : (d < 10 ? 5 : 0)));
+                else
+                    inc = 22 + off + (d == 0 ? 5 : 0);
+                t1[c1++] = tok_ctx(CTXD_GTX + inc, gt1);
+                if (gt1) {
+                    t1[c1++] = tok_ctx(CTXD_PAR + inc, a & 1);
+                    t1[c1++] = tok_ctx(CTXD_GTX + 32 + inc, gt3);
+                }
+            }
+            if (gt3) c2 = remainder_tokens((a - 4) >> 1, rice_of(asum - 20), &t2[0], &t2[1]);   // abs_remainder (pass 2)
+        } else {
+            const int kr = rice_of(asum);                                                        // dec_abs_level (pass 3)
+            const int zero_pos = (q_in < 2 ? 1 : 2) << kr;
+            c2 = remainder_tokens(a == 0 ? zero_pos : (a <= zero_pos ? a - 1 : a), kr, &t2[0], &t2[1]);
+        }
+    }
+    // signs of the block in coding order, first one in the most significant bit
+    const unsigned long long nzm = __ballot(act && v != 0);
+    const unsigned srow = (unsigned)((nzm >> (lane & 48)) & 0xFFFFULL);
+    const int n_signs = __popc(srow);
+    const int my_bit = __popc(srow >> (i16 + 1));
+    const int sign_val = row_sum_i32((act && v < 0) ? (1 << my_bit) : 0);
+    // where everything goes: per block [header, if its own] [last position] [pass-1 bins] [remainders] [signs]
+    int C1, C2;
+    const int e1 = row_excl_sum(c1, &C1), e2 = row_excl_sum(c2, &C2);
+    const int n_tok = has ? last_n + C1 + C2 + (n_signs ? 1 : 0) : 0;
+    const int hd = own_headers ? 1 : 0;
+    const int row_size = mine ? hd + n_tok : 0;
+    const int s0 = __builtin_amdgcn_readlane(row_size, 0), s1 = __builtin_amdgcn_readlane(row_size, 16),
+              s2 = __builtin_amdgcn_readlane(row_size, 32), s3 = __builtin_amdgcn_readlane(row_size, 48);
+    const int row_base = row == 0 ? 0 : (row == 1 ? s0 : (row == 2 ? s0 + s1 : s0 + s1 + s2));
+    const int total = s0 + s1 + s2 + s3;
+    tok_reserve(o, total);
+    const uint32_t h = has ? (0x80000000u | ((c == 0 && p_last != 15) ? 1u << 30 : 0u) | (uint32_t)n_tok) : 0u; // (bit 30: MtsDcOnly = 0, :1945-1947)
+    const int base = o.n_tok + row_base + hd;
+    if (own_headers && mine && i16 == 0) tok_put(o, base - 1, h);
+    if (has) {
+        if (i16 < nx)
+            tok_put(o, base + i16, tok_ctx(CTXD_LAST_X + i16 + loff, i16 < px));
+        else if (i16 < last_n)
+            tok_put(o, base + i16, tok_ctx(CTXD_LAST_Y + (i16 - nx) + loff, (i16 - nx) < py));
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (j < c1) tok_put(o, base + last_n + e1 + j, t1[j]);
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+            if (j < c2) tok_put(o, base + last_n + C1 + e2 + j, t2[j]);
+        if (n_signs && i16 == 15) tok_put(o, base + last_n + C1 + C2, tok_bypass((uint32_t)sign_val, n_signs));
+    }
+    o.n_tok += total;
+    hdr[0] = (uint32_t)__builtin_amdgcn_readlane((int)h, 0);
+    hdr[1] = (uint32_t)__builtin_amdgcn_readlane((int)h, 16);
+    hdr[2] = (uint32_t)__builtin_amdgcn_readlane((int)h, 32);
+    hdr[3] = (uint32_t)__builtin_amdgcn_readlane((int)h, 48);
+    WSYNC();
+}
+
 // One wavefront per CTU: its transform units in coding order (coding_tree, ctu_encoder.rs:227-438), per unit the header
 // words of its components, then their tokens.
 __global__ __launch_bounds__(256) void residual_tokens_kernel(const DevConst* __restrict__ kc, const PicBufs* __restrict__ slots,
-                                                              int first_slot, int n_pictures, uint32_t* pool, unsigned pool_pages,
+                                                              int first_slot, int n_pictures, uint32_t* pool, unsigned pool_pages, int pool_mask,
                                                               unsigned* page_counter, uint32_t* first_page, int* overflow) {
     const CONST_AS DevConst* k = (const CONST_AS DevConst*)kc;
     const int ctus = k->ctu_cols * k->ctu_rows;
@@ -381,7 +532,8 @@ __global__ __launch_bounds__(256) void residual_tokens_kernel(const DevConst* __
     const int W = k->W, Wc = W >> 1;
     TokOut o;
     o.pool = (GLOBAL_AS uint32_t*)pool;
-    o.page_counter = page_counter;
+    o.page_counter = page_counter + (g & pool_mask) * kTokCounterStride;
+    o.pool_first = (unsigned)(g & pool_mask) * pool_pages;
     o.pool_pages = pool_pages;
     o.n_tok = 0;
     o.n_pages = 0;
@@ -402,8 +554,18 @@ __global__ __launch_bounds__(256) void residual_tokens_kernel(const DevConst* __
             const int h = o.n_tok;
             o.n_tok += 3;
             const uint32_t hy = tb_tokens(k, o, 0, lg, ly + (size_t)y0 * W + x0, W);
-            const uint32_t hb = tb_tokens(k, o, 1, lg - 1, lcb + (size_t)(y0 >> 1) * Wc + (x0 >> 1), Wc);
-            const uint32_t hr = tb_tokens(k, o, 2, lg - 1, lcr + (size_t)(y0 >> 1) * Wc + (x0 >> 1), Wc);
+            uint32_t hb, hr;
+            if (WRENC_TOKENS_4X4_ROWS && lg == 3) { // the 4x4 chroma pair in one step
+                const int cs[4] = {1, 2, 0, 0}, st[4] = {Wc, Wc, 0, 0};
+                const GLOBAL_AS int16_t* const l[4] = {lcb + (size_t)(y0 >> 1) * Wc + (x0 >> 1), lcr + (size_t)(y0 >> 1) * Wc + (x0 >> 1), nullptr, nullptr};
+                uint32_t hd4[4];
+                tb4_tokens(k, o, 2, cs, l, st, false, hd4);
+                hb = hd4[0];
+                hr = hd4[1];
+            } else {
+                hb = tb_tokens(k, o, 1, lg - 1, lcb + (size_t)(y0 >> 1) * Wc + (x0 >> 1), Wc);
+                hr = tb_tokens(k, o, 2, lg - 1, lcr + (size_t)(y0 >> 1) * Wc + (x0 >> 1), Wc);
+            }
             if (LANE == 0) {
                 tok_put(o, h, hy);
                 tok_put(o, h + 1, hb);
@@ -412,6 +574,27 @@ __global__ __launch_bounds__(256) void residual_tokens_kernel(const DevConst* __
             z += 1 << (2 * (lg - 2));
         } else {
             // an 8x8 CU split into four 4x4 luma CUs (one transform unit each), then the chroma CU of the 8x8
+            if (WRENC_TOKENS_4X4_ROWS) {
+                uint32_t hd4[4];
+                {
+                    const int cs[4] = {0, 0, 0, 0}, st[4] = {W, W, W, W};
+                    const GLOBAL_AS int16_t* b = ly + (size_t)y0 * W + x0;
+                    const GLOBAL_AS int16_t* const l[4] = {b, b + 4, b + (size_t)4 * W, b + (size_t)4 * W + 4};
+                    tb4_tokens(k, o, 4, cs, l, st, true, hd4);
+                }
+                tok_reserve(o, 2);
+                const int h = o.n_tok;
+                o.n_tok += 2;
+                const int cs[4] = {1, 2, 0, 0}, st[4] = {Wc, Wc, 0, 0};
+                const GLOBAL_AS int16_t* const l[4] = {lcb + (size_t)(y0 >> 1) * Wc + (x0 >> 1), lcr + (size_t)(y0 >> 1) * Wc + (x0 >> 1), nullptr, nullptr};
+                tb4_tokens(k, o, 2, cs, l, st, false, hd4);
+                if (LANE == 0) {
+                    tok_put(o, h, hd4[0]);
+                    tok_put(o, h + 1, hd4[1]);
+                }
+                z += 4;
+                continue;
+            }
             for (int i = 0; i < 4; ++i) {
                 tok_reserve(o, 1);
                 const int h = o.n_tok;

@@ -306,11 +306,17 @@ int main(int argc, char** argv) {
     // run that nothing overlaps.  A pipe is read in order by this thread.
     const bool seekable = fin != stdin && lseek(fileno(fin), 0, SEEK_CUR) != (off_t)-1;
     const int n_readers = seekable ? (n_threads < 8 ? n_threads : 8) : 1;
+    bool tail_heavy = false; // writing a batch's slices keeps the threads busy for more than 0.4 of the batch's turn
     const auto submit = [&](HostSet& s) {
         s.count = 0;
         s.first_poc = (int)poc;
-        int want = 0;
-        while (want < batch && poc + want < num_pictures) ++want;
+        // The last batch's read-back and entropy coding overlap with nothing.  Where that is a good part of a batch's turn
+        // (tail_heavy: textured content), the run ends on smaller batches -- a half, a quarter, a quarter of --batch, each a
+        // little slower to search -- so that what is left at the end is a quarter's work.
+        const long left = num_pictures - poc;
+        int want = (int)(left < batch ? left : batch);
+        if (per_dev == 2 && tail_heavy && left <= batch && left > batch / 4) want = (int)(left / 2 > batch / 4 ? left / 2 : batch / 4);
+        if (want < 1 && left > 0) want = 1;
         if (seekable && want > 0) { // (always pread then: the FILE's own position is never used)
             // readers fill the pictures (striped), this thread uploads each one as soon as it is there
             std::vector<std::atomic<int>> ready((size_t)want);
@@ -372,7 +378,7 @@ int main(int argc, char** argv) {
             const uint8_t* m = s.maps + maps * k;
             if (s.bs_tokens) {
                 // the device made the residual tokens: CU-level syntax + arithmetic coder here
-                const wrenc_bs_tokens tk = {m, m + n4, m + 2 * n4, s.tok_pool, s.tok_used, s.tok_first + n_ctus * k};
+                const wrenc_bs_tokens tk = {m, m + n4, m + 2 * n4, s.tok_pool, s.tok_cap, s.tok_first + n_ctus * k};
                 std::vector<uint8_t>& out = s.nal[(size_t)k];
                 if (out.size() < first_guess) out.resize(first_guess);
                 size_t n = 0;
@@ -482,6 +488,7 @@ int main(int argc, char** argv) {
             t_flush += waited;
             if (pending && pending->bs_count > 0 && turn > 0) {
                 const double busy = (double)pending->busy_ns.load() * 1e-9 * (pending->bs_tokens ? 1.8 : 1.0); // as if from the compact record
+                tail_heavy = (double)pending->busy_ns.load() * 1e-9 > 0.4 * n_threads * turn;
                 const bool many_tokens = !pending->bs_tokens || (double)pending->tok_used * 4.0 > 2.0 * (double)ysz * pending->bs_count;
                 if (host_bound)
                     host_bound = !(many_tokens && busy < 0.6 * n_threads * turn);

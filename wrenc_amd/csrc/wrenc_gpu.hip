@@ -1362,7 +1362,8 @@ int wrenc_gpu_download_tokens(wrenc_gpu_ctx* ctx, int first_slot, int n, wrenc_g
         HIP_TRY(ctx, hipMalloc((void**)&ctx->d_tok_pool, pages * kTokPage * sizeof(uint32_t)));
         ctx->tok_pool_words = pages * kTokPage;
     }
-    if (!ctx->d_tok_counter) HIP_TRY(ctx, hipMalloc((void**)&ctx->d_tok_counter, 2 * sizeof(unsigned)));
+    constexpr int kCounterWords = kTokPools * kTokCounterStride + 1; // the sub-pools' page counters, the "a sub-pool ran out" flag
+    if (!ctx->d_tok_counter) HIP_TRY(ctx, hipMalloc((void**)&ctx->d_tok_counter, kCounterWords * sizeof(unsigned)));
     if (ctx->tok_first_cap < n) {
         if (ctx->d_tok_first) (void)hipFree(ctx->d_tok_first);
         ctx->d_tok_first = nullptr;
@@ -1377,21 +1378,34 @@ int wrenc_gpu_download_tokens(wrenc_gpu_ctx* ctx, int first_slot, int n, wrenc_g
             last = ctx->slot_event[s];
             HIP_TRY(ctx, hipStreamWaitEvent(cs, last, 0));
         }
-    HIP_TRY(ctx, hipMemsetAsync(ctx->d_tok_counter, 0, 2 * sizeof(unsigned), cs));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->d_tok_counter, 0, kCounterWords * sizeof(unsigned), cs));
     const int waves = n * ctus;
+    // sub-pools: enough CTUs in each (16 or more) that they fill evenly; one for a handful of CTUs
+    int n_pools = 1;
+    while (n_pools < kTokPools && n_pools * 32 <= waves) n_pools *= 2;
+    const size_t sub = pages / (size_t)n_pools; // pages per sub-pool
     hipLaunchKernelGGL(residual_tokens_kernel, dim3((waves + 3) / 4), dim3(256), 0, cs, ctx->d_const, ctx->d_slots, first_slot, n,
-                       ctx->d_tok_pool, (unsigned)pages, ctx->d_tok_counter, ctx->d_tok_first, (int*)(ctx->d_tok_counter + 1));
+                       ctx->d_tok_pool, (unsigned)sub, n_pools - 1, ctx->d_tok_counter, ctx->d_tok_first, (int*)(ctx->d_tok_counter + kCounterWords - 1));
     HIP_TRY(ctx, hipGetLastError());
-    unsigned cnt[2] = {0, 0};
+    std::vector<unsigned> cnt((size_t)kCounterWords);
     int ovf = 0;
-    HIP_TRY(ctx, hipMemcpyAsync(cnt, ctx->d_tok_counter, sizeof(cnt), hipMemcpyDeviceToHost, cs));
+    HIP_TRY(ctx, hipMemcpyAsync(cnt.data(), ctx->d_tok_counter, kCounterWords * sizeof(unsigned), hipMemcpyDeviceToHost, cs));
     HIP_TRY(ctx, hipMemcpyAsync(&ovf, ctx->d_overflow, sizeof(int), hipMemcpyDeviceToHost, cs));
     HIP_TRY(ctx, hipStreamSynchronize(cs));
     if (ovf & 2) return fail(ctx, WRENC_GPU_EHIP, "internal: a team member never reached a meeting point of the level schedule");
     if (ovf) return fail(ctx, WRENC_GPU_ELEVEL, "a quantised level reached 1024 (reference panics: block_splitter.rs:453)");
-    *pool_words_used = (size_t)cnt[0] * kTokPage;
-    if (cnt[1] || cnt[0] > pages) return fail(ctx, WRENC_GPU_ENOMEM, "wrenc_gpu_download_tokens: the token pool is too small for these pictures");
-    HIP_TRY(ctx, hipMemcpyAsync(pool, ctx->d_tok_pool, (size_t)cnt[0] * kTokPage * sizeof(uint32_t), hipMemcpyDeviceToHost, cs));
+    size_t asked = 0;
+    bool short_of = cnt[(size_t)kCounterWords - 1] != 0;
+    for (int p = 0; p < n_pools; ++p) {
+        asked += cnt[(size_t)p * kTokCounterStride];
+        short_of = short_of || cnt[(size_t)p * kTokCounterStride] > sub;
+    }
+    *pool_words_used = asked * kTokPage;
+    if (short_of) return fail(ctx, WRENC_GPU_ENOMEM, "wrenc_gpu_download_tokens: the token pool is too small for these pictures");
+    for (int p = 0; p < n_pools; ++p) // every sub-pool's pages in use, to the same place in the caller's pool
+        if (cnt[(size_t)p * kTokCounterStride])
+            HIP_TRY(ctx, hipMemcpyAsync(pool + (size_t)p * sub * kTokPage, ctx->d_tok_pool + (size_t)p * sub * kTokPage,
+                                        (size_t)cnt[(size_t)p * kTokCounterStride] * kTokPage * sizeof(uint32_t), hipMemcpyDeviceToHost, cs));
     const size_t n4 = (size_t)(c.width / 4) * (c.height / 4), n8 = (size_t)(c.width / 8) * (c.height / 8);
     for (int k = 0; k < n; ++k) {
         wrenc_gpu_tokens& o = out[k];

@@ -239,7 +239,8 @@ class Encoder:
             pool = np.zeros(pool_words, np.uint32)
             rc = self.lib.wrenc_gpu_download_tokens(self.ctx, first_slot, n, outs, _p(pool), pool_words, C.byref(used))
         self._check(rc)
-        return pool[:used.value], pics
+        self.last_token_words = int(used.value)   # words of the pages in use (they are spread over the whole pool)
+        return pool, pics
 
     def device_info(self):
         """(wavefronts of the search kernel the device holds at once, HIP streams an encode call uses)."""
