@@ -430,7 +430,6 @@ int main(int argc, char** argv) {
     HostSet* pending = nullptr;
     // --verbose: where the main thread spends the run (waiting for slices, for the search + read-back, reading + uploading)
     double t_flush = 0, t_readback = 0, t_submit = 0;
-    bool host_bound = true; // (--tokens auto starts with tokens: nothing is known yet, and they are never much worse)
     int n_token_batches = 0;
     auto t_turn = std::chrono::steady_clock::now();
     const auto now = [] { return std::chrono::steady_clock::now(); };
@@ -443,13 +442,10 @@ int main(int argc, char** argv) {
         // slices (other buffers): the residual tokens the device made of it, or -- when they do not fit, or with
         // --no-tokens -- the compact level record (mask of coded 4x4 blocks + those blocks); either way with the maps.
         bool tokens_done = false;
-        // --tokens auto: the token pass costs device time and bus bytes in proportion to the tokens (textured 1080p at QP 32:
-        // 7 MB per picture and a fifth of the search's time; smooth content: next to nothing), so the compact level record
-        // is the better read-back exactly when there are many tokens AND the host threads have time to spare.  Decided per
-        // batch from the last one written: compact when its tokens exceed 2 bytes per luma sample and writing it from the
-        // compact record takes (or, from tokens at 1 / 1.8 of the time, would take) less than 0.6 of the threads for the
-        // whole turn of a batch; back to tokens above 0.8
-        const bool want_tokens = use_tokens && (tokens_mode == 1 || host_bound);
+        // --tokens auto = tokens: the pass costs the device about 2 % of the search's time and the host writes a picture 1.8 ..
+        // 2.1x faster from them; the compact level record is what a batch falls back to when its tokens do not fit the pool
+        // (and what --tokens off reads)
+        const bool want_tokens = use_tokens;
         if (want_tokens) {
             for (int k = 0; k < s.count; ++k) {
                 uint8_t* m = s.maps + maps * k;
@@ -486,15 +482,7 @@ int main(int argc, char** argv) {
         {
             const double waited = since(tp), turn = since(t_turn);
             t_flush += waited;
-            if (pending && pending->bs_count > 0 && turn > 0) {
-                const double busy = (double)pending->busy_ns.load() * 1e-9 * (pending->bs_tokens ? 1.8 : 1.0); // as if from the compact record
-                tail_heavy = (double)pending->busy_ns.load() * 1e-9 > 0.4 * n_threads * turn;
-                const bool many_tokens = !pending->bs_tokens || (double)pending->tok_used * 4.0 > 2.0 * (double)ysz * pending->bs_count;
-                if (host_bound)
-                    host_bound = !(many_tokens && busy < 0.6 * n_threads * turn);
-                else
-                    host_bound = busy > 0.8 * n_threads * turn;
-            }
+            if (pending && pending->bs_count > 0 && turn > 0) tail_heavy = (double)pending->busy_ns.load() * 1e-9 > 0.4 * n_threads * turn;
             n_token_batches += tokens_done ? 1 : 0;
             t_turn = now();
         }
