@@ -39,6 +39,8 @@ PASSES=(
  "WRITE_SIZE"
 )
 [ -n "$PROFILE_TRAFFIC_ONLY" ] && PASSES=("FETCH_SIZE" "WRITE_SIZE")
+[ -n "$PROFILE_INSTS_ONLY" ] && PASSES=("${PASSES[0]}")   # instruction counts only (experiment builds: what a stage issues)
+[ -n "$PROFILE_PMC" ] && IFS=';' read -r -a PASSES <<< "$PROFILE_PMC"   # passes of one's own: "A B C;D E"
 i=0; FAILED=0
 for PC in "${PASSES[@]}"; do
   run p$i --kernel-trace --pmc $PC || FAILED=1

@@ -666,6 +666,9 @@ __device__ __forceinline__ unsigned sad_list_cclm(const Ctx& c, int tx, int ty, 
     bool flat[3], avail_l = false;
     const CclmParams cp = cclm_params_all(c, tx, ty, tlg);
     if (all) *all = cp;
+#ifdef WRENC_EXP_SKIP_SAD
+    return (unsigned)LANE;
+#endif
 #pragma unroll
     for (int m = 0; m < 3; ++m) {
 #pragma unroll
@@ -717,9 +720,17 @@ constexpr int kNoMode = 255; // list entry that is not evaluated (cost f32::MAX)
 #ifndef WRENC_SAD4X4
 #define WRENC_SAD4X4 1 // 0: one sample per lane and iteration (rounds 1 .. 3a; kept for A/B runs)
 #endif
-__device__ __forceinline__ unsigned sad_list_angular(const Ctx& c, int comps, int tx, int ty, int tlg, int nmodes,
+#ifdef WRENC_EXP_NOINLINE_SAD // code-size experiment (profiles/r04_issue_model.md): one copy of the list, called
+#define WRENC_SAD_INLINE __attribute__((noinline))
+#else
+#define WRENC_SAD_INLINE __forceinline__
+#endif
+__device__ WRENC_SAD_INLINE unsigned sad_list_angular(const Ctx& c, int comps, int tx, int ty, int tlg, int nmodes,
                                                      unsigned long long modes_lo, unsigned long long modes_hi) {
     unsigned acc = 0;
+#ifdef WRENC_EXP_SKIP_SAD // instruction-count experiment only (profiles/r04_issue_model.md)
+    return (unsigned)LANE;
+#endif
     const int my_mode = LANE < nmodes ? (int)(((LANE < 8 ? modes_lo : modes_hi) >> (8 * (LANE & 7))) & 255u) : kNoMode;
     // [entry][blk][4n] projected references as bytes, each XOR 0x80 (= ref - 128 as a signed byte) so that
     // the interpolation filters run as one v_dot4_i32_i8 over four packed taps: sum(c * (ref - 128)) + 128 *

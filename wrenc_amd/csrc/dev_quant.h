@@ -553,6 +553,11 @@ __device__ __forceinline__ long long quantize_solo(Ctx c, int lg, int nb, int* o
     uint16_t* dec16 = (uint16_t*)SH.decw;    // decisions: [blk][sub-block][state] 16-bit masks
     PROF_MARK(q0_);
     *any_level = false;
+#ifdef WRENC_EXP_SKIP_QUANT // instruction-count experiment only (profiles/r04_issue_model.md): every level zero, nothing computed
+    for (int i = LANE; i < (nb * P) / 8; i += 64) *(uint4*)&SH.r1[8 * i] = make_uint4(0u, 0u, 0u, 0u);
+    WSYNC();
+    return 0;
+#endif
     const HeadK hk = head_consts(sh, off, lsc);
     const HeadT ht = head_ranges(k, lg);
     const int nsb = P >> 4;
@@ -1001,6 +1006,13 @@ __device__ __forceinline__ void quantize_p16(Ctx c, int nb, int* overflow, long 
     PROF_MARK(q0_);
     const int blk = lane >> 4, p = lane & 15;
     const bool mine = blk < nb;
+#ifdef WRENC_EXP_SKIP_QUANT
+    lvl[0] = lvl[1] = lvl[2] = lvl[3] = 0;
+    *any_mask = 0;
+    if (lane < 16 * nb) SH.r1[lane] = 0;
+    WSYNC();
+    return;
+#endif
     const HeadT ht = head_ranges(k, 2);
     const int tc = mine ? (int)SH.r1[blk * P + scan[p]] : 0;
     const int istar = row_min_i32(head_sig(tc, ht) ? p : P); // of this lane's block
@@ -1297,6 +1309,11 @@ __device__ __forceinline__ void quantize_pk(Ctx c, int nc, int* overflow, long l
     lvl_c[0] = lvl_c[1] = lvl_c[2] = 0;
     *any_y = false;
     *any_c = false;
+#ifdef WRENC_EXP_SKIP_QUANT
+    for (int i = lane; i < (nL + nch * PC) / 8; i += 64) *(uint4*)&SH.r1[8 * i] = make_uint4(0u, 0u, 0u, 0u);
+    WSYNC();
+    return;
+#endif
     // ---- coefficients into scan order, the first significant position of every chain, and how far down its head is
     //      provably zero (head_batch): lane i of v_low / v_amin = chain i (luma candidate i; 4 + b: chroma chain b) ----
     int nzl = 0;

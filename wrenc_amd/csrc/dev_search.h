@@ -293,87 +293,110 @@ __device__ __forceinline__ ListOut angular_list(const Ctx& c, const Req& q, int 
 #endif
 // The SAD part of a luma / single-tree leaf search: the 13 directional candidates, their first minimum and the two
 // step-search rounds around it (block_splitter.rs:899-973).  cm: the mode found, smin: its SAD.
+// ONE copy of the list code (sad_list_angular is a couple of thousand instructions, inlined): the rounds are iterations
+// of one loop that differ in the list they ask for and in what they do with its SADs.  (Until round 4 the three kinds of
+// round were three inlined copies at each of four call sites: a fifth of the kernel's code, in an instruction cache that
+// misses on 2.6 % of its fetches -- profiles/r04_issue_model.md.)
 __device__ __forceinline__ void sad_search(const Ctx& c, const Req& q, int& cm_out, unsigned& smin_out) {
-    // the 13 directional candidates {2,7,13,18,23,29,34,39,45,50,55,60,66}: SAD, first minimum (:899-904)
-    const ListOut l = angular_list(c, q, 13, 2ULL | (7ULL << 8) | (13ULL << 16) | (18ULL << 24) | (23ULL << 32) | (29ULL << 40) |
-                                                (34ULL << 48) | (39ULL << 56),
-                                   45ULL | (50ULL << 8) | (55ULL << 16) | (60ULL << 24) | (66ULL << 32));
-    const int j = l.imin + 2; // entry i = candidate i + 2 of the 15, 7 bits each
-    int cm = j < 8 ? (int)((0x3A5C90D0E08080ULL >> (7 * j)) & 127) : (int)((0x109E3764B53A2ULL >> (7 * (j - 8))) & 127);
-    unsigned cur = l.smin;
-    // step_search(mode, 2, cost, aux = true) (:905-973): rounds with step 2 and 1; keep the current mode on ties,
-    // then the lower probe (Q12).  The SADs are integers < 2^20, so comparing them as integers is comparing the
-    // reference's f32 values; a probe outside 2..66 is kNoSad = f32::MAX.
-    if (WRENC_STEP_ONE_LIST && q.tlg <= 3) {
-        // Small blocks (8x8 single-tree and 4x4 luma leaves): a list of two entries costs nearly what a list of six does
-        // (parameters, tables, reductions: two thirds of it), so BOTH rounds' probes come from ONE list -- round 1's
-        // cm -+ 2 and the four modes round 2 can ask for around cm - 2, cm or cm + 2: cm - 3, cm - 1, cm + 1, cm + 3.  A
-        // mode's SAD does not depend on the list it is in; the decisions below are the two rounds' in their order, an
-        // entry the reference would not evaluate (Q12) is kNoMode here as there, and only the probes the reference makes
-        // are traced.
-        constexpr unsigned kNoSad = 0xFFFFFFFFu;
-        const int e0 = !(cm < 4) ? cm - 2 : kNoMode, e1 = !(cm + 2 > 66) ? cm + 2 : kNoMode;
-        const int e2 = !(cm < 5) ? cm - 3 : kNoMode, e3 = !(cm < 3) ? cm - 1 : kNoMode;
-        const int e4 = !(cm + 1 > 66) ? cm + 1 : kNoMode, e5 = !(cm + 3 > 66) ? cm + 3 : kNoMode;
-        const unsigned long long lo6 = (unsigned long long)e0 | ((unsigned long long)e1 << 8) | ((unsigned long long)e2 << 16) |
-                                       ((unsigned long long)e3 << 24) | ((unsigned long long)e4 << 32) | ((unsigned long long)e5 << 40);
-        const unsigned acc = sad_list_angular(c, q.comps, q.tx, q.ty, q.tlg, 6, lo6, 0);
-        const unsigned s0 = (unsigned)__builtin_amdgcn_readlane((int)acc, 0), s1 = (unsigned)__builtin_amdgcn_readlane((int)acc, 1);
-        const unsigned s2 = (unsigned)__builtin_amdgcn_readlane((int)acc, 2), s3 = (unsigned)__builtin_amdgcn_readlane((int)acc, 3);
-        const unsigned s4 = (unsigned)__builtin_amdgcn_readlane((int)acc, 4), s5 = (unsigned)__builtin_amdgcn_readlane((int)acc, 5);
-        // round 1, step 2
-        const unsigned c0 = e0 != kNoMode ? s0 : kNoSad, c1 = e1 != kNoMode ? s1 : kNoSad;
-        const unsigned mn = min(min(cur, c0), c1);
-        int d = 0; // cm' - cm
-        if (cur == mn) {
-        } else if (c0 == mn) {
-            d = -2;
-            cur = c0;
-        } else {
-            d = 2;
-            cur = c1;
-        }
-        // round 2, step 1, around cm' = cm + d: its probes are entries 2 + (d + 2) / 2 and 3 + (d + 2) / 2
-        const int elo = d < 0 ? e2 : (d == 0 ? e3 : e4), ehi = d < 0 ? e3 : (d == 0 ? e4 : e5);
-        const unsigned slo = d < 0 ? s2 : (d == 0 ? s3 : s4), shi = d < 0 ? s3 : (d == 0 ? s4 : s5);
-        const unsigned p0 = elo != kNoMode ? slo : kNoSad, p1 = ehi != kNoMode ? shi : kNoSad;
-        int cm2 = cm + d;
-        const unsigned mn2 = min(min(cur, p0), p1);
-        if (cur == mn2) {
-        } else if (p0 == mn2) {
-            cm2 -= 1;
-            cur = p0;
-        } else {
-            cm2 += 1;
-            cur = p1;
-        }
-        if (c.trace) {
-            const int ilo = d < 0 ? 2 : (d == 0 ? 3 : 4);
-            const int my = LANE < 6 ? (int)((lo6 >> (8 * (LANE & 7))) & 255u) : kNoMode;
-            const bool used = LANE < 2 || LANE == ilo || LANE == ilo + 1;
-            if (my != kNoMode && used)
-                TRACE_REC(c.ctu_x + q.tx, c.ctu_y + q.ty, q.tlg, q.tree, (q.comps & 1) ? 0 : 2, (q.comps & 1) ? my : 0, my,
-                          __float_as_int((float)acc));
-        }
-        cm_out = cm2;
-        smin_out = cur;
-        return;
-    }
+    constexpr unsigned kNoSad = 0xFFFFFFFFu;
+    // Small blocks (8x8 single-tree and 4x4 luma leaves): a list of two entries costs nearly what a list of six does
+    // (parameters, tables, reductions: two thirds of it), so BOTH step-search rounds' probes come from ONE list -- round 1's
+    // cm -+ 2 and the four modes round 2 can ask for around cm - 2, cm or cm + 2: cm - 3, cm - 1, cm + 1, cm + 3.  A
+    // mode's SAD does not depend on the list it is in; the decisions below are the two rounds' in their order, an
+    // entry the reference would not evaluate (Q12) is kNoMode here as there, and only the probes the reference makes
+    // are traced.
+    const bool six = WRENC_STEP_ONE_LIST && q.tlg <= 3;
+    const int rounds = six ? 2 : 3;
+    int cm = 0;
+    unsigned cur = kNoSad;
 #pragma unroll 1
-    for (int st = 2; st > 0; st >>= 1) {
-        const int lo = !(cm < 2 + st) ? cm - st : kNoMode;
-        const int hi = !(cm + st > 66) ? cm + st : kNoMode;
-        const ListOut p = angular_list(c, q, 2, (unsigned long long)lo | ((unsigned long long)hi << 8), 0);
-        const unsigned c0 = p.s0, c1 = p.s1;
-        const unsigned mn = min(min(cur, c0), c1);
-        if (cur == mn) {
-        } else if (c0 == mn) {
-            cm -= st;
-            cur = c0;
+    for (int r = 0; r < rounds; ++r) {
+        // ---- the round's list ----
+        int n;
+        unsigned long long lo, hi = 0;
+        int e0 = kNoMode, e1 = kNoMode, e2 = kNoMode, e3 = kNoMode, e4 = kNoMode, e5 = kNoMode;
+        const int st = r == 1 ? 2 : 1; // (the step of a two-probe round)
+        if (r == 0) {
+            // the 13 directional candidates {2,7,13,18,23,29,34,39,45,50,55,60,66} (:899-904)
+            n = 13;
+            lo = 2ULL | (7ULL << 8) | (13ULL << 16) | (18ULL << 24) | (23ULL << 32) | (29ULL << 40) | (34ULL << 48) | (39ULL << 56);
+            hi = 45ULL | (50ULL << 8) | (55ULL << 16) | (60ULL << 24) | (66ULL << 32);
+        } else if (six) {
+            e0 = !(cm < 4) ? cm - 2 : kNoMode;
+            e1 = !(cm + 2 > 66) ? cm + 2 : kNoMode;
+            e2 = !(cm < 5) ? cm - 3 : kNoMode;
+            e3 = !(cm < 3) ? cm - 1 : kNoMode;
+            e4 = !(cm + 1 > 66) ? cm + 1 : kNoMode;
+            e5 = !(cm + 3 > 66) ? cm + 3 : kNoMode;
+            n = 6;
+            lo = (unsigned long long)e0 | ((unsigned long long)e1 << 8) | ((unsigned long long)e2 << 16) | ((unsigned long long)e3 << 24) |
+                 ((unsigned long long)e4 << 32) | ((unsigned long long)e5 << 40);
         } else {
-            cm += st;
-            cur = c1;
+            // step_search(mode, 2, cost, aux = true) (:905-973): rounds with step 2 and 1; a probe outside 2..66 is f32::MAX
+            e0 = !(cm < 2 + st) ? cm - st : kNoMode;
+            e1 = !(cm + st > 66) ? cm + st : kNoMode;
+            n = 2;
+            lo = (unsigned long long)e0 | ((unsigned long long)e1 << 8);
         }
+        const unsigned acc = sad_list_angular(c, q.comps, q.tx, q.ty, q.tlg, n, lo, hi);
+        const int my_mode = LANE < n ? (int)(((LANE < 8 ? lo : hi) >> (8 * (LANE & 7))) & 255u) : kNoMode;
+        const unsigned s0 = (unsigned)__builtin_amdgcn_readlane((int)acc, 0), s1 = (unsigned)__builtin_amdgcn_readlane((int)acc, 1);
+        // ---- what the round does with the SADs.  They are integers < 2^20, so comparing them as integers is comparing the
+        // reference's f32 values; keep the current mode on ties, then the lower probe (Q12) ----
+        bool traced = my_mode != kNoMode;
+        if (r == 0) {
+            // first minimum = smallest (sad, index) pair
+            const int key = my_mode != kNoMode ? (int)((acc << 4) | (unsigned)LANE) : 0x7FFFFFFF;
+            const int kmin = wave_min_i32(key);
+            const int j = (kmin & 15) + 2; // entry i = candidate i + 2 of the 15, 7 bits each
+            cm = j < 8 ? (int)((0x3A5C90D0E08080ULL >> (7 * j)) & 127) : (int)((0x109E3764B53A2ULL >> (7 * (j - 8))) & 127);
+            cur = (unsigned)kmin >> 4;
+        } else if (six) {
+            const unsigned s2 = (unsigned)__builtin_amdgcn_readlane((int)acc, 2), s3 = (unsigned)__builtin_amdgcn_readlane((int)acc, 3);
+            const unsigned s4 = (unsigned)__builtin_amdgcn_readlane((int)acc, 4), s5 = (unsigned)__builtin_amdgcn_readlane((int)acc, 5);
+            // round 1, step 2
+            const unsigned c0 = e0 != kNoMode ? s0 : kNoSad, c1 = e1 != kNoMode ? s1 : kNoSad;
+            const unsigned mn = min(min(cur, c0), c1);
+            int d = 0; // cm' - cm
+            if (cur == mn) {
+            } else if (c0 == mn) {
+                d = -2;
+                cur = c0;
+            } else {
+                d = 2;
+                cur = c1;
+            }
+            // round 2, step 1, around cm' = cm + d: its probes are entries 2 + (d + 2) / 2 and 3 + (d + 2) / 2
+            const int elo = d < 0 ? e2 : (d == 0 ? e3 : e4), ehi = d < 0 ? e3 : (d == 0 ? e4 : e5);
+            const unsigned slo = d < 0 ? s2 : (d == 0 ? s3 : s4), shi = d < 0 ? s3 : (d == 0 ? s4 : s5);
+            const unsigned p0 = elo != kNoMode ? slo : kNoSad, p1 = ehi != kNoMode ? shi : kNoSad;
+            cm += d;
+            const unsigned mn2 = min(min(cur, p0), p1);
+            if (cur == mn2) {
+            } else if (p0 == mn2) {
+                cm -= 1;
+                cur = p0;
+            } else {
+                cm += 1;
+                cur = p1;
+            }
+            const int ilo = d < 0 ? 2 : (d == 0 ? 3 : 4);
+            traced = traced && (LANE < 2 || LANE == ilo || LANE == ilo + 1);
+        } else {
+            const unsigned c0 = e0 != kNoMode ? s0 : kNoSad, c1 = e1 != kNoMode ? s1 : kNoSad;
+            const unsigned mn = min(min(cur, c0), c1);
+            if (cur == mn) {
+            } else if (c0 == mn) {
+                cm -= st;
+                cur = c0;
+            } else {
+                cm += st;
+                cur = c1;
+            }
+        }
+        if (c.trace && traced)
+            TRACE_REC(c.ctu_x + q.tx, c.ctu_y + q.ty, q.tlg, q.tree, (q.comps & 1) ? 0 : 2, (q.comps & 1) ? my_mode : 0, my_mode,
+                      __float_as_int((float)acc));
     }
     cm_out = cm;
     smin_out = cur;
