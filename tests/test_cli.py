@@ -164,6 +164,32 @@ def test_native_and_python_front_ends_write_the_same_bytes(built, tmp_path):
 
 
 @pytest.mark.gpu
+def test_a_run_that_ends_on_smaller_batches_writes_the_same_bytes(built, tmp_path):
+    """The native program ends a run whose host tail is heavy on smaller batches (a half, a quarter, a quarter of --batch);
+    forced here (--ramp-down always) on 21 pictures in batches of 8 -- 8, 8 (the run is not over), then 4, 2, 2 ... down to the
+    last picture -- with tokens and with the compact record: the streams and reconstructions are those of plain batches."""
+    w, h = 64, 64
+    kinds = ("cclm", "noise", "ramp", "checker", "stripes70", "flat", "extremes")
+    frames = [content(kinds[i % 7], w, h, i) for i in range(21)]
+    src = tmp_path / "in.yuv"
+    src.write_bytes(b"".join(p.tobytes() for f in frames for p in f))
+    outs = []
+    for extra in (["--ramp-down", "never"], ["--ramp-down", "always"], ["--ramp-down", "always", "--tokens", "off"],
+                  ["--ramp-down", "always", "--batch", "5"]):
+        out, rec = tmp_path / ("o%d.vvc" % len(outs)), tmp_path / ("o%d.yuv" % len(outs))
+        r = _run("native", ["-i", str(src), "-o", str(out), "-r", str(rec), "--input-size", "64x64", "--output-size", "64x64",
+                            "--num-pictures", "21", "--qp", "30", "--max-split-depth", "2", "--batch", "8", "--threads", "3", "--verbose"] + extra)
+        assert r.returncode == 0 and b"21 pictures" in r.stderr, r.stderr
+        outs.append((out.read_bytes(), rec.read_bytes(), r.stderr.count(b"read back (")))
+    assert outs[0][2] == 3 and outs[1][2] > 3 and outs[2][2] > 3      # 8 + 8 + 5 pictures against more, smaller batches
+    for o in outs[1:]:
+        assert o[:2] == outs[0][:2]
+    r = _run("native", ["-i", str(src), "-o", str(tmp_path / "x.vvc"), "--input-size", "64x64", "--output-size", "64x64",
+                        "--num-pictures", "21", "--ramp-down", "sometimes"])
+    assert r.returncode == 0 and b"error: Invalid ramp-down: sometimes" in r.stderr
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("front", FRONT_ENDS)
 def test_a_failure_inside_the_search_is_not_status_zero(built, tmp_path, front):
     """argument / I/O errors exit 0 like the reference (main.rs:127-133), but where the reference

@@ -165,6 +165,7 @@ int main(int argc, char** argv) {
     int depth = 3, batch = 64, n_threads = 8, device = 0;
     bool verbose = false, use_tokens = true;
     int tokens_mode = 0; // --tokens auto (0) | on (1) | off (2)
+    int ramp_mode = 0;   // --ramp-down auto (0) | always (1) | never (2)
     const char* device_list = nullptr;
     for (int i = 1; i < argc; ++i) {
         const std::string a = argv[i];
@@ -187,6 +188,11 @@ int main(int argc, char** argv) {
         else if (a == "--devices") device_list = val();
         else if (a == "--verbose") verbose = true;
         else if (a == "--no-tokens") tokens_mode = 2;
+        else if (a == "--ramp-down") { // how a run ends: auto (smaller last batches when the host's tail is heavy), always, never
+            const std::string v = val();
+            ramp_mode = v == "always" ? 1 : (v == "never" ? 2 : (v == "auto" ? 0 : -1));
+            if (ramp_mode < 0) die("Invalid ramp-down: %s (auto, always, never)", v.c_str());
+        }
         else if (a == "--tokens") {
             const std::string v = val();
             tokens_mode = v == "on" ? 1 : (v == "off" ? 2 : (v == "auto" ? 0 : -1));
@@ -315,7 +321,7 @@ int main(int argc, char** argv) {
         // little slower to search -- so that what is left at the end is a quarter's work.
         const long left = num_pictures - poc;
         int want = (int)(left < batch ? left : batch);
-        if (per_dev == 2 && tail_heavy && left <= batch && left > batch / 4) want = (int)(left / 2 > batch / 4 ? left / 2 : batch / 4);
+        if (per_dev == 2 && ramp_mode != 2 && (tail_heavy || ramp_mode == 1) && left <= batch && left > batch / 4) want = (int)(left / 2 > batch / 4 ? left / 2 : batch / 4);
         if (want < 1 && left > 0) want = 1;
         if (seekable && want > 0) { // (always pread then: the FILE's own position is never used)
             // readers fill the pictures (striped), this thread uploads each one as soon as it is there
