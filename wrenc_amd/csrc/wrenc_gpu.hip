@@ -713,6 +713,8 @@ void fill_dev_const(const wrenc_gpu_config& cfg, DevConst& k) {
     {
         // n / lsc for n < 2^26 (|tc << sh| of a 16-bit coefficient) as mul_hi(n, m) >> s: with k = 26 + ceil(log2 lsc) and
         // m = floor(2^k / lsc) + 1 the error n (m lsc - 2^k) / (lsc 2^k) stays below 1 / lsc, and m < 2^28 fits 32 bits
+        // (n itself does not depend on the QP: a 16-bit coefficient, the largest shift 8 + 5 - 5 + 1 = 9 of a 32x32 block, the rounding offset)
+        static_assert((32768LL << 9) + (1 << 8) < (1LL << 26), "quotient(): |(tc << sh) - off| stays below 2^26");
         int lg = 0;
         while ((1 << lg) < k.lsc) ++lg;
         const int kk = 26 + lg;
