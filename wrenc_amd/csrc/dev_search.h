@@ -920,7 +920,10 @@ __device__ __forceinline__ Res leaf4_search(const Ctx& c, const Req& q, int* ove
     }
     if (served) {
         // [planar, DC] from the server against pack B's first minimum, which wins only if strictly cheaper
+        PROF_MARK(sw0_);
         lv_word_wait(&SHT.lvb.job4_done, my_job);
+        PROF_MARK(sw1_);
+        PROF_ADDM(3, sw0_, sw1_); // (profile build: mem_nop_m3 = what member 3 waits for the server)
         const uint8_t* sv = (const uint8_t*)team_lds(c, 0).decw + kSrv4Byte;
         const float bestB = best;
         const int modeB = best_mode;
@@ -1278,7 +1281,10 @@ __device__ __forceinline__ Res leaf8_search(const Ctx& c, const Req& q, int* ove
     if (served) {
         // the server's pack A: first minimum of [planar, DC] against the first minimum of pack B found above; the
         // reference's order is [planar, DC, cm, cm - 1, cm + 1], so pack B's best wins only if strictly cheaper
+        PROF_MARK(sw0_);
         lv_word_wait(&SHT.lvb.job_done, my_job);
+        PROF_MARK(sw1_);
+        PROF_ADDM(3, sw0_, sw1_); // (mem_nop_m2)
         const Lds& srv = team_lds(c, 0);
         const float bestB = best;
         const int modeB = best_mode, clsB = best_cls;
