@@ -336,10 +336,19 @@ def e2e_native(w, h, qp, depth, n_pictures, batch, threads, textured):
         m = re.search(rb"(\d+) pictures, (\d+) bytes, ([\d.]+) s, ([\d.]+) pictures/s", r.stderr)
         if r.returncode != 0 or not m:
             return {"error": "status %d: %s" % (r.returncode, r.stderr[-300:].decode(errors="replace"))}
-        return {"value": float(m.group(4)), "unit": "frames/s", "pictures": int(m.group(1)), "stream_bytes": int(m.group(2)),
-                "seconds": float(m.group(3)), "batch": batch, "host_threads": threads,
-                "content": "synth_textured_frame" if textured else "synth_frame",
-                "what": "raw YUV file -> .vvc file: read, upload, search + final pass, read-back, host CABAC, write"}
+        out = {"value": float(m.group(4)), "unit": "frames/s", "pictures": int(m.group(1)), "stream_bytes": int(m.group(2)),
+               "seconds": float(m.group(3)), "batch": batch, "host_threads": threads,
+               "content": "synth_textured_frame" if textured else "synth_frame",
+               "what": "raw YUV file -> .vvc file: read, upload, search + final pass, read-back, host CABAC, write"}
+        # the program's timeline (--verbose): when each batch came back from the device.  Between the first and the last
+        # read-back the pipeline is full: pictures that came back in that interval / its length = the rate a long run has
+        tl = [(float(t), int(p)) for t, p in re.findall(rb"([\d.]+) s: batch at picture (\d+) read back", r.stderr)]
+        if len(tl) >= 3 and tl[-1][0] > tl[0][0]:
+            last_count = int(m.group(1)) - tl[-1][1]
+            out["batches"] = len(tl)
+            out["steady_state"] = {"value": round((tl[-1][1] + last_count - tl[1][1]) / (tl[-1][0] - tl[0][0]), 1), "unit": "frames/s",
+                                   "what": "pictures read back after the first batch / time from the first to the last read-back"}
+        return out
     except (OSError, subprocess.TimeoutExpired) as e:
         return {"error": repr(e)}
     finally:
