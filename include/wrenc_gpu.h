@@ -104,6 +104,11 @@ int wrenc_gpu_default_config(wrenc_gpu_config* cfg, int width, int height, int q
  * is not KEY=VALUE or a live key whose value is not a number.  NULL or "" gives the defaults again. */
 int wrenc_gpu_config_extra_params(wrenc_gpu_config* cfg, const char* extra_params);
 
+/* WRENC_GPU_EINVAL for a geometry that is not whole CTUs, a QP outside 0..63 -- and for a quantiser rate model the device's
+ * arithmetic does not cover: the trellis keeps its path costs in 32 bits, exact while 128 * 65535 + lambda_q * dq_table[i]
+ * < 2^25 for every i.  That holds for the reference's defaults at every QP and for tuned models near them; it does not
+ * for values such as quant_lv_pow = 2.5 or quant_qp_div_trellis = 1.5, which are refused here (the reference computes those
+ * products in i64) instead of being searched with other results.  WRENC_GPU_ENODEV without an MI355X. */
 int wrenc_gpu_create(const wrenc_gpu_config* cfg, wrenc_gpu_ctx** out);
 void wrenc_gpu_destroy(wrenc_gpu_ctx* ctx);
 const char* wrenc_gpu_last_error(const wrenc_gpu_ctx* ctx); /* ctx may be NULL: create errors */

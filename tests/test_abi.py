@@ -105,6 +105,17 @@ def test_create_rejects_bad_arguments_and_never_falls_back(built):
         rc = lib.wrenc_gpu_create(C.byref(cfg), C.byref(ctx))
         assert rc == -1 and not ctx.value           # WRENC_GPU_EINVAL
         assert lib.wrenc_gpu_last_error(None)
+    # a quantiser rate model whose step costs do not fit the device's 32-bit trellis arithmetic is refused, not searched
+    # with other results than the reference's (include/wrenc_gpu.h); the defaults fit at every QP, with room
+    for extra in ("quant_lv_pow=2.5", "quant_qp_div_trellis=1.5", "quant_lambda_mul_trellis=-3"):
+        cfg = gpu.default_config(64, 64, 37, 2, extra_params=extra)
+        ctx = C.c_void_p()
+        rc = lib.wrenc_gpu_create(C.byref(cfg), C.byref(ctx))
+        assert rc == -1 and not ctx.value, extra
+        assert b"rate model" in lib.wrenc_gpu_last_error(None)
+    for qp in (0, 32, 63):
+        cfg = gpu.default_config(64, 64, qp, 2)
+        assert 0 <= cfg.lambda_q * max(cfg.dq_table) < (1 << 25) - 128 * 65535
     import torch
     if not torch.cuda.is_available():
         cfg = gpu.default_config(64, 64, 32, 2)

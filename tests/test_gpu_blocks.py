@@ -157,6 +157,30 @@ def test_head_proof_ranges_equal_the_formulas_at_every_qp(built):
         assert (ranges[:, 5] > 0).all(), (qp, ranges.tolist())  # a zero coefficient has quotient 0
 
 
+@pytest.mark.parametrize("extra", ["quant_lambda_mul_trellis=0.02", "quant_lambda_mul_trellis=60", "quant_qp_div_trellis=3.2",
+                                   "quant_lv_pow=0.8,quant_lambda_offset_trellis=9", "quant_lambda_mul_trellis=0"])
+def test_head_proof_ranges_never_admit_too_much_under_other_rate_models(built, extra):
+    """The CLI's --extra-params change lambda_q and the level-cost table the quantiser works from: whatever they are, a
+    range may end a region early (counts[1], costing a longer walk) but never admits a coefficient the formulas reject,
+    and the quotient and alpha tests stay exact -- at every QP of five at which the library takes the model at all (it
+    refuses one whose step costs do not fit the trellis' 32 bits: tests/test_abi.py)."""
+    from wrenc_amd import gpu
+    ran = 0
+    for qp in (22, 27, 32, 37, 45):
+        try:
+            e = gpu.Encoder(64, 64, qp=qp, max_split_depth=0, extra_params=extra)
+        except gpu.WrencGpuError as err:
+            assert "rate model" in str(err), err
+            continue
+        try:
+            counts, ranges = e.test_head_ranges()
+        finally:
+            e.close()
+        assert counts[0] == 0 and counts[2] == 0 and counts[3] == 0, (extra, qp, counts, ranges.tolist())
+        ran += 1
+    assert ran >= 1, extra
+
+
 @pytest.mark.parametrize("qp", [18, 27, 34, 45, 51])
 def test_packed_quantisers_at_other_qps(enc_at, qp):
     """quantize_p16 and quantize_pk<3 / 4> at other QPs: every block of every pack equals the literal DFS."""

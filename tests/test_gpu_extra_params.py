@@ -15,6 +15,9 @@ KEYS = ("cu_log2_size", "luma_mode", "chroma_mode", "lev_y", "lev_cb", "lev_cr",
 @pytest.mark.parametrize("kind,w,h,qp,depth,extra", [
     ("cclm", 96, 64, 32, 2, EXTRA), ("noise", 64, 64, 27, 3, EXTRA), ("stripes70", 64, 96, 37, 2, EXTRA),
     ("stripes45", 64, 64, 22, 3, "a=0.05"), ("cclm", 64, 64, 22, 3, "a=3.0"), ("cclm", 64, 64, 32, 2, "quant_lambda_mul_trellis=3.0,quant_lambda_offset_trellis=40"),
+    # the quantiser's lambda far from its default: the head proof's ranges (DevConst::head_rng) are derived from it
+    ("noise", 64, 64, 32, 3, "quant_lambda_mul_trellis=0.02"), ("noise", 64, 64, 32, 3, "quant_lambda_mul_trellis=60"),
+    ("cclm", 96, 64, 22, 2, "quant_lv_pow=0.8,quant_lambda_offset_trellis=9"), ("stripes70", 64, 64, 37, 3, "quant_qp_div_trellis=3.2"),
 ])
 def test_extra_params_parity(built, kind, w, h, qp, depth, extra):
     from wrenc_amd import gpu

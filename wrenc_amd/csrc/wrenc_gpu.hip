@@ -995,6 +995,20 @@ int wrenc_gpu_create(const wrenc_gpu_config* cfg, wrenc_gpu_ctx** out) {
     if (cfg->max_split_depth < 0 || cfg->max_split_depth > 3)
         return fail(nullptr, WRENC_GPU_EINVAL, "max_split_depth out of range 0..3");
     if (cfg->n_slots < 1) return fail(nullptr, WRENC_GPU_EINVAL, "n_slots must be >= 1");
+    // The trellis keeps path costs in 32 bits (dev_quant.h, above kNoBranch): exact as long as one step costs less than 2^25,
+    // i.e. 128 * 65535 + lambda_q * dq_table[bits] < 2^25 for every table entry -- true for the reference's defaults at every
+    // QP (22.6 M at QP 63) and for rate models anywhere near them, not for e.g. quant_lv_pow = 2.5 or quant_qp_div_trellis =
+    // 1.5 (--extra-params), where the reference's own i64 products reach 10^11 .. 10^19.  Refused rather than searched
+    // with other results than the reference's.
+    {
+        constexpr long long kStepRoom = (1LL << 25) - 128LL * 65535LL;
+        bool fits = cfg->lambda_q >= 0 && cfg->lambda_q < kStepRoom;
+        for (int i = 0; fits && i < 1024; ++i)
+            fits = cfg->dq_table[i] >= 0 && cfg->dq_table[i] < kStepRoom && cfg->lambda_q * cfg->dq_table[i] < kStepRoom;
+        if (!fits)
+            return fail(nullptr, WRENC_GPU_EINVAL,
+                        "the quantiser's rate model (lambda_q x dq_table) is outside the range the device's 32-bit trellis costs cover");
+    }
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
         return fail(nullptr, WRENC_GPU_ENODEV, "no HIP device available");
