@@ -18,6 +18,8 @@ KEYS = ("cu_log2_size", "luma_mode", "chroma_mode", "lev_y", "lev_cb", "lev_cr",
     # the quantiser's lambda far from its default: the head proof's ranges (DevConst::head_rng) are derived from it
     ("noise", 64, 64, 32, 3, "quant_lambda_mul_trellis=0.02"), ("noise", 64, 64, 32, 3, "quant_lambda_mul_trellis=60"),
     ("cclm", 96, 64, 22, 2, "quant_lv_pow=0.8,quant_lambda_offset_trellis=9"), ("stripes70", 64, 64, 37, 3, "quant_qp_div_trellis=3.2"),
+    # ... and at the edge of what wrenc_gpu_create accepts: lambda_q x dq_table[1023] = 24.9 M and 24.75 M of 25.17 M
+    ("noise", 64, 64, 32, 3, "quant_lambda_mul_trellis=86"), ("stripes70", 64, 64, 37, 3, "quant_lambda_mul_trellis=44"),
 ])
 def test_extra_params_parity(built, kind, w, h, qp, depth, extra):
     from wrenc_amd import gpu

@@ -38,6 +38,24 @@ def test_picture_matches_oracle(built, w, h, qp, depth, tex, schedule):
     _compare(got, ref, "%dx%d qp%d d%d" % (w, h, qp, depth))
 
 
+@pytest.mark.parametrize("kind,w,h,qp,depth", [("noise", 64, 64, 63, 3), ("cclm", 96, 64, 63, 2), ("extremes", 64, 64, 63, 3),
+                                               ("stripes70", 64, 64, 60, 3), ("noise", 64, 64, 57, 3), ("cclm", 96, 64, 4, 2),
+                                               ("noise", 64, 64, 12, 3)])
+@pytest.mark.parametrize("schedule", [1, 2])
+def test_both_ends_of_the_qp_range(built, kind, w, h, qp, depth, schedule):
+    """QP 57 .. 63 -- where lambda_q x dq_table comes closest to what the trellis' 32-bit path costs cover (22.6 M of 25.2 M at
+    QP 63) -- and QP 4 / 12, where levels are large (noise at QP 0 reaches level 1024: WRENC_GPU_ELEVEL, as in the oracle)."""
+    from content import content
+    from wrenc_amd import gpu
+    from oracle import pyoracle as po
+    y, cb, cr = content(kind, w, h, 17)
+    enc = gpu.Encoder(w, h, qp=qp, max_split_depth=depth, schedule=schedule)
+    got = enc.encode_picture(y, cb, cr)
+    assert enc.final_pass_mismatches() == 0
+    enc.close()
+    _compare(got, po.encode_picture(y, cb, cr, qp, depth), "%s qp%d d%d" % (kind, qp, depth))
+
+
 @pytest.mark.parametrize("schedule", [0, 1, 2])    # AUTO / wave / team
 def test_the_reference_own_test_geometry(built, schedule):
     """wrenc's only end-to-end test encodes CIF 352x288 at QP 20 with the default max-split-depth 3
