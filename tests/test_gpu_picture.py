@@ -56,6 +56,30 @@ def test_both_ends_of_the_qp_range(built, kind, w, h, qp, depth, schedule):
     _compare(got, po.encode_picture(y, cb, cr, qp, depth), "%s qp%d d%d" % (kind, qp, depth))
 
 
+@pytest.mark.parametrize("w,h,qp,depth", [(512, 32, 32, 3), (32, 512, 32, 3), (2048, 32, 27, 1), (32, 1024, 37, 2)])
+def test_one_row_and_one_column_pictures(built, w, h, qp, depth):
+    """A single row of CTUs (every anti-diagonal holds one CTU, nothing above it) and a single column (every CTU is a
+    picture's left AND right edge, two diagonals apart): two pictures per call in all three schedules, the record against
+    the oracle and the device's token stream against the stream from the planes."""
+    from wrenc_amd import bitstream as bs, gpu, synth
+    from oracle import pyoracle as po
+    frames = [synth.synth_textured_frame(w, h, 11), synth.synth_frame(w, h, 2)]
+    refs = [po.encode_picture(*f, qp, depth) for f in frames]
+    for schedule in (0, 1, 2):
+        enc = gpu.Encoder(w, h, qp=qp, max_split_depth=depth, n_slots=2, schedule=schedule)
+        for s, f in enumerate(frames):
+            enc.upload(s, *f)
+        enc.encode(0, 2)
+        enc.sync()
+        assert enc.final_pass_mismatches() == 0
+        pool, pics = enc.download_tokens(0, 2)
+        for s in range(2):
+            got = enc.download(s)
+            _compare(got, refs[s], "%dx%d schedule %d slot %d" % (w, h, schedule, s))
+            assert bs.write_picture(w, h, qp, s, got) == bs.write_picture_tokens(w, h, qp, s, pool, pics[s])
+        enc.close()
+
+
 @pytest.mark.parametrize("schedule", [0, 1, 2])    # AUTO / wave / team
 def test_the_reference_own_test_geometry(built, schedule):
     """wrenc's only end-to-end test encodes CIF 352x288 at QP 20 with the default max-split-depth 3
