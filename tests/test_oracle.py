@@ -145,6 +145,24 @@ def test_trellis_shortcuts_equal_the_literal_dfs(qp):
                 assert np.array_equal(po.quantize_sc(c, qp, head, False, True), want), (qp, it, head, "segments")
 
 
+@pytest.mark.parametrize("extra", ["quant_lambda_mul_trellis=0.02", "quant_lambda_mul_trellis=60", "quant_lambda_mul_trellis=0",
+                                   "quant_qp_div_trellis=3.2", "quant_lv_pow=0.8,quant_lambda_offset_trellis=9", "quant_lv_pow=0.3"])
+def test_trellis_shortcuts_under_other_rate_models(extra):
+    """The same comparison with the quantiser's lambda and level-cost table moved far from their defaults (--extra-params):
+    the proofs make no assumption about their size, only about their sign -- whole-block proof on and off."""
+    try:
+        po.set_extra_params(extra)
+        for qp in (22, 32, 37):
+            rng = np.random.default_rng(700 + qp)
+            for it in range(120):
+                c = _trellis_block(rng, it)
+                want = po.quantize(c, qp)
+                assert np.array_equal(po.quantize_sc(c, qp, True, True), want), (extra, qp, it)
+                assert np.array_equal(po.quantize_sc(c, qp, True, False, False, False), want), (extra, qp, it, "no whole-block proof")
+    finally:
+        po.set_extra_params(None)
+
+
 def test_trellis_shortcuts_on_the_search_own_blocks():
     """... and on every block the search itself quantises (smooth and textured content, two QPs); the exits do fire."""
     from wrenc_amd import synth
