@@ -235,6 +235,11 @@ int wrenc_gpu_test_scratch_overflows(wrenc_gpu_ctx* ctx, long long* count);
  * expected); counts[2]: quotient differences (must be 0); counts[3]: differences of the two alpha formulas (must be 0).
  * ranges (may be NULL): the 4 x 6 bounds.  Waits for the device. */
 int wrenc_gpu_test_head_ranges(wrenc_gpu_ctx* ctx, int counts[4], int ranges[24]);
+/* Test entry: which reference segments of a block are available (below-left, left, corner, above, above-right) comes
+ * from a table of the block's place in its CTU plus the picture's edges; this counts the blocks -- every CTU of the
+ * context's picture, every size and position, luma and chroma spacing -- at which that differs from the reference's rules
+ * (ctu.rs:2083-2188, encoder_context.rs:918-956) evaluated directly.  Must be 0.  Waits for the device. */
+int wrenc_gpu_test_avail_tab(wrenc_gpu_ctx* ctx, int* differences);
 
 /* Per-launch timing (two HIP events around every kernel launch) is OFF by default: the product path
  * (CLI, native program) never reads it.  bench.py / profiling switch it on.  While it is on, an encode

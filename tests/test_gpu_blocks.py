@@ -142,6 +142,19 @@ def test_quantize_trellis_at_every_qp_class(enc_at, qp):
             assert np.array_equal(deq[i], po.dequantize(ref, qp)), (qp, n, i)
 
 
+@pytest.mark.parametrize("w,h", [(32, 32), (64, 32), (32, 64), (64, 64), (96, 96), (160, 128), (96, 32), (32, 96)])
+def test_segment_availability_table_equals_the_rules(built, w, h):
+    """build_refs reads a block's five segment availabilities from a table of its place in the CTU, cut by the picture's
+    edges: the same as the reference's rules evaluated directly, for every block of every CTU of pictures one to five CTUs
+    wide and high (every combination of left / right / top / bottom edge), luma and chroma."""
+    from wrenc_amd import gpu
+    e = gpu.Encoder(w, h, qp=32, max_split_depth=0)
+    try:
+        assert e.test_avail_tab() == 0
+    finally:
+        e.close()
+
+
 def test_head_proof_ranges_equal_the_formulas_at_every_qp(built):
     """The head proof reads "ends the region" and "quotient >= 2" off range tests whose bounds the host derives per QP and
     block size (DevConst::head_rng): at every QP 0..63 they say what the device's formulas (head_alpha, quotient) say for

@@ -47,6 +47,11 @@ struct DevConst {
     // (c) has a quotient below 2  <=>  (unsigned)(tc + r[4]) < (unsigned)r[5].  Filled by the host from the same formulas
     // (fill_head_ranges; test_head_ranges_kernel compares them with the device functions over every 16-bit coefficient).
     int32_t head_rng[4][6];
+    // Which of a block's five reference segments (bit 0 below-left, 1 left, 2 corner, 3 above, 4 above-right) the coding
+    // order makes available, for a block at (bx, by) of log2 size lg inside a CTU away from every picture edge:
+    // [lg - 2][(by / 4) * 8 + bx / 4] (block_avail_mask adds the edges).  From the formulas themselves on the host
+    // (fill_avail_tab); test_avail_tab_kernel holds the two against each other at every position of small pictures.
+    uint8_t avail_tab[4][64];
 };
 
 // Pointers that are loaded from memory (PicBufs) lose their address space; these casts tell the
@@ -624,6 +629,37 @@ __device__ __forceinline__ bool nb_avail(Ctx c, int gx, int gy, int tn, int xn, 
     return xn >= 0 && yn >= 0 && xn < c.W && yn < c.k->H &&
            ((xn >> 5) <= (gx >> 5) || (yn >> 5) < (gy >> 5)) && (yn >> 5) < (gy >> 5) + 1 &&
            (xn < gx + tn || ar) && (yn < gy + tn || bl);
+}
+// The five segment availabilities of build_refs (dev_predict.h) as one mask, from the formulas above (the reference's:
+// above_right_avail, below_left_avail, five nb_avail -- some 150 scalar instructions per block, a tenth of the kernel's
+// scalar stream at max-split-depth 3, profiles/r04_issue_model.md).
+__device__ __forceinline__ int block_avail_formula(Ctx c, int tx, int ty, int tlg, int st) {
+    const int tn = 1 << tlg;
+    const int gx = c.ctu_x + tx, gy = c.ctu_y + ty;
+    const bool ar = above_right_avail(c, tx, ty, tlg);
+    const bool bl = below_left_avail(c, tx, ty, tlg);
+    int avm = 0;
+    avm |= nb_avail(c, gx, gy, tn, gx - st, gy + tn, ar, bl) ? 1 : 0;
+    avm |= nb_avail(c, gx, gy, tn, gx - st, gy, ar, bl) ? 2 : 0;
+    avm |= nb_avail(c, gx, gy, tn, gx - st, gy - st, ar, bl) ? 4 : 0;
+    avm |= nb_avail(c, gx, gy, tn, gx, gy - st, ar, bl) ? 8 : 0;
+    avm |= nb_avail(c, gx, gy, tn, gx + tn, gy - st, ar, bl) ? 16 : 0;
+    return avm;
+}
+// The same from the table: what the coding order allows inside the CTU (and across its borders) is a function of the
+// block's place in the CTU alone; the picture's edges take segments away: everything left of the block needs a column
+// left of it, everything above a row above it, above-right a column right of it, below-left a row below it.
+#ifndef WRENC_AVAIL_TAB
+#define WRENC_AVAIL_TAB 1 // 0: the formulas at every call (until round 4; for A/B runs)
+#endif
+__device__ __forceinline__ int block_avail_mask(Ctx c, int tx, int ty, int tlg, int st) {
+    if (!WRENC_AVAIL_TAB) return block_avail_formula(c, tx, ty, tlg, st);
+    const int tn = 1 << tlg;
+    const int gx = c.ctu_x + tx, gy = c.ctu_y + ty;
+    const int in_ctu = c.k->avail_tab[tlg - 2][(ty >> 2) * 8 + (tx >> 2)];
+    const int left = gx > 0 ? 7 : 0, top = gy > 0 ? 28 : 0;       // BL, L, corner | corner, A, AR
+    const int right = gx + tn < c.W ? 31 : 15, bottom = gy + tn < c.k->H ? 31 : 30;
+    return in_ctu & ((left | 24) & (top | 3)) & right & bottom;
 }
 
 } // namespace wrenc

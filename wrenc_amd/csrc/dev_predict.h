@@ -21,6 +21,9 @@ __device__ __forceinline__ int pdpc_w(int n_scale, int i) {
 // The neighbourhood of a block does not change while its candidate modes are evaluated
 // (evaluations only write inside the block), so this runs once per block instead of once per mode.
 __device__ __forceinline__ void build_refs(Ctx c, int comp, int tx, int ty, int tlg) {
+#ifdef WRENC_EXP_SKIP_REFS
+    return;
+#endif
     c = uni(c);
     comp = uni(comp);
     tx = uni(tx);
@@ -31,17 +34,9 @@ __device__ __forceinline__ void build_refs(Ctx c, int comp, int tx, int ty, int 
     const int n = 1 << (tlg - cs);
     const int tn = 1 << tlg;
     const int cx = tx >> cs, cy = ty >> cs;
-    const int gx = c.ctu_x + tx, gy = c.ctu_y + ty;
-    const bool ar = above_right_avail(c, tx, ty, tlg);
-    const bool bl = below_left_avail(c, tx, ty, tlg);
     const int st = 1 << cs;
     // segment availabilities in substitution-scan order: BL, L, corner, A, AR (bit j = segment j)
-    int avm = 0;
-    avm |= nb_avail(c, gx, gy, tn, gx - st, gy + tn, ar, bl) ? 1 : 0;
-    avm |= nb_avail(c, gx, gy, tn, gx - st, gy, ar, bl) ? 2 : 0;
-    avm |= nb_avail(c, gx, gy, tn, gx - st, gy - st, ar, bl) ? 4 : 0;
-    avm |= nb_avail(c, gx, gy, tn, gx, gy - st, ar, bl) ? 8 : 0;
-    avm |= nb_avail(c, gx, gy, tn, gx + tn, gy - st, ar, bl) ? 16 : 0;
+    const int avm = block_avail_mask(c, tx, ty, tlg, st);
     const bool any = avm != 0;
     const int total = 4 * n + 1;
     for (int tt = LANE; tt < nb * total; tt += 64) {
@@ -384,6 +379,9 @@ __device__ __forceinline__ int emit_sample(const Ctx& c, int o, int i, int v, in
 template <bool full>
 __device__ __forceinline__ int predict(Ctx c, int comp, int tx, int ty, int tlg, int mode, int rbase = 0,
                                        int to_tile = PRED_TILE, int nl = 0, CclmPick pick = CclmPick{}) {
+#ifdef WRENC_EXP_SKIP_PRED // instruction-count experiment only (profiles/r04_issue_model.md): nothing predicted
+    return 0;
+#endif
     c = uni(c);
     rbase = uni(rbase);
     to_tile = uni(to_tile);
@@ -568,6 +566,9 @@ constexpr int kTab4Byte = 1280; // byte offset in r2: 4 x 16 bytes + 4 of slack 
 // pl < 0: luma; pl = 0 / 1 (may differ per lane): the 4x4 Cb / Cr block of an 8x8 CU, predicted from that plane's
 // reference samples with the 2-tap chroma interpolation (build_refs(c, 1, ..) must have run).
 __device__ __forceinline__ int predict4_lane(const Ctx& c, int mode, int pl = -1) {
+#ifdef WRENC_EXP_SKIP_PRED
+    return 128;
+#endif
     constexpr int n = 4, lg = 2;
     const int lane = lane_fresh();
     const int s = lane >> 4, i = lane & 15;

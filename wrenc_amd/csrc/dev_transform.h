@@ -256,6 +256,9 @@ __device__ __forceinline__ void inv_dct32_mfma(Ctx c, int o1) {
 
 // o1: where the blocks start in r1 (i16 units, a multiple of 2)
 __device__ __forceinline__ void fwd_dct_lg(Ctx c, int lg, int nb, int o1 = 0) {
+#ifdef WRENC_EXP_SKIP_DCT // instruction-count experiment only: the residual stays where the coefficients should be
+    return;
+#endif
     c = uni(c);
     lg = uni(lg);
     nb = uni(nb);
@@ -275,6 +278,9 @@ __device__ __forceinline__ void fwd_dct_lg(Ctx c, int lg, int nb, int o1 = 0) {
     }
 }
 __device__ __forceinline__ void inv_dct_lg(Ctx c, int lg, int nb, int o1 = 0) {
+#ifdef WRENC_EXP_SKIP_DCT
+    return;
+#endif
     c = uni(c);
     lg = uni(lg);
     nb = uni(nb);

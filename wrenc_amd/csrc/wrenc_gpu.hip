@@ -352,6 +352,22 @@ __global__ __launch_bounds__(64) void test_head_ranges_kernel(const DevConst* __
     if (alpha != head_alpha1(tc, hk)) atomicAdd(out + 3, 1);
 }
 
+// DevConst::avail_tab + the picture's edges (block_avail_mask) against the formulas (block_avail_formula): one block per
+// thread -- blockIdx.x = CTU, threadIdx.x = 4x4 position, blockIdx.y = size -- for luma and chroma spacing; *out +=
+// differences
+__global__ __launch_bounds__(64) void test_avail_tab_kernel(const DevConst* __restrict__ kk, int* out) {
+    Ctx c = {};
+    c.k = (const CONST_AS DevConst*)kk;
+    c.W = kk->W;
+    c.ctu_x = 32 * (int)(blockIdx.x % (unsigned)kk->ctu_cols);
+    c.ctu_y = 32 * (int)(blockIdx.x / (unsigned)kk->ctu_cols);
+    const int lg = 2 + (int)blockIdx.y;
+    const int bx = 4 * (int)(threadIdx.x & 7), by = 4 * (int)(threadIdx.x >> 3);
+    if ((bx | by) & ((1 << lg) - 1)) return;
+    for (int st = 1; st <= 2; ++st)
+        if (block_avail_formula(c, bx, by, lg, st) != block_avail_mask(c, bx, by, lg, st)) atomicAdd(out, 1);
+}
+
 // quantize_p16 (the packed 4x4 leaf search's quantiser): each wave takes up to four consecutive 4x4 blocks
 __global__ __launch_bounds__(64) void test_quantize_p16_kernel(const DevConst* __restrict__ k, const int16_t* in, int count,
                                                                int16_t* out, long long* cost, int* overflow) {
@@ -700,6 +716,58 @@ void fill_head_ranges(DevConst& k) {
     }
 }
 
+// DevConst::avail_tab: the reference's availability rules (ctu.rs:2083-2188, encoder_context.rs:918-956 -- the same
+// arithmetic as above_right_avail / below_left_avail / nb_avail of dev_common.h) evaluated on the host for a CTU in the
+// middle of a 3 x 3-CTU picture, every block position and size.
+void fill_avail_tab(DevConst& k) {
+    const int W = 96, H = 96, ctu_x = 32, ctu_y = 32;
+    const auto above_right = [&](int bx, int by, int lg) {
+        for (;;) {
+            const int n = 1 << lg;
+            if (ctu_x + bx + n >= W) return false;
+            if (lg == 5) return ctu_y > 0 && ctu_x + 32 < W;
+            const int px = bx & ~(2 * n - 1), py = by & ~(2 * n - 1);
+            if (bx == px && by == py) return ctu_y + by > 0;
+            if (by == py) {
+                bx = px;
+                by = py;
+                lg += 1;
+                continue;
+            }
+            return bx == px;
+        }
+    };
+    const auto below_left = [&](int bx, int by, int lg) {
+        for (;;) {
+            const int n = 1 << lg;
+            if (ctu_y + by + n >= H) return false;
+            if (lg == 5) return false;
+            const int px = bx & ~(2 * n - 1), py = by & ~(2 * n - 1);
+            if (px < bx) return false;
+            if (by + n < py + 2 * n) return ctu_x + bx > 0;
+            bx = px;
+            by = py;
+            lg += 1;
+        }
+    };
+    for (int lg = 2; lg <= 5; ++lg)
+        for (int by = 0; by < 32; by += 4)
+            for (int bx = 0; bx < 32; bx += 4) {
+                int avm = 0;
+                if (!(bx & ((1 << lg) - 1)) && !(by & ((1 << lg) - 1))) {
+                    const int tn = 1 << lg, gx = ctu_x + bx, gy = ctu_y + by;
+                    const bool ar = above_right(bx, by, lg), bl = below_left(bx, by, lg);
+                    const auto nb = [&](int xn, int yn) {
+                        return xn >= 0 && yn >= 0 && xn < W && yn < H && ((xn >> 5) <= (gx >> 5) || (yn >> 5) < (gy >> 5)) &&
+                               (yn >> 5) < (gy >> 5) + 1 && (xn < gx + tn || ar) && (yn < gy + tn || bl);
+                    };
+                    avm = (nb(gx - 1, gy + tn) ? 1 : 0) | (nb(gx - 1, gy) ? 2 : 0) | (nb(gx - 1, gy - 1) ? 4 : 0) | (nb(gx, gy - 1) ? 8 : 0) |
+                          (nb(gx + tn, gy - 1) ? 16 : 0);
+                }
+                k.avail_tab[lg - 2][(by >> 2) * 8 + (bx >> 2)] = (uint8_t)avm;
+            }
+}
+
 void fill_dev_const(const wrenc_gpu_config& cfg, DevConst& k) {
     memset(&k, 0, sizeof(k));
     k.W = cfg.width;
@@ -781,6 +849,7 @@ void fill_dev_const(const wrenc_gpu_config& cfg, DevConst& k) {
     for (int h = 0; h < 2; ++h)
         for (int w = 0; w < 16; ++w) k.idct32_k2[h][w] = 128 * colsum[8 * (w / 4) + 4 * h + w % 4] + 2048;
     fill_head_ranges(k);
+    fill_avail_tab(k);
 }
 
 } // namespace
@@ -1598,6 +1667,23 @@ int wrenc_gpu_test_head_ranges(wrenc_gpu_ctx* ctx, int counts[4], int ranges[24]
         memcpy(ranges, hk->head_rng, sizeof(hk->head_rng));
         delete hk;
     }
+    return WRENC_GPU_OK;
+}
+
+int wrenc_gpu_test_avail_tab(wrenc_gpu_ctx* ctx, int* differences) {
+    if (!ctx || !differences) return WRENC_GPU_EINVAL;
+    HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
+    int* d = nullptr;
+    HIP_TRY(ctx, hipMalloc((void**)&d, sizeof(int)));
+    hipError_t e = hipMemset(d, 0, sizeof(int));
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(test_avail_tab_kernel, dim3(ctx->ctu_cols * ctx->ctu_rows, 4), dim3(64), 0, 0, ctx->d_const, d);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e == hipSuccess) e = hipMemcpy(differences, d, sizeof(int), hipMemcpyDeviceToHost);
+    (void)hipFree(d);
+    HIP_TRY(ctx, e);
     return WRENC_GPU_OK;
 }
 

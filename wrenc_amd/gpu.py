@@ -22,7 +22,7 @@ EXPORTED_SYMBOLS = [
     "wrenc_gpu_upload", "wrenc_gpu_encode", "wrenc_gpu_sync", "wrenc_gpu_download", "wrenc_gpu_download_compact", "wrenc_gpu_compact_mask_words", "wrenc_gpu_expand_levels", "wrenc_gpu_download_tokens", "wrenc_gpu_test_load_record", "wrenc_gpu_device_info",
     "wrenc_gpu_alloc_host", "wrenc_gpu_free_host", "wrenc_gpu_encode_picture", "wrenc_gpu_set_schedule", "wrenc_gpu_last_schedule", "wrenc_gpu_stats_enable", "wrenc_gpu_last_encode_stats", "wrenc_gpu_last_encode_kernel_stats", "wrenc_gpu_final_pass_mismatches",
     "wrenc_gpu_test_fwd_dct", "wrenc_gpu_test_inv_dct", "wrenc_gpu_test_quantize",
-    "wrenc_gpu_test_dequantize", "wrenc_gpu_test_predict", "wrenc_gpu_test_fwd_dct32", "wrenc_gpu_test_inv_dct32", "wrenc_gpu_test_quantize_p16", "wrenc_gpu_test_quantize_pk", "wrenc_gpu_test_set_wave_slots", "wrenc_gpu_test_scratch_overflows", "wrenc_gpu_test_head_ranges",
+    "wrenc_gpu_test_dequantize", "wrenc_gpu_test_predict", "wrenc_gpu_test_fwd_dct32", "wrenc_gpu_test_inv_dct32", "wrenc_gpu_test_quantize_p16", "wrenc_gpu_test_quantize_pk", "wrenc_gpu_test_set_wave_slots", "wrenc_gpu_test_scratch_overflows", "wrenc_gpu_test_head_ranges", "wrenc_gpu_test_avail_tab",
 ]
 
 
@@ -341,6 +341,13 @@ class Encoder:
         self.lib.wrenc_gpu_test_head_ranges.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         self._check(self.lib.wrenc_gpu_test_head_ranges(self.ctx, counts, ranges))
         return list(counts), np.array(list(ranges), dtype=np.int64).reshape(4, 6)
+
+    def test_avail_tab(self):
+        """Test entry: blocks whose table-derived segment availability differs from the reference's rules (must be 0)."""
+        n = C.c_int(0)
+        self.lib.wrenc_gpu_test_avail_tab.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
+        self._check(self.lib.wrenc_gpu_test_avail_tab(self.ctx, C.byref(n)))
+        return int(n.value)
 
     def stats_enable(self, on=True):
         """Per-launch timing events (measurement mode, see include/wrenc_gpu.h)."""
