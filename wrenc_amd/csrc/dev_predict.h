@@ -177,20 +177,22 @@ __device__ __forceinline__ CclmParams cclm_params(Ctx c, int tx, int ty, int tlg
     const int tw = tn >> 1, th = tw;
     const int cx = tx >> 1, cy = ty >> 1;
     const int gx = c.ctu_x + tx, gy = c.ctu_y + ty;
-    const bool avail_l = nb_avail(c, gx, gy, tn, gx - 1, gy, false, false);
-    const bool avail_t = nb_avail(c, gx, gy, tn, gx, gy - 1, false, false);
+    // left / above / above-right / below-left of the block: the segment mask of build_refs says all four (bit 1 = the
+    // neighbour left of the first row, 3 = above the first column, 4 = above_right_avail, 0 = below_left_avail:
+    // test_avail_tab_kernel checks exactly these identities)
+    const int avm = block_avail_mask(c, tx, ty, tlg, 1);
+    const bool avail_l = (avm & 2) != 0, avail_t = (avm & 8) != 0;
+    const bool ar = (avm & 16) != 0, bl = (avm & 1) != 0;
     r.avail_l = avail_l;
     int num_top_right = 0, num_below_left = 0;
     // (wave-wide: the position is the lane, whichever mode the lane itself derives)
     if (__ballot(mode == T_CCLM) != 0ULL) {
-        const bool ar = above_right_avail(c, tx, ty, tlg), bl = below_left_avail(c, tx, ty, tlg);
         // run of available above-right samples (:1881-1893): one position per lane, then the length
         // of the leading run of set bits
         const bool a = LANE < tw && nb_avail(c, gx, gy, tn, gx + (tw + LANE) * 2, gy - 1, ar, bl);
         num_top_right = min((int)__ffsll(~__ballot(a)) - 1, tw);
     }
     if (__ballot(mode == L_CCLM) != 0ULL) {
-        const bool ar = above_right_avail(c, tx, ty, tlg), bl = below_left_avail(c, tx, ty, tlg);
         const bool a = LANE < th && nb_avail(c, gx, gy, tn, gx - 1, gy + (th + LANE) * 2, ar, bl);
         num_below_left = min((int)__ffsll(~__ballot(a)) - 1, th);
     }

@@ -366,6 +366,12 @@ __global__ __launch_bounds__(64) void test_avail_tab_kernel(const DevConst* __re
     if ((bx | by) & ((1 << lg) - 1)) return;
     for (int st = 1; st <= 2; ++st)
         if (block_avail_formula(c, bx, by, lg, st) != block_avail_mask(c, bx, by, lg, st)) atomicAdd(out, 1);
+    // what cclm_params reads off the mask
+    const int m = block_avail_mask(c, bx, by, lg, 1), tn = 1 << lg, gx = c.ctu_x + bx, gy = c.ctu_y + by;
+    if (above_right_avail(c, bx, by, lg) != (((m >> 4) & 1) != 0)) atomicAdd(out, 1);
+    if (below_left_avail(c, bx, by, lg) != ((m & 1) != 0)) atomicAdd(out, 1);
+    if (nb_avail(c, gx, gy, tn, gx - 1, gy, false, false) != (((m >> 1) & 1) != 0)) atomicAdd(out, 1);
+    if (nb_avail(c, gx, gy, tn, gx, gy - 1, false, false) != (((m >> 3) & 1) != 0)) atomicAdd(out, 1);
 }
 
 // quantize_p16 (the packed 4x4 leaf search's quantiser): each wave takes up to four consecutive 4x4 blocks
